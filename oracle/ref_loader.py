@@ -1,0 +1,164 @@
+"""TEST INFRASTRUCTURE ONLY — loader for the *real* reference STDiT3 on CPU.
+
+Imports the reference's own Python (``/root/reference/videosys``) with its
+``videosys/__init__.py`` bypassed and the un-vendored third-party modules
+stubbed (SURVEY.md §8c recipe).  It exists ONLY in the build container: the
+GPU box has no ``/root/reference``.  It is used by ``oracle/make_golden.py``
+to mint the fixtures under ``tests/golden/`` and by the CPU tests that check
+the restatement (``oracle/stdit3_oracle.py``) against the real reference when
+the reference tree is present.
+
+Nothing under ``videosys_amd/`` may import this module.
+
+Stubbed third-party pieces (not in /root/reference, not installable here):
+  * ``timm.models.vision_transformer.Mlp`` / ``timm.models.layers.DropPath``
+    (unpinned dep; call sites open_sora_transformer_3d.py:18-19,130-133,
+    embeddings.py:11,197-203): fc1 -> act -> fc2 with biases; DropPath(0) = Identity.
+  * ``rotary_embedding_torch.RotaryEmbedding`` (unpinned dep; constructed at
+    open_sora_transformer_3d.py:388-390, called attentions.py:76-78): published
+    algorithm restated in ``_RotaryEmbedding`` below (freqs_for="lang",
+    theta=10000, interleaved pairs, seq_dim=-2).
+  * ``colossalai.cluster.process_group_mesh.ProcessGroupMesh``, ``diffusers``
+    type names, ``imageio``, ``omegaconf``: no arithmetic, empty shells.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+REFERENCE_ROOT = os.environ.get("VSYS_REFERENCE_ROOT", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "videosys", "models"))
+
+
+class _Mlp(nn.Module):
+    """timm.models.vision_transformer.Mlp restated: fc1 -> act -> drop -> fc2 -> drop."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, bias=True, drop=0.0):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class _RotaryEmbedding(nn.Module):
+    """rotary_embedding_torch.RotaryEmbedding(dim) restated (lang freqs, theta 1e4)."""
+
+    def __init__(self, dim, theta=10000):
+        super().__init__()
+        freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: (dim // 2)].float() / dim))
+        self.freqs = nn.Parameter(freqs, requires_grad=False)
+
+    def rotate_queries_or_keys(self, t, seq_dim=-2):
+        seq_len = t.shape[seq_dim]
+        seq = torch.arange(seq_len, device=t.device, dtype=t.dtype)
+        freqs = torch.einsum("..., f -> ... f", seq.type(self.freqs.dtype), self.freqs)
+        freqs = freqs.repeat_interleave(2, dim=-1)  # '... n -> ... (n r)', r=2
+        dtype = t.dtype
+        x = t.reshape(*t.shape[:-1], -1, 2)
+        x1, x2 = x.unbind(dim=-1)
+        rot = torch.stack((-x2, x1), dim=-1).reshape(t.shape)
+        out = (t * freqs.cos()) + (rot * freqs.sin())
+        return out.type(dtype)
+
+
+class _SPStub:
+    sp_size = 1
+    cp_size = 1
+    sp_group = None
+    cp_group = None
+    dp_rank = 0
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+_INSTALLED = False
+
+
+def install_stubs():
+    global _INSTALLED
+    if _INSTALLED:
+        return
+    if not reference_available():
+        raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
+    import transformers  # noqa: F401  (must be imported before the fake package is installed)
+
+    pkg = types.ModuleType("videosys")
+    pkg.__path__ = [os.path.join(REFERENCE_ROOT, "videosys")]
+    sys.modules["videosys"] = pkg
+
+    if "timm" not in sys.modules:
+        _mod("timm")
+        _mod("timm.models")
+        _mod("timm.models.layers", DropPath=lambda *a, **k: nn.Identity())
+        _mod("timm.models.vision_transformer", Mlp=_Mlp)
+    if "colossalai" not in sys.modules:
+        _mod("colossalai")
+        _mod("colossalai.cluster")
+
+        class ProcessGroupMesh:  # no arithmetic
+            def __init__(self, *a, **k):
+                pass
+
+        _mod("colossalai.cluster.process_group_mesh", ProcessGroupMesh=ProcessGroupMesh)
+    if "diffusers" not in sys.modules:
+        _mod("diffusers")
+        _mod("diffusers.models")
+        _mod("diffusers.models.attention", Attention=object)
+        _mod("diffusers.models.attention_processor", AttnProcessor=object)
+    if "rotary_embedding_torch" not in sys.modules:
+        _mod("rotary_embedding_torch", RotaryEmbedding=_RotaryEmbedding)
+    if "imageio" not in sys.modules:
+        _mod("imageio")
+    if "omegaconf" not in sys.modules:
+        _mod("omegaconf", OmegaConf=object, DictConfig=dict, ListConfig=list)
+    _INSTALLED = True
+
+
+def load_reference_modules():
+    """Returns the reference modules used on the hot path (imported from /root/reference)."""
+    install_stubs()
+    import importlib
+
+    names = {
+        "stdit3": "videosys.models.transformers.open_sora_transformer_3d",
+        "attentions": "videosys.models.modules.attentions",
+        "normalization": "videosys.models.modules.normalization",
+        "embeddings": "videosys.models.modules.embeddings",
+        "rflow": "videosys.schedulers.scheduling_rflow_open_sora",
+        "pab_mgr": "videosys.core.pab.pab_mgr",
+        "comm": "videosys.core.distributed.comm",
+    }
+    return {k: importlib.import_module(v) for k, v in names.items()}
+
+
+def build_reference_stdit3(cfg_kwargs: dict, state_dict=None, dtype=torch.float32):
+    """Instantiate the reference STDiT3 on CPU (sp=cp=1) and optionally load weights."""
+    mods = load_reference_modules()
+    m = mods["stdit3"]
+    model = m.STDiT3(m.STDiT3Config(**cfg_kwargs))
+    model.parallel_manager = _SPStub()
+    for blk in list(model.spatial_blocks) + list(model.temporal_blocks):
+        blk.parallel_manager = _SPStub()
+        blk.grad_checkpointing = False  # pure wrapper in no-grad inference (recompute.py:141-153)
+    if state_dict is not None:
+        missing, unexpected = model.load_state_dict(state_dict, strict=False)
+        assert not unexpected, unexpected
+        assert all("pos_embed" in k or "inv_freq" in k for k in missing), missing
+    return model.to(dtype).eval()

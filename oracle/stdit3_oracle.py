@@ -1,0 +1,511 @@
+"""TEST INFRASTRUCTURE ONLY — CPU restatement (oracle) of the reference hot path.
+
+Plain fp32 torch-on-CPU restatement of the Open-Sora STDiT3 denoise step, the
+RFLOW sampler, the PAB schedule and the DSP layout switch, each function citing
+the reference file:line it follows (paths relative to /root/reference).  It is
+the checker for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under
+``videosys_amd/`` imports it and the product never falls back to it.
+
+Pinning status: the reference's own tests hold NO golden vectors / KATs for
+this path, so the restatement is pinned against outputs of
+the reference itself run in the build container: ``oracle/make_golden.py``
+imports the real reference (``oracle/ref_loader.py``) and writes
+``tests/golden/*.pt``; ``tests/test_oracle_vs_golden.py`` checks this file
+against those fixtures (and live against the reference when /root/reference
+exists).  Third-party arithmetic restated from its published algorithm:
+rotary-embedding-torch (unpinned in requirements.txt) and timm ``Mlp``.
+
+Everything operates on a flat ``state_dict`` with the HF checkpoint key names
+(``spatial_blocks.N.attn.qkv.weight`` ...), so the same weights drive the
+reference, this oracle and the HIP path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------
+# elementary ops
+# --------------------------------------------------------------------------
+def layer_norm(x: Tensor, eps: float = 1e-6) -> Tensor:
+    """nn.LayerNorm(C, eps=1e-6, elementwise_affine=False) — open_sora_transformer_3d.py:117,129,58."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps)
+
+
+def t2i_modulate(x: Tensor, shift: Tensor, scale: Tensor) -> Tensor:
+    """open_sora_transformer_3d.py:47-48."""
+    return x * (1 + scale) + shift
+
+
+def rms_norm(x: Tensor, weight: Tensor, eps: float = 1e-6) -> Tensor:
+    """LlamaRMSNorm.forward — modules/normalization.py:28-33 (fp32 inside, weight applied after)."""
+    xf = x.to(torch.float32)
+    var = xf.pow(2).mean(-1, keepdim=True)
+    xf = xf * torch.rsqrt(var + eps)
+    return weight * xf.to(x.dtype)
+
+
+def gelu_tanh(x: Tensor) -> Tensor:
+    """nn.GELU(approximate='tanh') — modules/activations.py:3."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x**3)))
+
+
+def linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
+    w = sd[prefix + ".weight"]
+    b = sd.get(prefix + ".bias")
+    y = x @ w.t()
+    return y + b if b is not None else y
+
+
+def rope_table(freqs: Tensor, seq_len: int, pos_dtype=torch.float32):
+    """cos/sin table of rotary_embedding_torch.RotaryEmbedding.forward (third-party, restated):
+    angle[p, 2i] = angle[p, 2i+1] = p * freqs[i]."""
+    seq = torch.arange(seq_len, dtype=pos_dtype)
+    ang = torch.einsum("p,f->pf", seq.type(freqs.dtype), freqs)
+    ang = ang.repeat_interleave(2, dim=-1)
+    return ang.cos(), ang.sin()
+
+
+def rope_rotate(t: Tensor, freqs: Tensor) -> Tensor:
+    """RotaryEmbedding.rotate_queries_or_keys(t, seq_dim=-2) (called attentions.py:76-78):
+    out = t*cos + rotate_half(t)*sin with rotate_half((a,b)) = (-b,a) on interleaved pairs."""
+    cos, sin = rope_table(freqs, t.shape[-2], pos_dtype=t.dtype)
+    x = t.reshape(*t.shape[:-1], -1, 2)
+    x1, x2 = x.unbind(-1)
+    rot = torch.stack((-x2, x1), dim=-1).reshape(t.shape)
+    return ((t * cos) + (rot * sin)).type(t.dtype)
+
+
+def sdpa(q: Tensor, k: Tensor, v: Tensor, key_len: Optional[Sequence[int]] = None) -> Tensor:
+    """softmax(q k^T / sqrt(d)) v in fp32 — what F.scaled_dot_product_attention (attentions.py:100,269)
+    and native_attention (attentions.py:111-120) both compute; key_len[i] masks keys >= len for batch i
+    (torch_impl mask, attentions.py:264-266)."""
+    d = q.shape[-1]
+    s = (q @ k.transpose(-2, -1)) * (d**-0.5)
+    if key_len is not None:
+        L = k.shape[-2]
+        for i, m in enumerate(key_len):
+            if m < L:
+                s[i, ..., m:] = float("-inf")
+    return s.softmax(dim=-1) @ v
+
+
+# --------------------------------------------------------------------------
+# attention modules
+# --------------------------------------------------------------------------
+def self_attention(x: Tensor, sd, prefix: str, num_heads: int, rope_freqs: Optional[Tensor]) -> Tensor:
+    """OpenSoraAttention.forward — modules/attentions.py:55-109.  x: [B', N', C]."""
+    Bp, Np, C = x.shape
+    D = C // num_heads
+    qkv = linear(x, sd, prefix + ".qkv").view(Bp, Np, 3, num_heads, D).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv.unbind(0)  # [B', H, N', D]
+    if Np == 1:
+        o = v  # attentions.py:65-66
+    else:
+        q = rms_norm(q, sd[prefix + ".q_norm.weight"])
+        k = rms_norm(k, sd[prefix + ".k_norm.weight"])
+        if rope_freqs is not None:  # attentions.py:76-78 (after the norm)
+            q = rope_rotate(q, rope_freqs)
+            k = rope_rotate(k, rope_freqs)
+        o = sdpa(q, k, v)
+    o = o.transpose(1, 2).reshape(Bp, Np, C)
+    return linear(o, sd, prefix + ".proj")
+
+
+def cross_attention(x: Tensor, y: Tensor, y_lens: List[int], sd, prefix: str, num_heads: int) -> Tensor:
+    """OpenSoraMultiHeadCrossAttention.forward/torch_impl — attentions.py:152-185,259-270.
+    x: [B, N, C]; y: packed text [1, sum(y_lens), C] (equal lengths, as the reference requires)."""
+    B, N, C = x.shape
+    D = C // num_heads
+    q = linear(x, sd, prefix + ".q_linear").view(1, -1, num_heads, D)
+    kv = linear(y, sd, prefix + ".kv_linear").view(1, -1, 2, num_heads, D)
+    k, v = kv.unbind(2)
+    q = q.view(B, -1, num_heads, D).transpose(1, 2)
+    k = k.view(B, -1, num_heads, D).transpose(1, 2)
+    v = v.view(B, -1, num_heads, D).transpose(1, 2)
+    o = sdpa(q, k, v, key_len=y_lens)
+    o = o.transpose(1, 2).contiguous().view(B, N, C)
+    return linear(o, sd, prefix + ".proj")
+
+
+def mlp(x: Tensor, sd, prefix: str) -> Tensor:
+    """timm Mlp(fc1 -> GELU(tanh) -> fc2) — used open_sora_transformer_3d.py:130-132 (third-party, restated)."""
+    return linear(gelu_tanh(linear(x, sd, prefix + ".fc1")), sd, prefix + ".fc2")
+
+
+# --------------------------------------------------------------------------
+# PAB schedule — core/pab/pab_mgr.py
+# --------------------------------------------------------------------------
+class PABSchedule:
+    """Restates PABManager.if_broadcast_{spatial,temporal,cross} (pab_mgr.py:54-91):
+    flag = enabled and count % range != 0 and lo < t < hi ; count = (count+1) % steps."""
+
+    def __init__(self, steps, spatial=None, temporal=None, cross=None):
+        # each of spatial/temporal/cross: None (disabled) or (threshold_lo, threshold_hi, range)
+        self.steps = steps
+        self.cfg = {"spatial": spatial, "temporal": temporal, "cross": cross}
+
+    def enabled(self):
+        return any(v is not None for v in self.cfg.values())
+
+    def decide(self, kind: str, timestep: int, count: int):
+        c = self.cfg[kind]
+        flag = bool(c is not None and timestep is not None and (count % c[2] != 0) and (c[0] < timestep < c[1]))
+        return flag, (count + 1) % self.steps
+
+
+class _BlockState:
+    def __init__(self):
+        self.attn_count = 0
+        self.cross_count = 0
+        self.last_attn = None
+        self.last_cross = None
+
+
+# --------------------------------------------------------------------------
+# DSP layout switch (pure tensor emulation over P in-process shards)
+# --------------------------------------------------------------------------
+def dsp_pad(n: int, P: int) -> int:
+    """set_pad — comm.py:271-275."""
+    return (P - n % P) % P
+
+
+def dsp_split_sequence(x: Tensor, P: int, dim: int) -> List[Tensor]:
+    """_split_sequence_func for every rank — comm.py:148-167 (zero pad then equal split)."""
+    pad = dsp_pad(x.shape[dim], P)
+    if pad:
+        shp = list(x.shape)
+        shp[dim] = pad
+        x = torch.cat([x, torch.zeros(shp, dtype=x.dtype)], dim=dim)
+    return [c.contiguous() for c in torch.split(x, x.shape[dim] // P, dim=dim)]
+
+
+def dsp_gather_sequence(shards: List[Tensor], dim: int, pad: int) -> Tensor:
+    """_gather_sequence_func — comm.py:170-190."""
+    out = torch.cat(shards, dim=dim)
+    return out.narrow(dim, 0, out.size(dim) - pad) if pad else out
+
+
+def dsp_all_to_all(shards: List[Tensor], scatter_dim: int, gather_dim: int, scatter_pad: int, gather_pad: int):
+    """all_to_all_with_pad on every rank at once — comm.py:104-108,282-304.
+    shards[r] is rank r's [b, t, s, d] tensor; returns the list of per-rank outputs."""
+    P = len(shards)
+    ins = []
+    for x in shards:
+        if scatter_pad:
+            shp = list(x.shape)
+            shp[scatter_dim] = scatter_pad
+            x = torch.cat([x, torch.zeros(shp, dtype=x.dtype)], dim=scatter_dim)
+        assert x.shape[scatter_dim] % P == 0
+        ins.append([t.contiguous() for t in torch.tensor_split(x, P, scatter_dim)])
+    outs = []
+    for r in range(P):
+        o = torch.cat([ins[src][r] for src in range(P)], dim=gather_dim)
+        if gather_pad:
+            o = o.narrow(gather_dim, 0, o.size(gather_dim) - gather_pad)
+        outs.append(o.contiguous())
+    return outs
+
+
+# --------------------------------------------------------------------------
+# STDiT3
+# --------------------------------------------------------------------------
+def timestep_embedding(t: Tensor, dim: int = 256, max_period: int = 10000) -> Tensor:
+    """TimestepEmbedder.timestep_embedding — modules/embeddings.py:123-141."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def embed_mlp(t_freq: Tensor, sd, prefix: str) -> Tensor:
+    """Linear -> SiLU -> Linear (TimestepEmbedder/SizeEmbedder.mlp) — embeddings.py:114-118,143-146."""
+    return linear(F.silu(linear(t_freq, sd, prefix + ".mlp.0")), sd, prefix + ".mlp.2")
+
+
+def pos_embed_2d(dim: int, h: int, w: int, scale: float, base_size: int) -> Tensor:
+    """OpenSoraPositionEmbedding2D._get_cached_emb — embeddings.py:231-272."""
+    half = dim // 2
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, half, 2).float() / half))
+    grid_h = torch.arange(h) / scale
+    grid_w = torch.arange(w) / scale
+    grid_h = grid_h * (base_size / h)
+    grid_w = grid_w * (base_size / w)
+    gh, gw = torch.meshgrid(grid_w, grid_h, indexing="ij")  # "here w goes first"
+    gh = gh.t().reshape(-1)
+    gw = gw.t().reshape(-1)
+
+    def sc(t):
+        out = torch.einsum("i,d->id", t, inv_freq)
+        return torch.cat((torch.sin(out), torch.cos(out)), dim=-1)
+
+    return torch.cat([sc(gh), sc(gw)], dim=-1).unsqueeze(0)
+
+
+def patch_embed(x: Tensor, sd, patch=(1, 2, 2)) -> Tensor:
+    """OpenSoraPatchEmbed3D.forward — embeddings.py:85-104 (pad, Conv3d k=s=patch, flatten)."""
+    _, _, D, H, W = x.shape
+    if W % patch[2]:
+        x = F.pad(x, (0, patch[2] - W % patch[2]))
+    if H % patch[1]:
+        x = F.pad(x, (0, 0, 0, patch[1] - H % patch[1]))
+    if D % patch[0]:
+        x = F.pad(x, (0, 0, 0, 0, 0, patch[0] - D % patch[0]))
+    x = F.conv3d(x, sd["x_embedder.proj.weight"], sd["x_embedder.proj.bias"], stride=patch)
+    return x.flatten(2).transpose(1, 2)
+
+
+def encode_text(y: Tensor, mask: Optional[Tensor], sd):
+    """STDiT3.encode_text — open_sora_transformer_3d.py:526-537 (+ OpenSoraCaptionEmbedder y_proj Mlp)."""
+    y = mlp(y, sd, "y_embedder.y_proj")  # [B,1,L,C]
+    C = y.shape[-1]
+    if mask is not None:
+        if mask.shape[0] != y.shape[0]:
+            mask = mask.repeat(y.shape[0] // mask.shape[0], 1)
+        mask = mask.squeeze(1).squeeze(1)
+        y = y.squeeze(1).masked_select(mask.unsqueeze(-1) != 0).view(1, -1, C)
+        y_lens = mask.sum(dim=1).tolist()
+    else:
+        y_lens = [y.shape[2]] * y.shape[0]
+        y = y.squeeze(1).view(1, -1, C)
+    return y, y_lens
+
+
+def stdit3_block(
+    x, y, t_mlp, y_lens, T, S, sd, prefix, num_heads, temporal, rope_freqs,
+    pab: Optional[PABSchedule] = None, state: Optional[_BlockState] = None, timestep_int: Optional[int] = None,
+    sp_shards: int = 1,
+):
+    """STDiT3Block.forward — open_sora_transformer_3d.py:162-286 (x_mask=None path; attention-only PAB)."""
+    B, N, C = x.shape
+    mods = (sd[prefix + ".scale_shift_table"][None] + t_mlp.reshape(B, 6, -1)).chunk(6, dim=1)
+    shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mods
+
+    broadcast_attn = False
+    if pab is not None and pab.enabled():
+        broadcast_attn, state.attn_count = pab.decide("temporal" if temporal else "spatial", timestep_int, state.attn_count)
+    if broadcast_attn:
+        x_m_s = state.last_attn
+    else:
+        x_m = t2i_modulate(layer_norm(x), shift_msa, scale_msa)
+        if temporal:
+            x_m = x_m.view(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
+            x_m = self_attention(x_m, sd, prefix + ".attn", num_heads, rope_freqs)
+            x_m = x_m.view(B, S, T, C).permute(0, 2, 1, 3).reshape(B, T * S, C)
+        else:
+            x_m = x_m.view(B * T, S, C)
+            x_m = self_attention(x_m, sd, prefix + ".attn", num_heads, None)
+            x_m = x_m.view(B, T * S, C)
+        x_m_s = gate_msa * x_m
+        if pab is not None and pab.enabled():
+            state.last_attn = x_m_s
+    x = x + x_m_s
+
+    broadcast_cross = False
+    if pab is not None and pab.enabled():
+        broadcast_cross, state.cross_count = pab.decide("cross", timestep_int, state.cross_count)
+    if broadcast_cross:
+        x = x + state.last_cross
+    else:
+        x_cross = cross_attention(x, y, y_lens, sd, prefix + ".cross_attn", num_heads)
+        if pab is not None and pab.enabled():
+            state.last_cross = x_cross
+        x = x + x_cross
+
+    x_m = t2i_modulate(layer_norm(x), shift_mlp, scale_mlp)
+    x_m = mlp(x_m, sd, prefix + ".mlp")
+    return x + gate_mlp * x_m
+
+
+def final_layer(x, t, sd):
+    """T2IFinalLayer.forward — open_sora_transformer_3d.py:75-87 (x_mask=None)."""
+    shift, scale = (sd["final_layer.scale_shift_table"][None] + t[:, None]).chunk(2, dim=1)
+    x = t2i_modulate(layer_norm(x), shift, scale)
+    return linear(x, sd, "final_layer.linear")
+
+
+def unpatchify(x, N_t, N_h, N_w, R_t, R_h, R_w, patch, c_out):
+    """STDiT3.unpatchify — open_sora_transformer_3d.py:634-658."""
+    B = x.shape[0]
+    Tp, Hp, Wp = patch
+    x = x.view(B, N_t, N_h, N_w, Tp, Hp, Wp, c_out)
+    x = x.permute(0, 7, 1, 4, 2, 5, 3, 6).reshape(B, c_out, N_t * Tp, N_h * Hp, N_w * Wp)
+    return x[:, :, :R_t, :R_h, :R_w]
+
+
+class STDiT3Oracle:
+    """STDiT3.forward — open_sora_transformer_3d.py:539-632, sp=cp=1, fp32, x_mask=None."""
+
+    def __init__(self, sd: Dict[str, Tensor], depth: int, hidden_size: int, num_heads: int,
+                 patch_size=(1, 2, 2), in_channels: int = 4, input_sq_size: int = 512, pred_sigma: bool = True):
+        self.sd = {k: v.to(torch.float32) for k, v in sd.items()}
+        self.depth, self.C, self.H = depth, hidden_size, num_heads
+        self.patch = tuple(patch_size)
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if pred_sigma else in_channels
+        self.input_sq_size = input_sq_size
+        self.pab: Optional[PABSchedule] = None
+        self.states = {}
+
+    def set_pab(self, pab: Optional[PABSchedule]):
+        self.pab = pab
+        self.states = {}
+
+    def _state(self, key):
+        if key not in self.states:
+            self.states[key] = _BlockState()
+        return self.states[key]
+
+    def embed(self, x, timestep, y, mask, fps, height, width):
+        sd = self.sd
+        _, _, Tx, Hx, Wx = x.shape
+        p = self.patch
+        T, H, W = -(-Tx // p[0]), -(-Hx // p[1]), -(-Wx // p[2])
+        S = H * W
+        base_size = round(S**0.5)
+        scale = ((float(height[0]) * float(width[0])) ** 0.5) / self.input_sq_size
+        pos = pos_embed_2d(self.C, H, W, scale, base_size)
+        B = x.shape[0]
+        t = embed_mlp(timestep_embedding(timestep.float()), sd, "t_embedder")
+        f = fps.unsqueeze(1) if fps.ndim == 1 else fps
+        if f.shape[0] != B:
+            f = f.repeat(B // f.shape[0], 1)
+        fe = embed_mlp(timestep_embedding(f.reshape(-1).float()), sd, "fps_embedder").view(B, -1)
+        t = t + fe
+        t_mlp = linear(F.silu(t), sd, "t_block.1")
+        yy, y_lens = encode_text(y.float(), mask, sd)
+        xe = patch_embed(x.float(), sd, p).view(B, T, S, self.C) + pos
+        return xe.reshape(B, T * S, self.C), t, t_mlp, yy, y_lens, (T, H, W, Tx, Hx, Wx)
+
+    def forward(self, x, timestep, y, mask=None, fps=None, height=None, width=None, valid_depth=None,
+                return_hidden=False):
+        x, t, t_mlp, yy, y_lens, (T, H, W, Tx, Hx, Wx) = self.embed(x, timestep, y, mask, fps, height, width)
+        S = H * W
+        rope_freqs = self.sd["rope.freqs"]
+        ts_int = int(timestep[0]) if self.pab is not None else None
+        depth = self.depth if valid_depth is None else valid_depth
+        hidden = []
+        for d in range(depth):
+            x = stdit3_block(x, yy, t_mlp, y_lens, T, S, self.sd, f"spatial_blocks.{d}", self.H, False, None,
+                             self.pab, self._state(("s", d)), ts_int)
+            x = stdit3_block(x, yy, t_mlp, y_lens, T, S, self.sd, f"temporal_blocks.{d}", self.H, True, rope_freqs,
+                             self.pab, self._state(("t", d)), ts_int)
+            if return_hidden:
+                hidden.append(x.clone())
+        out = final_layer(x, t, self.sd)
+        out = unpatchify(out, T, H, W, Tx, Hx, Wx, self.patch, self.out_channels).to(torch.float32)
+        return (out, hidden) if return_hidden else out
+
+    __call__ = forward
+
+
+# --------------------------------------------------------------------------
+# RFLOW sampler — schedulers/scheduling_rflow_open_sora.py
+# --------------------------------------------------------------------------
+def timestep_transform(t, height, width, num_frames, base_resolution=512 * 512, base_num_frames=1, scale=1.0,
+                       num_timesteps=1):
+    """scheduling_rflow_open_sora.py:47-70."""
+    t = t / num_timesteps
+    resolution = height * width
+    ratio_space = (resolution / base_resolution).sqrt()
+    if num_frames[0] == 1:
+        nf = torch.ones_like(num_frames)
+    else:
+        nf = num_frames // 17 * 5
+    ratio_time = (nf / base_num_frames).sqrt()
+    ratio = ratio_space * ratio_time * scale
+    new_t = ratio * t / (1 + (ratio - 1) * t)
+    return new_t * num_timesteps
+
+
+def rflow_timesteps(num_sampling_steps, batch, height, width, num_frames, num_timesteps=1000,
+                    use_timestep_transform=True):
+    """scheduling_rflow_open_sora.py:208-213."""
+    ts = [(1.0 - i / num_sampling_steps) * num_timesteps for i in range(num_sampling_steps)]
+    ts = [torch.tensor([t] * batch) for t in ts]
+    if use_timestep_transform:
+        ts = [timestep_transform(t, height, width, num_frames, num_timesteps=num_timesteps) for t in ts]
+    return ts
+
+
+def rflow_sample(model, z, y, y_null, mask, fps, height, width, num_frames, num_sampling_steps=30,
+                 cfg_scale=7.0, num_timesteps=1000, use_timestep_transform=True, model_dtype=torch.float32,
+                 return_all=False):
+    """RFLOW.sample — scheduling_rflow_open_sora.py:188-257 (mask=None path)."""
+    yy = torch.cat([y, y_null], 0)
+    timesteps = rflow_timesteps(num_sampling_steps, z.shape[0], height, width, num_frames, num_timesteps,
+                                use_timestep_transform)
+    all_timesteps = [int(t.to(model_dtype).item()) for t in timesteps]
+    zs = []
+    for i, t in enumerate(timesteps):
+        z_in = torch.cat([z, z], 0)
+        tt = torch.cat([t, t], 0).to(model_dtype)  # STDiT3.forward casts timestep to model dtype (:562)
+        out = model(z_in, tt, yy, mask=mask, fps=torch.cat([fps, fps]), height=torch.cat([height, height]),
+                    width=torch.cat([width, width]))
+        pred = out.chunk(2, dim=1)[0]
+        pred_cond, pred_uncond = pred.chunk(2, dim=0)
+        v_pred = pred_uncond + cfg_scale * (pred_cond - pred_uncond)
+        dt = timesteps[i] - timesteps[i + 1] if i < len(timesteps) - 1 else timesteps[i]
+        dt = dt / num_timesteps
+        z = z + v_pred * dt[:, None, None, None, None]
+        if return_all:
+            zs.append(z.clone())
+    return (z, zs, all_timesteps) if return_all else z
+
+
+# --------------------------------------------------------------------------
+# synthetic weights: seeded, zero-initialised tensors re-drawn
+# --------------------------------------------------------------------------
+def synth_state_dict(depth, hidden_size, num_heads, caption_channels=4096, model_max_length=300,
+                     in_channels=4, patch_size=(1, 2, 2), pred_sigma=True, mlp_ratio=4.0, seed=1234,
+                     freq_dim=256) -> Dict[str, Tensor]:
+    """Random-init weights with the HF-checkpoint key names/shapes of STDiT3 (open_sora_transformer_3d.py:364-446).
+    Distribution is ours (no pretrained weights offline): N(0, 0.02)-scaled linears (std 1/sqrt(fan_in) capped),
+    q/k norm weights 1+N(0,0.1), nothing left at zero so every path is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    C, D = hidden_size, hidden_size // num_heads
+    Hm = int(hidden_size * mlp_ratio)
+    out_ch = in_channels * 2 if pred_sigma else in_channels
+    sd: Dict[str, Tensor] = {}
+
+    def lin(name, n_out, n_in, bias=True, std=None):
+        s = std if std is not None else min(0.02 * 4, 1.0 / math.sqrt(n_in))
+        sd[name + ".weight"] = torch.randn(n_out, n_in, generator=g) * s
+        if bias:
+            sd[name + ".bias"] = torch.randn(n_out, generator=g) * 0.02
+
+    sd["x_embedder.proj.weight"] = torch.randn(C, in_channels, *patch_size, generator=g) * 0.1
+    sd["x_embedder.proj.bias"] = torch.randn(C, generator=g) * 0.02
+    for e in ("t_embedder", "fps_embedder"):
+        lin(e + ".mlp.0", C, freq_dim)
+        lin(e + ".mlp.2", C, C)
+    lin("t_block.1", 6 * C, C)
+    lin("y_embedder.y_proj.fc1", C, caption_channels)
+    lin("y_embedder.y_proj.fc2", C, C)
+    sd["y_embedder.y_embedding"] = torch.randn(model_max_length, caption_channels, generator=g) / caption_channels**0.5
+    sd["rope.freqs"] = 1.0 / (10000 ** (torch.arange(0, D, 2)[: (D // 2)].float() / D))
+    for kind in ("spatial_blocks", "temporal_blocks"):
+        for i in range(depth):
+            p = f"{kind}.{i}"
+            sd[p + ".scale_shift_table"] = torch.randn(6, C, generator=g) / C**0.5
+            lin(p + ".attn.qkv", 3 * C, C)
+            sd[p + ".attn.q_norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+            sd[p + ".attn.k_norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+            lin(p + ".attn.proj", C, C)
+            lin(p + ".cross_attn.q_linear", C, C)
+            lin(p + ".cross_attn.kv_linear", 2 * C, C)
+            lin(p + ".cross_attn.proj", C, C)
+            lin(p + ".mlp.fc1", Hm, C)
+            lin(p + ".mlp.fc2", C, Hm)
+    sd["final_layer.scale_shift_table"] = torch.randn(2, C, generator=g) / C**0.5
+    lin("final_layer.linear", int(math.prod(patch_size)) * out_ch, C)
+    return sd
