@@ -298,13 +298,13 @@ def stdit3_block(
     else:
         x_m = t2i_modulate(layer_norm(x), shift_msa, scale_msa)
         if temporal:
-            x_m = x_m.view(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
+            x_m = x_m.reshape(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
             x_m = self_attention(x_m, sd, prefix + ".attn", num_heads, rope_freqs)
-            x_m = x_m.view(B, S, T, C).permute(0, 2, 1, 3).reshape(B, T * S, C)
+            x_m = x_m.reshape(B, S, T, C).permute(0, 2, 1, 3).reshape(B, T * S, C)
         else:
-            x_m = x_m.view(B * T, S, C)
+            x_m = x_m.reshape(B * T, S, C)
             x_m = self_attention(x_m, sd, prefix + ".attn", num_heads, None)
-            x_m = x_m.view(B, T * S, C)
+            x_m = x_m.reshape(B, T * S, C)
         x_m_s = gate_msa * x_m
         if pab is not None and pab.enabled():
             state.last_attn = x_m_s
