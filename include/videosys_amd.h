@@ -1,0 +1,121 @@
+/* videosys_amd — C ABI of the MI355X (gfx950) STDiT3 denoise-step kernels.
+ *
+ * The reference (NUS-HPC-AI-Lab/VideoSys @ 2024-12-20) has NO FFI: its hot path is torch ops inside
+ * videosys/models/transformers/open_sora_transformer_3d.py and videosys/models/modules/.  This header is the
+ * drop-in boundary for that path: every entry point below replaces the torch op sequence at the cited reference
+ * lines and is what a reference-side ctypes binding calls (INTEGRATION.md shows the stub).  Plain C: device pointers
+ * and sizes only, no torch types.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless named host_*; bf16 tensors are raw uint16 bit patterns;
+ *  - all tensors row-major, inner (channel) dimension contiguous; "stride"/"ld*" arguments are in ELEMENTS;
+ *  - `stream` is a hipStream_t (NULL = the null stream); every call only enqueues work on it — no host sync,
+ *    no allocation; the caller owns all buffers;
+ *  - return 0 on success, a negative VSYS_ERR_* code otherwise (nothing is enqueued on error);
+ *    vsys_strerror() names the code.  There is NO CPU fallback anywhere in the library.
+ */
+#ifndef VIDEOSYS_AMD_H
+#define VIDEOSYS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSYS_ABI_VERSION 1
+
+#define VSYS_ERR_SHAPE  (-1)  /* unsupported size / divisibility */
+#define VSYS_ERR_ALIGN  (-2)  /* stride or pointer not 16-byte friendly */
+#define VSYS_ERR_ARG    (-3)  /* bad enum / null pointer */
+#define VSYS_ERR_LAUNCH (-4)  /* HIP launch error */
+
+/* GEMM epilogues */
+#define VSYS_EPI_BIAS      0  /* out = x W^T + b */
+#define VSYS_EPI_BIAS_GELU 1  /* out = gelu_tanh(x W^T + b) */
+#define VSYS_EPI_GATE_RES  2  /* u = gate[sample] * (x W^T + b); aux = u (optional); out = res + u */
+
+#define VSYS_ACT_NONE      0
+#define VSYS_ACT_SILU      1
+#define VSYS_ACT_GELU_TANH 2
+
+int vsys_abi_version(void);
+const char* vsys_strerror(int code);
+/* number of HIP devices visible to the library (fails loudly instead of falling back when 0) */
+int vsys_device_count(void);
+
+/* nn.Linear on token rows with fused epilogue (bf16 in/out, fp32 MFMA accumulate).
+ * Replaces: attentions.py:59 (qkv), :107 (proj) + open_sora_transformer_3d.py:219,228 (gate, residual);
+ * attentions.py:156,183 + open_sora_transformer_3d.py:237-240 (cross q / proj + residual);
+ * timm Mlp fc1+GELU(tanh)/fc2 (open_sora_transformer_3d.py:130-132,267,270,284).
+ * Requires N % 192 == 0, K % 64 == 0, strides % 8 == 0; any M.  gate may be NULL (= 1), res/aux may be NULL. */
+int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                   int64_t M, int64_t N, int64_t K, int epilogue, const void* gate, int64_t gate_sample_stride,
+                   int64_t rows_per_sample, const void* res, int64_t ldr, void* aux, int64_t ldaux, void* stream);
+
+/* Small / odd-shaped nn.Linear (any M, N; K % 8 == 0): act_in is applied to x (SiLU of t_block,
+ * open_sora_transformer_3d.py:396-399), act_out to the result (TimestepEmbedder/SizeEmbedder mlp, embeddings.py:114-118;
+ * OpenSoraCaptionEmbedder y_proj, embeddings.py:197-203). */
+int vsys_linear_small(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                      int64_t M, int64_t N, int64_t K, int act_in, int act_out, void* stream);
+
+/* y = LayerNorm(x, eps, no affine) * (1 + scale[b]) + shift[b], b = row / rows_per_sample.
+ * Replaces nn.LayerNorm + t2i_modulate (open_sora_transformer_3d.py:47-48,117,129,196-197,260-261). C % 8 == 0, C <= 2048. */
+int vsys_adaln_modulate(const void* x, const void* shift, const void* scale, void* y, int64_t rows, int64_t C,
+                        int64_t rows_per_sample, int64_t mod_sample_stride, float eps, void* stream);
+
+/* out[blk][b][6*C] = bf16(table[blk][6*C] + t_mlp[b][6*C])  (open_sora_transformer_3d.py:177-179 for all blocks). */
+int vsys_mod_table(const void* table, const void* t_mlp, void* out, int64_t nblk, int64_t B, int64_t C6, void* stream);
+
+/* TimestepEmbedder.timestep_embedding (embeddings.py:123-141): t fp32 [B] -> out bf16 [B, dim] = [cos | sin]. */
+int vsys_timestep_embedding(const void* t_f32, void* out, int64_t B, int64_t dim, void* stream);
+
+/* OpenSoraPatchEmbed3D + "x + pos_emb" (embeddings.py:85-104; open_sora_transformer_3d.py:593-595).
+ * z fp32 [Bz, Cin, T, H, W]; sample b reads z[b % Bz] (CFG duplicate, scheduling_rflow_open_sora.py:239);
+ * w bf16 [C, Cin*ph*pw]; pos bf16 [Hp*Wp, C]; out bf16 [B, T, Hp*Wp, C]. */
+int vsys_patch_embed(const void* z_f32, int64_t Bz, const void* w, const void* bias, const void* pos, void* out, int64_t B,
+                     int64_t Cin, int64_t T, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t C, void* stream);
+
+/* T2IFinalLayer + unpatchify + .to(float32) (open_sora_transformer_3d.py:75-87,622-630,634-658).
+ * x bf16 [B, T*Hp*Wp, C]; table bf16 [2, C]; tvec bf16 [B, C]; w bf16 [ph*pw*Cout, C]; out fp32 [B, Cout, T, H, W]. */
+int vsys_final_layer(const void* x, const void* table, const void* tvec, const void* w, const void* bias, void* out_f32,
+                     int64_t B, int64_t T, int64_t Hp, int64_t Wp, int64_t H, int64_t W, int64_t ph, int64_t pw,
+                     int64_t Cout, int64_t C, float eps, void* stream);
+
+/* RFLOW CFG combine + Euler update (scheduling_rflow_open_sora.py:245-252): z fp32 [Bz, Cin, thw] +=
+ * (uncond + g (cond - uncond)) * dt with cond = model_out[b, :Cin], uncond = model_out[b + Bz, :Cin]. */
+int vsys_cfg_euler_step(void* z_f32, const void* model_out_f32, int64_t Bz, int64_t Cin, int64_t Cout, int64_t thw,
+                        float guidance, float dt, void* stream);
+
+/* x += y over n bf16 elements (PAB broadcast step: x + last_attn / last_cross, open_sora_transformer_3d.py:192-193,228,234-235). */
+int vsys_add_rows(void* x, const void* y, int64_t n, void* stream);
+
+/* 4-D strided row copy with zero fill outside (n1_valid, n2_valid): DSP all-to-all pack/unpack
+ * (core/distributed/comm.py:104-108,282-304; open_sora_transformer_3d.py:288-315). */
+int vsys_copy_4d(const void* src, void* dst, int64_t n0, int64_t n1, int64_t n2, int64_t C, int64_t ss0, int64_t ss1,
+                 int64_t ss2, int64_t ds0, int64_t ds1, int64_t ds2, int64_t n1_valid, int64_t n2_valid, void* stream);
+
+/* K RMS-norm (normalization.py:28-33; k_norm_w NULL = none) + head-major K and transposed V for vsys_flash_attn_d72.
+ * k(b,s,h) at k + (b*kv_len + s)*k_stride + h*72, same for v.  kp [batch, H, kv_pad, 72]; vt [batch, H, 96, kv_pad]
+ * (rows 72..95 must be zero-initialised by the caller once).  kv_pad % 64 == 0. */
+int vsys_attn_prep_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, const void* k_norm_w, void* kp,
+                      void* vt, int64_t batch, int64_t heads, int64_t kv_len, int64_t kv_pad, float eps, void* stream);
+
+/* softmax(q k^T / sqrt(72)) v for head_dim 72, non-causal, keys >= kv_len masked; optional q RMS-norm.
+ * Spatial self-attention (attentions.py:75,100) and cross-attention (attentions.py:259-270).
+ * q(b,s,h) at q + (b*q_len + s)*q_stride + h*72; out likewise with out_stride. */
+int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, const void* kp, const void* vt, void* out,
+                        int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
+                        float eps, void* stream);
+
+/* Temporal self-attention over the T frames of every (b, s) token: RMS qk-norm, RoPE (cos/sin fp32 [T, 72], NULL =
+ * none), fp32 softmax (attentions.py:75-78,95-97,111-120; open_sora_transformer_3d.py:203-206).
+ * qkv bf16 rows ordered (b, t, s), row_stride elements per row, q|k|v at column offsets 0|C|2C, head h at h*72. */
+int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const void* q_norm_w, const void* k_norm_w,
+                           const void* rope_cos_f32, const void* rope_sin_f32, void* out, int64_t out_stride, int64_t B,
+                           int64_t T, int64_t S, int64_t heads, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIDEOSYS_AMD_H */

@@ -1,0 +1,67 @@
+"""ctypes binding of libvideosys_amd.so (the C ABI declared in include/videosys_amd.h).
+
+The library is the product: there is NO fallback.  Importing this module on a machine where the shared object has
+not been built (``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C videosys_amd/csrc``) raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvideosys_amd.so")
+
+_i64, _f32, _ptr, _int = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+
+# name -> argtypes, exactly as declared in include/videosys_amd.h
+SIGNATURES = {
+    "vsys_abi_version": [],
+    "vsys_device_count": [],
+    "vsys_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _ptr, _i64,
+                       _ptr, _i64, _ptr],
+    "vsys_linear_small": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],
+    "vsys_adaln_modulate": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "vsys_mod_table": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "vsys_timestep_embedding": [_ptr, _ptr, _i64, _i64, _ptr],
+    "vsys_patch_embed": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_final_layer": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64,
+                         _f32, _ptr],
+    "vsys_cfg_euler_step": [_ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _f32, _ptr],
+    "vsys_add_rows": [_ptr, _ptr, _i64, _ptr],
+    "vsys_copy_4d": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_attn_prep_kv": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "vsys_flash_attn_d72": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "vsys_attn_temporal_d72": [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
+}
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP library first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "videosys_amd has no CPU/PyTorch fallback for its kernels."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = _int
+    lib.vsys_strerror.argtypes = [_int]
+    lib.vsys_strerror.restype = ctypes.c_char_p
+    _lib = lib
+    return lib
+
+
+class VsysError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().vsys_strerror(code).decode()
+        raise VsysError(f"{what}: {msg} (code {code})")

@@ -1,0 +1,493 @@
+// Attention kernels for head_dim 72 (STDiT3-XL/2: 1152 / 16) on gfx950.
+//
+// Reference call sites replaced (/root/reference/videosys):
+//   flash_attn_d72 (spatial)  OpenSoraAttention.forward: q/k LlamaRMSNorm + SDPA          modules/attentions.py:75,100; normalization.py:28-33
+//   flash_attn_d72 (cross)    OpenSoraMultiHeadCrossAttention.torch_impl (mask + SDPA)      modules/attentions.py:259-270
+//   attn_prep_kv              the k half of the qk-norm + the layout the PV contraction needs
+//   attn_temporal_d72         OpenSoraAttention.forward temporal branch: RMS qk-norm, RoPE (rotary_embedding_torch,
+//                             third-party), native_attention with fp32 softmax, incl. the two "B (T S) C <-> (B S) T C"
+//                             rearranges (open_sora_transformer_3d.py:203-206) which are never materialised
+//
+// flash_attn_d72: one workgroup = 4 waves = 128 query rows of one (batch, head); KV tiles of 64 keys staged
+// HBM/L2 -> VGPR -> LDS, double-buffered, one barrier per tile.  Both contractions run on
+// v_mfma_f32_32x32x16_bf16 in the "swapped" form so the softmax row of a query is lane-local:
+//   S^T[kv][q] = K[kv][d] . Q[q][d]^T      (A = K rows, B = Q fragment, d padded 72 -> 80 with zero chunks)
+//   O^T[d][q]  = Vt[d][kv] . P^T[kv][q]    (A = Vt rows (V pre-transposed by attn_prep_kv), B = P fragment)
+// The K rows fed to MFMA row i are permuted (kv = 16*((i>>2)&1) + 4*(i>>3) + (i&3)) so that a lane's 16 accumulator
+// registers of a 32-key tile are 16 CONSECUTIVE keys: P converts to the PV B-fragment with no cross-lane traffic and Vt
+// is read with plain ds_read_b128.  LDS images use 144-byte rows (K: natural 72*2; Vt: 128+16 pad): conflict-free for
+// ds_read_b128 lane groups.  Online softmax in fp32 (exp2 with the 1/sqrt(72)*log2e scale folded in).
+#include "common.h"
+#include "vsys_internal.h"
+
+namespace vsys {
+namespace {
+
+constexpr int HD = 72;          // head dim
+constexpr int HD_ROWS = 96;     // Vt rows per head (3 MFMA tiles of 32; rows 72..95 are zero)
+constexpr int KROW = 144;       // bytes per K row in LDS (72 bf16)
+constexpr int VROW = 144;       // bytes per Vt row in LDS (64 keys * 2 + 16 pad)
+constexpr int K_TILE_BYTES = 64 * KROW;        // 9216
+constexpr int V_TILE_BYTES = HD_ROWS * VROW;   // 13824
+constexpr int KV_STAGE = K_TILE_BYTES + V_TILE_BYTES;  // 23040
+constexpr float NEG_BIG = -1.0e30f;
+
+// ---------------------------------------------------------------------------------------------------------
+// attn_prep_kv: k,v rows (strided, heads interleaved) -> Kp[batch][H][kv_pad][72] (RMS-normed, rows >= kv_len zero)
+//                                                     -> Vt[batch][H][96][kv_pad] (transposed; cols >= kv_len zero)
+// grid: (kv_pad/64, batch*H); block 256.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_prep_kv_kernel(const bf16_t* __restrict__ k, int64_t k_stride,
+                                                           const bf16_t* __restrict__ v, int64_t v_stride,
+                                                           const bf16_t* __restrict__ k_norm_w, bf16_t* __restrict__ kp,
+                                                           bf16_t* __restrict__ vt, int heads, int kv_len, int kv_pad,
+                                                           float eps) {
+  __shared__ __attribute__((aligned(16))) bf16_t vs[64][HD + 8];  // [token][d], 160-byte rows
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int s0 = blockIdx.x * 64;
+  const int bh = blockIdx.y;
+  const int b = bh / heads, h = bh - b * heads;
+
+  // ---- V tile -> LDS (64 tokens x 9 chunks)
+  for (int q = tid; q < 64 * 9; q += 256) {
+    const int r = q / 9, c = q - r * 9;
+    const int s = s0 + r;
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (s < kv_len) val = *reinterpret_cast<const uint4*>(v + ((int64_t)b * kv_len + s) * v_stride + h * HD + c * 8);
+    *reinterpret_cast<uint4*>(&vs[r][c * 8]) = val;
+  }
+
+  // ---- K: 3 lanes per token row (24 dims each), 21 rows per wave
+  {
+    const int g = lane / 3, part = lane - g * 3;
+    const int r = wave * 21 + g;
+    const bool active = (lane < 63) && (r < 64);
+    const int s = s0 + r;
+    float x[24];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) x[e] = 0.f;
+    if (active && s < kv_len) {
+      const bf16_t* src = k + ((int64_t)b * kv_len + s) * k_stride + h * HD + part * 24;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) unpack8(*reinterpret_cast<const uint4*>(src + c * 8), x + c * 8);
+    }
+    if (k_norm_w != nullptr) {
+      float ss = 0.f;
+#pragma unroll
+      for (int e = 0; e < 24; ++e) ss += x[e] * x[e];
+      const int base = g * 3;
+      const float tot = __shfl(ss, base, 64) + __shfl(ss, base + 1, 64) + __shfl(ss, base + 2, 64);
+      const float rstd = rsqrtf(tot / (float)HD + eps);
+#pragma unroll
+      for (int e = 0; e < 24; ++e) {
+        const float nrm = bf2f(f2bf(x[e] * rstd));  // hidden_states.to(input_dtype) before the weight multiply
+        x[e] = nrm * bf2f(k_norm_w[part * 24 + e]);
+      }
+    }
+    if (active) {
+      bf16_t* dst = kp + (((int64_t)bh * kv_pad) + s) * HD + part * 24;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) *reinterpret_cast<uint4*>(dst + c * 8) = pack8(x + c * 8);
+    }
+  }
+  __syncthreads();
+
+  // ---- Vt rows: thread -> (d, 8-token chunk)
+  for (int q = tid; q < HD * 8; q += 256) {
+    const int d = q >> 3, c = q & 7;
+    uint4 o;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w[e] = (uint32_t)vs[c * 8 + 2 * e][d] | ((uint32_t)vs[c * 8 + 2 * e + 1][d] << 16);
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    *reinterpret_cast<uint4*>(vt + ((int64_t)bh * HD_ROWS + d) * kv_pad + s0 + c * 8) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// flash_attn_d72.  grid: (ceil(q_len/128), batch*heads); block 256 (4 waves x 32 query rows).
+// ---------------------------------------------------------------------------------------------------------
+struct FlashParams {
+  const bf16_t* q; int64_t q_stride;      // q(b, s, h) at q + (b*q_len + s)*q_stride + h*72
+  const bf16_t* q_norm_w;                  // [72] or null
+  const bf16_t* kp;                        // [batch][H][kv_pad][72]
+  const bf16_t* vt;                        // [batch][H][96][kv_pad]
+  bf16_t* out; int64_t out_stride;         // out(b, s, h) at out + (b*q_len + s)*out_stride + h*72
+  int heads, q_len, kv_len, kv_pad;
+  float eps, scale_log2e;
+};
+
+__global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+
+  // ---- Q fragment (B operand): lane holds Q[q0 + l31][16c + 8hi .. +8], c = 0..4 (d >= 72 -> 0)
+  bf16x8 qf[5];
+  {
+    int qs = q0 + l31;
+    qs = qs < p.q_len ? qs : p.q_len - 1;
+    const bf16_t* qrow = p.q + ((int64_t)b * p.q_len + qs) * p.q_stride + h * HD;
+    float x[5][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int d0 = 16 * c + 8 * hi;
+      if (d0 < HD) {
+        unpack8(*reinterpret_cast<const uint4*>(qrow + d0), x[c]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[c][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
+    }
+    if (p.q_norm_w != nullptr) {
+      ss += __shfl_xor(ss, 32, 64);
+      const float rstd = rsqrtf(ss / (float)HD + p.eps);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int d0 = 16 * c + 8 * hi;
+        if (d0 < HD) {
+          float w[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.q_norm_w + d0), w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[c][e] = bf2f(f2bf(x[c][e] * rstd)) * w[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[c][e] = (__bf16)x[c][e];
+  }
+
+  // ---- KV staging assignment
+  const bf16_t* kbase = p.kp + (int64_t)bh * p.kv_pad * HD;         // tile t: + t*64*72 (contiguous 9216 bytes)
+  const bf16_t* vbase = p.vt + (int64_t)bh * HD_ROWS * p.kv_pad;    // row d: + d*kv_pad, tile t: + t*64
+  int k_off[3], v_goff[3], v_lds[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int q = tid + 256 * i;
+    // K tile = 576 chunks; threads past the end re-copy chunks 384..575 (same data, same LDS slot: benign) so the
+    // staging registers are written unconditionally (a predicated load parks them in scratch).
+    k_off[i] = (q < 576 ? q : q - 192) * 8;  // elements == LDS byte offset / 2
+    const int d = q >> 3, c = q & 7;  // 768 chunks: 96 rows x 8
+    v_goff[i] = d * p.kv_pad + c * 8;
+    v_lds[i] = K_TILE_BYTES + d * VROW + c * 16;
+  }
+  uint4 rk0, rk1, rk2, rv0, rv1, rv2;
+#define FLASH_GLOAD(t_)                                                                              \
+  do {                                                                                               \
+    const bf16_t* kb_ = kbase + (int64_t)(t_) * 64 * HD;                                             \
+    const bf16_t* vb_ = vbase + (int64_t)(t_) * 64;                                                  \
+    rk0 = *reinterpret_cast<const uint4*>(kb_ + k_off[0]);                                           \
+    rk1 = *reinterpret_cast<const uint4*>(kb_ + k_off[1]);                                           \
+    rk2 = *reinterpret_cast<const uint4*>(kb_ + k_off[2]);                                           \
+    rv0 = *reinterpret_cast<const uint4*>(vb_ + v_goff[0]);                                          \
+    rv1 = *reinterpret_cast<const uint4*>(vb_ + v_goff[1]);                                          \
+    rv2 = *reinterpret_cast<const uint4*>(vb_ + v_goff[2]);                                          \
+  } while (0)
+#define FLASH_LSTORE(buf_)                                                                           \
+  do {                                                                                               \
+    char* base_ = smem + (buf_) * KV_STAGE;                                                          \
+    *reinterpret_cast<uint4*>(base_ + k_off[0] * 2) = rk0;                                           \
+    *reinterpret_cast<uint4*>(base_ + k_off[1] * 2) = rk1;                                           \
+    *reinterpret_cast<uint4*>(base_ + k_off[2] * 2) = rk2;                                           \
+    *reinterpret_cast<uint4*>(base_ + v_lds[0]) = rv0;                                               \
+    *reinterpret_cast<uint4*>(base_ + v_lds[1]) = rv1;                                               \
+    *reinterpret_cast<uint4*>(base_ + v_lds[2]) = rv2;                                               \
+  } while (0)
+
+  // permuted K row for MFMA row i = l31: lane's 16 acc regs <-> 16 consecutive keys (16*hi + reg)
+  const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+
+  f32x16 o[3];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = NEG_BIG, l_run = 0.f;
+  const float c = p.scale_log2e;
+
+  const int ntiles = p.kv_pad / 64;
+  FLASH_GLOAD(0);
+  FLASH_LSTORE(0);
+  __syncthreads();
+
+  for (int t = 0; t < ntiles; ++t) {
+    const int cur = t & 1;
+    if (t + 1 < ntiles) FLASH_GLOAD(t + 1);
+    const char* sk = smem + cur * KV_STAGE;
+    const char* sv = sk + K_TILE_BYTES;
+
+    // ---- S^T = K Q^T : two 32-key tiles
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const char* krp = sk + (kt * 32 + krow) * KROW;
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) {
+        const int d0 = 16 * cc + 8 * hi;
+        bf16x8 kf;
+        if (d0 < HD) {
+          kf = *reinterpret_cast<const bf16x8*>(krp + d0 * 2);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) kf[e] = (__bf16)0.f;
+        }
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[cc], s[kt], 0, 0, 0);
+      }
+    }
+
+    // ---- online softmax (lane: query l31; keys 64t + 32kt + 16hi + r)
+    const int kv0 = t * 64 + 16 * hi;
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float sv_ = s[kt][r];
+        if (kv0 + kt * 32 + r >= p.kv_len) sv_ = NEG_BIG;
+        s[kt][r] = sv_;
+        mx = fmaxf(mx, sv_);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    const float mc = m_new * c;
+    float lsum = 0.f;
+    bf16x8 pf[2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(s[kt][r] * c - mc);
+        lsum += pv;
+        pf[kt][r >> 3][r & 7] = (__bf16)pv;
+      }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- O^T += Vt P^T
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) {
+        const int kvl = kt * 32 + 16 * hi + 8 * cc;
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) {
+          bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + (dt * 32 + l31) * VROW + kvl * 2);
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][cc], o[dt], 0, 0, 0);
+        }
+      }
+
+    if (t + 1 < ntiles) FLASH_LSTORE(cur ^ 1);
+    __syncthreads();
+  }
+#undef FLASH_GLOAD
+#undef FLASH_LSTORE
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.0f / l_tot;
+  const int qs = q0 + l31;
+  if (qs < p.q_len) {
+    bf16_t* orow = p.out + ((int64_t)b * p.q_len + qs) * p.out_stride + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * hi;
+        if (d < HD) {
+          uint2 w;
+          w.x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+          w.y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          *reinterpret_cast<uint2*>(orow + d) = w;
+        }
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// attn_temporal_d72: sequence = the T frames of one pixel token; batch = B*S; heads H.  qkv rows are the
+// (b, t, s)-ordered tokens: q(b,t,s,h) at qkv + ((b*T + t)*S + s)*row_stride + h*72 (k at +C, v at +2C), so the
+// "(B S) T C" view is just a stride of S rows.  One wave per (b, s, h); lane = (frame, third of the head dim).
+// K,V rows (RMS-norm + RoPE applied to K) are parked in wave-private LDS as fp32; queries stay in registers.
+// T is small (19 / 38): this kernel is HBM/latency bound, not MFMA work.
+// grid: B*S*ceil(H/WPB) blocks of WPB waves; dynamic LDS = WPB * 2*T*72*4 bytes.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void attn_temporal_d72_kernel(const bf16_t* __restrict__ qkv, int64_t row_stride, int C,
+                                         const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
+                                         const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                         bf16_t* __restrict__ out, int64_t out_stride, int B, int T, int S, int heads,
+                                         int wpb, float eps, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hgroups = (heads + wpb - 1) / wpb;
+  const int hg = blockIdx.x % hgroups;
+  const int64_t bs = blockIdx.x / hgroups;
+  const int s = (int)(bs % S), b = (int)(bs / S);
+  const int h = hg * wpb + wave;
+  if (h >= heads) return;  // no block-level barrier is used below
+  float* ks = reinterpret_cast<float*>(smem) + (size_t)wave * 2 * T * HD;
+  float* vs = ks + (size_t)T * HD;
+  const int g = lane / 3, part = lane - g * 3;
+  const bool lane_ok = lane < 63;
+  const int npass = (T + 20) / 21;
+
+  auto norm_rope = [&](float* x, const bf16_t* w, int t) {
+    // LlamaRMSNorm over the 72 dims of the row (3 lanes), bf16 rounding, weight; then interleaved-pair RoPE at pos t
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 24; ++e) ss += x[e] * x[e];
+    const int base = g * 3;
+    const float tot = __shfl(ss, base, 64) + __shfl(ss, base + 1, 64) + __shfl(ss, base + 2, 64);
+    const float rstd = rsqrtf(tot / (float)HD + eps);
+#pragma unroll
+    for (int e = 0; e < 24; ++e) x[e] = bf2f(f2bf(bf2f(f2bf(x[e] * rstd)) * bf2f(w[part * 24 + e])));
+    if (rope_cos != nullptr) {
+      const float* cs = rope_cos + (int64_t)t * HD + part * 24;
+      const float* sn = rope_sin + (int64_t)t * HD + part * 24;
+#pragma unroll
+      for (int e = 0; e < 24; e += 2) {
+        const float a = x[e], bb = x[e + 1];
+        x[e] = bf2f(f2bf(a * cs[e] - bb * sn[e]));
+        x[e + 1] = bf2f(f2bf(bb * cs[e + 1] + a * sn[e + 1]));
+      }
+    }
+  };
+
+  // ---- pass A: K (norm + rope) and V of every frame -> LDS
+  for (int pss = 0; pss < npass; ++pss) {
+    const int t = pss * 21 + g;
+    const bool act = lane_ok && t < T;
+    const int tt = t < T ? t : T - 1;
+    const bf16_t* row = qkv + (((int64_t)b * T + tt) * S + s) * row_stride + h * HD + part * 24;
+    float kx[24], vx[24];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      unpack8(*reinterpret_cast<const uint4*>(row + C + cc * 8), kx + cc * 8);
+      unpack8(*reinterpret_cast<const uint4*>(row + 2 * C + cc * 8), vx + cc * 8);
+    }
+    norm_rope(kx, k_norm_w, tt);
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 24; e += 4) {
+        *reinterpret_cast<float4*>(ks + t * HD + part * 24 + e) = make_float4(kx[e], kx[e + 1], kx[e + 2], kx[e + 3]);
+        *reinterpret_cast<float4*>(vs + t * HD + part * 24 + e) = make_float4(vx[e], vx[e + 1], vx[e + 2], vx[e + 3]);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  // ---- pass B: queries, 21 frames per pass
+  for (int pss = 0; pss < npass; ++pss) {
+    const int t = pss * 21 + g;
+    const bool act = lane_ok && t < T;
+    const int tt = t < T ? t : T - 1;
+    const bf16_t* row = qkv + (((int64_t)b * T + tt) * S + s) * row_stride + h * HD + part * 24;
+    float qx[24];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) unpack8(*reinterpret_cast<const uint4*>(row + cc * 8), qx + cc * 8);
+    norm_rope(qx, q_norm_w, tt);
+    float m = NEG_BIG, l = 0.f;
+    float acc[24];
+#pragma unroll
+    for (int e = 0; e < 24; ++e) acc[e] = 0.f;
+    const int base = g * 3;
+    for (int j = 0; j < T; ++j) {
+      const float* kr = ks + j * HD + part * 24;
+      float d = 0.f;
+#pragma unroll
+      for (int e = 0; e < 24; e += 4) {
+        const float4 kk = *reinterpret_cast<const float4*>(kr + e);
+        d += qx[e] * kk.x + qx[e + 1] * kk.y + qx[e + 2] * kk.z + qx[e + 3] * kk.w;
+      }
+      const float sc = (__shfl(d, base, 64) + __shfl(d, base + 1, 64) + __shfl(d, base + 2, 64)) * scale;
+      const float m_new = fmaxf(m, sc);
+      const float alpha = __expf(m - m_new);
+      const float pj = __expf(sc - m_new);
+      l = l * alpha + pj;
+      m = m_new;
+      const float* vr = vs + j * HD + part * 24;
+#pragma unroll
+      for (int e = 0; e < 24; e += 4) {
+        const float4 vv = *reinterpret_cast<const float4*>(vr + e);
+        acc[e] = acc[e] * alpha + pj * vv.x;
+        acc[e + 1] = acc[e + 1] * alpha + pj * vv.y;
+        acc[e + 2] = acc[e + 2] * alpha + pj * vv.z;
+        acc[e + 3] = acc[e + 3] * alpha + pj * vv.w;
+      }
+    }
+    if (act) {
+      const float inv = 1.0f / l;
+#pragma unroll
+      for (int e = 0; e < 24; ++e) acc[e] *= inv;
+      bf16_t* orow = out + (((int64_t)b * T + t) * S + s) * out_stride + h * HD + part * 24;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) *reinterpret_cast<uint4*>(orow + cc * 8) = pack8(acc + cc * 8);
+    }
+  }
+}
+
+}  // namespace
+
+int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* k_norm_w,
+                        bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps,
+                        hipStream_t stream) {
+  if (batch <= 0 || heads <= 0 || kv_len <= 0) return 0;
+  if (kv_pad % 64 != 0 || kv_pad < kv_len || (k_stride % 8) || (v_stride % 8)) return VSYS_ERR_SHAPE;
+  dim3 grid(kv_pad / 64, batch * heads);
+  hipLaunchKernelGGL(attn_prep_kv_kernel, grid, dim3(256), 0, stream, k, k_stride, v, v_stride, k_norm_w, kp, vt, heads,
+                     kv_len, kv_pad, eps);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt,
+                          bf16_t* out, int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad,
+                          float eps, hipStream_t stream) {
+  if (batch <= 0 || heads <= 0 || q_len <= 0) return 0;
+  if (kv_len <= 0 || kv_pad % 64 != 0 || kv_pad < kv_len || (q_stride % 8) || (out_stride % 4)) return VSYS_ERR_SHAPE;
+  FlashParams p;
+  p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
+  p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
+  p.scale_log2e = 0.11785113019775793f * 1.4426950408889634f;  // 72^-0.5 * log2(e)
+  dim3 grid((q_len + 127) / 128, batch * heads);
+  const size_t lds = 2 * KV_STAGE;
+  hipLaunchKernelGGL(flash_attn_d72_kernel, grid, dim3(256), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
+                             const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T,
+                             int S, int heads, float eps, hipStream_t stream) {
+  if (B <= 0 || T <= 0 || S <= 0 || heads <= 0) return 0;
+  if ((row_stride % 8) || (out_stride % 8) || (C % 8) || q_norm_w == nullptr || k_norm_w == nullptr) return VSYS_ERR_SHAPE;
+  const size_t per_wave = (size_t)2 * T * HD * sizeof(float);
+  int wpb = 4;
+  while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;
+  if (per_wave * wpb > 160 * 1024) return VSYS_ERR_SHAPE;
+  const int hgroups = (heads + wpb - 1) / wpb;
+  const int64_t grid = (int64_t)B * S * hgroups;
+  if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
+  const size_t lds = per_wave * wpb;
+  if (lds > 64 * 1024)
+    (void)hipFuncSetAttribute((const void*)attn_temporal_d72_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(attn_temporal_d72_kernel, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
+                     k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, 0.11785113019775793f);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+}  // namespace vsys

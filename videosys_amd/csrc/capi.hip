@@ -1,0 +1,145 @@
+// extern "C" entry points declared in include/videosys_amd.h: argument validation + launch, nothing else.
+#include "vsys_internal.h"
+
+using namespace vsys;
+
+namespace {
+inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline const bf16_t* B16(const void* p) { return reinterpret_cast<const bf16_t*>(p); }
+inline bf16_t* B16(void* p) { return reinterpret_cast<bf16_t*>(p); }
+inline bool fits_int(int64_t v) { return v >= 0 && v <= 0x7fffffff; }
+}  // namespace
+
+extern "C" {
+
+int vsys_abi_version(void) { return VSYS_ABI_VERSION; }
+
+const char* vsys_strerror(int code) {
+  switch (code) {
+    case 0: return "ok";
+    case VSYS_ERR_SHAPE: return "unsupported shape";
+    case VSYS_ERR_ALIGN: return "stride/alignment not a multiple of 8 elements";
+    case VSYS_ERR_ARG: return "bad argument";
+    case VSYS_ERR_LAUNCH: return "HIP launch failed";
+    default: return "unknown error";
+  }
+}
+
+int vsys_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                   int64_t M, int64_t N, int64_t K, int epilogue, const void* gate, int64_t gate_sample_stride,
+                   int64_t rows_per_sample, const void* res, int64_t ldr, void* aux, int64_t ldaux, void* stream) {
+  if (!x || !w || !out) return VSYS_ERR_ARG;
+  if (!fits_int(M) || !fits_int(N) || !fits_int(K) || !fits_int(rows_per_sample)) return VSYS_ERR_SHAPE;
+  GemmParams p;
+  p.A = B16(x); p.lda = ldx; p.W = B16(w); p.ldw = ldw; p.bias = B16(bias); p.out = B16(out); p.ldo = ldo;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.gate = B16(gate); p.gate_stride = gate_sample_stride; p.res = B16(res); p.ldr = ldr; p.aux = B16(aux); p.ldaux = ldaux;
+  p.rows_per_sample = (int)rows_per_sample;
+  if (epilogue != VSYS_EPI_GATE_RES && (gate || res || aux)) return VSYS_ERR_ARG;
+  return launch_gemm(p, epilogue, S(stream));
+}
+
+int vsys_linear_small(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                      int64_t M, int64_t N, int64_t K, int act_in, int act_out, void* stream) {
+  if (!x || !w || !out) return VSYS_ERR_ARG;
+  if (!fits_int(M) || !fits_int(N) || !fits_int(K)) return VSYS_ERR_SHAPE;
+  return launch_linear_small(B16(x), ldx, B16(w), ldw, B16(bias), B16(out), ldo, (int)M, (int)N, (int)K, act_in, act_out,
+                             S(stream));
+}
+
+int vsys_adaln_modulate(const void* x, const void* shift, const void* scale, void* y, int64_t rows, int64_t C,
+                        int64_t rows_per_sample, int64_t mod_sample_stride, float eps, void* stream) {
+  if (!x || !shift || !scale || !y) return VSYS_ERR_ARG;
+  if (!fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_adaln_modulate(B16(x), B16(shift), B16(scale), B16(y), rows, (int)C, rows_per_sample, mod_sample_stride, eps,
+                               S(stream));
+}
+
+int vsys_mod_table(const void* table, const void* t_mlp, void* out, int64_t nblk, int64_t B, int64_t C6, void* stream) {
+  if (!table || !t_mlp || !out) return VSYS_ERR_ARG;
+  if (!fits_int(nblk) || !fits_int(B) || !fits_int(C6)) return VSYS_ERR_SHAPE;
+  return launch_mod_table(B16(table), B16(t_mlp), B16(out), (int)nblk, (int)B, (int)C6, S(stream));
+}
+
+int vsys_timestep_embedding(const void* t_f32, void* out, int64_t B, int64_t dim, void* stream) {
+  if (!t_f32 || !out) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(dim)) return VSYS_ERR_SHAPE;
+  return launch_timestep_embedding(reinterpret_cast<const float*>(t_f32), B16(out), (int)B, (int)dim, S(stream));
+}
+
+int vsys_patch_embed(const void* z_f32, int64_t Bz, const void* w, const void* bias, const void* pos, void* out, int64_t B,
+                     int64_t Cin, int64_t T, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t C, void* stream) {
+  if (!z_f32 || !w || !bias || !pos || !out) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(T) || !fits_int(H) || !fits_int(W) || !fits_int(C) || ph <= 0 || pw <= 0) return VSYS_ERR_SHAPE;
+  return launch_patch_embed(reinterpret_cast<const float*>(z_f32), (int)Bz, B16(w), B16(bias), B16(pos), B16(out), (int)B,
+                            (int)Cin, (int)T, (int)H, (int)W, (int)ph, (int)pw, (int)C, S(stream));
+}
+
+int vsys_final_layer(const void* x, const void* table, const void* tvec, const void* w, const void* bias, void* out_f32,
+                     int64_t B, int64_t T, int64_t Hp, int64_t Wp, int64_t H, int64_t W, int64_t ph, int64_t pw,
+                     int64_t Cout, int64_t C, float eps, void* stream) {
+  if (!x || !table || !tvec || !w || !bias || !out_f32) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(T) || !fits_int(Hp) || !fits_int(Wp) || !fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_final_layer(B16(x), B16(table), B16(tvec), B16(w), B16(bias), reinterpret_cast<float*>(out_f32), (int)B,
+                            (int)T, (int)Hp, (int)Wp, (int)H, (int)W, (int)ph, (int)pw, (int)Cout, (int)C, eps, S(stream));
+}
+
+int vsys_cfg_euler_step(void* z_f32, const void* model_out_f32, int64_t Bz, int64_t Cin, int64_t Cout, int64_t thw,
+                        float guidance, float dt, void* stream) {
+  if (!z_f32 || !model_out_f32) return VSYS_ERR_ARG;
+  if (!fits_int(Bz) || !fits_int(Cin) || !fits_int(Cout) || Cout < Cin) return VSYS_ERR_SHAPE;
+  return launch_cfg_euler(reinterpret_cast<float*>(z_f32), reinterpret_cast<const float*>(model_out_f32), (int)Bz, (int)Cin,
+                          (int)Cout, thw, guidance, dt, S(stream));
+}
+
+int vsys_add_rows(void* x, const void* y, int64_t n, void* stream) {
+  if (!x || !y) return VSYS_ERR_ARG;
+  return launch_add_rows(B16(x), B16(y), n, S(stream));
+}
+
+int vsys_copy_4d(const void* src, void* dst, int64_t n0, int64_t n1, int64_t n2, int64_t C, int64_t ss0, int64_t ss1,
+                 int64_t ss2, int64_t ds0, int64_t ds1, int64_t ds2, int64_t n1_valid, int64_t n2_valid, void* stream) {
+  if (!src || !dst) return VSYS_ERR_ARG;
+  if (!fits_int(n0) || !fits_int(n1) || !fits_int(n2) || !fits_int(C)) return VSYS_ERR_SHAPE;
+  if ((ss0 % 8) || (ss1 % 8) || (ss2 % 8) || (ds0 % 8) || (ds1 % 8) || (ds2 % 8)) return VSYS_ERR_ALIGN;
+  return launch_copy_4d(B16(src), B16(dst), (int)n0, (int)n1, (int)n2, (int)C, ss0, ss1, ss2, ds0, ds1, ds2, (int)n1_valid,
+                        (int)n2_valid, S(stream));
+}
+
+int vsys_attn_prep_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, const void* k_norm_w, void* kp,
+                      void* vt, int64_t batch, int64_t heads, int64_t kv_len, int64_t kv_pad, float eps, void* stream) {
+  if (!k || !v || !kp || !vt) return VSYS_ERR_ARG;
+  if (!fits_int(batch) || !fits_int(heads) || !fits_int(kv_len) || !fits_int(kv_pad) || batch * heads > 65535) return VSYS_ERR_SHAPE;
+  return launch_attn_prep_kv(B16(k), k_stride, B16(v), v_stride, B16(k_norm_w), B16(kp), B16(vt), (int)batch, (int)heads,
+                             (int)kv_len, (int)kv_pad, eps, S(stream));
+}
+
+int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, const void* kp, const void* vt, void* out,
+                        int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
+                        float eps, void* stream) {
+  if (!q || !kp || !vt || !out) return VSYS_ERR_ARG;
+  if (!fits_int(batch) || !fits_int(heads) || !fits_int(q_len) || !fits_int(kv_len) || !fits_int(kv_pad) ||
+      batch * heads > 65535)
+    return VSYS_ERR_SHAPE;
+  return launch_flash_attn_d72(B16(q), q_stride, B16(q_norm_w), B16(kp), B16(vt), B16(out), out_stride, (int)batch,
+                               (int)heads, (int)q_len, (int)kv_len, (int)kv_pad, eps, S(stream));
+}
+
+int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const void* q_norm_w, const void* k_norm_w,
+                           const void* rope_cos_f32, const void* rope_sin_f32, void* out, int64_t out_stride, int64_t B,
+                           int64_t T, int64_t S_, int64_t heads, float eps, void* stream) {
+  if (!qkv || !out || !q_norm_w || !k_norm_w) return VSYS_ERR_ARG;
+  if ((rope_cos_f32 == nullptr) != (rope_sin_f32 == nullptr)) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(T) || !fits_int(S_) || !fits_int(heads) || !fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_attn_temporal_d72(B16(qkv), row_stride, (int)C, B16(q_norm_w), B16(k_norm_w),
+                                  reinterpret_cast<const float*>(rope_cos_f32), reinterpret_cast<const float*>(rope_sin_f32),
+                                  B16(out), out_stride, (int)B, (int)T, (int)S_, (int)heads, eps, S(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,67 @@
+// Shared device helpers for the gfx950 (MI355X / CDNA4) kernels of videosys_amd.
+// Everything here is written for wave64 + MFMA on gfx950 only; there is no other backend.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsys {
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits in HBM
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+// 8 bf16 (one uint4) -> 8 floats
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+  f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+  f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+  uint4 v;
+  v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+  return v;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  // tanh(u) = 1 - 2/(exp(2u)+1); exp via exp2 (v_exp_f32)
+  float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);  // exp(2u)
+  float t = 1.0f - 2.0f / (e + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// XCD-aware bijective remap of a 1-D block id: block b runs on XCD b%8; give each XCD a contiguous
+// chunk of logical tile ids so neighbouring tiles (sharing an operand panel) hit the same L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int NX = 8;
+  int xcd = bid % NX, idx = bid / NX;
+  int q = nblocks / NX, r = nblocks % NX;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace vsys

@@ -1,0 +1,268 @@
+// bf16 MFMA GEMM for the STDiT3 linears (nn.Linear semantics: out = x @ W^T + b) with fused epilogues.
+//
+// Replaces the torch/cuBLAS GEMM + separate elementwise kernels at these reference call sites
+// (/root/reference/videosys):
+//   models/modules/attentions.py:59      qkv            (EPI_BIAS)
+//   models/modules/attentions.py:107 +   proj, then  x + gate_msa * proj(...)   open_sora_transformer_3d.py:219,228 (EPI_GATE_RES)
+//   models/modules/attentions.py:156,183 cross q_linear (EPI_BIAS) / proj + residual (EPI_GATE_RES, gate = null)
+//   timm Mlp fc1 + GELU(tanh)            open_sora_transformer_3d.py:130-132,267 (EPI_BIAS_GELU)
+//   timm Mlp fc2, x + gate_mlp * (...)   open_sora_transformer_3d.py:270,284     (EPI_GATE_RES)
+//
+// Design (gfx950): 256x192x64 block tile, 512 threads = 8 waves as 4(M) x 2(N), each wave a 64x96 output tile of
+// 2x3 v_mfma_f32_32x32x16_bf16 accumulators (96 acc VGPRs).  The MFMA is issued "swapped" (A operand = W fragment,
+// B operand = X fragment) so each lane ends up with ONE token row and runs of 4 consecutive output columns: bias/gate
+// broadcast along columns and the bf16 pack is a plain 8-byte LDS write.  Operand tiles are staged HBM/L2 -> VGPR ->
+// LDS (double-buffered, loads for tile t+1 issued before the MFMAs of tile t, one barrier per K-tile) in a 128-byte-row
+// image whose 16-byte slots are XOR-swizzled by (row>>1)&7 so every ds_read_b128 lane group hits 16 distinct slots.
+// The output tile goes back through LDS so HBM sees whole 192-byte row segments (16-byte stores), where the residual
+// is added and the optional PAB cache copy is written.  1-D grid with an XCD-aware bijective remap: consecutive
+// logical tiles (same token panel, different column tile) share an XCD's L2.
+#include "common.h"
+#include "vsys_internal.h"
+
+namespace vsys {
+
+namespace {
+
+constexpr int BM = 256, BN = 192, BK = 64, NTHREADS = 512;
+constexpr int A_BYTES = BM * BK * 2;  // 32768
+constexpr int B_BYTES = BN * BK * 2;  // 24576
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // 57344
+constexpr int OUT_ROW_BYTES = 96 * 2 + 16;      // per-wave epilogue image row (padded)
+constexpr int OUT_WAVE_BYTES = 64 * OUT_ROW_BYTES;  // 13312
+static_assert(8 * OUT_WAVE_BYTES <= 2 * STAGE_BYTES, "epilogue image must fit in the staging buffers");
+
+__device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+
+  const int nbn = p.N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int bm = tile / nbn, bn = tile - bm * nbn;
+  const int row0 = bm * BM, col0 = bn * BN;
+
+  // ---- staging assignment: chunk q = tid + 512*i -> (row = q>>3, 16-byte chunk = q&7)
+  const bf16_t* aptr[4];
+  const bf16_t* bptr[3];
+  int a_lds[4], b_lds[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    int q = tid + NTHREADS * i, r = q >> 3, c = q & 7;
+    int gr = row0 + r;
+    gr = gr < p.M ? gr : p.M - 1;
+    aptr[i] = p.A + (int64_t)gr * p.lda + c * 8;
+    a_lds[i] = swz(r, c);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    int q = tid + NTHREADS * i, r = q >> 3, c = q & 7;
+    bptr[i] = p.W + (int64_t)(col0 + r) * p.ldw + c * 8;
+    b_lds[i] = A_BYTES + swz(r, c);
+  }
+
+  uint4 ra[4], rb[3];
+  auto gload = [&](int kt) {
+    const int ko = kt * BK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(aptr[i] + ko);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) rb[i] = *reinterpret_cast<const uint4*>(bptr[i] + ko);
+  };
+  auto lstore = [&](int buf) {
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(base + a_lds[i]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(base + b_lds[i]) = rb[i];
+  };
+
+  // ---- fragment read offsets (per lane): X rows (tokens) for i=0,1; W rows (out cols) for j=0..2
+  int xrow[2], wrow[3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) xrow[i] = wm * 64 + i * 32 + l31;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) wrow[j] = wn * 96 + j * 32 + l31;
+
+  f32x16 acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = p.K / BK;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nt; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nt) gload(kt + 1);
+    const char* sa = smem + cur * STAGE_BYTES;
+    const char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int chunk = ks * 2 + hi;
+      bf16x8 xf[2], wf[3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + swz(xrow[i], chunk));
+#pragma unroll
+      for (int j = 0; j < 3; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz(wrow[j], chunk));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nt) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc (+bias, act, gate) -> bf16 -> per-wave LDS image [64 tokens][96 cols] -> 16-byte HBM stores
+  char* st = smem + wave * OUT_WAVE_BYTES;
+  const int ncol0 = col0 + wn * 96;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m_local = i * 32 + l31;
+    const bf16_t* gate_row = nullptr;
+    if (EPI == EPI_GATE_RES && p.gate != nullptr) {
+      int grow = row0 + wm * 64 + m_local;
+      grow = grow < p.M ? grow : p.M - 1;
+      gate_row = p.gate + (int64_t)(grow / p.rows_per_sample) * p.gate_stride;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n_local = j * 32 + 8 * g + 4 * hi;
+        const int n = ncol0 + n_local;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+        if (p.bias != nullptr) {
+          uint2 bb = *reinterpret_cast<const uint2*>(p.bias + n);
+          v[0] += bflo(bb.x); v[1] += bfhi(bb.x); v[2] += bflo(bb.y); v[3] += bfhi(bb.y);
+        }
+        if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+        }
+        if (EPI == EPI_GATE_RES && gate_row != nullptr) {
+          uint2 gg = *reinterpret_cast<const uint2*>(gate_row + n);
+          v[0] *= bflo(gg.x); v[1] *= bfhi(gg.x); v[2] *= bflo(gg.y); v[3] *= bfhi(gg.y);
+        }
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2) = o;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 12; ++it) {
+    const int q = lane + 64 * it;
+    const int m_local = q / 12, c = q - m_local * 12;
+    const int grow = row0 + wm * 64 + m_local;
+    if (grow < p.M) {
+      uint4 val = *reinterpret_cast<const uint4*>(st + m_local * OUT_ROW_BYTES + c * 16);
+      const int gcol = ncol0 + c * 8;
+      if (EPI == EPI_GATE_RES) {
+        if (p.aux != nullptr) *reinterpret_cast<uint4*>(p.aux + (int64_t)grow * p.ldaux + gcol) = val;
+        if (p.res != nullptr) {
+          uint4 rr = *reinterpret_cast<const uint4*>(p.res + (int64_t)grow * p.ldr + gcol);
+          float a[8], b[8];
+          unpack8(val, a);
+          unpack8(rr, b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          val = pack8(a);
+        }
+      }
+      *reinterpret_cast<uint4*>(p.out + (int64_t)grow * p.ldo + gcol) = val;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Small/odd-shape linear: one wave per output element.  Used for the per-step vectors (t_embedder, fps_embedder,
+// t_block: M = 2) and the once-per-video text projection (y_embedder: M = B*L), never for the token GEMMs.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restrict__ x, int64_t ldx,
+                                                           const bf16_t* __restrict__ w, int64_t ldw,
+                                                           const bf16_t* __restrict__ bias, bf16_t* __restrict__ out,
+                                                           int64_t ldo, int M, int N, int K, int act_in, int act_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t idx = (int64_t)blockIdx.x * 4 + wave;
+  if (idx >= (int64_t)M * N) return;
+  const int m = (int)(idx / N), n = (int)(idx - (int64_t)m * N);
+  const bf16_t* xr = x + (int64_t)m * ldx;
+  const bf16_t* wr = w + (int64_t)n * ldw;
+  float s = 0.f;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    uint4 xv = *reinterpret_cast<const uint4*>(xr + k);
+    uint4 wv = *reinterpret_cast<const uint4*>(wr + k);
+    float a[8], b[8];
+    unpack8(xv, a);
+    unpack8(wv, b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float xe = a[e];
+      if (act_in == ACT_SILU) xe = bf2f(f2bf(silu(xe)));  // nn.SiLU on a bf16 tensor rounds before the Linear
+      s += xe * b[e];
+    }
+  }
+  s = wave_sum(s);
+  if (lane == 0) {
+    if (bias != nullptr) s += bf2f(bias[n]);
+    if (act_out == ACT_SILU) s = silu(s);
+    else if (act_out == ACT_GELU_TANH) s = gelu_tanh(s);
+    out[(int64_t)m * ldo + n] = f2bf(s);
+  }
+}
+
+}  // namespace
+
+int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
+  if (p.M <= 0) return 0;
+  if (p.N % BN != 0 || p.K % BK != 0 || p.N <= 0 || p.K <= 0) return VSYS_ERR_SHAPE;
+  if ((p.lda % 8) || (p.ldw % 8) || (p.ldo % 8) || (p.res && (p.ldr % 8)) || (p.aux && (p.ldaux % 8))) return VSYS_ERR_ALIGN;
+  if (epi == EPI_GATE_RES && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+  const int grid = nbm * nbn;
+  const size_t lds = 2 * STAGE_BYTES;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_GATE_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL(gemm_256x192_kernel<EPI_BIAS>, dim3(grid), dim3(NTHREADS), lds, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_256x192_kernel<EPI_BIAS_GELU>, dim3(grid), dim3(NTHREADS), lds, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL(gemm_256x192_kernel<EPI_GATE_RES>, dim3(grid), dim3(NTHREADS), lds, stream, p); break;
+    default: return VSYS_ERR_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,
+                        int64_t ldo, int M, int N, int K, int act_in, int act_out, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (K % 8 != 0 || (ldx % 8) || (ldw % 8)) return VSYS_ERR_ALIGN;
+  const int64_t total = (int64_t)M * N;
+  const int64_t grid = (total + 3) / 4;
+  if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
+  hipLaunchKernelGGL(linear_small_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, ldx, w, ldw, bias, out, ldo, M, N,
+                     K, act_in, act_out);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+}  // namespace vsys

@@ -1,0 +1,380 @@
+// HBM-bound row-wise / element-wise kernels of the STDiT3 denoise step (gfx950).
+//
+// Reference call sites replaced (/root/reference/videosys):
+//   adaln_modulate      nn.LayerNorm(eps 1e-6, no affine) + t2i_modulate      open_sora_transformer_3d.py:47-48,117,196-197,260-261
+//   mod_table           scale_shift_table[None] + t.reshape(B,6,C)            open_sora_transformer_3d.py:177-179 (all blocks at once)
+//   timestep_embedding  TimestepEmbedder.timestep_embedding                    modules/embeddings.py:123-141
+//   patch_embed         OpenSoraPatchEmbed3D (Conv3d k=s=(1,2,2)) + pos_emb    modules/embeddings.py:85-104; open_sora_transformer_3d.py:593-595
+//   final_layer         T2IFinalLayer + unpatchify + fp32 cast                 open_sora_transformer_3d.py:75-87,622-630,634-658
+//   cfg_euler_step      RFLOW.sample CFG combine + Euler update                schedulers/scheduling_rflow_open_sora.py:245-252
+//   add_rows            x = x + last_attn / last_cross (PAB broadcast step)    open_sora_transformer_3d.py:192-193,228,234-235
+//   copy_4d             DSP all-to-all pack/unpack (tensor_split/.contiguous/cat/pad/narrow)  core/distributed/comm.py:104-108,282-304
+//
+// All are one pass over their operands with 16-byte per-lane accesses; the algorithmic HBM bytes of each are the
+// mandatory tensor reads + writes.
+#include "common.h"
+#include "vsys_internal.h"
+
+namespace vsys {
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm (no affine) + modulate: y = LN(x) * (1 + scale[b]) + shift[b].  One wave per row; the row lives in
+// registers (C <= 64*8*MAXV elements), so x is read exactly once.  fp32 statistics (two-pass in registers).
+// ---------------------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void adaln_modulate_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ shift,
+                                                             const bf16_t* __restrict__ scale, bf16_t* __restrict__ y,
+                                                             int64_t rows, int C, int64_t rows_per_sample,
+                                                             int64_t mod_stride, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = C >> 3;
+  const bf16_t* xr = x + row * C;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      uint4 u = *reinterpret_cast<const uint4*>(xr + c * 8);
+      unpack8(u, v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const int64_t b = row / rows_per_sample;
+  const bf16_t* sh = shift + b * mod_stride;
+  const bf16_t* sc = scale + b * mod_stride;
+  bf16_t* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float a[8], m[8], o[8];
+      unpack8(*reinterpret_cast<const uint4*>(sh + c * 8), a);
+      unpack8(*reinterpret_cast<const uint4*>(sc + c * 8), m);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd * (1.0f + m[e]) + a[e];
+      *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+    }
+  }
+}
+
+// mod[blk][b][6][C] = bf16(table[blk][6][C] + t_mlp[b][6*C])   (bf16 add, as the reference's bf16 tensors do)
+__global__ void mod_table_kernel(const bf16_t* __restrict__ table, const bf16_t* __restrict__ t_mlp, bf16_t* __restrict__ out,
+                                 int nblk, int B, int C6) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)nblk * B * C6;
+  if (i >= total) return;
+  const int c = (int)(i % C6);
+  const int b = (int)((i / C6) % B);
+  const int k = (int)(i / ((int64_t)C6 * B));
+  out[i] = f2bf(bf2f(table[(int64_t)k * C6 + c]) + bf2f(t_mlp[(int64_t)b * C6 + c]));
+}
+
+// out[b][0:half] = cos(t*f_i), out[b][half:] = sin(t*f_i), f_i = exp(-ln(10000) i/half)   (dim even)
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* __restrict__ out, int B, int dim) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim / 2;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  const float f = expf(-9.210340371976184f * (float)k / (float)half);
+  const float a = t[b] * f;
+  out[(int64_t)b * dim + k] = f2bf(cosf(a));
+  out[(int64_t)b * dim + half + k] = f2bf(sinf(a));
+}
+
+// Patch embed: fp32 latent z [Bz, Cin, T, H, W] (sample b reads z[b % Bz]: the CFG duplicate torch.cat([z, z]) of
+// scheduling_rflow_open_sora.py:239 is never materialised; x.to(bf16) of open_sora_transformer_3d.py:561 happens at
+// the load) -> out [B, T, Hp*Wp, C] = conv(k=s=(1,ph,pw)) + bias + pos[s][C].
+// K = Cin*ph*pw (16 for STDiT3) is far too small for MFMA: each thread produces 8 output channels of one token
+// from K inputs (broadcast within the token) and K*8 weights; the store side (N*C bf16) is the HBM term.
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, int Bz, const bf16_t* __restrict__ w,
+                                                          const bf16_t* __restrict__ bias, const bf16_t* __restrict__ pos,
+                                                          bf16_t* __restrict__ out, int B, int Cin, int T, int H, int W,
+                                                          int ph, int pw, int C) {
+  const int Hp = (H + ph - 1) / ph, Wp = (W + pw - 1) / pw;
+  const int S = Hp * Wp;
+  const int cchunks = C >> 3;
+  const int64_t total = (int64_t)B * T * S * cchunks;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cc = (int)(i % cchunks);
+  const int64_t tok = i / cchunks;
+  const int s = (int)(tok % S);
+  const int t = (int)((tok / S) % T);
+  const int b = (int)(tok / ((int64_t)S * T));
+  const int bz = b % Bz;
+  const int hp = s / Wp, wp = s - hp * Wp;
+  float acc[8];
+  {
+    float bb[8];
+    unpack8(*reinterpret_cast<const uint4*>(bias + cc * 8), bb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bb[e];
+  }
+  const int K = Cin * ph * pw;
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int dy = 0; dy < ph; ++dy)
+      for (int dx = 0; dx < pw; ++dx) {
+        const int hh = hp * ph + dy, ww = wp * pw + dx;
+        float xv = 0.f;  // zero padding of odd H/W (F.pad in the reference)
+        if (hh < H && ww < W) xv = bf2f(f2bf(x[((((int64_t)bz * Cin + ci) * T + t) * H + hh) * W + ww]));
+        const int k = (ci * ph + dy) * pw + dx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += xv * bf2f(w[(int64_t)(cc * 8 + e) * K + k]);
+      }
+  float pp[8];
+  unpack8(*reinterpret_cast<const uint4*>(pos + (int64_t)s * C + cc * 8), pp);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = bf2f(f2bf(acc[e])) + pp[e];  // conv output is a bf16 tensor before "+ pos_emb"
+  *reinterpret_cast<uint4*>(out + tok * C + cc * 8) = pack8(acc);
+}
+
+// Final layer: y = Linear(LN(x)*(1+scale_b)+shift_b) with (shift,scale) = table[2,C] + t[b,C]; then unpatchify into
+// out[B, Cout, T, H, W] fp32 (cropped to the un-padded latent size).  One wave per token row; NOUT = ph*pw*Cout <= 64.
+template <int MAXV>
+__global__ __launch_bounds__(256) void final_layer_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ table,
+                                                          const bf16_t* __restrict__ tvec, const bf16_t* __restrict__ w,
+                                                          const bf16_t* __restrict__ bias, float* __restrict__ out,
+                                                          int B, int T, int Hp, int Wp, int H, int W, int ph, int pw,
+                                                          int Cout, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int S = Hp * Wp;
+  const int64_t rows = (int64_t)B * T * S;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = C >> 3;
+  const bf16_t* xr = x + row * C;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const int b = (int)(row / ((int64_t)T * S));
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float sh[8], sc[8], tt[8];
+      unpack8(*reinterpret_cast<const uint4*>(table + c * 8), sh);
+      unpack8(*reinterpret_cast<const uint4*>(table + C + c * 8), sc);
+      unpack8(*reinterpret_cast<const uint4*>(tvec + (int64_t)b * C + c * 8), tt);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float shift = bf2f(f2bf(sh[e] + tt[e])), scale = bf2f(f2bf(sc[e] + tt[e]));
+        v[i][e] = bf2f(f2bf((v[i][e] - mean) * rstd * (1.0f + scale) + shift));  // bf16 activation into the Linear
+      }
+    }
+  }
+  const int NOUT = ph * pw * Cout;
+  const int64_t tok = row % ((int64_t)T * S);
+  const int t = (int)(tok / S), sidx = (int)(tok % S);
+  const int hp = sidx / Wp, wp = sidx - hp * Wp;
+  for (int n = 0; n < NOUT; ++n) {
+    const bf16_t* wr = w + (int64_t)n * C;
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nchunk) {
+        float ww[8];
+        unpack8(*reinterpret_cast<const uint4*>(wr + c * 8), ww);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += v[i][e] * ww[e];
+      }
+    }
+    d = wave_sum(d);
+    if (lane == 0) {
+      d = bf2f(f2bf(d + bf2f(bias[n])));  // Linear output is bf16, then .to(float32)
+      // "(T_p H_p W_p C_out)" ordering of the channel axis, T_p = 1
+      const int co = n % Cout;
+      const int dx = (n / Cout) % pw, dy = n / (Cout * pw);
+      const int hh = hp * ph + dy, ww2 = wp * pw + dx;
+      if (hh < H && ww2 < W) out[((((int64_t)b * Cout + co) * T + t) * H + hh) * W + ww2] = d;
+    }
+  }
+}
+
+// RFLOW step: pred = model_out[:, :Cin] ; v = uncond + g*(cond - uncond) ; z += v*dt    (cond = batch half 0)
+__global__ void cfg_euler_kernel(float* __restrict__ z, const float* __restrict__ model_out, int Bz, int Cin, int Cout,
+                                 int64_t thw, float guidance, float dt) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)Bz * Cin * thw;
+  if (i >= total) return;
+  const int64_t sp = i % thw;
+  const int c = (int)((i / thw) % Cin);
+  const int b = (int)(i / (thw * Cin));
+  const float cond = model_out[((int64_t)b * Cout + c) * thw + sp];
+  const float unc = model_out[((int64_t)(b + Bz) * Cout + c) * thw + sp];
+  z[i] = z[i] + (unc + guidance * (cond - unc)) * dt;
+}
+
+// x[i] = bf16(x[i] + y[i]) over n8 16-byte chunks
+__global__ void add_rows_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ y, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float a[8], b[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[i], a);
+    unpack8(reinterpret_cast<const uint4*>(y)[i], b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] += b[e];
+    reinterpret_cast<uint4*>(x)[i] = pack8(a);
+  }
+}
+
+// Generic 4-D strided copy of rows of C bf16 (C % 8 == 0): dst[i0][i1][i2][:] = src[i0][i1][i2][:] or zero when
+// (i1 >= n1_valid || i2 >= n2_valid) — the zero-pad of all_to_all_with_pad.  Strides in elements.
+__global__ void copy_4d_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int n0, int n1, int n2, int C,
+                               int64_t ss0, int64_t ss1, int64_t ss2, int64_t ds0, int64_t ds1, int64_t ds2,
+                               int n1_valid, int n2_valid) {
+  const int cch = C >> 3;
+  const int64_t total = (int64_t)n0 * n1 * n2 * cch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cch);
+    int64_t r = i / cch;
+    const int i2 = (int)(r % n2);
+    r /= n2;
+    const int i1 = (int)(r % n1);
+    const int i0 = (int)(r / n1);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i1 < n1_valid && i2 < n2_valid) v = *reinterpret_cast<const uint4*>(src + i0 * ss0 + i1 * ss1 + i2 * ss2 + c * 8);
+    *reinterpret_cast<uint4*>(dst + i0 * ds0 + i1 * ds1 + i2 * ds2 + c * 8) = v;
+  }
+}
+
+}  // namespace
+
+int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* scale, bf16_t* y, int64_t rows, int C,
+                          int64_t rows_per_sample, int64_t mod_stride, float eps, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (C % 8 != 0 || C > 64 * 8 * 4 || rows_per_sample <= 0 || (mod_stride % 8)) return VSYS_ERR_SHAPE;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (C <= 64 * 8 * 2)
+    hipLaunchKernelGGL(adaln_modulate_kernel<2>, dim3(grid), dim3(256), 0, stream, x, shift, scale, y, rows, C,
+                       rows_per_sample, mod_stride, eps);
+  else if (C <= 64 * 8 * 3)
+    hipLaunchKernelGGL(adaln_modulate_kernel<3>, dim3(grid), dim3(256), 0, stream, x, shift, scale, y, rows, C,
+                       rows_per_sample, mod_stride, eps);
+  else
+    hipLaunchKernelGGL(adaln_modulate_kernel<4>, dim3(grid), dim3(256), 0, stream, x, shift, scale, y, rows, C,
+                       rows_per_sample, mod_stride, eps);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_mod_table(const bf16_t* table, const bf16_t* t_mlp, bf16_t* out, int nblk, int B, int C6, hipStream_t stream) {
+  const int64_t total = (int64_t)nblk * B * C6;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(mod_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, table, t_mlp, out, nblk,
+                     B, C6);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_timestep_embedding(const float* t, bf16_t* out, int B, int dim, hipStream_t stream) {
+  if (dim % 2) return VSYS_ERR_SHAPE;
+  const int total = B * (dim / 2);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 127) / 128), dim3(128), 0, stream, t, out, B, dim);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_patch_embed(const float* x, int Bz, const bf16_t* w, const bf16_t* bias, const bf16_t* pos, bf16_t* out, int B,
+                       int Cin, int T, int H, int W, int ph, int pw, int C, hipStream_t stream) {
+  if (C % 8 || Bz <= 0) return VSYS_ERR_SHAPE;
+  const int Hp = (H + ph - 1) / ph, Wp = (W + pw - 1) / pw;
+  const int64_t total = (int64_t)B * T * Hp * Wp * (C / 8);
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(patch_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, Bz, w, bias, pos, out,
+                     B, Cin, T, H, W, ph, pw, C);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_final_layer(const bf16_t* x, const bf16_t* table, const bf16_t* tvec, const bf16_t* w, const bf16_t* bias,
+                       float* out, int B, int T, int Hp, int Wp, int H, int W, int ph, int pw, int Cout, int C, float eps,
+                       hipStream_t stream) {
+  if (C % 8 != 0 || C > 64 * 8 * 4) return VSYS_ERR_SHAPE;
+  const int64_t rows = (int64_t)B * T * Hp * Wp;
+  if (rows <= 0) return 0;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+  if (C <= 64 * 8 * 2)
+    hipLaunchKernelGGL(final_layer_kernel<2>, dim3(grid), dim3(256), 0, stream, x, table, tvec, w, bias, out, B, T, Hp, Wp,
+                       H, W, ph, pw, Cout, C, eps);
+  else if (C <= 64 * 8 * 3)
+    hipLaunchKernelGGL(final_layer_kernel<3>, dim3(grid), dim3(256), 0, stream, x, table, tvec, w, bias, out, B, T, Hp, Wp,
+                       H, W, ph, pw, Cout, C, eps);
+  else
+    hipLaunchKernelGGL(final_layer_kernel<4>, dim3(grid), dim3(256), 0, stream, x, table, tvec, w, bias, out, B, T, Hp, Wp,
+                       H, W, ph, pw, Cout, C, eps);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_cfg_euler(float* z, const float* model_out, int Bz, int Cin, int Cout, int64_t thw, float guidance, float dt,
+                     hipStream_t stream) {
+  const int64_t total = (int64_t)Bz * Cin * thw;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, model_out, Bz, Cin,
+                     Cout, thw, guidance, dt);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_add_rows(bf16_t* x, const bf16_t* y, int64_t n, hipStream_t stream) {
+  if (n <= 0) return 0;
+  if (n % 8) return VSYS_ERR_SHAPE;
+  const int64_t n8 = n / 8;
+  int64_t grid = (n8 + 255) / 256;
+  if (grid > 2048 * 4) grid = 2048 * 4;
+  hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, y, n8);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_copy_4d(const bf16_t* src, bf16_t* dst, int n0, int n1, int n2, int C, int64_t ss0, int64_t ss1, int64_t ss2,
+                   int64_t ds0, int64_t ds1, int64_t ds2, int n1_valid, int n2_valid, hipStream_t stream) {
+  if (C % 8) return VSYS_ERR_SHAPE;
+  const int64_t total = (int64_t)n0 * n1 * n2 * (C / 8);
+  if (total <= 0) return 0;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 2048 * 4) grid = 2048 * 4;
+  hipLaunchKernelGGL(copy_4d_kernel, dim3((unsigned)grid), dim3(256), 0, stream, src, dst, n0, n1, n2, C, ss0, ss1, ss2, ds0,
+                     ds1, ds2, n1_valid, n2_valid);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+}  // namespace vsys

@@ -1,0 +1,54 @@
+// Internal launch declarations shared by the .hip translation units and the C-ABI layer (capi.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/videosys_amd.h"
+
+namespace vsys {
+
+typedef uint16_t bf16_t;
+
+enum { EPI_BIAS = VSYS_EPI_BIAS, EPI_BIAS_GELU = VSYS_EPI_BIAS_GELU, EPI_GATE_RES = VSYS_EPI_GATE_RES };
+enum { ACT_NONE = VSYS_ACT_NONE, ACT_SILU = VSYS_ACT_SILU, ACT_GELU_TANH = VSYS_ACT_GELU_TANH };
+
+struct GemmParams {
+  const bf16_t* A; int64_t lda;   // activations [M, K]
+  const bf16_t* W; int64_t ldw;   // nn.Linear weight [N, K]
+  const bf16_t* bias;             // [N] or null
+  bf16_t* out; int64_t ldo;       // [M, N]
+  int M, N, K;
+  const bf16_t* gate; int64_t gate_stride;  // per-sample gate row [N] at gate + sample*gate_stride, or null (gate = 1)
+  const bf16_t* res; int64_t ldr;           // residual [M, N] or null
+  bf16_t* aux; int64_t ldaux;               // optional copy of gate*(acc+bias) (PAB cache slab) or null
+  int rows_per_sample;
+};
+
+int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,
+                        int64_t ldo, int M, int N, int K, int act_in, int act_out, hipStream_t stream);
+int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* scale, bf16_t* y, int64_t rows, int C,
+                          int64_t rows_per_sample, int64_t mod_stride, float eps, hipStream_t stream);
+int launch_mod_table(const bf16_t* table, const bf16_t* t_mlp, bf16_t* out, int nblk, int B, int C6, hipStream_t stream);
+int launch_timestep_embedding(const float* t, bf16_t* out, int B, int dim, hipStream_t stream);
+int launch_patch_embed(const float* x, int Bz, const bf16_t* w, const bf16_t* bias, const bf16_t* pos, bf16_t* out, int B,
+                       int Cin, int T, int H, int W, int ph, int pw, int C, hipStream_t stream);
+int launch_final_layer(const bf16_t* x, const bf16_t* table, const bf16_t* tvec, const bf16_t* w, const bf16_t* bias,
+                       float* out, int B, int T, int Hp, int Wp, int H, int W, int ph, int pw, int Cout, int C, float eps,
+                       hipStream_t stream);
+int launch_cfg_euler(float* z, const float* model_out, int Bz, int Cin, int Cout, int64_t thw, float guidance, float dt,
+                     hipStream_t stream);
+int launch_add_rows(bf16_t* x, const bf16_t* y, int64_t n, hipStream_t stream);
+int launch_copy_4d(const bf16_t* src, bf16_t* dst, int n0, int n1, int n2, int C, int64_t ss0, int64_t ss1, int64_t ss2,
+                   int64_t ds0, int64_t ds1, int64_t ds2, int n1_valid, int n2_valid, hipStream_t stream);
+int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* k_norm_w,
+                        bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps,
+                        hipStream_t stream);
+int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt,
+                          bf16_t* out, int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad,
+                          float eps, hipStream_t stream);
+int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
+                             const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T,
+                             int S, int heads, float eps, hipStream_t stream);
+
+}  // namespace vsys

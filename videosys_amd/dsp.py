@@ -1,0 +1,216 @@
+"""Dynamic Sequence Parallelism over RCCL/xGMI — host mirror of videosys/core/distributed/{parallel_mgr,comm}.py.
+
+Reference behaviour kept (file:line relative to /root/reference/videosys/core/distributed):
+  * ``initialize``            parallel_mgr.py:103-117  (one process per GPU, backend "nccl" == RCCL on ROCm)
+  * ``ParallelManager``       parallel_mgr.py:14-39    (dp x cp x sp mesh; built on dist.new_group, no colossalai)
+  * ``set_pad/get_pad``       comm.py:268-279
+  * ``split_sequence``        comm.py:148-167,256-258  (zero pad + local slice)
+  * ``gather_sequence``       comm.py:170-190,260-262  (all-gather + un-pad)
+  * ``all_to_all_with_pad``   comm.py:104-108,282-304  (the DSP layout switch)
+
+MI355X design: the reference's tensor_split / P x .contiguous() / list all_to_all / cat / .contiguous() (two extra
+full copies around every NCCL call) becomes ONE packed send buffer -> ``all_to_all_single`` -> ONE unpack, with the
+zero-padding / narrowing folded into the pack/unpack copies (``vsys_copy_4d``).  xGMI is point-to-point, so the
+all-to-all uses all 7 links of a GPU at once; a single large message per peer is the efficient shape.  The pack/unpack
+*plans* (pure Python: which strided region goes where) are separated from the copy *executor* so the plans are
+testable with gloo on CPU; on a GPU the executor is the HIP kernel and nothing else.
+"""
+from __future__ import annotations
+
+import logging
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+PAD_DICT = {}
+
+
+def initialize(rank=0, world_size=1, init_method=None, backend: Optional[str] = None):
+    """parallel_mgr.py:103-117.  backend defaults to "nccl" (RCCL) when a GPU is present, "gloo" otherwise."""
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend=backend, init_method=init_method, world_size=world_size, rank=rank)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(rank % torch.cuda.device_count())
+
+
+class ParallelManager:
+    """dp x cp x sp process-group mesh (row-major rank = (dp*cp_size + cp)*sp_size + sp), parallel_mgr.py:14-39."""
+
+    def __init__(self, dp_size, cp_size, sp_size):
+        self.dp_size, self.cp_size, self.sp_size = dp_size, cp_size, sp_size
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        assert dp_size * cp_size * sp_size == world, f"mesh {dp_size}x{cp_size}x{sp_size} != world {world}"
+        self.dp_group = self.cp_group = self.sp_group = None
+        self.dp_rank, self.cp_rank, self.sp_rank = 0, None, None
+        if world > 1:
+            coords = lambda r: (r // (cp_size * sp_size), (r // sp_size) % cp_size, r % sp_size)
+            me = coords(rank)
+            for axis, size in ((0, dp_size), (1, cp_size), (2, sp_size)):
+                # every rank must create every group (collective), keep the one it belongs to
+                seen = {}
+                for r in range(world):
+                    c = coords(r)
+                    key = tuple(v for i, v in enumerate(c) if i != axis)
+                    seen.setdefault(key, []).append(r)
+                for key, ranks in sorted(seen.items()):
+                    g = dist.new_group(ranks) if size > 1 else None
+                    if key == tuple(v for i, v in enumerate(me) if i != axis) and g is not None:
+                        if axis == 0:
+                            self.dp_group, self.dp_rank = g, dist.get_rank(g)
+                        elif axis == 1:
+                            self.cp_group, self.cp_rank = g, dist.get_rank(g)
+                        else:
+                            self.sp_group, self.sp_rank = g, dist.get_rank(g)
+        logging.info(f"Init parallel manager with dp_size: {dp_size}, cp_size: {cp_size}, sp_size: {sp_size}")
+
+
+def set_pad(name: str, dim_size: int, parallel_group) -> None:
+    sp_size = dist.get_world_size(parallel_group)
+    PAD_DICT[name] = (sp_size - (dim_size % sp_size)) % sp_size
+
+
+def get_pad(name) -> int:
+    return PAD_DICT[name]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# copy plans: a plan is a list of CopyOp(src_offset, dst_offset, n0, n1, n2, run, sstr, dstr, n1_valid, n2_valid)
+# over flat bf16 buffers; "run" contiguous elements are moved per (i0, i1, i2).
+# ---------------------------------------------------------------------------------------------------------
+@dataclass
+class CopyOp:
+    src_off: int
+    dst_off: int
+    n0: int
+    n1: int
+    n2: int
+    run: int
+    sstr: tuple
+    dstr: tuple
+    n1_valid: int
+    n2_valid: int
+
+
+def plan_split(B, T, S, C, P, rank):
+    """split_sequence(x[B,T,S,C], dim=2): local [B,T,Sl,C], Sl = (S+pad)/P, zero rows past S."""
+    Sl = (S + (P - S % P) % P) // P
+    valid = max(0, min(Sl, S - rank * Sl))
+    return [CopyOp(rank * Sl * C, 0, B, T, Sl, C, (T * S * C, S * C, C), (T * Sl * C, Sl * C, C), T, valid)], (B, T, Sl, C)
+
+
+def plan_switch_to_temporal_shard(B, T, Sl, S, C, P):
+    """[B,T,Sl,C] (S-shard) -> send [P][B,Tp,Sl,C]; after all_to_all_single recv [P][B,Tp,Sl,C] -> [B,Tp,S,C].
+    (all_to_all_with_pad with scatter_dim=1 (T, padded), gather_dim=2 (S, un-padded); open_sora_transformer_3d.py:299-303)"""
+    Tp = (T + (P - T % P) % P) // P
+    run = Sl * C
+    pack = [CopyOp(r * Tp * run, r * B * Tp * run, B, Tp, 1, run, (T * run, run, run), (Tp * run, run, run),
+                   max(0, min(Tp, T - r * Tp)), 1) for r in range(P)]
+    unpack = []
+    for src in range(P):
+        valid = max(0, min(Sl, S - src * Sl))
+        unpack.append(CopyOp(src * B * Tp * run, src * Sl * C, B, Tp, Sl, C, (Tp * run, run, C), (Tp * S * C, S * C, C),
+                             Tp, valid))
+    unpack = [u for u in unpack if u.n2_valid > 0]
+    return pack, unpack, (P, B, Tp, Sl, C), (B, Tp, S, C)
+
+
+def plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, P):
+    """[B,Tp,S,C] (T-shard) -> send [P][B,Tp,Sl,C]; recv -> [B,T,Sl,C] (scatter_dim=2 padded, gather_dim=1 narrowed)."""
+    run = Sl * C
+    pack = []
+    for r in range(P):
+        valid = max(0, min(Sl, S - r * Sl))
+        pack.append(CopyOp(r * Sl * C, r * B * Tp * run, B, Tp, Sl, C, (Tp * S * C, S * C, C), (Tp * run, run, C), Tp, valid))
+    unpack = []
+    for src in range(P):
+        valid = max(0, min(Tp, T - src * Tp))
+        if valid > 0:
+            unpack.append(CopyOp(src * B * Tp * run, src * Tp * run, B, valid, 1, run, (Tp * run, run, run),
+                                 (T * run, run, run), valid, 1))
+    return pack, unpack, (P, B, Tp, Sl, C), (B, T, Sl, C)
+
+
+def plan_gather(B, T, Sl, S, C, P):
+    """gather_sequence(dim=2): recv [P][B,T,Sl,C] -> [B,T,S,C] (un-padded)."""
+    ops = []
+    for src in range(P):
+        valid = max(0, min(Sl, S - src * Sl))
+        if valid > 0:
+            ops.append(CopyOp(src * B * T * Sl * C, src * Sl * C, B, T, Sl, C, (T * Sl * C, Sl * C, C), (T * S * C, S * C, C),
+                              T, valid))
+    return ops, (B, T, S, C)
+
+
+def hip_copy_executor(src: torch.Tensor, dst: torch.Tensor, ops: List[CopyOp]):
+    """The product executor: one vsys_copy_4d launch per op (device tensors only)."""
+    from . import ops as vops
+
+    s, d = src.view(-1), dst.view(-1)
+    for o in ops:
+        vops.copy_4d(s[o.src_off:], d[o.dst_off:], o.n0, o.n1, o.n2, o.run, o.sstr, o.dstr, o.n1_valid, o.n2_valid)
+
+
+class SequenceParallel:
+    """The DSP data path of one rank: owns the packed send/recv buffers and the side stream."""
+
+    def __init__(self, group, copy_executor: Callable = hip_copy_executor):
+        self.group = group
+        self.P = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.exec = copy_executor
+        self._bufs = {}
+
+    def _buf(self, name, shape, like):
+        key = (name, tuple(shape))
+        b = self._bufs.get(key)
+        if b is None or b.device != like.device or b.dtype != like.dtype:
+            b = torch.empty(shape, dtype=like.dtype, device=like.device)
+            self._bufs[key] = b
+        return b
+
+    def split(self, x):
+        B, T, S, C = x.shape
+        ops, shape = plan_split(B, T, S, C, self.P, self.rank)
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+        self.exec(x, out, ops)
+        return out
+
+    def gather(self, x, S):
+        B, T, Sl, C = x.shape
+        recv = self._buf("gather_recv", (self.P, B, T, Sl, C), x)
+        dist.all_gather_into_tensor(recv.view(self.P * B, T, Sl, C), x.contiguous(), group=self.group)
+        ops, shape = plan_gather(B, T, Sl, S, C, self.P)
+        out = torch.empty(shape, dtype=x.dtype, device=x.device)
+        self.exec(recv, out, ops)
+        return out
+
+    def to_temporal_shard(self, x, S, out=None):
+        """[B,T,Sl,C] -> [B,Tp,S,C]  (before spatial attention)."""
+        B, T, Sl, C = x.shape
+        pack, unpack, sshape, oshape = plan_switch_to_temporal_shard(B, T, Sl, S, C, self.P)
+        send = self._buf("a2a_send", sshape, x)
+        recv = self._buf("a2a_recv", sshape, x)
+        self.exec(x, send, pack)
+        dist.all_to_all_single(recv, send, group=self.group)
+        if out is None:
+            out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+        self.exec(recv, out, unpack)
+        return out
+
+    def to_spatial_shard(self, x, T, Sl, out=None):
+        """[B,Tp,S,C] -> [B,T,Sl,C]  (after spatial attention)."""
+        B, Tp, S, C = x.shape
+        pack, unpack, sshape, oshape = plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, self.P)
+        send = self._buf("a2a_send", sshape, x)
+        recv = self._buf("a2a_recv", sshape, x)
+        self.exec(x, send, pack)
+        dist.all_to_all_single(recv, send, group=self.group)
+        if out is None:
+            out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+        self.exec(recv, out, unpack)
+        return out

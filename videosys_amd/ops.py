@@ -1,0 +1,218 @@
+"""Tensor-level wrappers over the C ABI (include/videosys_amd.h).
+
+PyTorch is plumbing here: it owns the HBM allocations and the HIP stream; every wrapper passes raw device pointers
+and sizes to libvideosys_amd.so.  All wrappers require CUDA(HIP) tensors and raise otherwise — no eager fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+EPI_BIAS, EPI_BIAS_GELU, EPI_GATE_RES = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
+HEAD_DIM = 72
+VT_ROWS = 96
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.VsysError("videosys_amd ops need HIP device tensors (no CPU fallback)")
+
+
+def _bf16(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.bfloat16:
+            raise _lib.VsysError(f"expected bf16 tensor, got {t.dtype}")
+
+
+def gemm(x, w, bias=None, *, epilogue=EPI_BIAS, gate=None, gate_stride=0, rows_per_sample=0, res=None, aux=None, out=None):
+    """out[M,N] = epilogue(x[M,K] @ w[N,K]^T + bias). x may be a row-strided 2-D view (last dim contiguous)."""
+    _chk(x, w, bias, gate, res, aux, out)
+    _bf16(x, w, bias, gate, res, aux, out)
+    assert x.dim() == 2 and w.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    assert out.stride(1) == 1
+    lib = _lib.load()
+    _lib.check(lib.vsys_gemm_bf16(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, epilogue,
+                                  _p(gate), gate_stride, rows_per_sample, _p(res), res.stride(0) if res is not None else 0,
+                                  _p(aux), aux.stride(0) if aux is not None else 0, _stream()), "vsys_gemm_bf16")
+    return out
+
+
+def linear_small(x, w, bias=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
+    _chk(x, w, bias, out)
+    _bf16(x, w, bias, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.vsys_linear_small(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, act_in,
+                                     act_out, _stream()), "vsys_linear_small")
+    return out
+
+
+def adaln_modulate(x, shift, scale, rows_per_sample, mod_stride, eps=1e-6, out=None):
+    """x [rows, C] contiguous; shift/scale point at sample-0 vectors, sample stride mod_stride elements."""
+    _chk(x, shift, scale, out)
+    _bf16(x, shift, scale, out)
+    assert x.is_contiguous()
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.vsys_adaln_modulate(_p(x), _p(shift), _p(scale), _p(out), rows, C, rows_per_sample, mod_stride, eps,
+                                       _stream()), "vsys_adaln_modulate")
+    return out
+
+
+def mod_table(table, t_mlp, out=None):
+    """table [nblk, 6*C], t_mlp [B, 6*C] -> [nblk, B, 6*C]"""
+    _chk(table, t_mlp, out)
+    _bf16(table, t_mlp, out)
+    nblk, C6 = table.shape
+    B = t_mlp.shape[0]
+    if out is None:
+        out = torch.empty(nblk, B, C6, dtype=torch.bfloat16, device=table.device)
+    lib = _lib.load()
+    _lib.check(lib.vsys_mod_table(_p(table), _p(t_mlp), _p(out), nblk, B, C6, _stream()), "vsys_mod_table")
+    return out
+
+
+def timestep_embedding(t_f32, dim=256):
+    _chk(t_f32)
+    assert t_f32.dtype == torch.float32 and t_f32.is_contiguous()
+    B = t_f32.numel()
+    out = torch.empty(B, dim, dtype=torch.bfloat16, device=t_f32.device)
+    lib = _lib.load()
+    _lib.check(lib.vsys_timestep_embedding(_p(t_f32), _p(out), B, dim, _stream()), "vsys_timestep_embedding")
+    return out
+
+
+def patch_embed(z_f32, w, bias, pos, B, patch, C):
+    """z fp32 [Bz, Cin, T, H, W] -> bf16 [B, T, S, C] (sample b reads z[b % Bz])."""
+    _chk(z_f32, w, bias, pos)
+    _bf16(w, bias, pos)
+    assert z_f32.dtype == torch.float32 and z_f32.is_contiguous() and w.is_contiguous() and pos.is_contiguous()
+    Bz, Cin, T, H, W = z_f32.shape
+    assert patch[0] == 1
+    ph, pw = patch[1], patch[2]
+    Hp, Wp = -(-H // ph), -(-W // pw)
+    out = torch.empty(B, T, Hp * Wp, C, dtype=torch.bfloat16, device=z_f32.device)
+    lib = _lib.load()
+    _lib.check(lib.vsys_patch_embed(_p(z_f32), Bz, _p(w), _p(bias), _p(pos), _p(out), B, Cin, T, H, W, ph, pw, C, _stream()),
+               "vsys_patch_embed")
+    return out
+
+
+def final_layer(x, table, tvec, w, bias, B, T, Hp, Wp, H, W, patch, Cout, eps=1e-6):
+    _chk(x, table, tvec, w, bias)
+    _bf16(x, table, tvec, w, bias)
+    assert x.is_contiguous() and w.is_contiguous() and table.is_contiguous() and tvec.is_contiguous()
+    C = x.shape[-1]
+    out = torch.empty(B, Cout, T, H, W, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.vsys_final_layer(_p(x), _p(table), _p(tvec), _p(w), _p(bias), _p(out), B, T, Hp, Wp, H, W, patch[1],
+                                    patch[2], Cout, C, eps, _stream()), "vsys_final_layer")
+    return out
+
+
+def cfg_euler_step(z_f32, model_out_f32, guidance, dt):
+    _chk(z_f32, model_out_f32)
+    assert z_f32.dtype == torch.float32 and model_out_f32.dtype == torch.float32
+    assert z_f32.is_contiguous() and model_out_f32.is_contiguous()
+    Bz, Cin = z_f32.shape[:2]
+    Cout = model_out_f32.shape[1]
+    assert model_out_f32.shape[0] == 2 * Bz
+    thw = z_f32[0, 0].numel()
+    lib = _lib.load()
+    _lib.check(lib.vsys_cfg_euler_step(_p(z_f32), _p(model_out_f32), Bz, Cin, Cout, thw, float(guidance), float(dt), _stream()),
+               "vsys_cfg_euler_step")
+    return z_f32
+
+
+def add_rows(x, y):
+    _chk(x, y)
+    _bf16(x, y)
+    assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
+    lib = _lib.load()
+    _lib.check(lib.vsys_add_rows(_p(x), _p(y), x.numel(), _stream()), "vsys_add_rows")
+    return x
+
+
+def copy_4d(src, dst, n0, n1, n2, C, sstr, dstr, n1_valid=None, n2_valid=None):
+    _chk(src, dst)
+    _bf16(src, dst)
+    lib = _lib.load()
+    _lib.check(lib.vsys_copy_4d(_p(src), _p(dst), n0, n1, n2, C, sstr[0], sstr[1], sstr[2], dstr[0], dstr[1], dstr[2],
+                                n1 if n1_valid is None else n1_valid, n2 if n2_valid is None else n2_valid, _stream()),
+               "vsys_copy_4d")
+    return dst
+
+
+def kv_pad_len(kv_len: int) -> int:
+    return (kv_len + 63) // 64 * 64
+
+
+def alloc_kv_buffers(batch, heads, kv_len, device):
+    kv_pad = kv_pad_len(kv_len)
+    kp = torch.zeros(batch, heads, kv_pad, HEAD_DIM, dtype=torch.bfloat16, device=device)
+    vt = torch.zeros(batch, heads, VT_ROWS, kv_pad, dtype=torch.bfloat16, device=device)  # rows 72..95 stay zero
+    return kp, vt
+
+
+def attn_prep_kv(k, v, k_norm_w, kp, vt, batch, heads, kv_len, eps=1e-6):
+    """k, v: 2-D row-strided views [batch*kv_len, >= heads*72] (head h at column h*72)."""
+    _chk(k, v, k_norm_w, kp, vt)
+    _bf16(k, v, k_norm_w, kp, vt)
+    assert k.stride(1) == 1 and v.stride(1) == 1 and kp.is_contiguous() and vt.is_contiguous()
+    kv_pad = kp.shape[2]
+    assert vt.shape[3] == kv_pad and vt.shape[2] == VT_ROWS
+    lib = _lib.load()
+    _lib.check(lib.vsys_attn_prep_kv(_p(k), k.stride(0), _p(v), v.stride(0), _p(k_norm_w), _p(kp), _p(vt), batch, heads,
+                                     kv_len, kv_pad, eps, _stream()), "vsys_attn_prep_kv")
+
+
+def flash_attn(q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
+    """q/out: 2-D row-strided views [batch*q_len, >= heads*72]."""
+    _chk(q, q_norm_w, kp, vt, out)
+    _bf16(q, q_norm_w, kp, vt, out)
+    assert q.stride(1) == 1 and out.stride(1) == 1
+    kv_pad = kp.shape[2]
+    lib = _lib.load()
+    _lib.check(lib.vsys_flash_attn_d72(_p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
+                                       q_len, kv_len, kv_pad, eps, _stream()), "vsys_flash_attn_d72")
+    return out
+
+
+def attn_temporal(qkv, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, B, T, S, heads, eps=1e-6):
+    """qkv [B*T*S, 3C] rows ordered (b,t,s); out [B*T*S, C]."""
+    _chk(qkv, q_norm_w, k_norm_w, rope_cos, rope_sin, out)
+    _bf16(qkv, q_norm_w, k_norm_w, out)
+    assert qkv.stride(1) == 1 and out.stride(1) == 1
+    if rope_cos is not None:
+        assert rope_cos.dtype == torch.float32 and rope_cos.is_contiguous() and rope_cos.shape == (T, HEAD_DIM)
+        assert rope_sin.dtype == torch.float32 and rope_sin.is_contiguous() and rope_sin.shape == (T, HEAD_DIM)
+    lib = _lib.load()
+    _lib.check(lib.vsys_attn_temporal_d72(_p(qkv), qkv.stride(0), C, _p(q_norm_w), _p(k_norm_w), _p(rope_cos), _p(rope_sin),
+                                          _p(out), out.stride(0), B, T, S, heads, eps, _stream()), "vsys_attn_temporal_d72")
+    return out

@@ -1,0 +1,205 @@
+"""Open-Sora pipeline plug-in — host mirror of videosys/pipelines/open_sora/pipeline_open_sora.py
+(OpenSoraPABConfig :32-69, OpenSoraConfig :72-163, OpenSoraPipeline :166-659) for the denoising hot path.
+
+``OpenSoraConfig`` / ``OpenSoraPABConfig`` take the same kwargs with the same defaults, expose ``pipeline_cls`` and
+``num_gpus`` and drop into ``VideoSysEngine(config)`` unchanged.  This round builds the path from text embeddings +
+noise to denoised latents; the T5 text encoder and the VAE decoder are the "next" rows
+(§8f) and are pluggable callables here: ``generate`` accepts ``prompt_embeds``/``prompt_mask`` and returns latents
+when no VAE is attached, and raises a clear error if a raw prompt string arrives without a text encoder.
+No pretrained weights exist offline: ``transformer="synthetic:<seed>"`` (default when the HF name cannot be resolved
+locally) builds seeded random weights of the real STDiT3-XL/2 geometry.
+"""
+from __future__ import annotations
+
+import os
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+
+from . import pab
+from .pab import PABConfig
+from .rflow import RFLOW
+from .stdit3 import STDiT3, STDiT3Config, synth_state_dict
+
+
+class OpenSoraPABConfig(PABConfig):
+    """pipeline_open_sora.py:32-69 — identical defaults (note: mlp_broadcast=True is the reference default and raises
+    in the reference too; use mlp_broadcast=False for attention-only PAB, BASELINE config 3)."""
+
+    def __init__(
+        self,
+        spatial_broadcast: bool = True,
+        spatial_threshold: list = [450, 930],
+        spatial_range: int = 2,
+        temporal_broadcast: bool = True,
+        temporal_threshold: list = [450, 930],
+        temporal_range: int = 4,
+        cross_broadcast: bool = True,
+        cross_threshold: list = [450, 930],
+        cross_range: int = 6,
+        mlp_broadcast: bool = True,
+        mlp_spatial_broadcast_config: dict = None,
+        mlp_temporal_broadcast_config: dict = None,
+    ):
+        default_mlp = {
+            676: {"block": [0, 1, 2, 3, 4], "skip_count": 2},
+            788: {"block": [0, 1, 2, 3, 4], "skip_count": 2},
+            864: {"block": [0, 1, 2, 3, 4], "skip_count": 2},
+        }
+        super().__init__(
+            spatial_broadcast=spatial_broadcast, spatial_threshold=spatial_threshold, spatial_range=spatial_range,
+            temporal_broadcast=temporal_broadcast, temporal_threshold=temporal_threshold, temporal_range=temporal_range,
+            cross_broadcast=cross_broadcast, cross_threshold=cross_threshold, cross_range=cross_range,
+            mlp_broadcast=mlp_broadcast,
+            mlp_spatial_broadcast_config=mlp_spatial_broadcast_config or dict(default_mlp),
+            mlp_temporal_broadcast_config=mlp_temporal_broadcast_config or dict(default_mlp),
+        )
+
+
+class OpenSoraConfig:
+    """pipeline_open_sora.py:72-163 — identical kwargs/defaults."""
+
+    def __init__(
+        self,
+        transformer: str = "hpcai-tech/OpenSora-STDiT-v3",
+        vae: str = "hpcai-tech/OpenSora-VAE-v1.2",
+        text_encoder: str = "DeepFloyd/t5-v1_1-xxl",
+        num_gpus: int = 1,
+        num_sampling_steps: int = 30,
+        cfg_scale: float = 7.0,
+        cpu_offload: bool = False,
+        tiling_size: int = 4,
+        enable_flash_attn: bool = False,
+        enable_pab: bool = False,
+        pab_config: PABConfig = None,
+        **extra,
+    ):
+        self.pipeline_cls = OpenSoraPipeline
+        self.transformer = transformer
+        self.vae = vae
+        self.text_encoder = text_encoder
+        self.num_gpus = num_gpus
+        self.num_sampling_steps = num_sampling_steps
+        self.cfg_scale = cfg_scale
+        self.tiling_size = tiling_size
+        self.cpu_offload = cpu_offload
+        self.enable_flash_attn = enable_flash_attn
+        self.enable_pab = enable_pab
+        self.pab_config = pab_config if pab_config is not None else OpenSoraPABConfig()
+        # extensions (not in the reference): geometry override for tests, e.g. transformer_config=dict(depth=2, ...)
+        self.transformer_config = extra.pop("transformer_config", None)
+        if extra:
+            raise TypeError(f"unexpected OpenSoraConfig kwargs: {sorted(extra)}")
+
+
+@dataclass
+class VideoSysPipelineOutput:
+    """core/pipeline/pipeline.py:47-53."""
+
+    video: torch.Tensor
+
+
+def get_latent_size(num_frames: int, height: int, width: int):
+    """OpenSoraVAE_V1_2.get_latent_size (autoencoder_kl_open_sora.py:706-717): spatial /8; time 17-frame micro
+    batches compress x4 with a causal first frame: 64 frames -> 3*5 + 4 = 19."""
+    micro = 17
+
+    def tlat(n):
+        return -(-n // 4) if n > 1 else 1  # ceil(n/4) per micro batch (time_downsample_factor 4, causal pad)
+
+    if num_frames == 1:
+        t = 1
+    else:
+        t = (num_frames // micro) * tlat(micro) + (tlat(num_frames % micro) if num_frames % micro else 0)
+    return (t, height // 8, width // 8)
+
+
+class OpenSoraPipeline:
+    """The per-rank pipeline object the engine instantiates (engine.py:68-72) and whose ``generate`` it calls."""
+
+    def __init__(self, config: OpenSoraConfig, device=None, text_encoder: Optional[Callable] = None,
+                 vae_decoder: Optional[Callable] = None):
+        self._config = config
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("OpenSoraPipeline needs a HIP device (videosys_amd has no CPU execution path)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._device = torch.device(device)
+        tcfg = STDiT3Config(**(config.transformer_config or {}))
+        self.transformer = STDiT3(tcfg, device=self._device)
+        name = config.transformer
+        if isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "model.safetensors")):
+            from safetensors.torch import load_file
+
+            sd = load_file(os.path.join(name, "model.safetensors"))
+        else:
+            seed = int(name.split(":", 1)[1]) if isinstance(name, str) and name.startswith("synthetic:") else 1234
+            sd = synth_state_dict(tcfg, seed=seed)
+        self.transformer.load_state_dict(sd)
+        self.scheduler = RFLOW(num_sampling_steps=config.num_sampling_steps, cfg_scale=config.cfg_scale,
+                               use_timestep_transform=True)
+        self.text_encoder = text_encoder
+        self.vae_decoder = vae_decoder
+        if config.enable_pab:
+            pab.set_pab_manager(config.pab_config)
+        else:
+            pab.set_pab_manager(None)
+        self._set_parallel()
+
+    def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: bool = False):
+        """pipeline_open_sora.py:253-267: dp=1, sp=world."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if world > 1:
+            self.transformer.enable_parallel(dp_size or 1, sp_size or world, enable_cp)
+
+    def null(self, n):
+        """pipeline_open_sora.py:294-296."""
+        return self.transformer.y_embedder.y_embedding[None].repeat(n, 1, 1)[:, None]
+
+    @torch.no_grad()
+    def generate(self, prompt=None, resolution="480p", aspect_ratio="9:16", num_frames="2s", loop=1, seed: int = -1,
+                 verbose: bool = False, *, height: Optional[int] = None, width: Optional[int] = None,
+                 prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
+                 fps: float = 24.0, output_type: str = "auto"):
+        """pipeline_open_sora.py:426-656 for plain text-to-video.  ``height``/``width``/integer ``num_frames`` give the
+        geometry directly (the reference's "512"/"1:1" table lookup asserts, SURVEY.md §7, so 512x512 cannot be named
+        through it)."""
+        from .utils import set_seed
+
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise RuntimeError("no text encoder attached: pass prompt_embeds=[B,1,L,4096] (+ prompt_mask) — the T5 "
+                                   "encoder is a 'next' row (SURVEY.md §8f) and has no weights offline")
+            prompt_embeds, prompt_mask = self.text_encoder(prompt)
+        if height is None or width is None or not isinstance(num_frames, int):
+            raise ValueError("give the geometry as height=, width=, num_frames=<int>")
+        if seed >= 0:
+            set_seed(seed)
+        pab.update_steps(self._config.num_sampling_steps)
+        self.transformer.reset_pab_state()
+        B = prompt_embeds.shape[0]
+        T, Hl, Wl = get_latent_size(num_frames, height, width)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(seed if seed >= 0 else 0)
+        z = torch.randn(B, self.transformer.in_channels, T, Hl, Wl, generator=g, dtype=torch.float32)
+        z = z.to(torch.bfloat16).float()  # the reference draws z in bf16 (pipeline_open_sora.py:622-624)
+        margs = dict(
+            y=prompt_embeds, mask=prompt_mask,
+            height=torch.tensor([float(height)] * B), width=torch.tensor([float(width)] * B),
+            num_frames=torch.tensor([float(num_frames)] * B), fps=torch.tensor([float(fps)] * B),
+        )
+        y_null = self.null(B)
+        samples = self.scheduler.sample(self.transformer, z, margs, y_null, device=self._device, progress=verbose)
+        if self.vae_decoder is None or output_type == "latent":
+            return VideoSysPipelineOutput(video=samples)
+        video = self.vae_decoder(samples.to(torch.bfloat16), num_frames=num_frames)
+        video = (video.clamp(-1, 1) * 0.5 + 0.5).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
+        return VideoSysPipelineOutput(video=video)
+
+    def save_video(self, video, output_path):
+        from .utils import save_video
+
+        save_video(video, output_path)

@@ -1,0 +1,73 @@
+"""Rectified-flow sampler — host mirror of videosys/schedulers/scheduling_rflow_open_sora.py (RFLOW :164-257,
+timestep_transform :47-70).  Same constructor kwargs and ``sample(model, z, model_args, y_null, device, ...)``
+signature; the per-step CFG combine + Euler update is one HIP kernel (vsys_cfg_euler_step) and the timestep
+schedule stays on the host so nothing in the loop syncs the device (the reference calls ``t.item()`` per step, :222).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def timestep_transform(t, model_kwargs, base_resolution=512 * 512, base_num_frames=1, scale=1.0, num_timesteps=1):
+    """scheduling_rflow_open_sora.py:47-70 (host scalars/tensors)."""
+    t = t / num_timesteps
+    resolution = model_kwargs["height"] * model_kwargs["width"]
+    ratio_space = (resolution / base_resolution).sqrt()
+    if model_kwargs["num_frames"][0] == 1:
+        num_frames = torch.ones_like(model_kwargs["num_frames"])
+    else:
+        num_frames = model_kwargs["num_frames"] // 17 * 5
+    ratio_time = (num_frames / base_num_frames).sqrt()
+    ratio = ratio_space * ratio_time * scale
+    new_t = ratio * t / (1 + (ratio - 1) * t)
+    return new_t * num_timesteps
+
+
+class RFLOW:
+    def __init__(self, num_sampling_steps=10, num_timesteps=1000, cfg_scale=4.0, use_discrete_timesteps=False,
+                 use_timestep_transform=False, **kwargs):
+        self.num_sampling_steps = num_sampling_steps
+        self.num_timesteps = num_timesteps
+        self.cfg_scale = cfg_scale
+        self.use_discrete_timesteps = use_discrete_timesteps
+        self.use_timestep_transform = use_timestep_transform
+
+    def prepare_timesteps(self, batch, model_args):
+        """:208-213 — host tensors [batch] per step."""
+        ts = [(1.0 - i / self.num_sampling_steps) * self.num_timesteps for i in range(self.num_sampling_steps)]
+        if self.use_discrete_timesteps:
+            ts = [int(round(t)) for t in ts]
+        ts = [torch.tensor([t] * batch, dtype=torch.float32) for t in ts]
+        if self.use_timestep_transform:
+            host_args = {k: model_args[k].detach().to("cpu").float() for k in ("height", "width", "num_frames")}
+            ts = [timestep_transform(t, host_args, num_timesteps=self.num_timesteps) for t in ts]
+        return ts
+
+    @torch.no_grad()
+    def sample(self, model, z, model_args, y_null, device=None, mask=None, guidance_scale=None, progress=True,
+               verbose=False):
+        if mask is not None:
+            raise NotImplementedError("mask-conditioned sampling (image/video conditioning) is outside the MI355X hot path")
+        if guidance_scale is None:
+            guidance_scale = self.cfg_scale
+        model_args = dict(model_args)
+        model_args["y"] = torch.cat([model_args["y"], y_null.to(model_args["y"].dtype).to(model_args["y"].device)], 0)
+        B = z.shape[0]
+        timesteps = self.prepare_timesteps(B, model_args)
+        dtype = model.x_embedder.proj.weight.dtype
+        model_args["all_timesteps"] = [int(t.to(dtype)[0]) for t in timesteps]
+        fwd_args = {k: v for k, v in model_args.items() if k != "num_frames"}
+        for k in ("height", "width", "fps"):  # model is called on the CFG-doubled batch
+            if k in fwd_args and fwd_args[k] is not None and fwd_args[k].shape[0] == B:
+                fwd_args[k] = torch.cat([fwd_args[k], fwd_args[k]], 0)
+        z = z.to(device=model.device, dtype=torch.float32).contiguous().clone()
+        for i, t in enumerate(timesteps):
+            z_in = torch.cat([z, z], 0)
+            tt = torch.cat([t, t], 0)
+            out = model(z_in, tt, **fwd_args)
+            dt = timesteps[i] - timesteps[i + 1] if i < len(timesteps) - 1 else timesteps[i]
+            dt = float(dt[0]) / self.num_timesteps
+            ops.cfg_euler_step(z, out, guidance_scale, dt)
+        return z

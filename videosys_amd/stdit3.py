@@ -1,0 +1,476 @@
+"""STDiT3 (Open-Sora v1.2) denoise step on MI355X — host mirror of
+videosys/models/transformers/open_sora_transformer_3d.py (reference :318-667).
+
+Same constructor config, same ``forward(x, timestep, y, all_timesteps=None, mask=None, x_mask=None, fps=None,
+height=None, width=None, **kwargs)`` signature and return (``[B, 2*C_in, T, H, W]`` fp32), same state-dict key names
+as the HF checkpoint ``hpcai-tech/OpenSora-STDiT-v3`` — but every tensor op of the per-step path is a call into
+libvideosys_amd.so (hand-written gfx950 kernels behind the C ABI of include/videosys_amd.h).  PyTorch only owns the
+HBM buffers, the stream and torch.distributed.  There is no eager fallback: on a machine without the library or
+without a HIP device, constructing the model raises.
+
+Differences from the reference that do not change results (SURVEY.md §7 "hard parts"):
+  * step-invariant work is hoisted: y_embedder(y), the 2*depth kv_linear(y) projections and their attention layouts
+    are computed once per prompt and cached (the reference recomputes them every step, attentions.py:157);
+  * the 2*depth x 6 modulation vectors of a step come from one kernel (open_sora_transformer_3d.py:177-179);
+  * no torch.utils.checkpoint wrapper around blocks (core/dcp/recompute.py:141-153 is pure overhead under no_grad);
+  * PAB decisions use the host-side integer timestep (no ``int(timestep[0])`` device sync per block);
+  * ``all_timesteps`` IS forwarded to the blocks (the reference forgets to: SURVEY.md §0.9);
+  * x_mask (image/video conditioning masks) is not supported on this path and raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from . import dsp, ops, pab
+
+
+class STDiT3Config:
+    """Same kwargs/defaults as the reference STDiT3Config (open_sora_transformer_3d.py:318-361)."""
+
+    model_type = "STDiT3"
+
+    def __init__(self, input_size=(None, None, None), input_sq_size=512, in_channels=4, patch_size=(1, 2, 2),
+                 hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4.0, class_dropout_prob=0.1, pred_sigma=True,
+                 drop_path=0.0, caption_channels=4096, model_max_length=300, qk_norm=True, enable_flash_attn=False,
+                 only_train_temporal=False, freeze_y_embedder=False, skip_y_embedder=False, **kwargs):
+        self.input_size = input_size
+        self.input_sq_size = input_sq_size
+        self.in_channels = in_channels
+        self.patch_size = tuple(patch_size)
+        self.hidden_size = hidden_size
+        self.depth = depth
+        self.num_heads = num_heads
+        self.mlp_ratio = mlp_ratio
+        self.class_dropout_prob = class_dropout_prob
+        self.pred_sigma = pred_sigma
+        self.drop_path = drop_path
+        self.caption_channels = caption_channels
+        self.model_max_length = model_max_length
+        self.qk_norm = qk_norm
+        self.enable_flash_attn = enable_flash_attn
+        self.only_train_temporal = only_train_temporal
+        self.freeze_y_embedder = freeze_y_embedder
+        self.skip_y_embedder = skip_y_embedder
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+def pos_embed_2d(dim: int, h: int, w: int, scale: float, base_size: int) -> torch.Tensor:
+    """Constant table of OpenSoraPositionEmbedding2D (modules/embeddings.py:231-272); built once per resolution on
+    the host exactly as the reference does (it lru_caches the same table), then uploaded."""
+    half = dim // 2
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, half, 2).float() / half))
+    gh = torch.arange(h) / scale
+    gw = torch.arange(w) / scale
+    gh = gh * (base_size / h)
+    gw = gw * (base_size / w)
+    gh, gw = torch.meshgrid(gw, gh, indexing="ij")
+    gh = gh.t().reshape(-1)
+    gw = gw.t().reshape(-1)
+
+    def sincos(t):
+        out = torch.einsum("i,d->id", t, inv_freq)
+        return torch.cat((torch.sin(out), torch.cos(out)), dim=-1)
+
+    return torch.cat([sincos(gh), sincos(gw)], dim=-1)  # [h*w, dim]
+
+
+def rope_tables(freqs: torch.Tensor, T: int, pos_dtype: torch.dtype):
+    """cos/sin tables [T, head_dim] of rotary_embedding_torch.RotaryEmbedding (third-party; positions arange(T) in the
+    activation dtype, angles in the dtype of ``freqs`` — so a bf16-cast model reproduces the reference's bf16 angles)."""
+    seq = torch.arange(T, dtype=pos_dtype)
+    ang = torch.einsum("p,f->pf", seq.type(freqs.dtype), freqs)
+    ang = ang.repeat_interleave(2, dim=-1)
+    return ang.cos().float().contiguous(), ang.sin().float().contiguous()
+
+
+class _BlockState:
+    """PAB bookkeeping of one STDiT3Block (open_sora_transformer_3d.py:141-147)."""
+
+    def __init__(self, block_idx, temporal):
+        self.block_idx = block_idx
+        self.temporal = temporal
+        self.attn_count = 0
+        self.cross_count = 0
+        self.mlp_count = 0
+        self.last_attn: Optional[torch.Tensor] = None
+        self.last_cross: Optional[torch.Tensor] = None
+
+
+class STDiT3:
+    """Drop-in for the reference STDiT3 at the operator boundary ``model(z_in, t, **model_args)``."""
+
+    config_class = STDiT3Config
+
+    def __init__(self, config: STDiT3Config, device="cuda", dtype=torch.bfloat16):
+        if dtype != torch.bfloat16:
+            raise ValueError("the MI355X path computes in bf16 (fp32 accumulate); got %s" % dtype)
+        from . import _lib
+
+        _lib.load()  # fail loudly if the HIP library is missing
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.pred_sigma = config.pred_sigma
+        self.in_channels = config.in_channels
+        self.out_channels = config.in_channels * 2 if config.pred_sigma else config.in_channels
+        self.depth = config.depth
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_heads
+        self.patch_size = tuple(config.patch_size)
+        self.input_sq_size = config.input_sq_size
+        if self.hidden_size // self.num_heads != ops.HEAD_DIM:
+            raise ValueError("attention kernels are built for head_dim 72 (STDiT3-XL/2)")
+        if self.patch_size[0] != 1:
+            raise ValueError("temporal patch size must be 1")
+        self.w: Dict[str, torch.Tensor] = {}
+        self.rope_freqs: Optional[torch.Tensor] = None  # kept in the checkpoint dtype on the host
+        self.parallel_manager = SimpleNamespace(sp_size=1, cp_size=1, dp_size=1, dp_rank=0, sp_group=None, cp_group=None)
+        self._sp: Optional[dsp.SequenceParallel] = None
+        self.states = [_BlockState(i // 2, bool(i % 2)) for i in range(2 * self.depth)]
+        self._pos_cache = {}
+        self._rope_cache = {}
+        self._text_cache = None
+        self._fps_cache = {}
+        self._ws = {}
+        # attribute paths the reference's callers read (scheduling_rflow_open_sora.py:221, pipeline_open_sora.py:295)
+        self.x_embedder = SimpleNamespace(proj=SimpleNamespace(weight=torch.empty(0, dtype=dtype)))
+        self.y_embedder = SimpleNamespace(y_embedding=None)
+
+    # ------------------------------------------------------------------ weights
+    def block_prefix(self, i):
+        return f"{'temporal' if i % 2 else 'spatial'}_blocks.{i // 2}"
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        need = self.expected_keys()
+        missing = [k for k in need if k not in sd]
+        if strict and missing:
+            raise KeyError(f"missing keys: {missing[:8]}{'...' if len(missing) > 8 else ''}")
+        for k in need:
+            if k not in sd:
+                continue
+            t = sd[k]
+            if k == "rope.freqs":
+                self.rope_freqs = t.detach().cpu().clone()
+                continue
+            if k == "x_embedder.proj.weight":
+                t = t.reshape(t.shape[0], -1)
+            self.w[k] = t.detach().to(device=self.device, dtype=self.dtype).contiguous()
+        tabs = [self.w[self.block_prefix(i) + ".scale_shift_table"].reshape(-1) for i in range(2 * self.depth)]
+        self.w["_all_tables"] = torch.stack(tabs).contiguous()  # [2*depth, 6*C] in execution order
+        self.x_embedder.proj.weight = self.w["x_embedder.proj.weight"]
+        self.y_embedder.y_embedding = self.w["y_embedder.y_embedding"]
+        self._text_cache = None
+        self._rope_cache = {}
+        return self
+
+    def expected_keys(self):
+        keys = ["x_embedder.proj.weight", "x_embedder.proj.bias", "t_block.1.weight", "t_block.1.bias",
+                "y_embedder.y_proj.fc1.weight", "y_embedder.y_proj.fc1.bias", "y_embedder.y_proj.fc2.weight",
+                "y_embedder.y_proj.fc2.bias", "y_embedder.y_embedding", "rope.freqs",
+                "final_layer.scale_shift_table", "final_layer.linear.weight", "final_layer.linear.bias"]
+        for e in ("t_embedder", "fps_embedder"):
+            for l in ("0", "2"):
+                keys += [f"{e}.mlp.{l}.weight", f"{e}.mlp.{l}.bias"]
+        for i in range(2 * self.depth):
+            p = self.block_prefix(i)
+            keys += [p + ".scale_shift_table", p + ".attn.q_norm.weight", p + ".attn.k_norm.weight"]
+            for l in ("attn.qkv", "attn.proj", "cross_attn.q_linear", "cross_attn.kv_linear", "cross_attn.proj", "mlp.fc1",
+                      "mlp.fc2"):
+                keys += [f"{p}.{l}.weight", f"{p}.{l}.bias"]
+        return keys
+
+    def state_dict(self):
+        sd = {k: v for k, v in self.w.items() if not k.startswith("_")}
+        sd["rope.freqs"] = self.rope_freqs
+        return sd
+
+    # ------------------------------------------------------------------ parallel
+    def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None, parallel_mgr=None, copy_executor=None):
+        """open_sora_transformer_3d.py:466-482.  cp (CFG batch split) is not built in this round: enable_cp is accepted
+        and ignored exactly like the reference's default (pipeline_open_sora.py:254 passes False)."""
+        if parallel_mgr is not None:
+            self.parallel_manager = parallel_mgr
+        else:
+            self.parallel_manager = dsp.ParallelManager(dp_size or 1, 1, sp_size or 1)
+        if self.parallel_manager.sp_size > 1:
+            kw = {} if copy_executor is None else {"copy_executor": copy_executor}
+            self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
+        else:
+            self._sp = None
+
+    # ------------------------------------------------------------------ helpers
+    def get_dynamic_size(self, x):
+        _, _, T, H, W = x.shape
+        p = self.patch_size
+        return (-(-T // p[0]), -(-H // p[1]), -(-W // p[2]))
+
+    def _buf(self, name, shape):
+        b = self._ws.get(name)
+        n = 1
+        for s in shape:
+            n *= s
+        if b is None or b.numel() < n:
+            b = torch.empty(n, dtype=self.dtype, device=self.device)
+            self._ws[name] = b
+        return b[:n].view(*shape)
+
+    def _pos(self, Hp, Wp, height, width):
+        S = Hp * Wp
+        base_size = round(S**0.5)
+        scale = ((float(height) * float(width)) ** 0.5) / self.input_sq_size
+        key = (Hp, Wp, scale, base_size)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = pos_embed_2d(self.hidden_size, Hp, Wp, scale, base_size).to(
+                device=self.device, dtype=self.dtype).contiguous()
+        return self._pos_cache[key]
+
+    def _rope(self, T):
+        if T not in self._rope_cache:
+            c, s = rope_tables(self.rope_freqs, T, self.dtype if self.rope_freqs.dtype != torch.float32 else torch.float32)
+            self._rope_cache[T] = (c.to(self.device), s.to(self.device))
+        return self._rope_cache[T]
+
+    def _embed_vec(self, vals_f32, prefix):
+        w = self.w
+        f = ops.timestep_embedding(vals_f32.contiguous(), 256)
+        h = ops.linear_small(f, w[prefix + ".mlp.0.weight"], w[prefix + ".mlp.0.bias"], act_out=ops.ACT_SILU)
+        return ops.linear_small(h, w[prefix + ".mlp.2.weight"], w[prefix + ".mlp.2.bias"])
+
+    def _encode_text(self, y, mask):
+        """encode_text (open_sora_transformer_3d.py:526-537) + every block's kv_linear and attention layout, cached
+        while the same (y, mask) tensors are presented (they are constant over the steps of one generate())."""
+        key = (y.data_ptr(), tuple(y.shape), y._version, None if mask is None else (mask.data_ptr(), mask._version))
+        if self._text_cache is not None and self._text_cache["key"] == key:
+            return self._text_cache
+        w = self.w
+        B, _, L, Cc = y.shape
+        C, H = self.hidden_size, self.num_heads
+        yb = y.to(device=self.device, dtype=self.dtype).reshape(B * L, Cc).contiguous()
+        h = ops.linear_small(yb, w["y_embedder.y_proj.fc1.weight"], w["y_embedder.y_proj.fc1.bias"], act_out=ops.ACT_GELU_TANH)
+        ye = ops.linear_small(h, w["y_embedder.y_proj.fc2.weight"], w["y_embedder.y_proj.fc2.bias"]).view(B, L, C)
+        if mask is not None:
+            m = mask
+            if m.shape[0] != B:
+                m = m.repeat(B // m.shape[0], 1)
+            m = m.reshape(B, L)
+            y_lens = [int(v) for v in m.sum(dim=1).tolist()]
+            if len(set(y_lens)) != 1:
+                raise ValueError("cross-attention needs equal text lengths per sample (as the reference's torch_impl view does)")
+            idx = torch.nonzero(m.reshape(-1) != 0, as_tuple=False).reshape(-1).to(self.device)
+            yp = ye.reshape(B * L, C).index_select(0, idx).contiguous()  # masked_select packing
+        else:
+            y_lens = [L] * B
+            yp = ye.reshape(B * L, C)
+        Lk = y_lens[0]
+        nblk = 2 * self.depth
+        kv_pad = ops.kv_pad_len(Lk)
+        kps = torch.zeros(nblk, B, H, kv_pad, ops.HEAD_DIM, dtype=self.dtype, device=self.device)
+        vts = torch.zeros(nblk, B, H, ops.VT_ROWS, kv_pad, dtype=self.dtype, device=self.device)
+        kv = torch.empty(B * Lk, 2 * C, dtype=self.dtype, device=self.device)
+        for i in range(nblk):
+            p = self.block_prefix(i) + ".cross_attn.kv_linear"
+            if (2 * C) % 192 == 0 and C % 64 == 0:
+                ops.gemm(yp, w[p + ".weight"], w[p + ".bias"], out=kv)
+            else:
+                ops.linear_small(yp, w[p + ".weight"], w[p + ".bias"], out=kv)
+            ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kps[i], vts[i], B, H, Lk)
+        self._text_cache = dict(key=key, y_lens=y_lens, kp=kps, vt=vts, Lk=Lk)
+        return self._text_cache
+
+    # ------------------------------------------------------------------ forward
+    @torch.no_grad()
+    def forward(self, x, timestep, y, all_timesteps=None, mask=None, x_mask=None, fps=None, height=None, width=None,
+                **kwargs):
+        if x_mask is not None:
+            raise NotImplementedError("x_mask (reference/mask conditioning) is outside the MI355X hot path")
+        w, C, H = self.w, self.hidden_size, self.num_heads
+        B, _, Tx, Hx, Wx = x.shape
+        T, Hp, Wp = self.get_dynamic_size(x)
+        S = Hp * Wp
+        dev = self.device
+
+        # ---- per-step vectors (tiny): t, fps, t_mlp and all modulation rows
+        # timestep.to(dtype) (:562) then .float() inside the embedder.  The sampler hands timesteps over as HOST tensors,
+        # so the integer the PAB policy needs is available without a device sync.
+        ts_host = timestep.detach().to("cpu").to(self.dtype).float()
+        ts = ts_host.to(dev)
+        t = self._embed_vec(ts, "t_embedder")
+        fkey = tuple(float(v) for v in fps.reshape(-1).tolist()) + (B,)
+        if fkey not in self._fps_cache:
+            f = fps.to(dev).float().reshape(-1)
+            if f.numel() != B:
+                f = f.repeat(B // f.numel())
+            self._fps_cache[fkey] = self._embed_vec(f, "fps_embedder")
+        ops.add_rows(t, self._fps_cache[fkey])
+        t_mlp = ops.linear_small(t, w["t_block.1.weight"], w["t_block.1.bias"], act_in=ops.ACT_SILU)  # [B, 6C]
+        mod = ops.mod_table(w["_all_tables"], t_mlp)  # [2*depth, B, 6C]
+
+        txt = self._encode_text(y, mask)
+
+        # ---- x embed (+ pos)
+        pos = self._pos(Hp, Wp, height[0], width[0])
+        xz = x.to(device=dev, dtype=torch.float32).contiguous()
+        xe = ops.patch_embed(xz, w["x_embedder.proj.weight"], w["x_embedder.proj.bias"], pos, B, self.patch_size, C)
+
+        sp = self._sp
+        S_full = S
+        if sp is not None:
+            xe = sp.split(xe)  # [B, T, S/P, C]
+            S = xe.shape[2]
+        xcur = xe.view(B * T * S, C)
+
+        timestep_int = int(ts_host[0]) if pab.enable_pab() else None
+        valid_depth = kwargs.get("valid_depth", self.depth)
+        for d in range(valid_depth):
+            for i in (2 * d, 2 * d + 1):
+                xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, timestep_int, all_timesteps)
+
+        if sp is not None:
+            xg = sp.gather(xcur.view(B, T, S, C), S_full)
+            xcur = xg.view(B * T * S_full, C)
+            S = S_full
+
+        out = ops.final_layer(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
+                              w["final_layer.linear.bias"], B, T, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
+        return out
+
+    __call__ = forward
+
+    def _block(self, i, x, mod_i, txt, B, T, S, S_full, timestep_int, all_timesteps):
+        """STDiT3Block.forward (open_sora_transformer_3d.py:162-286). x: [B*T*S, C] (S = local shard), updated in place."""
+        w, C, H = self.w, self.hidden_size, self.num_heads
+        p = self.block_prefix(i)
+        st = self.states[i]
+        temporal = st.temporal
+        N = B * T * S
+        C6 = 6 * C
+        shift_msa, scale_msa, gate_msa = mod_i[0, 0:C], mod_i[0, C:2 * C], mod_i[0, 2 * C:3 * C]
+        shift_mlp, scale_mlp, gate_mlp = mod_i[0, 3 * C:4 * C], mod_i[0, 4 * C:5 * C], mod_i[0, 5 * C:6 * C]
+        use_pab = pab.enable_pab()
+        sp = self._sp
+
+        # ---------------- self attention
+        broadcast_attn = False
+        if use_pab:
+            fn = pab.if_broadcast_temporal if temporal else pab.if_broadcast_spatial
+            broadcast_attn, st.attn_count = fn(timestep_int, st.attn_count)
+        if broadcast_attn:
+            ops.add_rows(x, st.last_attn)
+        else:
+            xm = ops.adaln_modulate(x, shift_msa, scale_msa, T * S, C6, out=self._buf("xm", (N, C)))
+            aux = None
+            if use_pab:
+                if st.last_attn is None or st.last_attn.shape != x.shape:
+                    st.last_attn = torch.empty_like(x)
+                aux = st.last_attn
+            if temporal:
+                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (N, 3 * C)))
+                ao = self._buf("attn_out", (N, C))
+                cos, sin = self._rope(T)
+                ops.attn_temporal(qkv, C, w[p + ".attn.q_norm.weight"], w[p + ".attn.k_norm.weight"], cos, sin, ao, B, T, S, H)
+            else:
+                if sp is not None and T > 1:
+                    xt = sp.to_temporal_shard(xm.view(B, T, S, C), S_full)  # [B, Tp, S_full, C]
+                    Tp = xt.shape[1]
+                    xa, Ta, Sa = xt.view(B * Tp * S_full, C), Tp, S_full
+                elif sp is not None:
+                    raise NotImplementedError("DSP image case (T == 1, batch scatter) is not built")
+                else:
+                    xa, Ta, Sa = xm, T, S
+                Na = B * Ta * Sa
+                qkv = ops.gemm(xa, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (Na, 3 * C)))
+                kp, vt = self._kv_spatial(B * Ta, Sa)
+                ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * Ta, H, Sa)
+                ao = self._buf("attn_out", (Na, C))
+                ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * Ta, H, Sa, Sa)
+                if sp is not None:
+                    ao = sp.to_spatial_shard(ao.view(B, Ta, Sa, C), T, S, out=self._buf("attn_back", (B, T, S, C))).view(N, C)
+            ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
+                     gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
+
+        # ---------------- cross attention (no norm, no modulation, no gate)
+        broadcast_cross = False
+        if use_pab:
+            broadcast_cross, st.cross_count = pab.if_broadcast_cross(timestep_int, st.cross_count)
+        if broadcast_cross:
+            ops.add_rows(x, st.last_cross)
+        else:
+            q = ops.gemm(x, w[p + ".cross_attn.q_linear.weight"], w[p + ".cross_attn.q_linear.bias"], out=self._buf("xm", (N, C)))
+            ao = self._buf("attn_out", (N, C))
+            ops.flash_attn(q, None, txt["kp"][i], txt["vt"][i], ao, B, H, T * S, txt["Lk"])
+            aux = None
+            if use_pab:
+                if st.last_cross is None or st.last_cross.shape != x.shape:
+                    st.last_cross = torch.empty_like(x)
+                aux = st.last_cross
+            ops.gemm(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], epilogue=ops.EPI_GATE_RES,
+                     res=x, aux=aux, out=x)
+
+        # ---------------- MLP
+        if use_pab and pab.PAB_MANAGER.config.mlp_broadcast:
+            raise NotImplementedError("PAB mlp_broadcast: the reference path raises TypeError here (SURVEY.md §0.9); "
+                                      "attention-only PAB (mlp_broadcast=False) is what BASELINE config 3 names")
+        xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, T * S, C6, out=self._buf("xm", (N, C)))
+        hdim = w[p + ".mlp.fc1.weight"].shape[0]
+        hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
+                        out=self._buf("mlp_h", (N, hdim)))
+        ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
+                 gate_stride=C6, rows_per_sample=T * S, res=x, out=x)
+        return x
+
+    def _kv_spatial(self, batch, kv_len):
+        key = ("kv_spatial", batch, kv_len)
+        if key not in self._ws:
+            self._ws[key] = ops.alloc_kv_buffers(batch, self.num_heads, kv_len, self.device)
+        return self._ws[key]
+
+    def reset_pab_state(self):
+        for st in self.states:
+            st.attn_count = st.cross_count = st.mlp_count = 0
+
+
+def synth_state_dict(config: STDiT3Config, seed: int = 1234) -> Dict[str, torch.Tensor]:
+    """Seeded random-init weights with the checkpoint's key names/shapes (no pretrained weights offline).
+    Generated on the host CPU generator so every rank / the oracle see identical values."""
+    g = torch.Generator().manual_seed(seed)
+    C, D = config.hidden_size, config.hidden_size // config.num_heads
+    Hm = int(config.hidden_size * config.mlp_ratio)
+    out_ch = config.in_channels * 2 if config.pred_sigma else config.in_channels
+    sd: Dict[str, torch.Tensor] = {}
+
+    def lin(name, n_out, n_in):
+        s = min(0.08, 1.0 / math.sqrt(n_in))
+        sd[name + ".weight"] = torch.randn(n_out, n_in, generator=g) * s
+        sd[name + ".bias"] = torch.randn(n_out, generator=g) * 0.02
+
+    sd["x_embedder.proj.weight"] = torch.randn(C, config.in_channels, *config.patch_size, generator=g) * 0.1
+    sd["x_embedder.proj.bias"] = torch.randn(C, generator=g) * 0.02
+    for e in ("t_embedder", "fps_embedder"):
+        lin(e + ".mlp.0", C, 256)
+        lin(e + ".mlp.2", C, C)
+    lin("t_block.1", 6 * C, C)
+    lin("y_embedder.y_proj.fc1", C, config.caption_channels)
+    lin("y_embedder.y_proj.fc2", C, C)
+    sd["y_embedder.y_embedding"] = torch.randn(config.model_max_length, config.caption_channels, generator=g) / config.caption_channels**0.5
+    sd["rope.freqs"] = 1.0 / (10000 ** (torch.arange(0, D, 2)[: (D // 2)].float() / D))
+    for kind in ("spatial_blocks", "temporal_blocks"):
+        for i in range(config.depth):
+            p = f"{kind}.{i}"
+            sd[p + ".scale_shift_table"] = torch.randn(6, C, generator=g) / C**0.5
+            lin(p + ".attn.qkv", 3 * C, C)
+            sd[p + ".attn.q_norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+            sd[p + ".attn.k_norm.weight"] = 1 + 0.1 * torch.randn(D, generator=g)
+            lin(p + ".attn.proj", C, C)
+            lin(p + ".cross_attn.q_linear", C, C)
+            lin(p + ".cross_attn.kv_linear", 2 * C, C)
+            lin(p + ".cross_attn.proj", C, C)
+            lin(p + ".mlp.fc1", Hm, C)
+            lin(p + ".mlp.fc2", C, Hm)
+    sd["final_layer.scale_shift_table"] = torch.randn(2, C, generator=g) / C**0.5
+    lin("final_layer.linear", int(math.prod(config.patch_size)) * out_ch, C)
+    return sd
