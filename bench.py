@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""bench.py — BASELINE metric on MI355X: videos/min and sec/denoise-step for Open-Sora v1.2 STDiT3-XL/2 at
+512x512x64f (latent [4,19,64,64] -> 19,456 tokens, CFG batch 2 -> 38,912 token rows, 300 text tokens), bf16.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE denoise step: STDiT3 forward on the CFG-doubled batch (28 spatial + 28 temporal blocks, all GEMMs,
+attention, AdaLN, final layer) + the CFG/Euler latent update, inputs resident in HBM, synthetic latents / text
+embeddings / random-init weights of the real geometry (no datasets or checkpoints offline).  N > 1 shards ONE video
+over the N GPUs with Dynamic Sequence Parallelism (strong scaling).  ``value`` = 60 / (30 * sec_per_step): videos per
+minute of the 30-step denoising loop (DiT only — T5 text encode and VAE decode are the "next" rows of SURVEY.md §8f and
+are not in the number; said so in config).
+
+Extra objects on the JSON line:
+  roofline      dominant kernel = the bf16 MFMA GEMM family (91 % of the step's FLOPs): algorithmic FLOPs per launch /
+                average launch duration measured with HIP events on the launch stream in an instrumented replay of
+                the same steps; peak 2500 TFLOP/s dense bf16 (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (a port of the reference's fp32 PyTorch path) timed on this box's host cores on a
+                bounded sample (one block pair of the same geometry), extrapolated to the full step.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEPS_PER_VIDEO = 30
+PEAK_BF16_TFLOPS = 2500.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--depth", type=int, default=28, help="debug only; the reported config is depth 28")
+    ap.add_argument("--pab", action="store_true", help="BASELINE config 3: attention-only PAB (reported as a separate workload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--text-len", type=int, default=300)
+    return ap.parse_args()
+
+
+def gemm_flops_per_step(N, C, L, B, depth):
+    """Algorithmic GEMM FLOPs of one step (2*m*n*k), per launch shape: qkv, proj, q_cross, cross proj, fc1, fc2."""
+    per_block = [(N, 3 * C, C), (N, C, C), (N, C, C), (N, C, C), (N, 4 * C, C), (N, C, 4 * C)]
+    launches = [(m, n, k) for (m, n, k) in per_block] * (2 * depth)
+    return launches
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs MI355X devices"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import __graft_entry__ as ge
+
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+        dist.barrier()
+
+    from videosys_amd import ops, pab
+    from videosys_amd.pipeline_open_sora import OpenSoraPABConfig, get_latent_size
+    from videosys_amd.rflow import RFLOW
+    from videosys_amd.stdit3 import STDiT3, STDiT3Config, synth_state_dict
+
+    # ---- workload: BASELINE config 2 (config 3 with --pab)
+    frames, height, width = 64, 512, 512
+    T, Hl, Wl = get_latent_size(frames, height, width)
+    cfg = STDiT3Config(depth=args.depth)
+    model = STDiT3(cfg, device=dev)
+    model.load_state_dict(synth_state_dict(cfg, seed=1234))
+    if world > 1:
+        model.enable_parallel(dp_size=1, sp_size=world)
+    if args.pab:
+        pab.set_pab_manager(OpenSoraPABConfig(mlp_broadcast=False))
+        pab.update_steps(STEPS_PER_VIDEO)
+    g = torch.Generator().manual_seed(0)
+    z = torch.randn(1, 4, T, Hl, Wl, generator=g).to(torch.bfloat16).float().to(dev)
+    L = args.text_len
+    y = (torch.randn(1, 1, 300, cfg.caption_channels, generator=g) * 0.1).to(torch.bfloat16)
+    mask = torch.zeros(1, 300, dtype=torch.long)
+    mask[:, :L] = 1
+    y_null = model.y_embedder.y_embedding[None, None].cpu()
+    yy = torch.cat([y, y_null.to(y.dtype)], 0).to(dev)
+    sched = RFLOW(num_sampling_steps=STEPS_PER_VIDEO, cfg_scale=7.0, use_timestep_transform=True)
+    margs = dict(height=torch.tensor([float(height)]), width=torch.tensor([float(width)]),
+                 num_frames=torch.tensor([float(frames)]))
+    timesteps = sched.prepare_timesteps(1, margs)
+    kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([float(height)] * 2),
+              width=torch.tensor([float(width)] * 2))
+
+    def one_step(i):
+        t = timesteps[i % STEPS_PER_VIDEO]
+        out = model(torch.cat([z, z], 0), torch.cat([t, t], 0), yy, **kw)
+        nxt = timesteps[(i + 1) % STEPS_PER_VIDEO] if (i % STEPS_PER_VIDEO) < STEPS_PER_VIDEO - 1 else torch.zeros(1)
+        dt = float(t[0] - nxt[0]) / 1000.0
+        ops.cfg_euler_step(z, out, 7.0, dt)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(args.warmup + i)
+    barrier()
+    dt_s = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+
+        tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt_s = float(tt.item())
+    step_s = dt_s / args.steps
+
+    # ---- roofline of the dominant kernel family (instrumented replay; HIP events on the launch stream)
+    roof = None
+    if rank == 0:
+        ev = []
+        real_gemm = ops.gemm
+
+        def timed_gemm(x, w, bias=None, **k):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = real_gemm(x, w, bias, **k)
+            e.record()
+            ev.append((s, e, 2.0 * x.shape[0] * w.shape[0] * x.shape[1], k.get("epilogue", 0)))
+            return r
+
+    barrier()
+    nrep = min(args.steps, 3)
+    if rank == 0:
+        ops.gemm = timed_gemm  # every rank replays the steps (DSP collectives); only rank 0 is instrumented
+    try:
+        for i in range(nrep):
+            one_step(i)
+        torch.cuda.synchronize()
+    finally:
+        if rank == 0:
+            ops.gemm = real_gemm
+    if rank == 0:
+        # drop the once-per-prompt kv_linear launches (none after warm-up) and aggregate
+        tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in ev)
+        tot_fl = sum(f for _, _, f, _ in ev)
+        n = len(ev)
+        by_epi = {}
+        for s, e, f, epi in ev:
+            a = by_epi.setdefault(int(epi), [0.0, 0.0, 0])
+            a[0] += s.elapsed_time(e)
+            a[1] += f
+            a[2] += 1
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        roof = {
+            "bound": "mfma", "kernel": "vsys::gemm_256x192_kernel<EPI> (bf16 MFMA 32x32x16, all epilogues)",
+            "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches_per_step": n // nrep, "avg_launch_ms": round(tot_ms / n, 4),
+            "algorithmic_gflop_per_launch": round(tot_fl / n / 1e9, 2),
+            "gemm_ms_per_step": round(tot_ms / nrep, 2),
+            "per_epilogue_tflops": {str(k): round(v[1] / (v[0] * 1e-3) / 1e12, 1) for k, v in by_epi.items()},
+        }
+    if world > 1:
+        barrier()
+
+    # ---- CPU baseline (rank 0, N == 1 only): oracle = fp32 port of the reference path, bounded sample
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pab:
+        cpu = cpu_baseline(cfg, T, Hl, Wl, L)
+
+    if rank == 0:
+        vpm = 60.0 / (STEPS_PER_VIDEO * step_s)
+        line = {
+            "metric": "videos/min (Open-Sora 512x512x64f, 30 denoise steps, DiT denoising only) + sec/denoise-step",
+            "value": round(vpm, 4), "unit": "videos/min", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(step_s * 1e3, 3), "sec_per_denoise_step": round(step_s, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {
+                "workload": ("open-sora-v1.2 STDiT3-XL/2 512x512x64f, latent [4,19,64,64], CFG batch 2 = 38912 token rows, "
+                             f"{L} text tokens, depth {args.depth}" + (", PAB attention-only (config 3)" if args.pab else "")),
+                "steps_per_video": STEPS_PER_VIDEO, "parallelism": f"dsp{world}",
+                "not_included": "T5 text encode, VAE decode (SURVEY.md 8f next rows)",
+                "algorithmic_tflop_per_step": 89.4 if args.depth == 28 and L == 300 else None,
+            },
+            "step_tflops": round(89.4 / step_s, 1) if args.depth == 28 and L == 300 and not args.pab else None,
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, T, Hl, Wl, L):
+    """Oracle (port of the reference fp32 path) on the host cores; bounded sample = ONE block pair (1/28 of the depth)
+    of the same geometry on a reduced frame count, extrapolated linearly in tokens and depth."""
+    from oracle import stdit3_oracle as O
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Ts = T if cores >= 64 else (8 if cores >= 16 else 4)
+    c = dict(depth=1, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads, caption_channels=cfg.caption_channels,
+             model_max_length=300)
+    sd = O.synth_state_dict(**c, seed=1)
+    m = O.STDiT3Oracle(sd, 1, cfg.hidden_size, cfg.num_heads)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, Ts, Hl, Wl, generator=g)
+    y = torch.randn(2, 1, 300, cfg.caption_channels, generator=g) * 0.1
+    mask = torch.zeros(1, 300, dtype=torch.long)
+    mask[:, :L] = 1
+    kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([512.0, 512.0]), width=torch.tensor([512.0, 512.0]))
+    t = torch.tensor([500.0, 500.0])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        m.forward(x, t, y, **kw)
+        dt = time.perf_counter() - t0
+    step_s = dt * (T / Ts) * cfg.depth  # embed/final are <1 % of the sample
+    return {
+        "value": round(60.0 / (STEPS_PER_VIDEO * step_s), 6), "unit": "videos/min", "cores": cores, "kind": "port",
+        "sec_per_denoise_step_extrapolated": round(step_s, 2), "sample_seconds": round(dt, 2),
+        "sample": (f"CPU oracle (fp32 PyTorch port of reference STDiT3), ONE spatial+temporal block pair, hidden 1152, "
+                   f"CFG batch 2, {Ts} of {T} latent frames x 1024 tokens, {L} text tokens; extrapolated x{T / Ts:.2f} "
+                   f"tokens x{cfg.depth} depth"),
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -113,9 +113,10 @@ def plan_switch_to_temporal_shard(B, T, Sl, S, C, P):
     unpack = []
     for src in range(P):
         valid = max(0, min(Sl, S - src * Sl))
-        unpack.append(CopyOp(src * B * Tp * run, src * Sl * C, B, Tp, Sl, C, (Tp * run, run, C), (Tp * S * C, S * C, C),
+        # narrowing side: copy only the valid columns (never zero-fill past the row end)
+        unpack.append(CopyOp(src * B * Tp * run, src * Sl * C, B, Tp, valid, C, (Tp * run, run, C), (Tp * S * C, S * C, C),
                              Tp, valid))
-    unpack = [u for u in unpack if u.n2_valid > 0]
+    unpack = [u for u in unpack if u.n2 > 0]
     return pack, unpack, (P, B, Tp, Sl, C), (B, Tp, S, C)
 
 
@@ -141,7 +142,7 @@ def plan_gather(B, T, Sl, S, C, P):
     for src in range(P):
         valid = max(0, min(Sl, S - src * Sl))
         if valid > 0:
-            ops.append(CopyOp(src * B * T * Sl * C, src * Sl * C, B, T, Sl, C, (T * Sl * C, Sl * C, C), (T * S * C, S * C, C),
+            ops.append(CopyOp(src * B * T * Sl * C, src * Sl * C, B, T, valid, C, (T * Sl * C, Sl * C, C), (T * S * C, S * C, C),
                               T, valid))
     return ops, (B, T, S, C)
 
