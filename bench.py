@@ -49,13 +49,6 @@ def parse():
     return ap.parse_args()
 
 
-def gemm_flops_per_step(N, C, L, B, depth):
-    """Algorithmic GEMM FLOPs of one step (2*m*n*k), per launch shape: qkv, proj, q_cross, cross proj, fc1, fc2."""
-    per_block = [(N, 3 * C, C), (N, C, C), (N, C, C), (N, C, C), (N, 4 * C, C), (N, C, 4 * C)]
-    launches = [(m, n, k) for (m, n, k) in per_block] * (2 * depth)
-    return launches
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,7 +218,7 @@ def cpu_baseline(cfg, T, Hl, Wl, L):
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    Ts = T if cores >= 64 else (8 if cores >= 16 else 4)
+    Ts = 8 if cores >= 64 else (4 if cores >= 16 else 2)  # keeps the sample at ~10-30 s of CPU work
     c = dict(depth=1, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads, caption_channels=cfg.caption_channels,
              model_max_length=300)
     sd = O.synth_state_dict(**c, seed=1)

@@ -1,0 +1,43 @@
+"""CPU: cross-compile the hot kernels for gfx950 and check the resource usage the design depends on — no scratch
+(a spilled staging register serialises the HBM->LDS pipeline), VGPRs within the occupancy the launch assumes."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "videosys_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _usage(src):
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", "/dev/null",
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=CSRC)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = {}
+    cur = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark: .*?:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+)", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+@pytest.mark.parametrize("src,pattern,max_vgpr", [("gemm_bf16.hip", "gemm_256x192_kernel", 256),
+                                                  ("attention.hip", "flash_attn_d72_kernel", 256),
+                                                  ("attention.hip", "attn_temporal_d72_kernel", 128)])
+def test_hot_kernels_have_no_scratch(src, pattern, max_vgpr):
+    u = _usage(src)
+    hits = {k: v for k, v in u.items() if pattern in k}
+    assert hits, f"{pattern} not found in {src}"
+    for name, res in hits.items():
+        assert res.get("ScratchSize", 0) == 0, f"{name} uses scratch: {res}"
+        assert res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) == 0, f"{name} spills: {res}"
+        assert res.get("VGPRs", 0) <= max_vgpr, f"{name}: {res.get('VGPRs')} VGPRs"

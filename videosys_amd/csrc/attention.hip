@@ -218,9 +218,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
   FLASH_LSTORE(0);
   __syncthreads();
 
-  for (int t = 0; t < ntiles; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < ntiles) FLASH_GLOAD(t + 1);
+  auto tile = [&](int t, int cur) {
     const char* sk = smem + cur * KV_STAGE;
     const char* sv = sk + K_TILE_BYTES;
 
@@ -291,9 +289,18 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
         }
       }
 
-    if (t + 1 < ntiles) FLASH_LSTORE(cur ^ 1);
+  };
+
+  for (int t = 0; t < ntiles - 1; ++t) {  // last tile peeled: no conditional staging inside the loop
+    const int cur = t & 1;
+    FLASH_GLOAD(t + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads in flight above this tile's MFMAs
+    tile(t, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    FLASH_LSTORE(cur ^ 1);
     __syncthreads();
   }
+  tile(ntiles - 1, (ntiles - 1) & 1);
 #undef FLASH_GLOAD
 #undef FLASH_LSTORE
 

@@ -65,21 +65,31 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
     b_lds[i] = A_BYTES + swz(r, c);
   }
 
-  uint4 ra[4], rb[3];
-  auto gload = [&](int kt) {
-    const int ko = kt * BK;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const uint4*>(aptr[i] + ko);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) rb[i] = *reinterpret_cast<const uint4*>(bptr[i] + ko);
-  };
-  auto lstore = [&](int buf) {
-    char* base = smem + buf * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(base + a_lds[i]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) *reinterpret_cast<uint4*>(base + b_lds[i]) = rb[i];
-  };
+  // staging registers are named scalars + macros on purpose: arrays captured by a lambda and written under a
+  // condition get parked in scratch by hipcc (and the scratch store waits for the loads, killing the overlap)
+  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2;
+#define GEMM_GLOAD(kt_)                                                    \
+  do {                                                                     \
+    const int ko_ = (kt_) * BK;                                            \
+    ra0 = *reinterpret_cast<const uint4*>(aptr[0] + ko_);                  \
+    ra1 = *reinterpret_cast<const uint4*>(aptr[1] + ko_);                  \
+    ra2 = *reinterpret_cast<const uint4*>(aptr[2] + ko_);                  \
+    ra3 = *reinterpret_cast<const uint4*>(aptr[3] + ko_);                  \
+    rb0 = *reinterpret_cast<const uint4*>(bptr[0] + ko_);                  \
+    rb1 = *reinterpret_cast<const uint4*>(bptr[1] + ko_);                  \
+    rb2 = *reinterpret_cast<const uint4*>(bptr[2] + ko_);                  \
+  } while (0)
+#define GEMM_LSTORE(buf_)                                                  \
+  do {                                                                     \
+    char* base_ = smem + (buf_) * STAGE_BYTES;                             \
+    *reinterpret_cast<uint4*>(base_ + a_lds[0]) = ra0;                     \
+    *reinterpret_cast<uint4*>(base_ + a_lds[1]) = ra1;                     \
+    *reinterpret_cast<uint4*>(base_ + a_lds[2]) = ra2;                     \
+    *reinterpret_cast<uint4*>(base_ + a_lds[3]) = ra3;                     \
+    *reinterpret_cast<uint4*>(base_ + b_lds[0]) = rb0;                     \
+    *reinterpret_cast<uint4*>(base_ + b_lds[1]) = rb1;                     \
+    *reinterpret_cast<uint4*>(base_ + b_lds[2]) = rb2;                     \
+  } while (0)
 
   // ---- fragment read offsets (per lane): X rows (tokens) for i=0,1; W rows (out cols) for j=0..2
   int xrow[2], wrow[3];
@@ -96,14 +106,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = p.K / BK;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nt; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nt) gload(kt + 1);
+  auto compute = [&](int cur) {
     const char* sa = smem + cur * STAGE_BYTES;
     const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -120,42 +123,75 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
         for (int j = 0; j < 3; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nt) lstore(cur ^ 1);
+  };
+
+  const int nt = p.K / BK;
+  GEMM_GLOAD(0);
+  GEMM_LSTORE(0);
+  __syncthreads();
+  for (int kt = 0; kt < nt - 1; ++kt) {  // last tile peeled: no conditional staging inside the loop
+    const int cur = kt & 1;
+    GEMM_GLOAD(kt + 1);
+    __builtin_amdgcn_sched_barrier(0);  // keep the global loads ABOVE the MFMAs (hipcc otherwise sinks them to the ds_writes)
+    compute(cur);
+    __builtin_amdgcn_sched_barrier(0);
+    GEMM_LSTORE(cur ^ 1);
     __syncthreads();
   }
+  compute((nt - 1) & 1);
+  __syncthreads();
+#undef GEMM_GLOAD
+#undef GEMM_LSTORE
 
   // ---- epilogue: acc (+bias, act, gate) -> bf16 -> per-wave LDS image [64 tokens][96 cols] -> 16-byte HBM stores
   char* st = smem + wave * OUT_WAVE_BYTES;
   const int ncol0 = col0 + wn * 96;
+  // bias for this lane's 12 column groups (4 consecutive columns each), loaded back-to-back under one uniform branch
+  uint2 bb[3][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bb[j][g] = make_uint2(0, 0);
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bb[j][g] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * hi);
+  }
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m_local = i * 32 + l31;
-    const bf16_t* gate_row = nullptr;
-    if (EPI == EPI_GATE_RES && p.gate != nullptr) {
-      int grow = row0 + wm * 64 + m_local;
-      grow = grow < p.M ? grow : p.M - 1;
-      gate_row = p.gate + (int64_t)(grow / p.rows_per_sample) * p.gate_stride;
+    uint2 gg[3][4];
+    if (EPI == EPI_GATE_RES) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gg[j][g] = make_uint2(0x3f803f80u, 0x3f803f80u);  // bf16 1.0 pairs
+      if (p.gate != nullptr) {
+        int grow = row0 + wm * 64 + m_local;
+        grow = grow < p.M ? grow : p.M - 1;
+        const bf16_t* gate_row = p.gate + (int64_t)(grow / p.rows_per_sample) * p.gate_stride + ncol0 + 4 * hi;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gg[j][g] = *reinterpret_cast<const uint2*>(gate_row + j * 32 + 8 * g);
+      }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n_local = j * 32 + 8 * g + 4 * hi;
-        const int n = ncol0 + n_local;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
-        if (p.bias != nullptr) {
-          uint2 bb = *reinterpret_cast<const uint2*>(p.bias + n);
-          v[0] += bflo(bb.x); v[1] += bfhi(bb.x); v[2] += bflo(bb.y); v[3] += bfhi(bb.y);
-        }
+        v[0] += bflo(bb[j][g].x); v[1] += bfhi(bb[j][g].x); v[2] += bflo(bb[j][g].y); v[3] += bfhi(bb[j][g].y);
         if (EPI == EPI_BIAS_GELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
         }
-        if (EPI == EPI_GATE_RES && gate_row != nullptr) {
-          uint2 gg = *reinterpret_cast<const uint2*>(gate_row + n);
-          v[0] *= bflo(gg.x); v[1] *= bfhi(gg.x); v[2] *= bflo(gg.y); v[3] *= bfhi(gg.y);
+        if (EPI == EPI_GATE_RES) {
+          v[0] *= bflo(gg[j][g].x); v[1] *= bfhi(gg[j][g].x); v[2] *= bflo(gg[j][g].y); v[3] *= bfhi(gg[j][g].y);
         }
         uint2 o;
         o.x = pack2bf(v[0], v[1]);
