@@ -218,7 +218,7 @@ def cpu_baseline(cfg, T, Hl, Wl, L):
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    Ts = 8 if cores >= 64 else (4 if cores >= 16 else 2)  # keeps the sample at ~10-30 s of CPU work
+    Ts = 4 if cores >= 64 else 2  # keeps the sample at ~10-30 s of CPU work
     c = dict(depth=1, hidden_size=cfg.hidden_size, num_heads=cfg.num_heads, caption_channels=cfg.caption_channels,
              model_max_length=300)
     sd = O.synth_state_dict(**c, seed=1)

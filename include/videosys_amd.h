@@ -44,6 +44,10 @@ const char* vsys_strerror(int code);
 /* number of HIP devices visible to the library (fails loudly instead of falling back when 0) */
 int vsys_device_count(void);
 
+/* Tuning knob (A/B measurement only; results are identical): 1 = single-stage, 2 = two-stage (default) operand prefetch
+ * of vsys_gemm_bf16. */
+int vsys_tune_gemm_variant(int variant);
+
 /* nn.Linear on token rows with fused epilogue (bf16 in/out, fp32 MFMA accumulate).
  * Replaces: attentions.py:59 (qkv), :107 (proj) + open_sora_transformer_3d.py:219,228 (gate, residual);
  * attentions.py:156,183 + open_sora_transformer_3d.py:237-240 (cross q / proj + residual);

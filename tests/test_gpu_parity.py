@@ -408,6 +408,21 @@ def test_rflow_golden():
     assert [int(t[0]) for t in ts] == fx["all_timesteps"]  # the golden model is fp32: int(t.to(float32))
     z = sched.sample(m, fx["z0"], margs, fx["y_null"])
     out = z.float().cpu()
+    # (1) Against the oracle fed the timesteps a bf16 model really sees: STDiT3.forward casts timestep to the model dtype
+    # (open_sora_transformer_3d.py:562), e.g. 626.3 -> 628, and CFG (x7) amplifies that input change; the fp32 golden
+    # below used the un-rounded value.
+    cfg = fx["cfg"]
+    sd = O.synth_state_dict(**cfg, seed=fx["seed"])
+    sd = {k: (v if k == "rope.freqs" else v.to(torch.bfloat16).float()) for k, v in sd.items()}
+    om = O.STDiT3Oracle(sd, cfg["depth"], cfg["hidden_size"], cfg["num_heads"])
+    zref = O.rflow_sample(om, fx["z0"], fx["y"], fx["y_null"], fx["mask"], fx["fps"], fx["height"], fx["width"],
+                          fx["num_frames"], num_sampling_steps=fx["steps"], cfg_scale=fx["cfg_scale"],
+                          model_dtype=torch.bfloat16)
+    e = rel_err(out, zref)
+    cos = torch.nn.functional.cosine_similarity(out.flatten(), zref.flatten(), dim=0).item()
+    assert e <= 5e-2 and cos >= 0.999, f"RFLOW 4-step latents vs oracle(bf16 timesteps): rel err {e:.3e}, cosine {cos:.6f}"
+    # (2) Against the reference's fp32 run (golden): looser, dominated by the timestep rounding (oracle-vs-golden with
+    # only that change already differs by 6.4e-2 / cosine 0.9980).
     e = rel_err(out, fx["z_out"])
     cos = torch.nn.functional.cosine_similarity(out.flatten(), fx["z_out"].flatten(), dim=0).item()
-    assert e <= 5e-2 and cos >= 0.999, f"RFLOW 4-step latents: rel err {e:.3e}, cosine {cos:.6f}"
+    assert e <= 1e-1 and cos >= 0.995, f"RFLOW 4-step latents vs reference fp32 golden: rel err {e:.3e}, cosine {cos:.6f}"

@@ -1,0 +1,110 @@
+#!/usr/bin/env python
+"""Per-kernel timing at BASELINE config-2 shapes (HIP events on the launch stream, interleaved A/B of variants).
+Run on the GPU box:  python tools/kernel_bench.py [--reps 20]  -> table on stdout + gpurun_out/kernel_bench.json"""
+import argparse
+import json
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timeit(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True)
+    e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps  # ms
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=3)
+    args = ap.parse_args()
+    import __graft_entry__ as ge
+
+    ge.build()
+    from videosys_amd import _lib, ops
+
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(0)
+    N, C, H = 38912, 1152, 16
+    res = {}
+
+    def rnd(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).to(dev)
+
+    x = rnd(N, C)
+    h = rnd(N, 4 * C)
+    mod = rnd(2, 6 * C, scale=0.3)
+    shapes = [("qkv", 3 * C, C, ops.EPI_BIAS), ("proj", C, C, ops.EPI_GATE_RES), ("fc1", 4 * C, C, ops.EPI_BIAS_GELU),
+              ("fc2", C, 4 * C, ops.EPI_GATE_RES)]
+    bufs = {}
+    for name, n, k, epi in shapes:
+        bufs[name] = (rnd(n, k, scale=1 / math.sqrt(k)), rnd(n, scale=0.1), torch.empty(N, n, dtype=torch.bfloat16, device=dev))
+    resid = rnd(N, C)
+    for rd in range(args.rounds):
+        for variant in (1, 2):
+            lib.vsys_tune_gemm_variant(variant)
+            for name, n, k, epi in shapes:
+                w, b, out = bufs[name]
+                a = h if k == 4 * C else x
+                if epi == ops.EPI_GATE_RES:
+                    fn = lambda: ops.gemm(a, w, b, epilogue=epi, gate=mod[0, 2 * C:3 * C], gate_stride=6 * C,
+                                          rows_per_sample=N // 2, res=resid, out=out)
+                else:
+                    fn = lambda: ops.gemm(a, w, b, epilogue=epi, out=out)
+                ms = timeit(fn, args.reps)
+                tf = 2.0 * N * n * k / (ms * 1e-3) / 1e12
+                res.setdefault(f"gemm_{name}_pipe{variant}", []).append((ms, tf))
+    lib.vsys_tune_gemm_variant(2)
+
+    # attention: spatial (38 frames x 1024), cross (2 x 19456 q, 300 keys), temporal
+    qkv = rnd(N, 3 * C)
+    qw = rnd(72) + 1
+    ao = torch.empty(N, C, dtype=torch.bfloat16, device=dev)
+    kp, vt = ops.alloc_kv_buffers(38, H, 1024, dev)
+    ms = timeit(lambda: ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kp, vt, 38, H, 1024), args.reps)
+    res["attn_prep_kv_spatial"] = [(ms, (179.4 + 209.2) / ms)]  # GB/s
+    ms = timeit(lambda: ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024), args.reps)
+    res["flash_spatial"] = [(ms, 4.0 * 38 * H * 1024 * 1024 * 72 / (ms * 1e-3) / 1e12)]
+    kv = rnd(600, 2 * C)
+    kpc, vtc = ops.alloc_kv_buffers(2, H, 300, dev)
+    ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kpc, vtc, 2, H, 300)
+    ms = timeit(lambda: ops.flash_attn(x, None, kpc, vtc, ao, 2, H, 19456, 300), args.reps)
+    res["flash_cross_L300"] = [(ms, 4.0 * 2 * H * 19456 * 300 * 72 / (ms * 1e-3) / 1e12)]
+    freqs = 1.0 / (10000 ** (torch.arange(0, 72, 2).float() / 72))
+    ang = torch.einsum("p,f->pf", torch.arange(19).float(), freqs).repeat_interleave(2, -1)
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    ms = timeit(lambda: ops.attn_temporal(qkv, C, qw, qw, cos, sin, ao, 2, 19, 1024, H), args.reps)
+    res["attn_temporal"] = [(ms, (269.0 + 89.7) / ms)]  # GB/s
+    ms = timeit(lambda: ops.adaln_modulate(x, mod[0, :C], mod[0, C:2 * C], N // 2, 6 * C, out=ao), args.reps)
+    res["adaln_modulate"] = [(ms, 179.3 / ms)]  # GB/s
+    ms = timeit(lambda: ops.add_rows(ao, x), args.reps)
+    res["add_rows"] = [(ms, 269.0 / ms)]
+
+    out = {}
+    print(f"{'kernel':32s} {'ms(min)':>9s} {'ms(med)':>9s} {'rate(max)':>10s}")
+    for k, v in res.items():
+        mss = sorted(m for m, _ in v)
+        rate = max(r for _, r in v)
+        out[k] = {"ms_min": mss[0], "ms_med": mss[len(mss) // 2], "rate_max": rate}
+        print(f"{k:32s} {mss[0]:9.4f} {mss[len(mss) // 2]:9.4f} {rate:10.1f}")
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "kernel_bench.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

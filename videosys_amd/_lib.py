@@ -17,6 +17,7 @@ _i64, _f32, _ptr, _int = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes
 SIGNATURES = {
     "vsys_abi_version": [],
     "vsys_device_count": [],
+    "vsys_tune_gemm_variant": [_int],
     "vsys_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _ptr, _i64,
                        _ptr, _i64, _ptr],
     "vsys_linear_small": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],

@@ -34,7 +34,9 @@ static_assert(8 * OUT_WAVE_BYTES <= 2 * STAGE_BYTES, "epilogue image must fit in
 
 __device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-template <int EPI>
+// PIPE = 1: one staging register set (loads of tile t+1 fly during the MFMAs of tile t);
+// PIPE = 2: two sets (tile t+2 in flight while tile t+1 waits in registers) — the default.
+template <int EPI, int PIPE>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -65,30 +67,32 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
     b_lds[i] = A_BYTES + swz(r, c);
   }
 
-  // staging registers are named scalars + macros on purpose: arrays captured by a lambda and written under a
-  // condition get parked in scratch by hipcc (and the scratch store waits for the loads, killing the overlap)
-  uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2;
-#define GEMM_GLOAD(kt_)                                                    \
+  // Two staging register sets (named scalars + macros on purpose: arrays captured by a lambda and written under a
+  // condition get parked in scratch by hipcc).  Set X holds tile t+1 while the loads of tile t+2 fly into set Y, so a
+  // load has TWO tile-times of MFMA work to land before its ds_write needs it (1 block/CU: nothing else hides it).
+  uint4 ra0_0, ra1_0, ra2_0, ra3_0, rb0_0, rb1_0, rb2_0;
+  uint4 ra0_1, ra1_1, ra2_1, ra3_1, rb0_1, rb1_1, rb2_1;
+#define GEMM_GLOAD(S, kt_)                                                 \
   do {                                                                     \
     const int ko_ = (kt_) * BK;                                            \
-    ra0 = *reinterpret_cast<const uint4*>(aptr[0] + ko_);                  \
-    ra1 = *reinterpret_cast<const uint4*>(aptr[1] + ko_);                  \
-    ra2 = *reinterpret_cast<const uint4*>(aptr[2] + ko_);                  \
-    ra3 = *reinterpret_cast<const uint4*>(aptr[3] + ko_);                  \
-    rb0 = *reinterpret_cast<const uint4*>(bptr[0] + ko_);                  \
-    rb1 = *reinterpret_cast<const uint4*>(bptr[1] + ko_);                  \
-    rb2 = *reinterpret_cast<const uint4*>(bptr[2] + ko_);                  \
+    ra0_##S = *reinterpret_cast<const uint4*>(aptr[0] + ko_);              \
+    ra1_##S = *reinterpret_cast<const uint4*>(aptr[1] + ko_);              \
+    ra2_##S = *reinterpret_cast<const uint4*>(aptr[2] + ko_);              \
+    ra3_##S = *reinterpret_cast<const uint4*>(aptr[3] + ko_);              \
+    rb0_##S = *reinterpret_cast<const uint4*>(bptr[0] + ko_);              \
+    rb1_##S = *reinterpret_cast<const uint4*>(bptr[1] + ko_);              \
+    rb2_##S = *reinterpret_cast<const uint4*>(bptr[2] + ko_);              \
   } while (0)
-#define GEMM_LSTORE(buf_)                                                  \
+#define GEMM_LSTORE(S, buf_)                                               \
   do {                                                                     \
     char* base_ = smem + (buf_) * STAGE_BYTES;                             \
-    *reinterpret_cast<uint4*>(base_ + a_lds[0]) = ra0;                     \
-    *reinterpret_cast<uint4*>(base_ + a_lds[1]) = ra1;                     \
-    *reinterpret_cast<uint4*>(base_ + a_lds[2]) = ra2;                     \
-    *reinterpret_cast<uint4*>(base_ + a_lds[3]) = ra3;                     \
-    *reinterpret_cast<uint4*>(base_ + b_lds[0]) = rb0;                     \
-    *reinterpret_cast<uint4*>(base_ + b_lds[1]) = rb1;                     \
-    *reinterpret_cast<uint4*>(base_ + b_lds[2]) = rb2;                     \
+    *reinterpret_cast<uint4*>(base_ + a_lds[0]) = ra0_##S;                 \
+    *reinterpret_cast<uint4*>(base_ + a_lds[1]) = ra1_##S;                 \
+    *reinterpret_cast<uint4*>(base_ + a_lds[2]) = ra2_##S;                 \
+    *reinterpret_cast<uint4*>(base_ + a_lds[3]) = ra3_##S;                 \
+    *reinterpret_cast<uint4*>(base_ + b_lds[0]) = rb0_##S;                 \
+    *reinterpret_cast<uint4*>(base_ + b_lds[1]) = rb1_##S;                 \
+    *reinterpret_cast<uint4*>(base_ + b_lds[2]) = rb2_##S;                 \
   } while (0)
 
   // ---- fragment read offsets (per lane): X rows (tokens) for i=0,1; W rows (out cols) for j=0..2
@@ -126,20 +130,50 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
   };
 
   const int nt = p.K / BK;
-  GEMM_GLOAD(0);
-  GEMM_LSTORE(0);
-  __syncthreads();
-  for (int kt = 0; kt < nt - 1; ++kt) {  // last tile peeled: no conditional staging inside the loop
-    const int cur = kt & 1;
-    GEMM_GLOAD(kt + 1);
-    __builtin_amdgcn_sched_barrier(0);  // keep the global loads ABOVE the MFMAs (hipcc otherwise sinks them to the ds_writes)
-    compute(cur);
-    __builtin_amdgcn_sched_barrier(0);
-    GEMM_LSTORE(cur ^ 1);
+  const int last = nt - 1;
+  if constexpr (PIPE == 1) {
+    GEMM_GLOAD(0, 0);
+    GEMM_LSTORE(0, 0);
     __syncthreads();
+    for (int kt = 0; kt < last; ++kt) {  // last tile peeled: no conditional staging inside the loop
+      const int cur = kt & 1;
+      GEMM_GLOAD(0, kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_LSTORE(0, cur ^ 1);
+      __syncthreads();
+    }
+    compute(last & 1);
+    __syncthreads();
+  } else {
+    GEMM_GLOAD(0, 0);
+    GEMM_LSTORE(0, 0);
+    GEMM_GLOAD(0, last < 1 ? last : 1);
+    __syncthreads();
+    // Branch-free steady state: tile indices are clamped to the last tile, and the (at most two) stores past the end
+    // land in a buffer nobody reads again.
+    for (int kt = 0; kt + 1 < nt; kt += 2) {
+      // even step: buf0 = tile kt, set 0 = tile kt+1; fetch tile kt+2 into set 1
+      GEMM_GLOAD(1, (kt + 2 < last ? kt + 2 : last));
+      __builtin_amdgcn_sched_barrier(0);  // keep the global loads ABOVE the MFMAs (hipcc otherwise sinks them to the ds_writes)
+      compute(0);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_LSTORE(0, 1);
+      __syncthreads();
+      // odd step: buf1 = tile kt+1, set 1 = tile kt+2; fetch tile kt+3 into set 0
+      GEMM_GLOAD(0, (kt + 3 < last ? kt + 3 : last));
+      __builtin_amdgcn_sched_barrier(0);
+      compute(1);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_LSTORE(1, 0);
+      __syncthreads();
+    }
+    if (nt & 1) {
+      compute(0);
+      __syncthreads();
+    }
   }
-  compute((nt - 1) & 1);
-  __syncthreads();
 #undef GEMM_GLOAD
 #undef GEMM_LSTORE
 
@@ -265,6 +299,27 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 
 }  // namespace
 
+static int g_gemm_pipe = 2;
+void set_gemm_variant(int v) { g_gemm_pipe = (v == 1) ? 1 : 2; }
+
+template <int PIPE>
+static int launch_gemm_pipe(const GemmParams& p, int epi, int grid, size_t lds, hipStream_t stream) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS_GELU, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_GATE_RES, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_256x192_kernel<EPI_BIAS, PIPE>), dim3(grid), dim3(NTHREADS), lds, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_256x192_kernel<EPI_BIAS_GELU, PIPE>), dim3(grid), dim3(NTHREADS), lds, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_256x192_kernel<EPI_GATE_RES, PIPE>), dim3(grid), dim3(NTHREADS), lds, stream, p); break;
+    default: return VSYS_ERR_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.M <= 0) return 0;
   if (p.N % BN != 0 || p.K % BK != 0 || p.N <= 0 || p.K <= 0) return VSYS_ERR_SHAPE;
@@ -273,20 +328,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   const int grid = nbm * nbn;
   const size_t lds = 2 * STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_GATE_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
-  switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL(gemm_256x192_kernel<EPI_BIAS>, dim3(grid), dim3(NTHREADS), lds, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_256x192_kernel<EPI_BIAS_GELU>, dim3(grid), dim3(NTHREADS), lds, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL(gemm_256x192_kernel<EPI_GATE_RES>, dim3(grid), dim3(NTHREADS), lds, stream, p); break;
-    default: return VSYS_ERR_ARG;
-  }
-  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  return g_gemm_pipe == 1 ? launch_gemm_pipe<1>(p, epi, grid, lds, stream) : launch_gemm_pipe<2>(p, epi, grid, lds, stream);
 }
 
 int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,

@@ -130,16 +130,40 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
     for (int e = 0; e < 8; ++e) acc[e] = bb[e];
   }
   const int K = Cin * ph * pw;
-  for (int ci = 0; ci < Cin; ++ci)
-    for (int dy = 0; dy < ph; ++dy)
-      for (int dx = 0; dx < pw; ++dx) {
-        const int hh = hp * ph + dy, ww = wp * pw + dx;
-        float xv = 0.f;  // zero padding of odd H/W (F.pad in the reference)
-        if (hh < H && ww < W) xv = bf2f(f2bf(x[((((int64_t)bz * Cin + ci) * T + t) * H + hh) * W + ww]));
-        const int k = (ci * ph + dy) * pw + dx;
+  if (K == 16) {
+    // STDiT3 geometry (Cin 4, patch 2x2): gather the 16 inputs once, then two 16-byte weight loads per output channel
+    float xin[16];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] += xv * bf2f(w[(int64_t)(cc * 8 + e) * K + k]);
+    for (int k = 0; k < 16; ++k) {
+      const int ci = k >> 2, dy = (k >> 1) & 1, dx = k & 1;
+      const int hh = hp * 2 + dy, ww = wp * 2 + dx;
+      xin[k] = 0.f;
+      if (ph == 2 && pw == 2 && hh < H && ww < W) xin[k] = bf2f(f2bf(x[((((int64_t)bz * Cin + ci) * T + t) * H + hh) * W + ww]));
+    }
+    if (ph == 2 && pw == 2) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bf16_t* wr = w + (int64_t)(cc * 8 + e) * 16;
+        float wa[8], wb[8];
+        unpack8(*reinterpret_cast<const uint4*>(wr), wa);
+        unpack8(*reinterpret_cast<const uint4*>(wr + 8), wb);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[e] += xin[k] * wa[k] + xin[k + 8] * wb[k];
       }
+    }
+  }
+  if (!(K == 16 && ph == 2 && pw == 2)) {
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int dy = 0; dy < ph; ++dy)
+        for (int dx = 0; dx < pw; ++dx) {
+          const int hh = hp * ph + dy, ww = wp * pw + dx;
+          float xv = 0.f;  // zero padding of odd H/W (F.pad in the reference)
+          if (hh < H && ww < W) xv = bf2f(f2bf(x[((((int64_t)bz * Cin + ci) * T + t) * H + hh) * W + ww]));
+          const int k = (ci * ph + dy) * pw + dx;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[e] += xv * bf2f(w[(int64_t)(cc * 8 + e) * K + k]);
+        }
+  }
   float pp[8];
   unpack8(*reinterpret_cast<const uint4*>(pos + (int64_t)s * C + cc * 8), pp);
 #pragma unroll
