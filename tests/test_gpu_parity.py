@@ -60,6 +60,34 @@ def test_gemm_bias(ops, M, N, K):
     check(out, O.gelu_tanh(ref), what="gemm+gelu")
 
 
+@pytest.mark.parametrize("variant", [1, 2, 3])
+def test_gemm_pipeline_variants(ops, variant):
+    """Every operand-staging variant of the GEMM (register single/double stage, LDS-DMA) must give the same result;
+    K = 64 (one tile), 128 (two), 1152 (18) and an M tail exercise prologue / steady state / epilogue of each."""
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(40 + variant)
+    try:
+        lib.vsys_tune_gemm_variant(variant)
+        for M, N, K in ((515, 192, 64), (300, 384, 128), (1000, 576, 1152), (777, 576, 192)):
+            x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+            w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+            b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)
+            ref = x.float() @ w.float().t() + b.float()
+            out = ops.gemm(x.to(dev()), w.to(dev()), b.to(dev()))
+            check(out, ref, what=f"variant {variant} gemm {M}x{N}x{K}")
+        K = 576
+        x = torch.randn(700, K, generator=g).to(torch.bfloat16)
+        perm = torch.randperm(K, generator=g)
+        w = torch.zeros(K, K)
+        w[torch.arange(K), perm] = 1.0
+        out = ops.gemm(x.to(dev()), w.to(torch.bfloat16).to(dev()), None).cpu()
+        assert torch.equal(out, x[:, perm]), f"variant {variant}: permutation GEMM not bit exact"
+    finally:
+        lib.vsys_tune_gemm_variant(2)
+
+
 def test_gemm_is_transpose_exact(ops):
     """Permutation weight: out must be a bit-exact column permutation of x (catches any fragment/epilogue
     row<->col swap; asymmetric by construction)."""

@@ -48,23 +48,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
   const int bm = tile / nbn, bn = tile - bm * nbn;
   const int row0 = bm * BM, col0 = bn * BN;
 
-  // ---- staging assignment: chunk q = tid + 512*i -> (row = q>>3, 16-byte chunk = q&7)
+  // ---- staging assignment.
+  // PIPE 1/2 (register staged): chunk q = tid + 512*i -> (row = q>>3, logical 16-byte chunk = q&7), written to the
+  //   swizzled LDS slot by ds_write_b128.
+  // PIPE 3 (LDS-DMA): global_load_lds writes lane l of a wave to  M0_base + 16*l  (lane-linear), so each wave
+  //   instruction fills 8 whole 128-byte rows and the swizzle moves to the SOURCE: the lane that lands in physical
+  //   slot s of row r fetches logical chunk s ^ ((r>>1)&7)  (same involution as the fragment reads).
   const bf16_t* aptr[4];
   const bf16_t* bptr[3];
   int a_lds[4], b_lds[3];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    int q = tid + NTHREADS * i, r = q >> 3, c = q & 7;
+    int r, c;
+    if constexpr (PIPE == 3) {
+      r = wave_u * 32 + i * 8 + (lane >> 3);
+      c = (lane & 7) ^ ((r >> 1) & 7);
+      a_lds[i] = (wave_u * 32 + i * 8) * 128;  // wave-uniform row-block base
+    } else {
+      const int q = tid + NTHREADS * i;
+      r = q >> 3;
+      c = q & 7;
+      a_lds[i] = swz(r, c);
+    }
     int gr = row0 + r;
     gr = gr < p.M ? gr : p.M - 1;
     aptr[i] = p.A + (int64_t)gr * p.lda + c * 8;
-    a_lds[i] = swz(r, c);
   }
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    int q = tid + NTHREADS * i, r = q >> 3, c = q & 7;
+    int r, c;
+    if constexpr (PIPE == 3) {
+      r = wave_u * 24 + i * 8 + (lane >> 3);
+      c = (lane & 7) ^ ((r >> 1) & 7);
+      b_lds[i] = A_BYTES + (wave_u * 24 + i * 8) * 128;
+    } else {
+      const int q = tid + NTHREADS * i;
+      r = q >> 3;
+      c = q & 7;
+      b_lds[i] = A_BYTES + swz(r, c);
+    }
     bptr[i] = p.W + (int64_t)(col0 + r) * p.ldw + c * 8;
-    b_lds[i] = A_BYTES + swz(r, c);
   }
 
   // Two staging register sets (named scalars + macros on purpose: arrays captured by a lambda and written under a
@@ -131,7 +155,36 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 
   const int nt = p.K / BK;
   const int last = nt - 1;
-  if constexpr (PIPE == 1) {
+  if constexpr (PIPE == 3) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+#define GEMM_DMA(kt_, buf_)                                                                                         \
+  do {                                                                                                              \
+    const int ko_ = (kt_) * BK;                                                                                     \
+    char* base_ = smem + (buf_) * STAGE_BYTES;                                                                      \
+    __builtin_amdgcn_global_load_lds((const void*)(aptr[0] + ko_), (lds_ptr_t)(base_ + a_lds[0]), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((const void*)(aptr[1] + ko_), (lds_ptr_t)(base_ + a_lds[1]), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((const void*)(aptr[2] + ko_), (lds_ptr_t)(base_ + a_lds[2]), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((const void*)(aptr[3] + ko_), (lds_ptr_t)(base_ + a_lds[3]), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((const void*)(bptr[0] + ko_), (lds_ptr_t)(base_ + b_lds[0]), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((const void*)(bptr[1] + ko_), (lds_ptr_t)(base_ + b_lds[1]), 16, 0, 0);       \
+    __builtin_amdgcn_global_load_lds((const void*)(bptr[2] + ko_), (lds_ptr_t)(base_ + b_lds[2]), 16, 0, 0);       \
+  } while (0)
+    GEMM_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < last; ++kt) {
+      const int cur = kt & 1;
+      GEMM_DMA(kt + 1, cur ^ 1);  // safe: every wave finished reading buf[cur^1] before the barrier that ended step kt-1
+      __builtin_amdgcn_sched_barrier(0);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces have landed ...
+      __syncthreads();                                   // ... and so have everybody else's
+    }
+    compute(last & 1);
+    __syncthreads();
+#undef GEMM_DMA
+  } else if constexpr (PIPE == 1) {
     GEMM_GLOAD(0, 0);
     GEMM_LSTORE(0, 0);
     __syncthreads();
@@ -300,7 +353,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 }  // namespace
 
 static int g_gemm_pipe = 2;
-void set_gemm_variant(int v) { g_gemm_pipe = (v == 1) ? 1 : 2; }
+void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 3) ? v : 2; }
 
 template <int PIPE>
 static int launch_gemm_pipe(const GemmParams& p, int epi, int grid, size_t lds, hipStream_t stream) {
@@ -328,7 +381,9 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
   const int grid = nbm * nbn;
   const size_t lds = 2 * STAGE_BYTES;
-  return g_gemm_pipe == 1 ? launch_gemm_pipe<1>(p, epi, grid, lds, stream) : launch_gemm_pipe<2>(p, epi, grid, lds, stream);
+  if (g_gemm_pipe == 1) return launch_gemm_pipe<1>(p, epi, grid, lds, stream);
+  if (g_gemm_pipe == 3) return launch_gemm_pipe<3>(p, epi, grid, lds, stream);
+  return launch_gemm_pipe<2>(p, epi, grid, lds, stream);
 }
 
 int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,
