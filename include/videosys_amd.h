@@ -44,7 +44,7 @@ const char* vsys_strerror(int code);
 /* number of HIP devices visible to the library (fails loudly instead of falling back when 0) */
 int vsys_device_count(void);
 
-/* Tuning knob (A/B measurement only; results are identical): 1 = single-stage, 2 = two-stage (default) operand prefetch
+/* Tuning knob (A/B measurement only; results are identical): 1 = single-stage register prefetch, 2 = two-stage register prefetch, 3 = LDS-DMA staging (default)
  * of vsys_gemm_bf16. */
 int vsys_tune_gemm_variant(int variant);
 

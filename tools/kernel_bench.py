@@ -69,7 +69,7 @@ def main():
                 ms = timeit(fn, args.reps)
                 tf = 2.0 * N * n * k / (ms * 1e-3) / 1e12
                 res.setdefault(f"gemm_{name}_pipe{variant}", []).append((ms, tf))
-    lib.vsys_tune_gemm_variant(2)
+    lib.vsys_tune_gemm_variant(3)
 
     # attention: spatial (38 frames x 1024), cross (2 x 19456 q, 300 keys), temporal
     qkv = rnd(N, 3 * C)

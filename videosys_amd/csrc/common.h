@@ -43,14 +43,13 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+// nn.GELU(approximate="tanh"): 0.5 x (1 + tanh(u)), u = sqrt(2/pi) (x + 0.044715 x^3).
+// 0.5 (1 + tanh(u)) == sigmoid(2u) == 1 / (1 + exp(-2u)): one v_exp_f32 + one v_rcp_f32, no division sequence.
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  // tanh(u) = 1 - 2/(exp(2u)+1); exp via exp2 (v_exp_f32)
-  float e = __builtin_amdgcn_exp2f(u * 2.8853900817779268f);  // exp(2u)
-  float t = 1.0f - 2.0f / (e + 1.0f);
-  return 0.5f * x * (1.0f + t);
+  const float u = k0 * x * (1.0f + k1 * x * x);
+  const float e = __builtin_amdgcn_exp2f(u * -2.8853900817779268f);  // exp(-2u); +inf for very negative x -> result -0
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -231,6 +231,24 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 #undef GEMM_LSTORE
 
   // ---- epilogue: acc (+bias, act, gate) -> bf16 -> per-wave LDS image [64 tokens][96 cols] -> 16-byte HBM stores
+  // Residual rows for the store phase below are fetched NOW (12 x 16 B per lane, rows clamped instead of branched) so
+  // their HBM latency hides under the accumulator -> LDS transposition; a load-wait-store chain per 16 bytes would
+  // serialise 12 HBM round trips per wave (CDNA4 vmcnt also counts the stores).
+  uint4 rres[12];
+  if (EPI == EPI_GATE_RES) {
+#pragma unroll
+    for (int it = 0; it < 12; ++it) rres[it] = make_uint4(0, 0, 0, 0);
+    if (p.res != nullptr) {
+#pragma unroll
+      for (int it = 0; it < 12; ++it) {
+        const int q = lane + 64 * it;
+        const int m_local = q / 12, c = q - m_local * 12;
+        int grow = row0 + wm * 64 + m_local;
+        grow = grow < p.M ? grow : p.M - 1;
+        rres[it] = *reinterpret_cast<const uint4*>(p.res + (int64_t)grow * p.ldr + col0 + wn * 96 + c * 8);
+      }
+    }
+  }
   char* st = smem + wave * OUT_WAVE_BYTES;
   const int ncol0 = col0 + wn * 96;
   // bias for this lane's 12 column groups (4 consecutive columns each), loaded back-to-back under one uniform branch
@@ -293,23 +311,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
     const int q = lane + 64 * it;
     const int m_local = q / 12, c = q - m_local * 12;
     const int grow = row0 + wm * 64 + m_local;
-    if (grow < p.M) {
-      uint4 val = *reinterpret_cast<const uint4*>(st + m_local * OUT_ROW_BYTES + c * 16);
-      const int gcol = ncol0 + c * 8;
-      if (EPI == EPI_GATE_RES) {
-        if (p.aux != nullptr) *reinterpret_cast<uint4*>(p.aux + (int64_t)grow * p.ldaux + gcol) = val;
-        if (p.res != nullptr) {
-          uint4 rr = *reinterpret_cast<const uint4*>(p.res + (int64_t)grow * p.ldr + gcol);
-          float a[8], b[8];
-          unpack8(val, a);
-          unpack8(rr, b);
+    uint4 val = *reinterpret_cast<const uint4*>(st + m_local * OUT_ROW_BYTES + c * 16);
+    const int gcol = ncol0 + c * 8;
+    const bool ok = grow < p.M;
+    if (EPI == EPI_GATE_RES) {
+      if (p.aux != nullptr && ok) *reinterpret_cast<uint4*>(p.aux + (int64_t)grow * p.ldaux + gcol) = val;
+      if (p.res != nullptr) {
+        float a[8], b[8];
+        unpack8(val, a);
+        unpack8(rres[it], b);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) a[e] += b[e];
-          val = pack8(a);
-        }
+        for (int e = 0; e < 8; ++e) a[e] += b[e];
+        val = pack8(a);
       }
-      *reinterpret_cast<uint4*>(p.out + (int64_t)grow * p.ldo + gcol) = val;
     }
+    if (ok) *reinterpret_cast<uint4*>(p.out + (int64_t)grow * p.ldo + gcol) = val;
   }
 }
 
@@ -352,8 +368,8 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 
 }  // namespace
 
-static int g_gemm_pipe = 2;
-void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 3) ? v : 2; }
+static int g_gemm_pipe = 3;
+void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 3) ? v : 3; }
 
 template <int PIPE>
 static int launch_gemm_pipe(const GemmParams& p, int epi, int grid, size_t lds, hipStream_t stream) {
