@@ -60,7 +60,7 @@ def test_gemm_bias(ops, M, N, K):
     check(out, O.gelu_tanh(ref), what="gemm+gelu")
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
 def test_gemm_pipeline_variants(ops, variant):
     """Every operand-staging variant of the GEMM (register single/double stage, LDS-DMA) must give the same result;
     K = 64 (one tile), 128 (two), 1152 (18) and an M tail exercise prologue / steady state / epilogue of each."""

@@ -113,7 +113,7 @@ struct FlashParams {
   const bf16_t* kp;                        // [batch][H][kv_pad][72]
   const bf16_t* vt;                        // [batch][H][96][kv_pad]
   bf16_t* out; int64_t out_stride;         // out(b, s, h) at out + (b*q_len + s)*out_stride + h*72
-  int heads, q_len, kv_len, kv_pad;
+  int heads, q_len, kv_len, kv_pad, nqb;
   float eps, scale_log2e;
 };
 
@@ -121,9 +121,13 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
-  const int bh = blockIdx.y;
+  // 1-D grid with the XCD remap: the q-blocks of one (batch, head) share K/V, so they must be CONSECUTIVE on one XCD to
+  // hit its L2 (a 2-D grid with gridDim.x == 8 puts each of them on a different XCD: 5.7x over-fetch measured).
+  const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = tile_id / p.nqb;
+  const int qb = tile_id - bh * p.nqb;
   const int b = bh / p.heads, h = bh - b * p.heads;
-  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int q0 = qb * 128 + wave * 32;
 
   // ---- Q fragment (B operand): lane holds Q[q0 + l31][16c + 8hi .. +8], c = 0..4 (d >= 72 -> 0)
   bf16x8 qf[5];
@@ -471,7 +475,10 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
   p.scale_log2e = 0.11785113019775793f * 1.4426950408889634f;  // 72^-0.5 * log2(e)
-  dim3 grid((q_len + 127) / 128, batch * heads);
+  p.nqb = (q_len + 127) / 128;
+  const int64_t nblk = (int64_t)p.nqb * batch * heads;
+  if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
+  dim3 grid((unsigned)nblk);
   const size_t lds = 2 * KV_STAGE;
   hipLaunchKernelGGL(flash_attn_d72_kernel, grid, dim3(256), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;

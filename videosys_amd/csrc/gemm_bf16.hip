@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     int r, c;
-    if constexpr (PIPE == 3) {
+    if constexpr (PIPE >= 3) {
       r = wave_u * 32 + i * 8 + (lane >> 3);
       c = (lane & 7) ^ ((r >> 1) & 7);
       a_lds[i] = (wave_u * 32 + i * 8) * 128;  // wave-uniform row-block base
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     int r, c;
-    if constexpr (PIPE == 3) {
+    if constexpr (PIPE >= 3) {
       r = wave_u * 24 + i * 8 + (lane >> 3);
       c = (lane & 7) ^ ((r >> 1) & 7);
       b_lds[i] = A_BYTES + (wave_u * 24 + i * 8) * 128;
@@ -155,8 +155,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 
   const int nt = p.K / BK;
   const int last = nt - 1;
-  if constexpr (PIPE == 3) {
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
 #define GEMM_DMA(kt_, buf_)                                                                                         \
   do {                                                                                                              \
     const int ko_ = (kt_) * BK;                                                                                     \
@@ -169,6 +168,87 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
     __builtin_amdgcn_global_load_lds((const void*)(bptr[1] + ko_), (lds_ptr_t)(base_ + b_lds[1]), 16, 0, 0);       \
     __builtin_amdgcn_global_load_lds((const void*)(bptr[2] + ko_), (lds_ptr_t)(base_ + b_lds[2]), 16, 0, 0);       \
   } while (0)
+  if constexpr (PIPE == 4) {
+    // ---- ping-pong: the two waves of a SIMD (wave w and w+4) run the same program one barrier interval apart, so
+    // in every interval exactly one of them owns the matrix pipe (12 MFMAs = half a K-tile) while its partner issues
+    // the ds_reads (and the LDS-DMA of the next tile) for its own next half-tile.  Raw s_barrier + counted waits only:
+    // a __syncthreads() here would drain the in-flight DMA (vmcnt(0)) at every barrier.
+    //   per wave, tile t:  R(2t): DMA(t+1), read half 0 | M(2t): 12 MFMA | R(2t+1): read half 1 | M(2t+1): 12 MFMA
+    //   buffer of tile t+1 is free at R(2t): all reads of tile t-1 ended (lgkmcnt(0)) before the previous barrier;
+    //   DMA(t+1) is waited for (vmcnt(0)) one interval before the first wave reads it: at the end of M(2t+1) by the
+    //   leading group, at the end of R(2t+1) by the lagging group (it is the same barrier for both).
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    bf16x8 xf00, xf01, xf10, xf11, wf00, wf01, wf02, wf10, wf11, wf12;
+#define PP_BARRIER()                                   \
+  do {                                                 \
+    __builtin_amdgcn_sched_barrier(0);                 \
+    asm volatile("" ::: "memory");                     \
+    __builtin_amdgcn_s_barrier();                      \
+    asm volatile("" ::: "memory");                     \
+    __builtin_amdgcn_sched_barrier(0);                 \
+  } while (0)
+#define PP_READ(cur_, half_)                                                                   \
+  do {                                                                                         \
+    const char* sa_ = smem + (cur_) * STAGE_BYTES;                                             \
+    const char* sb_ = sa_ + A_BYTES;                                                           \
+    const int c0_ = (2 * (half_)) * 2 + hi, c1_ = (2 * (half_) + 1) * 2 + hi;                  \
+    xf00 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[0], c0_));                          \
+    xf01 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[1], c0_));                          \
+    wf00 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[0], c0_));                          \
+    wf01 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[1], c0_));                          \
+    wf02 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[2], c0_));                          \
+    xf10 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[0], c1_));                          \
+    xf11 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[1], c1_));                          \
+    wf10 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[0], c1_));                          \
+    wf11 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[1], c1_));                          \
+    wf12 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[2], c1_));                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+  } while (0)
+#define PP_MMA()                                                                               \
+  do {                                                                                         \
+    __builtin_amdgcn_s_setprio(1);                                                             \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf00, xf00, acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf01, xf00, acc[0][1], 0, 0, 0);       \
+    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf02, xf00, acc[0][2], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf00, xf01, acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf01, xf01, acc[1][1], 0, 0, 0);       \
+    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf02, xf01, acc[1][2], 0, 0, 0);       \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf10, xf10, acc[0][0], 0, 0, 0);       \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf11, xf10, acc[0][1], 0, 0, 0);       \
+    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf12, xf10, acc[0][2], 0, 0, 0);       \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf10, xf11, acc[1][0], 0, 0, 0);       \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf11, xf11, acc[1][1], 0, 0, 0);       \
+    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf12, xf11, acc[1][2], 0, 0, 0);       \
+    __builtin_amdgcn_s_setprio(0);                                                             \
+  } while (0)
+    GEMM_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PP_BARRIER();
+    if (grp) PP_BARRIER();  // the lagging group starts one interval late
+    for (int kt = 0; kt < nt; ++kt) {
+      const int cur = kt & 1;
+      // R(2t)
+      if (kt < last) GEMM_DMA(kt + 1, cur ^ 1);
+      PP_READ(cur, 0);
+      PP_BARRIER();
+      // M(2t)
+      PP_MMA();
+      PP_BARRIER();
+      // R(2t+1)
+      PP_READ(cur, 1);
+      if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_BARRIER();
+      // M(2t+1)
+      PP_MMA();
+      if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PP_BARRIER();
+    }
+    if (!grp) PP_BARRIER();  // balance the barrier count of the two groups
+    __syncthreads();
+#undef PP_BARRIER
+#undef PP_READ
+#undef PP_MMA
+  } else if constexpr (PIPE == 3) {
     GEMM_DMA(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -369,7 +449,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 }  // namespace
 
 static int g_gemm_pipe = 3;
-void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 3) ? v : 3; }
+void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 4) ? v : 3; }
 
 template <int PIPE>
 static int launch_gemm_pipe(const GemmParams& p, int epi, int grid, size_t lds, hipStream_t stream) {
@@ -399,6 +479,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   const size_t lds = 2 * STAGE_BYTES;
   if (g_gemm_pipe == 1) return launch_gemm_pipe<1>(p, epi, grid, lds, stream);
   if (g_gemm_pipe == 3) return launch_gemm_pipe<3>(p, epi, grid, lds, stream);
+  if (g_gemm_pipe == 4) return launch_gemm_pipe<4>(p, epi, grid, lds, stream);
   return launch_gemm_pipe<2>(p, epi, grid, lds, stream);
 }
 
