@@ -31,6 +31,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--variants", default="0", help="comma list of GEMM pipeline variants to A/B (interleaved); 0 = default")
+    ap.add_argument("--only", default="", help="'gemm' = skip the non-GEMM kernels")
     args = ap.parse_args()
     import __graft_entry__ as ge
 
@@ -56,7 +58,7 @@ def main():
         bufs[name] = (rnd(n, k, scale=1 / math.sqrt(k)), rnd(n, scale=0.1), torch.empty(N, n, dtype=torch.bfloat16, device=dev))
     resid = rnd(N, C)
     for rd in range(args.rounds):
-        for variant in (3, 4):
+        for variant in [int(v) for v in args.variants.split(',')]:
             lib.vsys_tune_gemm_variant(variant)
             for name, n, k, epi in shapes:
                 w, b, out = bufs[name]
@@ -69,7 +71,9 @@ def main():
                 ms = timeit(fn, args.reps)
                 tf = 2.0 * N * n * k / (ms * 1e-3) / 1e12
                 res.setdefault(f"gemm_{name}_pipe{variant}", []).append((ms, tf))
-    lib.vsys_tune_gemm_variant(3)
+    lib.vsys_tune_gemm_variant(0)
+    if args.only == "gemm":
+        return report(res)
 
     # attention: spatial (38 frames x 1024), cross (2 x 19456 q, 300 keys), temporal
     qkv = rnd(N, 3 * C)
@@ -95,6 +99,10 @@ def main():
     ms = timeit(lambda: ops.add_rows(ao, x), args.reps)
     res["add_rows"] = [(ms, 269.0 / ms)]
 
+    report(res)
+
+
+def report(res):
     out = {}
     print(f"{'kernel':32s} {'ms(min)':>9s} {'ms(med)':>9s} {'rate(max)':>10s}")
     for k, v in res.items():

@@ -248,6 +248,63 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 #undef PP_BARRIER
 #undef PP_READ
 #undef PP_MMA
+  } else if constexpr (PIPE == 5) {
+    // ---- LDS-DMA double buffer with the 7 DMA pieces of tile t+1 spread between the MFMA groups of tile t (2,2,2,1
+    // per k-step) instead of issued back-to-back at the top of the tile: a global_load_lds costs the issuing wave
+    // ~60-180 cycles, and seven of them in a row right after the barrier leave the matrix pipe idle on every SIMD.
+#define GEMM_DMA_A(i_, kt_, buf_)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const void*)(aptr[i_] + (kt_) * BK), (lds_ptr_t)(smem + (buf_) * STAGE_BYTES + a_lds[i_]), 16, 0, 0)
+#define GEMM_DMA_B(i_, kt_, buf_)                                                                                  \
+  __builtin_amdgcn_global_load_lds((const void*)(bptr[i_] + (kt_) * BK), (lds_ptr_t)(smem + (buf_) * STAGE_BYTES + b_lds[i_]), 16, 0, 0)
+#define GEMM_KSTEP(ks_, sa_, sb_)                                                                                  \
+  do {                                                                                                             \
+    const int chunk_ = (ks_) * 2 + hi;                                                                             \
+    bf16x8 x0_ = *reinterpret_cast<const bf16x8*>((sa_) + swz(xrow[0], chunk_));                                   \
+    bf16x8 x1_ = *reinterpret_cast<const bf16x8*>((sa_) + swz(xrow[1], chunk_));                                   \
+    bf16x8 w0_ = *reinterpret_cast<const bf16x8*>((sb_) + swz(wrow[0], chunk_));                                   \
+    bf16x8 w1_ = *reinterpret_cast<const bf16x8*>((sb_) + swz(wrow[1], chunk_));                                   \
+    bf16x8 w2_ = *reinterpret_cast<const bf16x8*>((sb_) + swz(wrow[2], chunk_));                                   \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0_, x0_, acc[0][0], 0, 0, 0);                             \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1_, x0_, acc[0][1], 0, 0, 0);                             \
+    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2_, x0_, acc[0][2], 0, 0, 0);                             \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0_, x1_, acc[1][0], 0, 0, 0);                             \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1_, x1_, acc[1][1], 0, 0, 0);                             \
+    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2_, x1_, acc[1][2], 0, 0, 0);                             \
+  } while (0)
+    GEMM_DMA(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < last; ++kt) {
+      const int cur = kt & 1, nxt = cur ^ 1;
+      const char* sa = smem + cur * STAGE_BYTES;
+      const char* sb = sa + A_BYTES;
+      GEMM_DMA_A(0, kt + 1, nxt);
+      GEMM_DMA_A(1, kt + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_KSTEP(0, sa, sb);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_DMA_A(2, kt + 1, nxt);
+      GEMM_DMA_A(3, kt + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_KSTEP(1, sa, sb);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_DMA_B(0, kt + 1, nxt);
+      GEMM_DMA_B(1, kt + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_KSTEP(2, sa, sb);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_DMA_B(2, kt + 1, nxt);
+      __builtin_amdgcn_sched_barrier(0);
+      GEMM_KSTEP(3, sa, sb);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    compute(last & 1);
+    __syncthreads();
+#undef GEMM_DMA_A
+#undef GEMM_DMA_B
+#undef GEMM_KSTEP
   } else if constexpr (PIPE == 3) {
     GEMM_DMA(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -449,7 +506,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 }  // namespace
 
 static int g_gemm_pipe = 3;
-void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 4) ? v : 3; }
+void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 5) ? v : 3; }
 
 template <int PIPE>
 static int launch_gemm_pipe(const GemmParams& p, int epi, int grid, size_t lds, hipStream_t stream) {
@@ -480,6 +537,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   if (g_gemm_pipe == 1) return launch_gemm_pipe<1>(p, epi, grid, lds, stream);
   if (g_gemm_pipe == 3) return launch_gemm_pipe<3>(p, epi, grid, lds, stream);
   if (g_gemm_pipe == 4) return launch_gemm_pipe<4>(p, epi, grid, lds, stream);
+  if (g_gemm_pipe == 5) return launch_gemm_pipe<5>(p, epi, grid, lds, stream);
   return launch_gemm_pipe<2>(p, epi, grid, lds, stream);
 }
 
