@@ -170,7 +170,7 @@ def main():
             a[2] += 1
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
         roof = {
-            "bound": "mfma", "kernel": "vsys::gemm_256x192_kernel<EPI> (bf16 MFMA 32x32x16, all epilogues)",
+            "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> (256x192x64 tile, bf16 MFMA 32x32x16, all epilogues)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
             "launches_per_step": n // nrep, "avg_launch_ms": round(tot_ms / n, 4),

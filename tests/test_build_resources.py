@@ -30,7 +30,7 @@ def _usage(src):
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
-@pytest.mark.parametrize("src,pattern,max_vgpr", [("gemm_bf16.hip", "gemm_256x192_kernel", 256),
+@pytest.mark.parametrize("src,pattern,max_vgpr", [("gemm_bf16.hip", "gemm_kernel", 256),
                                                   ("attention.hip", "flash_attn_d72_kernel", 256),
                                                   ("attention.hip", "attn_temporal_d72_kernel", 128)])
 def test_hot_kernels_have_no_scratch(src, pattern, max_vgpr):

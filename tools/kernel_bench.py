@@ -71,6 +71,13 @@ def main():
                 ms = timeit(fn, args.reps)
                 tf = 2.0 * N * n * k / (ms * 1e-3) / 1e12
                 res.setdefault(f"gemm_{name}_pipe{variant}", []).append((ms, tf))
+                if rd == 0 and variant % 100 < 10:  # schedules must not change results: same k order, same MFMA
+                    got = out.clone()
+                    lib.vsys_tune_gemm_variant(0)
+                    fn()
+                    lib.vsys_tune_gemm_variant(variant)
+                    same = torch.equal(got, out)
+                    print(f"  check gemm_{name} variant {variant} == default: {same}", flush=True)
     lib.vsys_tune_gemm_variant(0)
     if args.only == "gemm":
         return report(res)

@@ -13,7 +13,7 @@ from videosys_amd import _lib, ops  # noqa: E402
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(0)
 N, C, H = 38912, 1152, 16
-variant = int(os.environ.get("VSYS_GEMM_VARIANT", "3"))
+variant = int(os.environ.get("VSYS_GEMM_VARIANT", "0"))
 _lib.load().vsys_tune_gemm_variant(variant)
 
 

@@ -24,20 +24,43 @@ namespace vsys {
 
 namespace {
 
-constexpr int BM = 256, BN = 192, BK = 64, NTHREADS = 512;
-constexpr int A_BYTES = BM * BK * 2;  // 32768
-constexpr int B_BYTES = BN * BK * 2;  // 24576
-constexpr int STAGE_BYTES = A_BYTES + B_BYTES;  // 57344
+constexpr int BN = 192, BK = 64;
+constexpr int B_BYTES = BN * BK * 2;            // 24576
 constexpr int OUT_ROW_BYTES = 96 * 2 + 16;      // per-wave epilogue image row (padded)
 constexpr int OUT_WAVE_BYTES = 64 * OUT_ROW_BYTES;  // 13312
-static_assert(8 * OUT_WAVE_BYTES <= 2 * STAGE_BYTES, "epilogue image must fit in the staging buffers");
 
-__device__ __forceinline__ int swz(int row, int chunk) { return (row << 7) + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// Geometry for a BM_ x 192 x 64 block tile: BM_/64 (M) x 2 (N) waves, every wave a 64 x 96 output tile.
+//   BM_ = 256: 8 waves, 112 KiB of staging, one workgroup per CU (two waves per SIMD from ONE workgroup);
+//   BM_ = 128: 4 waves,  80 KiB of staging, two workgroups per CU (the two waves of a SIMD belong to DIFFERENT
+//              workgroups, so one workgroup's barrier / epilogue overlaps the other's MFMAs).
+template <int BM_>
+struct Geo {
+  static constexpr int NW = BM_ / 32;
+  static constexpr int NT = NW * 64;
+  static constexpr int A_BYTES = BM_ * BK * 2;
+  static constexpr int STAGE = A_BYTES + B_BYTES;
+  static constexpr int NA = 4;             // A LDS-DMA pieces (8 rows x 128 B) per wave per K-tile: BM_/NW/8
+  static constexpr int NB = BN / NW / 8;   // B pieces per wave per K-tile: 3 or 6
+  static_assert(NW * OUT_WAVE_BYTES <= 2 * STAGE, "epilogue image must fit in the staging buffers");
+};
 
-// PIPE = 1: one staging register set (loads of tile t+1 fly during the MFMAs of tile t);
-// PIPE = 2: two sets (tile t+2 in flight while tile t+1 waits in registers) — the default.
-template <int EPI, int PIPE>
-__global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p) {
+// Variant id = BASE + 10 * ABL.  BASE selects the main-loop schedule:
+//   3: LDS-DMA double buffer, the pieces of tile t+1 issued back-to-back at the top of tile t, one barrier per tile;
+//   6: fragment registers double-buffered by hand (k-step s+1 is read while k-step s multiplies), the tile barrier
+//      moved in front of the LAST k-step so the first fragments of tile t+1 are read under the MFMAs of tile t, and
+//      the DMA pieces of tile t+2 interleaved one by one with the MFMAs (a piece holds its wave ~60-180 cycles at
+//      issue; behind an MFMA of the same wave that time is covered by the matrix pipe);
+//   8: schedule 6 on THREE A slots + TWO W slots with counted vmcnt waits (A(t+2) and W(t+1) in flight during tile t)
+//      — the shipped default (measured at config 2: qkv 0.33 -> 0.31 ms, fc2 0.44 -> 0.39 ms over schedule 3).
+// ABL (lab builds only): 1 = no epilogue (accumulators kept alive), 2 = no LDS-DMA inside the loop, 3 = every tile reads
+// the A rows of tile 0 (A becomes L2-resident: separates HBM-miss latency from DMA issue / LDS-write cost), 4 = epilogue
+// arithmetic without the HBM stores, 5 = streaming (nt) stores.
+template <int EPI, int PIPE, int BM_>
+__global__ __launch_bounds__(Geo<BM_>::NT, 2) void gemm_kernel(GemmParams p) {
+#if __HIP_DEVICE_COMPILE__  // the buffer-resource type below exists in the device pass only; the host pass needs just the stub
+  using G = Geo<BM_>;
+  constexpr int BASE = PIPE % 10, ABL = PIPE / 10;
+  constexpr int A_BYTES = G::A_BYTES, STAGE_BYTES = G::STAGE, NA = G::NA, NB = G::NB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -46,85 +69,68 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
   const int nbn = p.N / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int bm = tile / nbn, bn = tile - bm * nbn;
-  const int row0 = bm * BM, col0 = bn * BN;
+  const int row0 = bm * BM_, col0 = bn * BN;
 
-  // ---- staging assignment.
-  // PIPE 1/2 (register staged): chunk q = tid + 512*i -> (row = q>>3, logical 16-byte chunk = q&7), written to the
-  //   swizzled LDS slot by ds_write_b128.
-  // PIPE 3 (LDS-DMA): global_load_lds writes lane l of a wave to  M0_base + 16*l  (lane-linear), so each wave
-  //   instruction fills 8 whole 128-byte rows and the swizzle moves to the SOURCE: the lane that lands in physical
-  //   slot s of row r fetches logical chunk s ^ ((r>>1)&7)  (same involution as the fragment reads).
-  const bf16_t* aptr[4];
-  const bf16_t* bptr[3];
-  int a_lds[4], b_lds[3];
+  // ---- LDS-DMA staging assignment.  global_load_lds writes lane l of a wave to  M0_base + 16*l  (lane-linear), so each
+  // wave instruction fills 8 whole 128-byte rows; the bank swizzle therefore sits on the SOURCE side: the lane that
+  // lands in physical 16-byte slot s of row r fetches logical chunk s ^ ((r>>1)&7) (the involution the reads apply).
+  // The buffer form (buffer_load_dwordx4 ... offen lds) is used on purpose: the global form is FLAT-encoded and touches two
+  // address spaces, which makes hipcc's wait-count pass treat every later wait as "flat pending" and emit lgkmcnt(0)
+  // instead of counted waits, draining the fragment-read pipeline at every k-step.  It also keeps the K advance in the
+  // scalar offset, so a piece costs no address VALU.
+  int a_off[NA], b_off[NB];  // per-lane byte offsets from the tile's first A row / W row
+  int a_lds[NA], b_lds[NB];
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r, c;
-    if constexpr (PIPE >= 3) {
-      r = wave_u * 32 + i * 8 + (lane >> 3);
-      c = (lane & 7) ^ ((r >> 1) & 7);
-      a_lds[i] = (wave_u * 32 + i * 8) * 128;  // wave-uniform row-block base
-    } else {
-      const int q = tid + NTHREADS * i;
-      r = q >> 3;
-      c = q & 7;
-      a_lds[i] = swz(r, c);
-    }
-    int gr = row0 + r;
-    gr = gr < p.M ? gr : p.M - 1;
-    aptr[i] = p.A + (int64_t)gr * p.lda + c * 8;
+  for (int i = 0; i < NA; ++i) {
+    const int r = wave_u * (NA * 8) + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    a_lds[i] = (wave_u * (NA * 8) + i * 8) * 128;  // wave-uniform row-block base
+    const int rl = row0 + r < p.M ? r : p.M - 1 - row0;  // rows past M re-read the last row (never stored)
+    a_off[i] = (rl * (int)p.lda + c * 8) * 2;
   }
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    int r, c;
-    if constexpr (PIPE >= 3) {
-      r = wave_u * 24 + i * 8 + (lane >> 3);
-      c = (lane & 7) ^ ((r >> 1) & 7);
-      b_lds[i] = A_BYTES + (wave_u * 24 + i * 8) * 128;
-    } else {
-      const int q = tid + NTHREADS * i;
-      r = q >> 3;
-      c = q & 7;
-      b_lds[i] = A_BYTES + swz(r, c);
-    }
-    bptr[i] = p.W + (int64_t)(col0 + r) * p.ldw + c * 8;
+  for (int i = 0; i < NB; ++i) {
+    const int r = wave_u * (NB * 8) + i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_lds[i] = A_BYTES + (wave_u * (NB * 8) + i * 8) * 128;
+    b_off[i] = (r * (int)p.ldw + c * 8) * 2;
   }
-
-  // Two staging register sets (named scalars + macros on purpose: arrays captured by a lambda and written under a
-  // condition get parked in scratch by hipcc).  Set X holds tile t+1 while the loads of tile t+2 fly into set Y, so a
-  // load has TWO tile-times of MFMA work to land before its ds_write needs it (1 block/CU: nothing else hides it).
-  uint4 ra0_0, ra1_0, ra2_0, ra3_0, rb0_0, rb1_0, rb2_0;
-  uint4 ra0_1, ra1_1, ra2_1, ra3_1, rb0_1, rb1_1, rb2_1;
-#define GEMM_GLOAD(S, kt_)                                                 \
-  do {                                                                     \
-    const int ko_ = (kt_) * BK;                                            \
-    ra0_##S = *reinterpret_cast<const uint4*>(aptr[0] + ko_);              \
-    ra1_##S = *reinterpret_cast<const uint4*>(aptr[1] + ko_);              \
-    ra2_##S = *reinterpret_cast<const uint4*>(aptr[2] + ko_);              \
-    ra3_##S = *reinterpret_cast<const uint4*>(aptr[3] + ko_);              \
-    rb0_##S = *reinterpret_cast<const uint4*>(bptr[0] + ko_);              \
-    rb1_##S = *reinterpret_cast<const uint4*>(bptr[1] + ko_);              \
-    rb2_##S = *reinterpret_cast<const uint4*>(bptr[2] + ko_);              \
+  // descriptors start at the tile's first row and end with the matrix: reads past the end return 0 instead of faulting
+  const int64_t a_row0 = (ABL == 3) ? 0 : row0;  // lab: every tile streams the SAME (L2-resident) A rows
+  const int64_t a_bytes = ((int64_t)(p.M - 1 - row0) * p.lda + p.K) * 2, b_bytes = ((int64_t)(p.N - 1 - col0) * p.ldw + p.K) * 2;
+  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + a_row0 * p.lda), 0,
+                                                        (int)(a_bytes < 0x7fffffff ? a_bytes : 0x7fffffff), 0x00020000);
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)col0 * p.ldw), 0,
+                                                        (int)(b_bytes < 0x7fffffff ? b_bytes : 0x7fffffff), 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  // piece i of tile kt_ into buffer buf_ (i < NA: A rows, else W rows); i must be a constant after unrolling
+  auto dma_piece = [&](int i, int kt_, int buf_) {
+    char* base_ = smem + buf_ * STAGE_BYTES;
+    if (i < NA)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base_ + a_lds[i < NA ? i : 0]), 16, a_off[i < NA ? i : 0], kt_ * (BK * 2), 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base_ + b_lds[i >= NA ? i - NA : 0]), 16, b_off[i >= NA ? i - NA : 0], kt_ * (BK * 2), 0, 0);
+  };
+#define GEMM_DMA_RANGE(lo_, hi_, kt_, buf_)                          \
+  do {                                                               \
+    _Pragma("unroll") for (int i_ = (lo_); i_ < (hi_); ++i_) dma_piece(i_, (kt_), (buf_)); \
   } while (0)
-#define GEMM_LSTORE(S, buf_)                                               \
-  do {                                                                     \
-    char* base_ = smem + (buf_) * STAGE_BYTES;                             \
-    *reinterpret_cast<uint4*>(base_ + a_lds[0]) = ra0_##S;                 \
-    *reinterpret_cast<uint4*>(base_ + a_lds[1]) = ra1_##S;                 \
-    *reinterpret_cast<uint4*>(base_ + a_lds[2]) = ra2_##S;                 \
-    *reinterpret_cast<uint4*>(base_ + a_lds[3]) = ra3_##S;                 \
-    *reinterpret_cast<uint4*>(base_ + b_lds[0]) = rb0_##S;                 \
-    *reinterpret_cast<uint4*>(base_ + b_lds[1]) = rb1_##S;                 \
-    *reinterpret_cast<uint4*>(base_ + b_lds[2]) = rb2_##S;                 \
-  } while (0)
+  constexpr int NP = NA + NB;  // 7 or 10 pieces per wave per K-tile
 
-  // ---- fragment read offsets (per lane): X rows (tokens) for i=0,1; W rows (out cols) for j=0..2
-  int xrow[2], wrow[3];
+  // ---- fragment read offsets (per lane).  swz(row, chunk) = row*128 + ((chunk ^ ((row>>1)&7)) << 4) with
+  // chunk = 2*ks + hi  ==  (row*128 + ((hi ^ ((row>>1)&7)) << 4)) ^ (ks << 5): one base per fragment row, the k-step is an XOR.
+  int xo[2], wo[3];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) xrow[i] = wm * 64 + i * 32 + l31;
+  for (int i = 0; i < 2; ++i) {
+    const int r = wm * 64 + i * 32 + l31;
+    xo[i] = (r << 7) + ((hi ^ ((r >> 1) & 7)) << 4);
+  }
 #pragma unroll
-  for (int j = 0; j < 3; ++j) wrow[j] = wn * 96 + j * 32 + l31;
+  for (int j = 0; j < 3; ++j) {
+    const int r = wn * 96 + j * 32 + l31;
+    wo[j] = A_BYTES + (r << 7) + ((hi ^ ((r >> 1) & 7)) << 4);
+  }
 
   f32x16 acc[2][3];
 #pragma unroll
@@ -135,16 +141,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   auto compute = [&](int cur) {
-    const char* sa = smem + cur * STAGE_BYTES;
-    const char* sb = sa + A_BYTES;
+    const char* sb_ = smem + cur * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const int chunk = ks * 2 + hi;
       bf16x8 xf[2], wf[3];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sa + swz(xrow[i], chunk));
+      for (int i = 0; i < 2; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb_ + (xo[i] ^ (ks << 5)));
 #pragma unroll
-      for (int j = 0; j < 3; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb + swz(wrow[j], chunk));
+      for (int j = 0; j < 3; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb_ + (wo[j] ^ (ks << 5)));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -155,163 +159,169 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
 
   const int nt = p.K / BK;
   const int last = nt - 1;
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-#define GEMM_DMA(kt_, buf_)                                                                                         \
-  do {                                                                                                              \
-    const int ko_ = (kt_) * BK;                                                                                     \
-    char* base_ = smem + (buf_) * STAGE_BYTES;                                                                      \
-    __builtin_amdgcn_global_load_lds((const void*)(aptr[0] + ko_), (lds_ptr_t)(base_ + a_lds[0]), 16, 0, 0);       \
-    __builtin_amdgcn_global_load_lds((const void*)(aptr[1] + ko_), (lds_ptr_t)(base_ + a_lds[1]), 16, 0, 0);       \
-    __builtin_amdgcn_global_load_lds((const void*)(aptr[2] + ko_), (lds_ptr_t)(base_ + a_lds[2]), 16, 0, 0);       \
-    __builtin_amdgcn_global_load_lds((const void*)(aptr[3] + ko_), (lds_ptr_t)(base_ + a_lds[3]), 16, 0, 0);       \
-    __builtin_amdgcn_global_load_lds((const void*)(bptr[0] + ko_), (lds_ptr_t)(base_ + b_lds[0]), 16, 0, 0);       \
-    __builtin_amdgcn_global_load_lds((const void*)(bptr[1] + ko_), (lds_ptr_t)(base_ + b_lds[1]), 16, 0, 0);       \
-    __builtin_amdgcn_global_load_lds((const void*)(bptr[2] + ko_), (lds_ptr_t)(base_ + b_lds[2]), 16, 0, 0);       \
-  } while (0)
-  if constexpr (PIPE == 4) {
-    // ---- ping-pong: the two waves of a SIMD (wave w and w+4) run the same program one barrier interval apart, so
-    // in every interval exactly one of them owns the matrix pipe (12 MFMAs = half a K-tile) while its partner issues
-    // the ds_reads (and the LDS-DMA of the next tile) for its own next half-tile.  Raw s_barrier + counted waits only:
-    // a __syncthreads() here would drain the in-flight DMA (vmcnt(0)) at every barrier.
-    //   per wave, tile t:  R(2t): DMA(t+1), read half 0 | M(2t): 12 MFMA | R(2t+1): read half 1 | M(2t+1): 12 MFMA
-    //   buffer of tile t+1 is free at R(2t): all reads of tile t-1 ended (lgkmcnt(0)) before the previous barrier;
-    //   DMA(t+1) is waited for (vmcnt(0)) one interval before the first wave reads it: at the end of M(2t+1) by the
-    //   leading group, at the end of R(2t+1) by the lagging group (it is the same barrier for both).
-    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
-    bf16x8 xf00, xf01, xf10, xf11, wf00, wf01, wf02, wf10, wf11, wf12;
-#define PP_BARRIER()                                   \
-  do {                                                 \
-    __builtin_amdgcn_sched_barrier(0);                 \
-    asm volatile("" ::: "memory");                     \
-    __builtin_amdgcn_s_barrier();                      \
-    asm volatile("" ::: "memory");                     \
-    __builtin_amdgcn_sched_barrier(0);                 \
-  } while (0)
-#define PP_READ(cur_, half_)                                                                   \
-  do {                                                                                         \
-    const char* sa_ = smem + (cur_) * STAGE_BYTES;                                             \
-    const char* sb_ = sa_ + A_BYTES;                                                           \
-    const int c0_ = (2 * (half_)) * 2 + hi, c1_ = (2 * (half_) + 1) * 2 + hi;                  \
-    xf00 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[0], c0_));                          \
-    xf01 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[1], c0_));                          \
-    wf00 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[0], c0_));                          \
-    wf01 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[1], c0_));                          \
-    wf02 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[2], c0_));                          \
-    xf10 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[0], c1_));                          \
-    xf11 = *reinterpret_cast<const bf16x8*>(sa_ + swz(xrow[1], c1_));                          \
-    wf10 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[0], c1_));                          \
-    wf11 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[1], c1_));                          \
-    wf12 = *reinterpret_cast<const bf16x8*>(sb_ + swz(wrow[2], c1_));                          \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
-  } while (0)
-#define PP_MMA()                                                                               \
-  do {                                                                                         \
-    __builtin_amdgcn_s_setprio(1);                                                             \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf00, xf00, acc[0][0], 0, 0, 0);       \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf01, xf00, acc[0][1], 0, 0, 0);       \
-    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf02, xf00, acc[0][2], 0, 0, 0);       \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf00, xf01, acc[1][0], 0, 0, 0);       \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf01, xf01, acc[1][1], 0, 0, 0);       \
-    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf02, xf01, acc[1][2], 0, 0, 0);       \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf10, xf10, acc[0][0], 0, 0, 0);       \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf11, xf10, acc[0][1], 0, 0, 0);       \
-    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf12, xf10, acc[0][2], 0, 0, 0);       \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf10, xf11, acc[1][0], 0, 0, 0);       \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf11, xf11, acc[1][1], 0, 0, 0);       \
-    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf12, xf11, acc[1][2], 0, 0, 0);       \
-    __builtin_amdgcn_s_setprio(0);                                                             \
-  } while (0)
-    GEMM_DMA(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    PP_BARRIER();
-    if (grp) PP_BARRIER();  // the lagging group starts one interval late
-    for (int kt = 0; kt < nt; ++kt) {
-      const int cur = kt & 1;
-      // R(2t)
-      if (kt < last) GEMM_DMA(kt + 1, cur ^ 1);
-      PP_READ(cur, 0);
-      PP_BARRIER();
-      // M(2t)
-      PP_MMA();
-      PP_BARRIER();
-      // R(2t+1)
-      PP_READ(cur, 1);
-      if (grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PP_BARRIER();
-      // M(2t+1)
-      PP_MMA();
-      if (!grp) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      PP_BARRIER();
-    }
-    if (!grp) PP_BARRIER();  // balance the barrier count of the two groups
-    __syncthreads();
-#undef PP_BARRIER
-#undef PP_READ
-#undef PP_MMA
-  } else if constexpr (PIPE == 5) {
-    // ---- LDS-DMA double buffer with the 7 DMA pieces of tile t+1 spread between the MFMA groups of tile t (2,2,2,1
-    // per k-step) instead of issued back-to-back at the top of the tile: a global_load_lds costs the issuing wave
-    // ~60-180 cycles, and seven of them in a row right after the barrier leave the matrix pipe idle on every SIMD.
-#define GEMM_DMA_A(i_, kt_, buf_)                                                                                  \
-  __builtin_amdgcn_global_load_lds((const void*)(aptr[i_] + (kt_) * BK), (lds_ptr_t)(smem + (buf_) * STAGE_BYTES + a_lds[i_]), 16, 0, 0)
-#define GEMM_DMA_B(i_, kt_, buf_)                                                                                  \
-  __builtin_amdgcn_global_load_lds((const void*)(bptr[i_] + (kt_) * BK), (lds_ptr_t)(smem + (buf_) * STAGE_BYTES + b_lds[i_]), 16, 0, 0)
-#define GEMM_KSTEP(ks_, sa_, sb_)                                                                                  \
-  do {                                                                                                             \
-    const int chunk_ = (ks_) * 2 + hi;                                                                             \
-    bf16x8 x0_ = *reinterpret_cast<const bf16x8*>((sa_) + swz(xrow[0], chunk_));                                   \
-    bf16x8 x1_ = *reinterpret_cast<const bf16x8*>((sa_) + swz(xrow[1], chunk_));                                   \
-    bf16x8 w0_ = *reinterpret_cast<const bf16x8*>((sb_) + swz(wrow[0], chunk_));                                   \
-    bf16x8 w1_ = *reinterpret_cast<const bf16x8*>((sb_) + swz(wrow[1], chunk_));                                   \
-    bf16x8 w2_ = *reinterpret_cast<const bf16x8*>((sb_) + swz(wrow[2], chunk_));                                   \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0_, x0_, acc[0][0], 0, 0, 0);                             \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1_, x0_, acc[0][1], 0, 0, 0);                             \
-    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2_, x0_, acc[0][2], 0, 0, 0);                             \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0_, x1_, acc[1][0], 0, 0, 0);                             \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1_, x1_, acc[1][1], 0, 0, 0);                             \
-    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w2_, x1_, acc[1][2], 0, 0, 0);                             \
-  } while (0)
-    GEMM_DMA(0, 0);
+  if constexpr (BASE != 8) {
+    GEMM_DMA_RANGE(0, NP, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (int kt = 0; kt < last; ++kt) {
-      const int cur = kt & 1, nxt = cur ^ 1;
-      const char* sa = smem + cur * STAGE_BYTES;
-      const char* sb = sa + A_BYTES;
-      GEMM_DMA_A(0, kt + 1, nxt);
-      GEMM_DMA_A(1, kt + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_KSTEP(0, sa, sb);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_DMA_A(2, kt + 1, nxt);
-      GEMM_DMA_A(3, kt + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_KSTEP(1, sa, sb);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_DMA_B(0, kt + 1, nxt);
-      GEMM_DMA_B(1, kt + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_KSTEP(2, sa, sb);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_DMA_B(2, kt + 1, nxt);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_KSTEP(3, sa, sb);
-      __builtin_amdgcn_sched_barrier(0);
+  }
+
+  if constexpr (BASE == 8) {
+    // ---- three A slots + two W slots (144 KiB).  A is streamed from HBM exactly once while W stays L2/MALL resident,
+    // and one tile of lead (~1.5-2k cycles) does not cover an HBM miss under load: A(t+2) and W(t+1) are issued during
+    // tile t, W first, so the wait in front of tile t's barrier is the COUNTED vmcnt(4) = "everything but the four newest
+    // pieces (= A(t+2)) has landed".  Raw s_barrier + inline waits: a __syncthreads() would drain the DMA queue.
+    // Fragment double-buffering and the barrier in front of the last k-step are as in schedule 6.
+    static_assert(BM_ == 256 || BASE != 8, "schedule 8 is laid out for the 8-wave geometry");
+    constexpr int W_BASE = 3 * A_BYTES;
+    auto dma_a = [&](int i, int kt_, int slot) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(smem + slot * A_BYTES + a_lds[i]), 16, a_off[i], kt_ * (BK * 2), 0, 0);
+    };
+    auto dma_w = [&](int i, int kt_, int slot) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(smem + W_BASE + slot * B_BYTES + (b_lds[i] - A_BYTES)), 16, b_off[i], kt_ * (BK * 2), 0, 0);
+    };
+    bf16x8 f0x0, f0x1, f0w0, f0w1, f0w2, f1x0, f1x1, f1w0, f1w1, f1w2;
+#define V8_READ(S, sa_, sw_, ks_)                                                               \
+  do {                                                                                          \
+    const char* ab_ = smem + (sa_) * A_BYTES;                                                   \
+    const char* wb_ = smem + W_BASE - A_BYTES + (sw_) * B_BYTES;                                \
+    S##x0 = *reinterpret_cast<const bf16x8*>(ab_ + (xo[0] ^ ((ks_) << 5)));                     \
+    S##x1 = *reinterpret_cast<const bf16x8*>(ab_ + (xo[1] ^ ((ks_) << 5)));                     \
+    S##w0 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[0] ^ ((ks_) << 5)));                     \
+    S##w1 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[1] ^ ((ks_) << 5)));                     \
+    S##w2 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[2] ^ ((ks_) << 5)));                     \
+  } while (0)
+#define V8_SB() __builtin_amdgcn_sched_barrier(0)
+    // one k-step of set S: MFMA pair, DMA d0_, MFMA pair, DMA d1_, MFMA pair (a DMA statement may be empty)
+#define V8_STEP(S, d0_, d1_)                                                                    \
+  do {                                                                                          \
+    V8_SB();                                                                                    \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w0, S##x0, acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w1, S##x0, acc[0][1], 0, 0, 0);      \
+    V8_SB();                                                                                    \
+    d0_;                                                                                        \
+    V8_SB();                                                                                    \
+    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w2, S##x0, acc[0][2], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w0, S##x1, acc[1][0], 0, 0, 0);      \
+    V8_SB();                                                                                    \
+    d1_;                                                                                        \
+    V8_SB();                                                                                    \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w1, S##x1, acc[1][1], 0, 0, 0);      \
+    acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w2, S##x1, acc[1][2], 0, 0, 0);      \
+    V8_SB();                                                                                    \
+  } while (0)
+    const bool dma_on = (ABL != 2);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dma_a(i, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) dma_w(i, 0, 0);
+    if (nt > 1) {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) dma_a(i, 1, 1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
     }
-    compute(last & 1);
+    V8_SB();
+    __builtin_amdgcn_s_barrier();
+    V8_SB();
+    int sa = 0, sw = 0;  // LDS slots of the current tile
+    V8_READ(f0, 0, 0, 0);
+    if (dma_on && nt > 1) { dma_w(0, 1, 1); dma_w(1, 1, 1); }
+    for (int t = 0; t < nt; ++t) {
+      const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1, sw1 = sw ^ 1;
+      const bool n1 = dma_on && (t + 1 < nt), n2 = dma_on && (t + 2 < nt);
+      V8_READ(f1, sa, sw, 1);
+      V8_STEP(f0, if (n1) dma_w(2, t + 1, sw1), if (n2) dma_a(0, t + 2, sa2));
+      V8_READ(f0, sa, sw, 2);
+      V8_STEP(f1, if (n2) dma_a(1, t + 2, sa2), if (n2) dma_a(2, t + 2, sa2));
+      V8_READ(f1, sa, sw, 3);
+      V8_STEP(f0, if (n2) dma_a(3, t + 2, sa2), (void)0);
+      if (n2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      V8_SB();
+      __builtin_amdgcn_s_barrier();  // tile t+1 has landed everywhere; nobody reads the slots of tile t any more
+      V8_SB();
+      V8_READ(f0, sa1, sw1, 0);
+      V8_STEP(f1, if (n2) dma_w(0, t + 2, sw), if (n2) dma_w(1, t + 2, sw));
+      sa = sa1;
+      sw = sw1;
+    }
     __syncthreads();
-#undef GEMM_DMA_A
-#undef GEMM_DMA_B
-#undef GEMM_KSTEP
-  } else if constexpr (PIPE == 3) {
-    GEMM_DMA(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef V8_READ
+#undef V8_SB
+#undef V8_STEP
+  } else if constexpr (BASE == 6) {
+    // fragment sets F0 / F1 as named registers (arrays selected by a runtime index would go to scratch)
+    bf16x8 f0x0, f0x1, f0w0, f0w1, f0w2, f1x0, f1x1, f1w0, f1w1, f1w2;
+#define V6_READ(S, buf_, ks_)                                                                   \
+  do {                                                                                          \
+    const char* b_ = smem + (buf_) * STAGE_BYTES;                                               \
+    S##x0 = *reinterpret_cast<const bf16x8*>(b_ + (xo[0] ^ ((ks_) << 5)));                      \
+    S##x1 = *reinterpret_cast<const bf16x8*>(b_ + (xo[1] ^ ((ks_) << 5)));                      \
+    S##w0 = *reinterpret_cast<const bf16x8*>(b_ + (wo[0] ^ ((ks_) << 5)));                      \
+    S##w1 = *reinterpret_cast<const bf16x8*>(b_ + (wo[1] ^ ((ks_) << 5)));                      \
+    S##w2 = *reinterpret_cast<const bf16x8*>(b_ + (wo[2] ^ ((ks_) << 5)));                      \
+  } while (0)
+#define V6_SB() __builtin_amdgcn_sched_barrier(0)
+#define V6_MMA2(S, i_, j0_, j1_)                                                                           \
+  do {                                                                                                     \
+    acc[i_][j0_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w##j0_, S##x##i_, acc[i_][j0_], 0, 0, 0);    \
+    acc[i_][j1_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w##j1_, S##x##i_, acc[i_][j1_], 0, 0, 0);    \
+  } while (0)
+    // one k-step: 6 MFMAs of set S in three pairs, the DMA pieces [lo_, hi_) of tile dkt_ slotted in after the pairs
+#define V6_STEP(S, do_dma_, lo_, hi_, dkt_, dbuf_)                                              \
+  do {                                                                                          \
+    V6_SB();                                                                                    \
+    V6_MMA2(S, 0, 0, 1);                                                                        \
+    V6_SB();                                                                                    \
+    if (do_dma_) GEMM_DMA_RANGE((lo_), ((lo_) + (hi_) + 1) / 2, (dkt_), (dbuf_));               \
+    V6_SB();                                                                                    \
+    acc[0][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w2, S##x0, acc[0][2], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w0, S##x1, acc[1][0], 0, 0, 0);      \
+    V6_SB();                                                                                    \
+    if (do_dma_) GEMM_DMA_RANGE(((lo_) + (hi_) + 1) / 2, (hi_), (dkt_), (dbuf_));               \
+    V6_SB();                                                                                    \
+    V6_MMA2(S, 1, 1, 2);                                                                        \
+    V6_SB();                                                                                    \
+  } while (0)
+    // piece split over the four steps that follow a tile barrier: D(ks=3 of tile t), A, B, C(ks=0..2 of tile t+1)
+    constexpr int P1 = (NP * 3 + 9) / 10, P2 = (NP * 6 + 9) / 10, P3 = (NP * 9 + 9) / 10;  // 7: 3,5,7,7   10: 3,6,9,10
+    // tile kt in buffer cur_: F0 holds (or is receiving) its ks=0 fragments; pieces [0,P1) of tile kt+1 are in flight
+#define V6_TILE(kt_, cur_)                                                                      \
+  do {                                                                                          \
+    const bool n1_ = (ABL != 2) && ((kt_) + 1 < nt), n2_ = (ABL != 2) && ((kt_) + 2 < nt);     \
+    V6_READ(f1, cur_, 1);                                                                       \
+    V6_STEP(f0, n1_, P1, P2, (kt_) + 1, (cur_) ^ 1);                                            \
+    V6_READ(f0, cur_, 2);                                                                       \
+    V6_STEP(f1, n1_, P2, P3, (kt_) + 1, (cur_) ^ 1);                                            \
+    V6_READ(f1, cur_, 3);                                                                       \
+    V6_STEP(f0, n1_, P3, NP, (kt_) + 1, (cur_) ^ 1);                                            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                 \
+    V6_SB();                                                                                    \
+    __builtin_amdgcn_s_barrier(); /* tile kt+1 has landed everywhere; nobody reads buffer cur_ any more */ \
+    V6_SB();                                                                                    \
+    V6_READ(f0, (cur_) ^ 1, 0);                                                                 \
+    V6_STEP(f1, n2_, 0, P1, (kt_) + 2, (cur_));                                                 \
+  } while (0)
+    if (ABL != 2 && nt > 1) GEMM_DMA_RANGE(0, P1, 1, 1);
+    V6_READ(f0, 0, 0);
+    int kt = 0;
+    for (; kt + 1 < nt; kt += 2) {
+      V6_TILE(kt, 0);
+      V6_TILE(kt + 1, 1);
+    }
+    if (kt < nt) V6_TILE(kt, 0);
     __syncthreads();
+#undef V6_READ
+#undef V6_SB
+#undef V6_MMA2
+#undef V6_STEP
+#undef V6_TILE
+  } else {
     for (int kt = 0; kt < last; ++kt) {
       const int cur = kt & 1;
-      GEMM_DMA(kt + 1, cur ^ 1);  // safe: every wave finished reading buf[cur^1] before the barrier that ended step kt-1
+      // safe: every wave finished reading buf[cur^1] before the barrier that ended step kt-1
+      if (ABL != 2) GEMM_DMA_RANGE(0, NP, kt + 1, cur ^ 1);
       __builtin_amdgcn_sched_barrier(0);
       compute(cur);
       __builtin_amdgcn_sched_barrier(0);
@@ -320,52 +330,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
     }
     compute(last & 1);
     __syncthreads();
-#undef GEMM_DMA
-  } else if constexpr (PIPE == 1) {
-    GEMM_GLOAD(0, 0);
-    GEMM_LSTORE(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < last; ++kt) {  // last tile peeled: no conditional staging inside the loop
-      const int cur = kt & 1;
-      GEMM_GLOAD(0, kt + 1);
-      __builtin_amdgcn_sched_barrier(0);
-      compute(cur);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_LSTORE(0, cur ^ 1);
-      __syncthreads();
-    }
-    compute(last & 1);
-    __syncthreads();
-  } else {
-    GEMM_GLOAD(0, 0);
-    GEMM_LSTORE(0, 0);
-    GEMM_GLOAD(0, last < 1 ? last : 1);
-    __syncthreads();
-    // Branch-free steady state: tile indices are clamped to the last tile, and the (at most two) stores past the end
-    // land in a buffer nobody reads again.
-    for (int kt = 0; kt + 1 < nt; kt += 2) {
-      // even step: buf0 = tile kt, set 0 = tile kt+1; fetch tile kt+2 into set 1
-      GEMM_GLOAD(1, (kt + 2 < last ? kt + 2 : last));
-      __builtin_amdgcn_sched_barrier(0);  // keep the global loads ABOVE the MFMAs (hipcc otherwise sinks them to the ds_writes)
-      compute(0);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_LSTORE(0, 1);
-      __syncthreads();
-      // odd step: buf1 = tile kt+1, set 1 = tile kt+2; fetch tile kt+3 into set 0
-      GEMM_GLOAD(0, (kt + 3 < last ? kt + 3 : last));
-      __builtin_amdgcn_sched_barrier(0);
-      compute(1);
-      __builtin_amdgcn_sched_barrier(0);
-      GEMM_LSTORE(1, 0);
-      __syncthreads();
-    }
-    if (nt & 1) {
-      compute(0);
-      __syncthreads();
-    }
   }
-#undef GEMM_GLOAD
-#undef GEMM_LSTORE
+#undef GEMM_DMA_RANGE
+
+  if constexpr (ABL == 1) {
+    // lab: keep the accumulators alive without an epilogue; lane 0 of a never-true condition writes them
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
 
   // ---- epilogue: acc (+bias, act, gate) -> bf16 -> per-wave LDS image [64 tokens][96 cols] -> 16-byte HBM stores
   // Residual rows for the store phase below are fetched NOW (12 x 16 B per lane, rows clamped instead of branched) so
@@ -443,6 +418,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
     }
   }
   __syncthreads();
+  // Store phase.  Full tiles (every launch on the denoise path: M is a multiple of 256) take the branch-free form:
+  // all 12 image reads are issued before the first store, so the stores do not each wait on their own LDS round trip.
+  const bool full = row0 + BM_ <= p.M;
+  if (full) {
+    uint4 val[12];
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int q = lane + 64 * it;
+      const int m_local = q / 12, c = q - m_local * 12;
+      val[it] = *reinterpret_cast<const uint4*>(st + m_local * OUT_ROW_BYTES + c * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int q = lane + 64 * it;
+      const int m_local = q / 12, c = q - m_local * 12;
+      const int64_t grow = row0 + wm * 64 + m_local;
+      const int gcol = ncol0 + c * 8;
+      uint4 v = val[it];
+      if (EPI == EPI_GATE_RES) {
+        if (p.aux != nullptr) *reinterpret_cast<uint4*>(p.aux + grow * p.ldaux + gcol) = v;
+        if (p.res != nullptr) {
+          float a[8], b[8];
+          unpack8(v, a);
+          unpack8(rres[it], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          v = pack8(a);
+        }
+      }
+      if constexpr (ABL == 4) {  // lab: epilogue arithmetic and LDS transposition, no HBM store
+        asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+      } else if constexpr (ABL == 5) {  // lab: streaming (nt) stores
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+        u32x4 vv = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(vv, reinterpret_cast<u32x4*>(p.out + grow * p.ldo + gcol));
+      } else {
+        *reinterpret_cast<uint4*>(p.out + grow * p.ldo + gcol) = v;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int it = 0; it < 12; ++it) {
     const int q = lane + 64 * it;
@@ -464,6 +480,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_256x192_kernel(GemmParams p)
     }
     if (ok) *reinterpret_cast<uint4*>(p.out + (int64_t)grow * p.ldo + gcol) = val;
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -505,22 +522,28 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 
 }  // namespace
 
-static int g_gemm_pipe = 3;
-void set_gemm_variant(int v) { g_gemm_pipe = (v >= 1 && v <= 5) ? v : 3; }
+// Variant id understood by set_gemm_variant / vsys_tune_gemm_variant:  PIPE (+ 100 for the 128-row, two-workgroups-per-CU
+// geometry).  0 = the shipped default.
+static int g_gemm_variant = 8;
+void set_gemm_variant(int v) { g_gemm_variant = v > 0 ? v : 8; }
 
-template <int PIPE>
-static int launch_gemm_pipe(const GemmParams& p, int epi, int grid, size_t lds, hipStream_t stream) {
+template <int PIPE, int BM_>
+static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
+  using G = Geo<BM_>;
+  const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
+  const int grid = nbm * nbn;
+  const size_t lds = (PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_BIAS_GELU, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_256x192_kernel<EPI_GATE_RES, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_256x192_kernel<EPI_BIAS, PIPE>), dim3(grid), dim3(NTHREADS), lds, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_256x192_kernel<EPI_BIAS_GELU, PIPE>), dim3(grid), dim3(NTHREADS), lds, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_256x192_kernel<EPI_GATE_RES, PIPE>), dim3(grid), dim3(NTHREADS), lds, stream, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_>), dim3(grid), dim3(G::NT), lds, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -531,14 +554,16 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.N % BN != 0 || p.K % BK != 0 || p.N <= 0 || p.K <= 0) return VSYS_ERR_SHAPE;
   if ((p.lda % 8) || (p.ldw % 8) || (p.ldo % 8) || (p.res && (p.ldr % 8)) || (p.aux && (p.ldaux % 8))) return VSYS_ERR_ALIGN;
   if (epi == EPI_GATE_RES && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;
-  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
-  const int grid = nbm * nbn;
-  const size_t lds = 2 * STAGE_BYTES;
-  if (g_gemm_pipe == 1) return launch_gemm_pipe<1>(p, epi, grid, lds, stream);
-  if (g_gemm_pipe == 3) return launch_gemm_pipe<3>(p, epi, grid, lds, stream);
-  if (g_gemm_pipe == 4) return launch_gemm_pipe<4>(p, epi, grid, lds, stream);
-  if (g_gemm_pipe == 5) return launch_gemm_pipe<5>(p, epi, grid, lds, stream);
-  return launch_gemm_pipe<2>(p, epi, grid, lds, stream);
+  // tile-relative operand offsets are 32-bit (buffer addressing)
+  if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 384 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
+  switch (g_gemm_variant) {
+    case 6: return launch_gemm_t<6, 256>(p, epi, stream);
+    case 18: return launch_gemm_t<18, 256>(p, epi, stream);
+    case 48: return launch_gemm_t<48, 256>(p, epi, stream);
+    case 103: return launch_gemm_t<3, 128>(p, epi, stream);
+    case 3: return launch_gemm_t<3, 256>(p, epi, stream);
+    default: return launch_gemm_t<8, 256>(p, epi, stream);
+  }
 }
 
 int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,
