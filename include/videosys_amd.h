@@ -44,9 +44,16 @@ const char* vsys_strerror(int code);
 /* number of HIP devices visible to the library (fails loudly instead of falling back when 0) */
 int vsys_device_count(void);
 
-/* Tuning knob (A/B measurement only; results are identical): 1 = single-stage register prefetch, 2 = two-stage register prefetch, 3 = LDS-DMA staging (default)
- * of vsys_gemm_bf16. */
+/* Tuning knobs (A/B measurement only; every non-lab variant gives identical results).
+ * gemm: 0 = shipped default (schedule 8: three A slots + two W slots, counted waits), 3 = two-stage LDS-DMA burst,
+ *       6 = two-stage with fragment double-buffering, 103 = 128-row tiles / two workgroups per CU; ids >= 10 with a
+ *       non-zero tens digit are lab ablations (skip epilogue / stores) whose OUTPUT IS NOT VALID.
+ * flash: 0 = shipped default (two workgroups per CU); 3 = three workgroups per CU; 1 = lab ablation (K/V tiles not
+ *        fetched), output not valid; 2 = lab phase timers (vsys_lab_flash_debug_buffer). */
 int vsys_tune_gemm_variant(int variant);
+int vsys_tune_flash_variant(int variant);
+/* lab: device buffer of 5 uint64 phase-cycle accumulators filled by flash variant 2 (NULL = off) */
+int vsys_lab_flash_debug_buffer(void* dev_u64x5);
 
 /* nn.Linear on token rows with fused epilogue (bf16 in/out, fp32 MFMA accumulate).
  * Replaces: attentions.py:59 (qkv), :107 (proj) + open_sora_transformer_3d.py:219,228 (gate, residual);
@@ -101,7 +108,10 @@ int vsys_copy_4d(const void* src, void* dst, int64_t n0, int64_t n1, int64_t n2,
 
 /* K RMS-norm (normalization.py:28-33; k_norm_w NULL = none) + head-major K and transposed V for vsys_flash_attn_d72.
  * k(b,s,h) at k + (b*kv_len + s)*k_stride + h*72, same for v.  kp [batch, H, kv_pad, 72]; vt [batch, H, 96, kv_pad]
- * (rows 72..95 must be zero-initialised by the caller once).  kv_pad % 64 == 0. */
+ * (rows 72..95 must be zero-initialised by the caller once).  kv_pad % 64 == 0.
+ * The pair (kp, vt) is an opaque operand of vsys_flash_attn_d72: kp carries the softmax scale 72^-1/2 * log2(e)
+ * (folded in before its single bf16 rounding) and vt rows 72 and 76 are written as ones over the valid keys, so the
+ * flash kernel gets exp2-ready logits and the softmax denominator from the matrix pipe. */
 int vsys_attn_prep_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, const void* k_norm_w, void* kp,
                       void* vt, int64_t batch, int64_t heads, int64_t kv_len, int64_t kv_pad, float eps, void* stream);
 

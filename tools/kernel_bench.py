@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--variants", default="0", help="comma list of GEMM pipeline variants to A/B (interleaved); 0 = default")
+    ap.add_argument("--flash-variants", default="0")
     ap.add_argument("--only", default="", help="'gemm' = skip the non-GEMM kernels")
     args = ap.parse_args()
     import __graft_entry__ as ge
@@ -89,8 +90,11 @@ def main():
     kp, vt = ops.alloc_kv_buffers(38, H, 1024, dev)
     ms = timeit(lambda: ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kp, vt, 38, H, 1024), args.reps)
     res["attn_prep_kv_spatial"] = [(ms, (179.4 + 209.2) / ms)]  # GB/s
-    ms = timeit(lambda: ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024), args.reps)
-    res["flash_spatial"] = [(ms, 4.0 * 38 * H * 1024 * 1024 * 72 / (ms * 1e-3) / 1e12)]
+    for fv in [int(v) for v in args.flash_variants.split(',')]:
+        lib.vsys_tune_flash_variant(fv)
+        ms = timeit(lambda: ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024), args.reps)
+        res["flash_spatial" + (f"_v{fv}" if fv else "")] = [(ms, 4.0 * 38 * H * 1024 * 1024 * 72 / (ms * 1e-3) / 1e12)]
+    lib.vsys_tune_flash_variant(0)
     kv = rnd(600, 2 * C)
     kpc, vtc = ops.alloc_kv_buffers(2, H, 300, dev)
     ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kpc, vtc, 2, H, 300)

@@ -18,6 +18,8 @@ SIGNATURES = {
     "vsys_abi_version": [],
     "vsys_device_count": [],
     "vsys_tune_gemm_variant": [_int],
+    "vsys_tune_flash_variant": [_int],
+    "vsys_lab_flash_debug_buffer": [_ptr],
     "vsys_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _ptr, _i64,
                        _ptr, _i64, _ptr],
     "vsys_linear_small": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],

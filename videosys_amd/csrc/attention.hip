@@ -15,8 +15,11 @@
 //   O^T[d][q]  = Vt[d][kv] . P^T[kv][q]    (A = Vt rows (V pre-transposed by attn_prep_kv), B = P fragment)
 // The K rows fed to MFMA row i are permuted (kv = 16*((i>>2)&1) + 4*(i>>3) + (i&3)) so that a lane's 16 accumulator
 // registers of a 32-key tile are 16 CONSECUTIVE keys: P converts to the PV B-fragment with no cross-lane traffic and Vt
-// is read with plain ds_read_b128.  LDS images use 144-byte rows (K: natural 72*2; Vt: 128+16 pad): conflict-free for
-// ds_read_b128 lane groups.  Online softmax in fp32 (exp2 with the 1/sqrt(72)*log2e scale folded in).
+// is read with plain ds_read_b128.  K/V tiles are staged by LDS-DMA (buffer_load ... lds, no staging registers and no
+// ds_write pass): the K image is the contiguous 9216-byte tile (144-byte rows, conflict-free for ds_read_b128 lane
+// groups), the Vt image has 128-byte rows whose 16-byte slots are XOR-swizzled by (row>>1)&7 on the SOURCE side of the
+// DMA and on the reads.  Online softmax in fp32; the scale 72^-1/2*log2e rides on K, the running max enters as the
+// MFMA C operand, the row sum comes out of the PV contraction (ones rows in Vt).
 #include "common.h"
 #include "vsys_internal.h"
 
@@ -26,7 +29,7 @@ namespace {
 constexpr int HD = 72;          // head dim
 constexpr int HD_ROWS = 96;     // Vt rows per head (3 MFMA tiles of 32; rows 72..95 are zero)
 constexpr int KROW = 144;       // bytes per K row in LDS (72 bf16)
-constexpr int VROW = 144;       // bytes per Vt row in LDS (64 keys * 2 + 16 pad)
+constexpr int VROW = 128;       // bytes per Vt row in LDS (64 keys * 2; 16-byte slots XOR-swizzled by (row>>1)&7)
 constexpr int K_TILE_BYTES = 64 * KROW;        // 9216
 constexpr int V_TILE_BYTES = HD_ROWS * VROW;   // 13824
 constexpr int KV_STAGE = K_TILE_BYTES + V_TILE_BYTES;  // 23040
@@ -41,7 +44,7 @@ __global__ __launch_bounds__(256) void attn_prep_kv_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ v, int64_t v_stride,
                                                            const bf16_t* __restrict__ k_norm_w, bf16_t* __restrict__ kp,
                                                            bf16_t* __restrict__ vt, int heads, int kv_len, int kv_pad,
-                                                           float eps) {
+                                                           float eps, float kscale) {
   __shared__ __attribute__((aligned(16))) bf16_t vs[64][HD + 8];  // [token][d], 160-byte rows
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s0 = blockIdx.x * 64;
@@ -84,6 +87,10 @@ __global__ __launch_bounds__(256) void attn_prep_kv_kernel(const bf16_t* __restr
         x[e] = nrm * bf2f(k_norm_w[part * 24 + e]);
       }
     }
+    // softmax scale 72^-1/2 and log2(e) ride on K (one rounding, the one the reference's k also gets), so that the
+    // QK^T accumulators are exp2-ready and the flash kernel spends no VALU on scaling
+#pragma unroll
+    for (int e = 0; e < 24; ++e) x[e] *= kscale;
     if (active) {
       bf16_t* dst = kp + (((int64_t)bh * kv_pad) + s) * HD + part * 24;
 #pragma unroll
@@ -102,6 +109,20 @@ __global__ __launch_bounds__(256) void attn_prep_kv_kernel(const bf16_t* __restr
     o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
     *reinterpret_cast<uint4*>(vt + ((int64_t)bh * HD_ROWS + d) * kv_pad + s0 + c * 8) = o;
   }
+  // rows 72 and 76 of Vt are all-ones over the valid keys: O^T rows 72/76 then accumulate sum_k P[k][q] on the matrix
+  // pipe (the rows are MFMA padding anyway), i.e. the softmax denominator costs no VALU adds.  Rows 73-75, 77-95 stay 0.
+  if (tid < 16) {
+    const int d = HD + 4 * (tid >> 3), c = tid & 7;
+    uint32_t w[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k0 = s0 + c * 8 + 2 * e;
+      w[e] = (k0 < kv_len ? 0x3f80u : 0u) | (k0 + 1 < kv_len ? 0x3f800000u : 0u);
+    }
+    uint4 o;
+    o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+    *reinterpret_cast<uint4*>(vt + ((int64_t)bh * HD_ROWS + d) * kv_pad + s0 + c * 8) = o;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -114,10 +135,17 @@ struct FlashParams {
   const bf16_t* vt;                        // [batch][H][96][kv_pad]
   bf16_t* out; int64_t out_stride;         // out(b, s, h) at out + (b*q_len + s)*out_stride + h*72
   int heads, q_len, kv_len, kv_pad, nqb;
-  float eps, scale_log2e;
+  float eps;
+  unsigned long long* dbg;                 // lab variant 2 only: 5 phase-cycle accumulators
 };
 
-__global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
+// WPS = waves per SIMD the register allocation targets: 2 (two workgroups per CU, no spills; shipped) or 3 (measured
+// slower: the peeled last tile spills and three workgroups per CU buy nothing — 0.31 vs 0.28 ms at config 2).
+// ABL (lab builds): 1 = K/V tiles after the first are not fetched (compute, LDS and barriers only); 2 = s_memtime stamps
+// at the phase boundaries of every tile, summed per wave into p.dbg[0..4] (QK issue | max chain | exp + PV | vmcnt | barrier).
+template <int ABL, int WPS>
+__global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p) {
+#if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -169,42 +197,34 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
       for (int e = 0; e < 8; ++e) qf[c][e] = (__bf16)x[c][e];
   }
 
-  // ---- KV staging assignment
+  // ---- K/V staging by LDS-DMA: 9 K pieces (1 KiB each, the tile is contiguous) + 10 Vt pieces (8 rows x 128 B each,
+  // rows 0..79; rows 80..95 of the LDS image are zeroed once and never overwritten); wave w issues pieces w, w+4, ...
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const bf16_t* kbase = p.kp + (int64_t)bh * p.kv_pad * HD;         // tile t: + t*64*72 (contiguous 9216 bytes)
   const bf16_t* vbase = p.vt + (int64_t)bh * HD_ROWS * p.kv_pad;    // row d: + d*kv_pad, tile t: + t*64
-  int k_off[3], v_goff[3], v_lds[3];
+  const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.kv_pad * HD * 2, 0x00020000);
+  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, HD_ROWS * p.kv_pad * 2, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int k_voff = lane * 16;
+  // Vt piece j: lane -> row 8j + (lane>>3), physical slot lane&7 holds logical slot (lane&7) ^ ((row>>1)&7);
+  // (row>>1)&7 = ((j&1)<<2) | (lane>>4), so odd pieces differ from even ones by XOR 64 in the byte offset
+  const int v_voff = (lane >> 3) * p.kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
+  auto stage = [&](int t, int buf) {
+    char* base = smem + buf * KV_STAGE;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int q = tid + 256 * i;
-    // K tile = 576 chunks; threads past the end re-copy chunks 384..575 (same data, same LDS slot: benign) so the
-    // staging registers are written unconditionally (a predicated load parks them in scratch).
-    k_off[i] = (q < 576 ? q : q - 192) * 8;  // elements == LDS byte offset / 2
-    const int d = q >> 3, c = q & 7;  // 768 chunks: 96 rows x 8
-    v_goff[i] = d * p.kv_pad + c * 8;
-    v_lds[i] = K_TILE_BYTES + d * VROW + c * 16;
-  }
-  uint4 rk0, rk1, rk2, rv0, rv1, rv2;
-#define FLASH_GLOAD(t_)                                                                              \
-  do {                                                                                               \
-    const bf16_t* kb_ = kbase + (int64_t)(t_) * 64 * HD;                                             \
-    const bf16_t* vb_ = vbase + (int64_t)(t_) * 64;                                                  \
-    rk0 = *reinterpret_cast<const uint4*>(kb_ + k_off[0]);                                           \
-    rk1 = *reinterpret_cast<const uint4*>(kb_ + k_off[1]);                                           \
-    rk2 = *reinterpret_cast<const uint4*>(kb_ + k_off[2]);                                           \
-    rv0 = *reinterpret_cast<const uint4*>(vb_ + v_goff[0]);                                          \
-    rv1 = *reinterpret_cast<const uint4*>(vb_ + v_goff[1]);                                          \
-    rv2 = *reinterpret_cast<const uint4*>(vb_ + v_goff[2]);                                          \
-  } while (0)
-#define FLASH_LSTORE(buf_)                                                                           \
-  do {                                                                                               \
-    char* base_ = smem + (buf_) * KV_STAGE;                                                          \
-    *reinterpret_cast<uint4*>(base_ + k_off[0] * 2) = rk0;                                           \
-    *reinterpret_cast<uint4*>(base_ + k_off[1] * 2) = rk1;                                           \
-    *reinterpret_cast<uint4*>(base_ + k_off[2] * 2) = rk2;                                           \
-    *reinterpret_cast<uint4*>(base_ + v_lds[0]) = rv0;                                               \
-    *reinterpret_cast<uint4*>(base_ + v_lds[1]) = rv1;                                               \
-    *reinterpret_cast<uint4*>(base_ + v_lds[2]) = rv2;                                               \
-  } while (0)
+    for (int idx = 0; idx < 5; ++idx) {
+      const int piece = wave_u + 4 * idx;
+      if (piece < 9) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
+      } else if (piece < 19) {
+        const int j = piece - 9;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((j & 1) << 6),
+                                                 j * 8 * p.kv_pad * 2 + t * 128, 0, 0);
+      }
+    }
+  };
+  // Vt fragment read offsets: row dt*32 + l31, logical slot kt*4 + 2hi + cc  ->  + dt*4096, ^ ((kt*4 + cc) << 4)
+  const int v_roff = K_TILE_BYTES + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4);
 
   // permuted K row for MFMA row i = l31: lane's 16 acc regs <-> 16 consecutive keys (16*hi + reg)
   const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
@@ -214,103 +234,150 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
   for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = NEG_BIG, l_run = 0.f;
-  const float c = p.scale_log2e;
+  // Running max m (exp2 domain: K carries scale*log2e) is kept NEGATED and splatted over 16 registers: it is the C input
+  // of the first QK^T MFMA of every 32-key tile, so the accumulators come out as s - m, ready for v_exp, with no
+  // per-tile zero-init and no per-element subtract.  The row sum l lives in o[2][4] (Vt rows 72/76 are ones).
+  f32x16 minit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
 
   const int ntiles = p.kv_pad / 64;
-  FLASH_GLOAD(0);
-  FLASH_LSTORE(0);
+  stage(0, 0);
+  {  // rows 80..95 of both Vt images (MFMA padding the DMA never writes): 2 x 2 KiB of zeros
+    char* z = smem + (tid >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (tid & 127) * 16;
+    *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  auto tile = [&](int t, int cur) {
+  // Deferred running max: the accumulators are rescaled only when some row's tile max exceeds its running max by more
+  // than 8 (exp2 domain), so P <= 2^8 (bf16 keeps fp32's exponent range, sums are fp32) and the common tile skips the
+  // 48-register O rescale.  Mathematically the same softmax.
+  const float defer_thr = 8.0f;
+
+  unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
+#define FLASH_STAMP(i_)                                              \
+  do {                                                               \
+    if (ABL == 2) {                                                  \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+      tacc[i_] += now_ - tprev;                                      \
+      tprev = now_;                                                  \
+    }                                                                \
+  } while (0)
+  auto tile = [&](int t, int cur, const bool masked) {
     const char* sk = smem + cur * KV_STAGE;
-    const char* sv = sk + K_TILE_BYTES;
 
-    // ---- S^T = K Q^T : two 32-key tiles
-    f32x16 s[2];
+    // ---- S^T - m = K Q^T - m : two 32-key tiles.  All 20 K fragment reads are issued before the first MFMA (hipcc
+    // otherwise alternates read / wait / MFMA and exposes one LDS round trip per MFMA: with two waves per SIMD nothing
+    // covers it).  The fifth chunk (d 64..79) is read unconditionally: for hi = 1 it is the first 16 bytes of the next
+    // row, multiplied by Q's zero chunk.
+    bf16x8 kf0[5], kf1[5];
+    {
+      const char* krp = sk + krow * KROW + 16 * hi;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      const char* krp = sk + (kt * 32 + krow) * KROW;
-#pragma unroll
-      for (int cc = 0; cc < 5; ++cc) {
-        const int d0 = 16 * cc + 8 * hi;
-        bf16x8 kf;
-        if (d0 < HD) {
-          kf = *reinterpret_cast<const bf16x8*>(krp + d0 * 2);
-        } else {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) kf[e] = (__bf16)0.f;
-        }
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[cc], s[kt], 0, 0, 0);
-      }
+      for (int cc = 0; cc < 5; ++cc) kf0[cc] = *reinterpret_cast<const bf16x8*>(krp + 32 * cc);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 s[2];
+    {
+      const char* krp = sk + (32 + krow) * KROW + 16 * hi;
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) kf1[cc] = *reinterpret_cast<const bf16x8*>(krp + 32 * cc);
+      // D != C on purpose (the builtin ties them and hipcc would first copy the 16 minit registers into s)
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[0]) : "v"(kf0[0]), "v"(qf[0]), "v"(minit));
+#pragma unroll
+      for (int cc = 1; cc < 5; ++cc) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[cc], qf[cc], s[0], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[1]) : "v"(kf1[0]), "v"(qf[0]), "v"(minit));
+#pragma unroll
+    for (int cc = 1; cc < 5; ++cc) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[cc], qf[cc], s[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    FLASH_STAMP(0);
+    // V fragments do not depend on the softmax: the reads for keys 0..31 are issued now so their LDS latency hides under
+    // the max / exp work below; those for keys 32..63 go out before the first PV MFMAs (register budget: 256).
+    bf16x8 vf0[2][3], vf1[2][3];
+#define FLASH_VREAD(dst_, kt_)                                                                                   \
+  _Pragma("unroll") for (int cc = 0; cc < 2; ++cc) _Pragma("unroll") for (int dt = 0; dt < 3; ++dt)              \
+    dst_[cc][dt] = *reinterpret_cast<const bf16x8*>(sk + dt * 32 * VROW + (v_roff ^ (((kt_) * 4 + cc) << 4)))
+    FLASH_VREAD(vf0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- online softmax (lane: query l31; keys 64t + 32kt + 16hi + r)
-    const int kv0 = t * 64 + 16 * hi;
-    float mx = NEG_BIG;
+    // ---- online softmax (lane: query l31; keys 64t + 32kt + 16hi + r).  Only the last tile of a ragged kv_len masks.
+    if (masked) {
+      const int lim = p.kv_len - (t * 64 + 16 * hi);  // keys with 32kt + r >= lim are padding
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + r >= lim) s[kt][r] = NEG_BIG;
+    }
+    float mx = s[0][0];  // tile max relative to the running max
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float sv_ = s[kt][r];
-        if (kv0 + kt * 32 + r >= p.kv_len) sv_ = NEG_BIG;
-        s[kt][r] = sv_;
-        mx = fmaxf(mx, sv_);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    const float mc = m_new * c;
-    float lsum = 0.f;
-    bf16x8 pf[2][2];
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+    {  // the other 16 keys of each 32-key tile live in lane l31 + 32: exchange on the VALU (no LDS round trip)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (t == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0) {  // wave-uniform
+      asm volatile("; rescale path (rare): kept out of line" ::: "memory");  // not if-convertible
+      const float delta = t == 0 ? mx : fmaxf(mx, 0.f);  // first tile: adopt its max (signed); later: only raise
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int r = 0; r < 16; ++r) minit[r] -= delta;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(s[kt][r] * c - mc);
-        lsum += pv;
-        pf[kt][r >> 3][r & 7] = (__bf16)pv;
-      }
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
+        for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-
-    // ---- O^T += Vt P^T
+      for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    FLASH_STAMP(1);
+    // ---- P = exp2(s - m), O^T += Vt P^T: the exps of keys 32..63 run under the MFMAs of keys 0..31
+    bf16x8 pf0[2], pf1[2];
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) {
-        const int kvl = kt * 32 + 16 * hi + 8 * cc;
+    for (int r = 0; r < 16; ++r) pf0[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[0][r]);
+    FLASH_VREAD(vf1, 1);
 #pragma unroll
-        for (int dt = 0; dt < 3; ++dt) {
-          bf16x8 vf = *reinterpret_cast<const bf16x8*>(sv + (dt * 32 + l31) * VROW + kvl * 2);
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kt][cc], o[dt], 0, 0, 0);
-        }
-      }
-
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[cc][dt], pf0[cc], o[dt], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pf1[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[1][r]);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[cc][dt], pf1[cc], o[dt], 0, 0, 0);
+#undef FLASH_VREAD
+    FLASH_STAMP(2);
   };
 
+  if (ABL == 2) tprev = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < ntiles - 1; ++t) {  // last tile peeled: no conditional staging inside the loop
     const int cur = t & 1;
-    FLASH_GLOAD(t + 1);
-    __builtin_amdgcn_sched_barrier(0);  // keep the next tile's loads in flight above this tile's MFMAs
-    tile(t, cur);
+    if (ABL != 1) stage(t + 1, cur ^ 1);  // every wave finished reading buffer cur^1 before the barrier of tile t-1
     __builtin_amdgcn_sched_barrier(0);
-    FLASH_LSTORE(cur ^ 1);
-    __syncthreads();
+    tile(t, cur, false);
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
+    FLASH_STAMP(3);
+    __syncthreads();                                   // ... and so have everybody else's
+    FLASH_STAMP(4);
   }
-  tile(ntiles - 1, (ntiles - 1) & 1);
-#undef FLASH_GLOAD
-#undef FLASH_LSTORE
+  if (p.kv_len < p.kv_pad) tile(ntiles - 1, (ntiles - 1) & 1, true);
+  else tile(ntiles - 1, (ntiles - 1) & 1, false);
 
+  if (ABL == 2 && lane == 0 && p.dbg != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) atomicAdd(p.dbg + i, tacc[i]);
+  }
+#undef FLASH_STAMP
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.0f / l_tot;
+  const float inv = 1.0f / o[2][4];  // d = 72 (hi = 0) / 76 (hi = 1): the ones rows of Vt, i.e. sum_k P[k][q]
   const int qs = q0 + l31;
   if (qs < p.q_len) {
     bf16_t* orow = p.out + ((int64_t)b * p.q_len + qs) * p.out_stride + h * HD;
@@ -327,6 +394,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d72_kernel(FlashParams p) {
         }
       }
   }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -455,6 +523,11 @@ __global__ void attn_temporal_d72_kernel(const bf16_t* __restrict__ qkv, int64_t
 
 }  // namespace
 
+static int g_flash_variant = 0;
+static unsigned long long* g_flash_dbg = nullptr;
+void set_flash_variant(int v) { g_flash_variant = v; }
+void set_flash_debug_buffer(void* p) { g_flash_dbg = reinterpret_cast<unsigned long long*>(p); }
+
 int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* k_norm_w,
                         bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps,
                         hipStream_t stream) {
@@ -462,7 +535,7 @@ int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int6
   if (kv_pad % 64 != 0 || kv_pad < kv_len || (k_stride % 8) || (v_stride % 8)) return VSYS_ERR_SHAPE;
   dim3 grid(kv_pad / 64, batch * heads);
   hipLaunchKernelGGL(attn_prep_kv_kernel, grid, dim3(256), 0, stream, k, k_stride, v, v_stride, k_norm_w, kp, vt, heads,
-                     kv_len, kv_pad, eps);
+                     kv_len, kv_pad, eps, 0.11785113019775793f * 1.4426950408889634f /* 72^-0.5 * log2(e) */);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
@@ -474,13 +547,16 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   FlashParams p;
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
-  p.scale_log2e = 0.11785113019775793f * 1.4426950408889634f;  // 72^-0.5 * log2(e)
   p.nqb = (q_len + 127) / 128;
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
   if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
   dim3 grid((unsigned)nblk);
   const size_t lds = 2 * KV_STAGE;
-  hipLaunchKernelGGL(flash_attn_d72_kernel, grid, dim3(256), lds, stream, p);
+  p.dbg = g_flash_dbg;
+  if (g_flash_variant == 1) hipLaunchKernelGGL((flash_attn_d72_kernel<1, 2>), grid, dim3(256), lds, stream, p);
+  else if (g_flash_variant == 2) hipLaunchKernelGGL((flash_attn_d72_kernel<2, 2>), grid, dim3(256), lds, stream, p);
+  else if (g_flash_variant == 3) hipLaunchKernelGGL((flash_attn_d72_kernel<0, 3>), grid, dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2>), grid, dim3(256), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

@@ -36,6 +36,16 @@ int vsys_tune_gemm_variant(int variant) {
   return 0;
 }
 
+int vsys_tune_flash_variant(int variant) {
+  set_flash_variant(variant);
+  return 0;
+}
+
+int vsys_lab_flash_debug_buffer(void* dev_u64x5) {
+  set_flash_debug_buffer(dev_u64x5);
+  return 0;
+}
+
 int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
                    int64_t M, int64_t N, int64_t K, int epilogue, const void* gate, int64_t gate_sample_stride,
                    int64_t rows_per_sample, const void* res, int64_t ldr, void* aux, int64_t ldaux, void* stream) {

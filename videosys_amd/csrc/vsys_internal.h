@@ -26,6 +26,8 @@ struct GemmParams {
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 void set_gemm_variant(int v);
+void set_flash_variant(int v);
+void set_flash_debug_buffer(void* p);
 int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,
                         int64_t ldo, int M, int N, int K, int act_in, int act_out, hipStream_t stream);
 int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* scale, bf16_t* y, int64_t rows, int C,
