@@ -98,6 +98,20 @@ int vsys_final_layer(const void* x, const void* table, const void* tvec, const v
 int vsys_cfg_euler_step(void* z_f32, const void* model_out_f32, int64_t Bz, int64_t Cin, int64_t Cout, int64_t thw,
                         float guidance, float dt, void* stream);
 
+/* CFG combine + one linear scheduler update, z fp32 [Bz, Cin, thw] = c_z z + c_eps (uncond + g (cond - uncond)) on the
+ * first Cin of Cout predicted channels (learned-sigma half dropped).  DDIM eta = 0
+ * (diffusers DDIMScheduler.step as called from pipelines/latte/pipeline_latte.py:864-876 and
+ * schedulers/scheduling_ddim_cogvideox.py:299-393 with v-prediction folded on the host):
+ * c_z = sqrt(a_prev / a_t), c_eps = sqrt(1 - a_prev) - sqrt(a_prev (1 - a_t) / a_t).
+ * cond_first != 0: model_out[b] is the conditional half (RFLOW order); 0: model_out[b + Bz] is (negative prompt first). */
+int vsys_cfg_linear_step(void* z_f32, const void* model_out_f32, int64_t Bz, int64_t Cin, int64_t Cout, int64_t thw,
+                         float guidance, float c_z, float c_eps, int cond_first, void* stream);
+
+/* x[r, :] += e[(r / group) % period, :] over rows of C bf16 — Latte's temporal position embedding added to the
+ * (b, f, s)-ordered hidden states before the first temporal block (latte_transformer_3d.py:1410-1411; group = S,
+ * period = F). */
+int vsys_add_bcast_rows(void* x, const void* e, int64_t rows, int64_t C, int64_t group, int64_t period, void* stream);
+
 /* x += y over n bf16 elements (PAB broadcast step: x + last_attn / last_cross, open_sora_transformer_3d.py:192-193,228,234-235). */
 int vsys_add_rows(void* x, const void* y, int64_t n, void* stream);
 
@@ -124,6 +138,7 @@ int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, c
 
 /* Temporal self-attention over the T frames of every (b, s) token: RMS qk-norm, RoPE (cos/sin fp32 [T, 72], NULL =
  * none), fp32 softmax (attentions.py:75-78,95-97,111-120; open_sora_transformer_3d.py:203-206).
+ * q_norm_w == k_norm_w == NULL: no qk-norm (Latte temporal blocks, latte_transformer_3d.py:680-760).
  * qkv bf16 rows ordered (b, t, s), row_stride elements per row, q|k|v at column offsets 0|C|2C, head h at h*72. */
 int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const void* q_norm_w, const void* k_norm_w,
                            const void* rope_cos_f32, const void* rope_sin_f32, void* out, int64_t out_stride, int64_t B,

@@ -1,0 +1,360 @@
+"""TEST INFRASTRUCTURE ONLY — restatement of the diffusers==0.30.0 leaf modules the reference's Latte / CogVideoX
+transformers import (diffusers is pinned in /root/reference/requirements.txt but is NOT installed here and NOT vendored
+in the reference tree: SURVEY.md §8c).
+
+With these stubs installed, ``oracle/ref_loader.py`` can import and run the reference's OWN
+``videosys/models/transformers/latte_transformer_3d.py`` (block algebra, rearranges, PAB hooks, final layer — all
+reference code) on CPU; only the leaves below are restated from the published diffusers 0.30.0 source:
+
+  diffusers.models.attention_processor.Attention (+ AttnProcessor2_0)   to_q/to_k/to_v/to_out, SDPA with additive mask
+  diffusers.models.activations.GELU / GEGLU / ApproximateGELU
+  diffusers.models.embeddings.PatchEmbed, get_2d_sincos_pos_embed, get_1d_sincos_pos_embed_from_grid,
+      Timesteps / get_timestep_embedding, TimestepEmbedding, PixArtAlphaCombinedTimestepSizeEmbeddings,
+      PixArtAlphaTextProjection
+  diffusers.models.lora.LoRACompatibleLinear / LoRACompatibleConv (plain Linear / Conv2d taking an ignored ``scale``)
+  diffusers.configuration_utils.ConfigMixin / register_to_config, diffusers.models.modeling_utils.ModelMixin
+  diffusers.schedulers.DDIMScheduler (set_timesteps "leading", step with eta = 0, epsilon prediction)
+
+Parity status: the reference holds no test that pins these leaves, so the Latte goldens are "reference block code over
+restated diffusers leaves" (parity unpinned for the leaves, stated in DESIGN.md).
+Nothing under ``videosys_amd/`` may import this module.
+"""
+from __future__ import annotations
+
+import functools
+import inspect
+import math
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ----------------------------------------------------------------------------------------------- config / model mixins
+class ConfigMixin:
+    config_name = "config.json"
+
+    @property
+    def config(self):
+        return self._internal_dict
+
+
+def register_to_config(init):
+    @functools.wraps(init)
+    def inner(self, *args, **kwargs):
+        sig = inspect.signature(init)
+        bound = sig.bind(self, *args, **kwargs)
+        bound.apply_defaults()
+        cfg = {k: v for k, v in bound.arguments.items() if k != "self"}
+        self._internal_dict = SimpleNamespace(**cfg)
+        init(self, *args, **kwargs)
+
+    return inner
+
+
+class ModelMixin(nn.Module):
+    pass
+
+
+class BaseOutput(dict):
+    pass
+
+
+def deprecate(*a, **k):
+    pass
+
+
+def maybe_allow_in_graph(cls):
+    return cls
+
+
+# ----------------------------------------------------------------------------------------------- lora shims
+class LoRACompatibleLinear(nn.Linear):
+    def forward(self, x, scale: float = 1.0):
+        return F.linear(x, self.weight, self.bias)
+
+
+class LoRACompatibleConv(nn.Conv2d):
+    def forward(self, x, scale: float = 1.0):
+        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
+# ----------------------------------------------------------------------------------------------- activations
+class GELU(nn.Module):
+    """diffusers.models.activations.GELU: gelu(Linear(x)) with optional tanh approximation."""
+
+    def __init__(self, dim_in, dim_out, approximate: str = "none", bias: bool = True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out, bias=bias)
+        self.approximate = approximate
+
+    def forward(self, x):
+        return F.gelu(self.proj(x), approximate=self.approximate)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out, bias: bool = True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2, bias=bias)
+
+    def forward(self, x, scale: float = 1.0):
+        h, gate = self.proj(x).chunk(2, dim=-1)
+        return h * F.gelu(gate)
+
+
+class ApproximateGELU(nn.Module):
+    def __init__(self, dim_in, dim_out, bias: bool = True):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out, bias=bias)
+
+    def forward(self, x):
+        x = self.proj(x)
+        return x * torch.sigmoid(1.702 * x)
+
+
+# ----------------------------------------------------------------------------------------------- attention
+class Attention(nn.Module):
+    """diffusers.models.attention_processor.Attention with AttnProcessor2_0 (the default under torch >= 2):
+    q = to_q(x), k = to_k(ctx), v = to_v(ctx), heads split as view(B, L, H, D).transpose(1, 2),
+    F.scaled_dot_product_attention(q, k, v, attn_mask=additive mask [B, H, Lq|1, Lk]), to_out[0] (Linear), to_out[1]
+    (Dropout).  qk_norm / added projections are not used by the Latte blocks."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                 upcast_attention=False, out_bias=True, **unused):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.inner_dim = inner
+        self.is_cross_attention = cross_attention_dim is not None
+        cdim = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(cdim, inner, bias=bias)
+        self.to_v = nn.Linear(cdim, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim, bias=out_bias), nn.Dropout(dropout)])
+
+    def prepare_attention_mask(self, attention_mask, target_length, batch_size):
+        if attention_mask is None:
+            return None
+        # [B, 1, Lk] -> [B*H, 1, Lk] (repeat_interleave over heads), as diffusers does for the SDPA processor
+        return attention_mask.repeat_interleave(self.heads, dim=0)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **unused):
+        B, Lq, _ = hidden_states.shape
+        ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
+        Lk = ctx.shape[1]
+        if attention_mask is not None:
+            attention_mask = self.prepare_attention_mask(attention_mask, Lk, B)
+            attention_mask = attention_mask.view(B, self.heads, -1, attention_mask.shape[-1])
+        q = self.to_q(hidden_states)
+        k = self.to_k(ctx)
+        v = self.to_v(ctx)
+        D = self.inner_dim // self.heads
+        q = q.view(B, Lq, self.heads, D).transpose(1, 2)
+        k = k.view(B, Lk, self.heads, D).transpose(1, 2)
+        v = v.view(B, Lk, self.heads, D).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=attention_mask, dropout_p=0.0, is_causal=False)
+        o = o.transpose(1, 2).reshape(B, Lq, self.inner_dim).to(q.dtype)
+        o = self.to_out[0](o)
+        return self.to_out[1](o)
+
+
+# ----------------------------------------------------------------------------------------------- embeddings
+def get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
+    """diffusers.models.embeddings.get_1d_sincos_pos_embed_from_grid (numpy, float64 omega)."""
+    if isinstance(pos, torch.Tensor):
+        pos = pos.numpy()
+    omega = np.arange(embed_dim // 2, dtype=np.float64)
+    omega /= embed_dim / 2.0
+    omega = 1.0 / 10000**omega
+    pos = pos.reshape(-1)
+    out = np.einsum("m,d->md", pos, omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_2d_sincos_pos_embed_from_grid(embed_dim, grid):
+    emb_h = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0])
+    emb_w = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])
+    return np.concatenate([emb_h, emb_w], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False, extra_tokens=0, interpolation_scale=1.0, base_size=16):
+    if isinstance(grid_size, int):
+        grid_size = (grid_size, grid_size)
+    grid_h = np.arange(grid_size[0], dtype=np.float32) / (grid_size[0] / base_size) / interpolation_scale
+    grid_w = np.arange(grid_size[1], dtype=np.float32) / (grid_size[1] / base_size) / interpolation_scale
+    grid = np.meshgrid(grid_w, grid_h)  # w goes first
+    grid = np.stack(grid, axis=0)
+    grid = grid.reshape([2, 1, grid_size[1], grid_size[0]])
+    return get_2d_sincos_pos_embed_from_grid(embed_dim, grid)
+
+
+class PatchEmbed(nn.Module):
+    """diffusers.models.embeddings.PatchEmbed (pos_embed_type="sincos", no layer norm, flatten)."""
+
+    def __init__(self, height=224, width=224, patch_size=16, in_channels=3, embed_dim=768, layer_norm=False, flatten=True,
+                 bias=True, interpolation_scale=1, pos_embed_type="sincos", pos_embed_max_size=None):
+        super().__init__()
+        num_patches = (height // patch_size) * (width // patch_size)
+        self.proj = nn.Conv2d(in_channels, embed_dim, kernel_size=(patch_size, patch_size), stride=patch_size, bias=bias)
+        self.patch_size = patch_size
+        self.height, self.width = height // patch_size, width // patch_size
+        self.base_size = height // patch_size
+        self.interpolation_scale = interpolation_scale
+        pos = get_2d_sincos_pos_embed(embed_dim, int(num_patches**0.5), base_size=self.base_size,
+                                      interpolation_scale=self.interpolation_scale)
+        self.register_buffer("pos_embed", torch.from_numpy(pos).float().unsqueeze(0), persistent=False)
+
+    def forward(self, latent):
+        height, width = latent.shape[-2] // self.patch_size, latent.shape[-1] // self.patch_size
+        latent = self.proj(latent).flatten(2).transpose(1, 2)
+        if self.height != height or self.width != width:
+            pos = get_2d_sincos_pos_embed(self.pos_embed.shape[-1], (height, width), base_size=self.base_size,
+                                          interpolation_scale=self.interpolation_scale)
+            pos = torch.from_numpy(pos).float().unsqueeze(0).to(latent.device)
+        else:
+            pos = self.pos_embed
+        return (latent + pos).to(latent.dtype)
+
+
+def get_timestep_embedding(timesteps, embedding_dim, flip_sin_to_cos=False, downscale_freq_shift=1.0, scale=1.0,
+                           max_period=10000):
+    half = embedding_dim // 2
+    exponent = -math.log(max_period) * torch.arange(0, half, dtype=torch.float32, device=timesteps.device)
+    exponent = exponent / (half - downscale_freq_shift)
+    emb = timesteps[:, None].float() * torch.exp(exponent)[None, :]
+    emb = scale * emb
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+class Timesteps(nn.Module):
+    def __init__(self, num_channels, flip_sin_to_cos, downscale_freq_shift, scale=1):
+        super().__init__()
+        self.num_channels, self.flip, self.shift, self.scale = num_channels, flip_sin_to_cos, downscale_freq_shift, scale
+
+    def forward(self, timesteps):
+        return get_timestep_embedding(timesteps, self.num_channels, self.flip, self.shift, self.scale)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_channels, time_embed_dim)
+        self.act = nn.SiLU()
+        self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
+
+    def forward(self, sample):
+        return self.linear_2(self.act(self.linear_1(sample)))
+
+
+class PixArtAlphaCombinedTimestepSizeEmbeddings(nn.Module):
+    def __init__(self, embedding_dim, size_emb_dim, use_additional_conditions: bool = False):
+        super().__init__()
+        assert not use_additional_conditions, "Latte-1 (sample_size 64) does not use the size/aspect-ratio conditions"
+        self.time_proj = Timesteps(num_channels=256, flip_sin_to_cos=True, downscale_freq_shift=0)
+        self.timestep_embedder = TimestepEmbedding(in_channels=256, time_embed_dim=embedding_dim)
+
+    def forward(self, timestep, resolution, aspect_ratio, batch_size, hidden_dtype):
+        proj = self.time_proj(timestep)
+        return self.timestep_embedder(proj.to(dtype=hidden_dtype))
+
+
+class PixArtAlphaTextProjection(nn.Module):
+    def __init__(self, in_features, hidden_size, out_features=None, act_fn="gelu_tanh"):
+        super().__init__()
+        out_features = out_features or hidden_size
+        self.linear_1 = nn.Linear(in_features, hidden_size, bias=True)
+        self.act_1 = nn.GELU(approximate="tanh")
+        self.linear_2 = nn.Linear(hidden_size, out_features, bias=True)
+
+    def forward(self, caption):
+        return self.linear_2(self.act_1(self.linear_1(caption)))
+
+
+class _Unused(nn.Module):
+    def __init__(self, *a, **k):
+        super().__init__()
+        raise NotImplementedError("diffusers class outside the Latte ada_norm_single path")
+
+
+# ----------------------------------------------------------------------------------------------- DDIM scheduler
+class DDIMScheduler:
+    """diffusers.schedulers.DDIMScheduler, the subset pipeline_latte.py uses: linear betas, timestep_spacing "leading",
+    steps_offset 0, set_alpha_to_one True, epsilon prediction, eta 0, clip_sample False (latent diffusion; the value
+    lives in the HF repo's scheduler_config.json, not in the reference tree)."""
+
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 clip_sample=False, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon", **unused):
+        assert beta_schedule == "linear" and prediction_type == "epsilon"
+        self.num_train_timesteps = num_train_timesteps
+        self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - self.betas, dim=0)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.steps_offset = steps_offset
+        self.clip_sample = clip_sample
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        self.num_inference_steps = num_inference_steps
+        step_ratio = self.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+        ts += self.steps_offset
+        self.timesteps = torch.from_numpy(ts)
+
+    def step(self, model_output, timestep, sample, eta=0.0, return_dict=False, **unused):
+        t = int(timestep)
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        beta_t = 1 - a_t
+        x0 = (sample - beta_t**0.5 * model_output) / a_t**0.5
+        if self.clip_sample:
+            x0 = x0.clamp(-1.0, 1.0)
+        pred_dir = (1 - a_prev) ** 0.5 * model_output
+        prev = a_prev**0.5 * x0 + pred_dir
+        return (prev,)
+
+
+# ----------------------------------------------------------------------------------------------- installation
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install():
+    """Install (or extend) the fake ``diffusers`` package in sys.modules."""
+    d = sys.modules.get("diffusers") or _mod("diffusers")
+    d.__dict__.setdefault("__path__", [])
+    _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
+    models = sys.modules.get("diffusers.models") or _mod("diffusers.models")
+    models.__dict__.setdefault("__path__", [])
+    _mod("diffusers.models.activations", GEGLU=GEGLU, GELU=GELU, ApproximateGELU=ApproximateGELU)
+    ap = _mod("diffusers.models.attention_processor", Attention=Attention, AttnProcessor=object)
+    sys.modules["diffusers.models.attention"] = _mod("diffusers.models.attention", Attention=Attention)
+    _mod("diffusers.models.embeddings", ImagePositionalEmbeddings=_Unused, PatchEmbed=PatchEmbed,
+         PixArtAlphaCombinedTimestepSizeEmbeddings=PixArtAlphaCombinedTimestepSizeEmbeddings,
+         PixArtAlphaTextProjection=PixArtAlphaTextProjection, SinusoidalPositionalEmbedding=_Unused,
+         get_1d_sincos_pos_embed_from_grid=get_1d_sincos_pos_embed_from_grid, Timesteps=Timesteps,
+         TimestepEmbedding=TimestepEmbedding, get_2d_sincos_pos_embed=get_2d_sincos_pos_embed)
+    _mod("diffusers.models.lora", LoRACompatibleConv=LoRACompatibleConv, LoRACompatibleLinear=LoRACompatibleLinear)
+    _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
+    _mod("diffusers.models.normalization", AdaLayerNorm=_Unused, AdaLayerNormContinuous=_Unused, AdaLayerNormZero=_Unused)
+    _mod("diffusers.utils", USE_PEFT_BACKEND=False, BaseOutput=BaseOutput, deprecate=deprecate)
+    _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=maybe_allow_in_graph)
+    _mod("diffusers.schedulers", DDIMScheduler=DDIMScheduler)
+    return ap

@@ -162,3 +162,25 @@ def build_reference_stdit3(cfg_kwargs: dict, state_dict=None, dtype=torch.float3
         assert not unexpected, unexpected
         assert all("pos_embed" in k or "inv_freq" in k for k in missing), missing
     return model.to(dtype).eval()
+
+
+# ---------------------------------------------------------------------------------------------------- Latte
+def build_reference_latte(cfg_kwargs: dict, state_dict=None, dtype=torch.float32):
+    """Instantiate the reference LatteT2V (videosys/models/transformers/latte_transformer_3d.py:893-1470) on CPU with
+    the restated diffusers leaves of oracle/diffusers_stub.py, sp = cp = 1."""
+    install_stubs()
+    from oracle import diffusers_stub
+
+    diffusers_stub.install()
+    import importlib
+
+    m = importlib.import_module("videosys.models.transformers.latte_transformer_3d")
+    model = m.LatteT2V(**cfg_kwargs)
+    model.parallel_manager = _SPStub()
+    for blk in list(model.transformer_blocks) + list(model.temporal_transformer_blocks):
+        blk.parallel_manager = _SPStub()
+    if state_dict is not None:
+        missing, unexpected = model.load_state_dict(state_dict, strict=False)
+        assert not unexpected, unexpected
+        assert all("pos_embed.pos_embed" in k or "temp_pos_embed" in k for k in missing), missing
+    return model.to(dtype).eval()

@@ -31,6 +31,8 @@ SIGNATURES = {
                          _f32, _ptr],
     "vsys_cfg_euler_step": [_ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _f32, _ptr],
     "vsys_add_rows": [_ptr, _ptr, _i64, _ptr],
+    "vsys_cfg_linear_step": [_ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _f32, _f32, _int, _ptr],
+    "vsys_add_bcast_rows": [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
     "vsys_copy_4d": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "vsys_attn_prep_kv": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
     "vsys_flash_attn_d72": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
 #pragma unroll
   for (int r = 0; r < 16; ++r) minit[r] = 0.f;
 
-  const int ntiles = p.kv_pad / 64;
+  const int ntiles = (p.kv_len + 63) / 64;  // tiles made only of keys >= kv_len are never touched (kv_pad is the stride)
   stage(0, 0);
   {  // rows 80..95 of both Vt images (MFMA padding the DMA never writes): 2 x 2 KiB of zeros
     char* z = smem + (tid >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (tid & 127) * 16;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
     __syncthreads();                                   // ... and so have everybody else's
     FLASH_STAMP(4);
   }
-  if (p.kv_len < p.kv_pad) tile(ntiles - 1, (ntiles - 1) & 1, true);
+  if (p.kv_len & 63) tile(ntiles - 1, (ntiles - 1) & 1, true);
   else tile(ntiles - 1, (ntiles - 1) & 1, false);
 
   if (ABL == 2 && lane == 0 && p.dbg != nullptr) {
@@ -432,8 +432,10 @@ __global__ void attn_temporal_d72_kernel(const bf16_t* __restrict__ qkv, int64_t
     const int base = g * 3;
     const float tot = __shfl(ss, base, 64) + __shfl(ss, base + 1, 64) + __shfl(ss, base + 2, 64);
     const float rstd = rsqrtf(tot / (float)HD + eps);
+    if (w != nullptr) {  // no qk-norm (Latte): q, k are used as projected
 #pragma unroll
-    for (int e = 0; e < 24; ++e) x[e] = bf2f(f2bf(bf2f(f2bf(x[e] * rstd)) * bf2f(w[part * 24 + e])));
+      for (int e = 0; e < 24; ++e) x[e] = bf2f(f2bf(bf2f(f2bf(x[e] * rstd)) * bf2f(w[part * 24 + e])));
+    }
     if (rope_cos != nullptr) {
       const float* cs = rope_cos + (int64_t)t * HD + part * 24;
       const float* sn = rope_sin + (int64_t)t * HD + part * 24;
@@ -564,7 +566,7 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
                              const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T,
                              int S, int heads, float eps, hipStream_t stream) {
   if (B <= 0 || T <= 0 || S <= 0 || heads <= 0) return 0;
-  if ((row_stride % 8) || (out_stride % 8) || (C % 8) || q_norm_w == nullptr || k_norm_w == nullptr) return VSYS_ERR_SHAPE;
+  if ((row_stride % 8) || (out_stride % 8) || (C % 8) || ((q_norm_w == nullptr) != (k_norm_w == nullptr))) return VSYS_ERR_SHAPE;
   const size_t per_wave = (size_t)2 * T * HD * sizeof(float);
   int wpb = 4;
   while (wpb > 1 && per_wave * wpb > 64 * 1024) wpb >>= 1;

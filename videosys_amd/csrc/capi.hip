@@ -113,6 +113,20 @@ int vsys_cfg_euler_step(void* z_f32, const void* model_out_f32, int64_t Bz, int6
                           (int)Cout, thw, guidance, dt, S(stream));
 }
 
+int vsys_cfg_linear_step(void* z_f32, const void* model_out_f32, int64_t Bz, int64_t Cin, int64_t Cout, int64_t thw,
+                         float guidance, float c_z, float c_eps, int cond_first, void* stream) {
+  if (!z_f32 || !model_out_f32) return VSYS_ERR_ARG;
+  if (!fits_int(Bz) || !fits_int(Cin) || !fits_int(Cout) || Cout < Cin) return VSYS_ERR_SHAPE;
+  return launch_cfg_axpby(reinterpret_cast<float*>(z_f32), reinterpret_cast<const float*>(model_out_f32), (int)Bz, (int)Cin,
+                          (int)Cout, thw, guidance, c_z, c_eps, cond_first, S(stream));
+}
+
+int vsys_add_bcast_rows(void* x, const void* e, int64_t rows, int64_t C, int64_t group, int64_t period, void* stream) {
+  if (!x || !e) return VSYS_ERR_ARG;
+  if (!fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_add_bcast_rows(B16(x), B16(e), rows, (int)C, group, period, S(stream));
+}
+
 int vsys_add_rows(void* x, const void* y, int64_t n, void* stream) {
   if (!x || !y) return VSYS_ERR_ARG;
   return launch_add_rows(B16(x), B16(y), n, S(stream));
@@ -149,7 +163,7 @@ int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, c
 int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const void* q_norm_w, const void* k_norm_w,
                            const void* rope_cos_f32, const void* rope_sin_f32, void* out, int64_t out_stride, int64_t B,
                            int64_t T, int64_t S_, int64_t heads, float eps, void* stream) {
-  if (!qkv || !out || !q_norm_w || !k_norm_w) return VSYS_ERR_ARG;
+  if (!qkv || !out || ((q_norm_w == nullptr) != (k_norm_w == nullptr))) return VSYS_ERR_ARG;
   if ((rope_cos_f32 == nullptr) != (rope_sin_f32 == nullptr)) return VSYS_ERR_ARG;
   if (!fits_int(B) || !fits_int(T) || !fits_int(S_) || !fits_int(heads) || !fits_int(C)) return VSYS_ERR_SHAPE;
   return launch_attn_temporal_d72(B16(qkv), row_stride, (int)C, B16(q_norm_w), B16(k_norm_w),

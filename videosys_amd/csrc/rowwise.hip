@@ -273,6 +273,40 @@ __global__ void cfg_euler_kernel(float* __restrict__ z, const float* __restrict_
   z[i] = z[i] + (unc + guidance * (cond - unc)) * dt;
 }
 
+// Generic CFG + linear scheduler step (DDIM eta = 0 and friends): eps = uncond + g (cond - uncond) on the first Cin of
+// Cout channels, z = c_z z + c_eps eps.  cond_first selects which batch half of model_out holds the conditional
+// prediction (RFLOW: first; Latte / CogVideoX pipelines put the negative prompt first).
+__global__ void cfg_axpby_kernel(float* __restrict__ z, const float* __restrict__ model_out, int Bz, int Cin, int Cout,
+                                 int64_t thw, float guidance, float c_z, float c_eps, int cond_first) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)Bz * Cin * thw;
+  if (i >= total) return;
+  const int64_t sp = i % thw;
+  const int c = (int)((i / thw) % Cin);
+  const int b = (int)(i / (thw * Cin));
+  const float h0 = model_out[((int64_t)b * Cout + c) * thw + sp];
+  const float h1 = model_out[((int64_t)(b + Bz) * Cout + c) * thw + sp];
+  const float cond = cond_first ? h0 : h1, unc = cond_first ? h1 : h0;
+  z[i] = c_z * z[i] + c_eps * (unc + guidance * (cond - unc));
+}
+
+// x[r][:] += e[(r / group) % period][:]  (Latte temporal position embedding: rows ordered (b, f, s), group = S, period = F)
+__global__ void add_bcast_rows_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ e, int64_t rows, int C8, int64_t group,
+                                      int64_t period) {
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C8;
+    const int c = (int)(i - r * C8);
+    const int64_t er = (r / group) % period;
+    float a[8], b[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[i], a);
+    unpack8(reinterpret_cast<const uint4*>(e)[er * C8 + c], b);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += b[k];
+    reinterpret_cast<uint4*>(x)[i] = pack8(a);
+  }
+}
+
 // x[i] = bf16(x[i] + y[i]) over n8 16-byte chunks
 __global__ void add_rows_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ y, int64_t n8) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
@@ -376,6 +410,24 @@ int launch_cfg_euler(float* z, const float* model_out, int Bz, int Cin, int Cout
   if (total <= 0) return 0;
   hipLaunchKernelGGL(cfg_euler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, model_out, Bz, Cin,
                      Cout, thw, guidance, dt);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_cfg_axpby(float* z, const float* model_out, int Bz, int Cin, int Cout, int64_t thw, float guidance, float c_z,
+                     float c_eps, int cond_first, hipStream_t stream) {
+  const int64_t total = (int64_t)Bz * Cin * thw;
+  if (total <= 0) return 0;
+  hipLaunchKernelGGL(cfg_axpby_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, model_out, Bz, Cin,
+                     Cout, thw, guidance, c_z, c_eps, cond_first);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_add_bcast_rows(bf16_t* x, const bf16_t* e, int64_t rows, int C, int64_t group, int64_t period, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (C % 8 || group <= 0 || period <= 0) return VSYS_ERR_SHAPE;
+  int64_t grid = (rows * (C / 8) + 255) / 256;
+  if (grid > 2048 * 4) grid = 2048 * 4;
+  hipLaunchKernelGGL(add_bcast_rows_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, e, rows, C / 8, group, period);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

@@ -41,6 +41,9 @@ int launch_final_layer(const bf16_t* x, const bf16_t* table, const bf16_t* tvec,
                        hipStream_t stream);
 int launch_cfg_euler(float* z, const float* model_out, int Bz, int Cin, int Cout, int64_t thw, float guidance, float dt,
                      hipStream_t stream);
+int launch_cfg_axpby(float* z, const float* model_out, int Bz, int Cin, int Cout, int64_t thw, float guidance, float c_z,
+                     float c_eps, int cond_first, hipStream_t stream);
+int launch_add_bcast_rows(bf16_t* x, const bf16_t* e, int64_t rows, int C, int64_t group, int64_t period, hipStream_t stream);
 int launch_add_rows(bf16_t* x, const bf16_t* y, int64_t n, hipStream_t stream);
 int launch_copy_4d(const bf16_t* src, bf16_t* dst, int n0, int n1, int n2, int C, int64_t ss0, int64_t ss1, int64_t ss2,
                    int64_t ds0, int64_t ds1, int64_t ds2, int n1_valid, int n2_valid, hipStream_t stream);

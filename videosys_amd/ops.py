@@ -150,6 +150,32 @@ def cfg_euler_step(z_f32, model_out_f32, guidance, dt):
     return z_f32
 
 
+def cfg_linear_step(z_f32, model_out_f32, guidance, c_z, c_eps, cond_first=False):
+    """z = c_z z + c_eps (uncond + g (cond - uncond)); model_out [2*Bz, Cout >= Cin, ...] fp32."""
+    _chk(z_f32, model_out_f32)
+    assert z_f32.dtype == torch.float32 and model_out_f32.dtype == torch.float32
+    assert z_f32.is_contiguous() and model_out_f32.is_contiguous()
+    Bz, Cin = z_f32.shape[:2]
+    Cout = model_out_f32.shape[1]
+    assert model_out_f32.shape[0] == 2 * Bz
+    thw = z_f32[0, 0].numel()
+    lib = _lib.load()
+    _lib.check(lib.vsys_cfg_linear_step(_p(z_f32), _p(model_out_f32), Bz, Cin, Cout, thw, float(guidance), float(c_z),
+                                        float(c_eps), 1 if cond_first else 0, _stream()), "vsys_cfg_linear_step")
+    return z_f32
+
+
+def add_bcast_rows(x, e, group, period):
+    """x [rows, C] += e[(row // group) % period]"""
+    _chk(x, e)
+    _bf16(x, e)
+    assert x.is_contiguous() and e.is_contiguous() and x.shape[-1] == e.shape[-1] and e.shape[0] >= period
+    rows = x.numel() // x.shape[-1]
+    lib = _lib.load()
+    _lib.check(lib.vsys_add_bcast_rows(_p(x), _p(e), rows, x.shape[-1], group, period, _stream()), "vsys_add_bcast_rows")
+    return x
+
+
 def add_rows(x, y):
     _chk(x, y)
     _bf16(x, y)

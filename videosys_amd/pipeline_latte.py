@@ -1,0 +1,167 @@
+"""Latte pipeline plug-in — host mirror of videosys/pipelines/latte/pipeline_latte.py (LattePABConfig :35-76,
+LatteConfig :79-160, LattePipeline :163-960) for the denoising hot path: text embeddings + noise -> latents.
+
+``LatteConfig`` / ``LattePABConfig`` take the same kwargs with the same defaults and drop into ``VideoSysEngine``.
+The T5 text encoder and the (temporal-decoder) VAE are pluggable callables like in the Open-Sora pipeline (no weights
+offline).  The scheduler is a host-side restatement of diffusers' DDIMScheduler as the pipeline uses it (set_timesteps
+"leading", eta = 0, epsilon prediction; diffusers==0.30.0 is pinned by the reference but not vendored) whose per-step
+CFG combine + update is one HIP kernel (vsys_cfg_linear_step).
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Callable, List, Optional
+
+import torch
+
+from . import ops, pab
+from .latte import LatteT2V, synth_state_dict
+from .pab import PABConfig
+from .pipeline_open_sora import VideoSysPipelineOutput
+
+_MLP = {k: {"block": [0, 1, 2, 3, 4], "skip_count": 2} for k in (720, 640, 560, 480, 400)}
+
+
+class LattePABConfig(PABConfig):
+    """pipeline_latte.py:35-76 — identical defaults."""
+
+    def __init__(self, spatial_broadcast: bool = True, spatial_threshold: list = [100, 800], spatial_range: int = 2,
+                 temporal_broadcast: bool = True, temporal_threshold: list = [100, 800], temporal_range: int = 3,
+                 cross_broadcast: bool = True, cross_threshold: list = [100, 800], cross_range: int = 6,
+                 mlp_broadcast: bool = True, mlp_spatial_broadcast_config: dict = None,
+                 mlp_temporal_broadcast_config: dict = None):
+        super().__init__(
+            spatial_broadcast=spatial_broadcast, spatial_threshold=spatial_threshold, spatial_range=spatial_range,
+            temporal_broadcast=temporal_broadcast, temporal_threshold=temporal_threshold, temporal_range=temporal_range,
+            cross_broadcast=cross_broadcast, cross_threshold=cross_threshold, cross_range=cross_range,
+            mlp_broadcast=mlp_broadcast,
+            mlp_spatial_broadcast_config=mlp_spatial_broadcast_config or {k: dict(v) for k, v in _MLP.items()},
+            mlp_temporal_broadcast_config=mlp_temporal_broadcast_config or {k: dict(v) for k, v in _MLP.items()},
+        )
+
+
+class LatteConfig:
+    """pipeline_latte.py:79-160 — identical kwargs/defaults."""
+
+    def __init__(self, model_path: str = "maxin-cn/Latte-1", num_gpus: int = 1, enable_vae_temporal_decoder: bool = True,
+                 beta_start: float = 0.0001, beta_end: float = 0.02, beta_schedule: str = "linear",
+                 variance_type: str = "learned_range", cpu_offload: bool = False, enable_pab: bool = False,
+                 pab_config: PABConfig = None, **extra):
+        self.model_path = model_path
+        self.pipeline_cls = LattePipeline
+        self.num_gpus = num_gpus
+        self.enable_vae_temporal_decoder = enable_vae_temporal_decoder
+        self.cpu_offload = cpu_offload
+        self.beta_start, self.beta_end, self.beta_schedule, self.variance_type = beta_start, beta_end, beta_schedule, variance_type
+        self.enable_pab = enable_pab
+        self.pab_config = pab_config if pab_config is not None else LattePABConfig()
+        self.transformer_config = extra.pop("transformer_config", None)  # extension: geometry override for tests
+        if extra:
+            raise TypeError(f"unexpected LatteConfig kwargs: {sorted(extra)}")
+
+
+class DDIMScheduler:
+    """diffusers DDIMScheduler as pipeline_latte.py:224-233,802-803,876 uses it."""
+
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.0001, beta_end: float = 0.02,
+                 beta_schedule: str = "linear", variance_type: str = "learned_range", set_alpha_to_one: bool = True,
+                 steps_offset: int = 0):
+        if beta_schedule != "linear":
+            raise NotImplementedError("Latte uses the linear beta schedule")
+        self.num_train_timesteps = num_train_timesteps
+        betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
+        self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(self.alphas_cumprod[0])
+        self.steps_offset = steps_offset
+        self.num_inference_steps = None
+        self.timesteps: List[int] = []
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        ratio = self.num_train_timesteps // num_inference_steps
+        self.timesteps = [int(round(i * ratio)) + self.steps_offset for i in range(num_inference_steps)][::-1]
+
+    def coeffs(self, t: int):
+        """prev_sample = c_z * sample + c_eps * eps (eta = 0, no clipping)."""
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else self.final_alpha_cumprod
+        return math.sqrt(a_prev / a_t), math.sqrt(1 - a_prev) - math.sqrt(a_prev * (1 - a_t) / a_t)
+
+
+class LattePipeline:
+    def __init__(self, config: LatteConfig, device=None, text_encoder: Optional[Callable] = None,
+                 vae_decoder: Optional[Callable] = None):
+        self._config = config
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("LattePipeline needs a HIP device (videosys_amd has no CPU execution path)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._device = torch.device(device)
+        tcfg = dict(config.transformer_config or {})
+        self.transformer = LatteT2V(**tcfg, device=self._device)
+        name = config.model_path
+        st = os.path.join(name, "transformer", "diffusion_pytorch_model.safetensors") if isinstance(name, str) else ""
+        if st and os.path.exists(st):
+            from safetensors.torch import load_file
+
+            sd = load_file(st)
+        else:
+            seed = int(name.split(":", 1)[1]) if isinstance(name, str) and name.startswith("synthetic:") else 4321
+            c = self.transformer.config
+            sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.caption_channels, c.in_channels,
+                                  c.out_channels, c.patch_size, seed=seed)
+        self.transformer.load_state_dict(sd)
+        self.scheduler = DDIMScheduler(beta_start=config.beta_start, beta_end=config.beta_end,
+                                       beta_schedule=config.beta_schedule, variance_type=config.variance_type)
+        self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
+        pab.set_pab_manager(config.pab_config if config.enable_pab else None)
+
+    @torch.no_grad()
+    def generate(self, prompt=None, negative_prompt: str = "", num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 seed: int = -1, verbose: bool = False, *, prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
+                 negative_mask: Optional[torch.Tensor] = None, latents: Optional[torch.Tensor] = None,
+                 video_length: int = 16, height: int = 512, width: int = 512, output_type: str = "auto"):
+        """pipeline_latte.py:675-900 for text-to-video: CFG batch [negative | prompt], learned-sigma half dropped,
+        DDIM eta = 0.  ``height/width/video_length`` are the reference's hard-coded 512/512/16 by default (:764-766);
+        BASELINE config 1 (256x256) passes them explicitly."""
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, L, 4096]")
+            prompt_embeds, prompt_mask = self.text_encoder(prompt)
+            negative_prompt_embeds, negative_mask = self.text_encoder(negative_prompt)
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("the MI355X path runs the classifier-free-guidance batch (guidance_scale > 1)")
+        pab.update_steps(num_inference_steps)
+        self.transformer.reset_pab_state()
+        B = prompt_embeds.shape[0]
+        emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        mask = None if prompt_mask is None else torch.cat([negative_mask, prompt_mask], dim=0)
+        self.scheduler.set_timesteps(num_inference_steps)
+        ts = self.scheduler.timesteps
+        cin = self.transformer.in_channels
+        if latents is None:
+            g = torch.Generator(device="cpu").manual_seed(seed if seed >= 0 else 0)
+            latents = torch.randn(B, cin, video_length, height // 8, width // 8, generator=g, dtype=torch.float32)
+        z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
+        all_ts = torch.tensor(ts)
+        for t in ts:
+            tt = torch.full((2 * B,), t, dtype=torch.int64)
+            out = self.transformer(z, timestep=tt, all_timesteps=all_ts, encoder_hidden_states=emb,
+                                   encoder_attention_mask=mask, added_cond_kwargs={"resolution": None, "aspect_ratio": None},
+                                   enable_temporal_attentions=True, return_dict=False)[0]
+            c_z, c_eps = self.scheduler.coeffs(t)
+            ops.cfg_linear_step(z, out, guidance_scale, c_z, c_eps, cond_first=False)
+        if self.vae_decoder is None or output_type in ("latent", "latents"):
+            return VideoSysPipelineOutput(video=z)
+        return VideoSysPipelineOutput(video=self.vae_decoder(z))
+
+    def save_video(self, video, output_path):
+        from .utils import save_video
+
+        save_video(video, output_path)
