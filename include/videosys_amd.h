@@ -136,6 +136,57 @@ int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, c
                         int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
                         float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * CogVideoX: joint [text | video] blocks, head_dim 64.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* vsys_gemm_bf16 with VSYS_EPI_GATE_RES and TWO gate vectors per sample: rows whose position inside the sample is
+ * < seg_split (the text tokens) read the gate gate_alt elements after the sample's gate pointer
+ * (CogVideoXBlock.forward: hidden + gate_msa * attn / encoder_hidden + enc_gate_msa * attn,
+ * cogvideox_transformer_3d.py:288-289,300-301; gates from CogVideoXLayerNormZero, modules/normalization.py:52-59). */
+int vsys_gemm_bf16_gate2(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                         int64_t M, int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride,
+                         int64_t rows_per_sample, int64_t seg_split, int64_t gate_alt, const void* res, int64_t ldr,
+                         void* aux, int64_t ldaux, void* stream);
+
+/* y = (LayerNorm(x) * ln_w + ln_b) * (1 + scale) + shift over rows of C bf16 (C <= 3072).  ln_w/ln_b NULL: no affine;
+ * shift/scale NULL: no modulation (nn.LayerNorm norm_final, cogvideox_transformer_3d.py:566-572).  shift/scale point at
+ * sample 0's vectors (sample stride mod_sample_stride); rows at position < seg_split inside their sample read them
+ * mod_alt elements further on (CogVideoXLayerNormZero, modules/normalization.py:36-60; AdaLayerNorm chunk_dim=1 :62-114). */
+int vsys_ln_modulate(const void* x, const void* ln_w, const void* ln_b, const void* shift, const void* scale, void* y,
+                     int64_t rows, int64_t C, int64_t rows_per_sample, int64_t mod_sample_stride, int64_t seg_split,
+                     int64_t mod_alt, float eps, void* stream);
+
+/* x[r] += gate[sample(r)] * y[r] with the two-segment gate addressing above: the PAB broadcast step of CogVideoXBlock
+ * re-gates the cached, un-gated attention output (cogvideox_transformer_3d.py:276-289). */
+int vsys_gate_add_rows(void* x, const void* y, const void* gate, int64_t rows, int64_t C, int64_t rows_per_sample,
+                       int64_t gate_sample_stride, int64_t seg_split, int64_t gate_alt, void* stream);
+
+/* CogVideoXPatchEmbed's Conv2d(k = s = p) operand (modules/embeddings.py:14-51): z fp32 [Bz, F, Cin, H, W] (sample b reads
+ * z[b % Bz]) -> out bf16 [B*F*(H/p)*(W/p), Cin*p*p] with columns ordered (c, dy, dx) like the flattened conv weight. */
+int vsys_im2col_patch(const void* z_f32, int64_t Bz, void* out, int64_t B, int64_t F, int64_t Cin, int64_t H, int64_t W,
+                      int64_t p, void* stream);
+
+/* CogVideoX unpatchify (cogvideox_transformer_3d.py:581-583): x bf16 [(b, f, hp, wp)] rows of ldx >= Cout*p*p elements,
+ * columns ordered (c, dy, dx) -> out fp32 [B, F, Cout, Hp*p, Wp*p]. */
+int vsys_unpatchify_cvx(const void* x, int64_t ldx, void* out_f32, int64_t B, int64_t F, int64_t Hp, int64_t Wp, int64_t Cout,
+                        int64_t p, void* stream);
+
+/* K side of CogVideoXAttnProcessor2_0 (cogvideox_transformer_3d.py:108,127-149): LayerNorm qk-norm (ln_w/ln_b [64] or NULL),
+ * rotary embedding on tokens rope_start <= s < rope_start + rope_len (cos/sin fp32 [rope_len, 64], NULL = none), softmax
+ * scale folded in; head-major K (16-byte chunks of a row stored at chunk ^ ((row>>1)&7): an operand private to
+ * vsys_flash_attn_d64) and transposed V.  kp [batch, H, kv_pad, 64], vt [batch, H, 64, kv_pad], kv_pad % 64 == 0. */
+int vsys_attn_prep_kv64(const void* k, int64_t k_stride, const void* v, int64_t v_stride, const void* ln_w, const void* ln_b,
+                        const void* rope_cos_f32, const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, void* kp,
+                        void* vt, int64_t batch, int64_t heads, int64_t kv_len, int64_t kv_pad, float eps, void* stream);
+
+/* softmax(q k^T / 8) v for head_dim 64, non-causal, with the q side of the processor above (LayerNorm + RoPE) applied on
+ * the fly.  q(b,s,h) at q + (b*q_len + s)*q_stride + h*64; out likewise. */
+int vsys_flash_attn_d64(const void* q, int64_t q_stride, const void* ln_w, const void* ln_b, const void* rope_cos_f32,
+                        const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, const void* kp, const void* vt, void* out,
+                        int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad, float eps,
+                        void* stream);
+
 /* Temporal self-attention over the T frames of every (b, s) token: RMS qk-norm, RoPE (cos/sin fp32 [T, 72], NULL =
  * none), fp32 softmax (attentions.py:75-78,95-97,111-120; open_sora_transformer_3d.py:203-206).
  * q_norm_w == k_norm_w == NULL: no qk-norm (Latte temporal blocks, latte_transformer_3d.py:680-760).

@@ -36,6 +36,16 @@ SIGNATURES = {
     "vsys_copy_4d": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "vsys_attn_prep_kv": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
     "vsys_flash_attn_d72": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "vsys_gemm_bf16_gate2": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64,
+                             _ptr, _i64, _ptr],
+    "vsys_ln_modulate": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "vsys_gate_add_rows": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_im2col_patch": [_ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_unpatchify_cvx": [_ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_attn_prep_kv64": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32,
+                            _ptr],
+    "vsys_flash_attn_d64": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
+                            _f32, _ptr],
     "vsys_attn_temporal_d72": [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
 }
 

@@ -56,8 +56,86 @@ int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.gate = B16(gate); p.gate_stride = gate_sample_stride; p.res = B16(res); p.ldr = ldr; p.aux = B16(aux); p.ldaux = ldaux;
   p.rows_per_sample = (int)rows_per_sample;
+  p.seg_split = 0; p.gate_alt = 0;
   if (epilogue != VSYS_EPI_GATE_RES && (gate || res || aux)) return VSYS_ERR_ARG;
   return launch_gemm(p, epilogue, S(stream));
+}
+
+int vsys_gemm_bf16_gate2(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                         int64_t M, int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride,
+                         int64_t rows_per_sample, int64_t seg_split, int64_t gate_alt, const void* res, int64_t ldr,
+                         void* aux, int64_t ldaux, void* stream) {
+  if (!x || !w || !out || !gate) return VSYS_ERR_ARG;
+  if (!fits_int(M) || !fits_int(N) || !fits_int(K) || !fits_int(rows_per_sample) || !fits_int(seg_split)) return VSYS_ERR_SHAPE;
+  if (seg_split < 0 || seg_split > rows_per_sample) return VSYS_ERR_SHAPE;
+  GemmParams p;
+  p.A = B16(x); p.lda = ldx; p.W = B16(w); p.ldw = ldw; p.bias = B16(bias); p.out = B16(out); p.ldo = ldo;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.gate = B16(gate); p.gate_stride = gate_sample_stride; p.res = B16(res); p.ldr = ldr; p.aux = B16(aux); p.ldaux = ldaux;
+  p.rows_per_sample = (int)rows_per_sample;
+  p.seg_split = (int)seg_split; p.gate_alt = gate_alt;
+  return launch_gemm(p, VSYS_EPI_GATE_RES, S(stream));
+}
+
+int vsys_ln_modulate(const void* x, const void* ln_w, const void* ln_b, const void* shift, const void* scale, void* y,
+                     int64_t rows, int64_t C, int64_t rows_per_sample, int64_t mod_sample_stride, int64_t seg_split,
+                     int64_t mod_alt, float eps, void* stream) {
+  if (!x || !y) return VSYS_ERR_ARG;
+  if (!fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_ln_modulate(B16(x), B16(ln_w), B16(ln_b), B16(shift), B16(scale), B16(y), rows, (int)C, rows_per_sample,
+                            mod_sample_stride, seg_split, mod_alt, eps, S(stream));
+}
+
+int vsys_gate_add_rows(void* x, const void* y, const void* gate, int64_t rows, int64_t C, int64_t rows_per_sample,
+                       int64_t gate_sample_stride, int64_t seg_split, int64_t gate_alt, void* stream) {
+  if (!x || !y || !gate) return VSYS_ERR_ARG;
+  if (!fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_gate_add_rows(B16(x), B16(y), B16(gate), rows, (int)C, rows_per_sample, gate_sample_stride, seg_split, gate_alt,
+                              S(stream));
+}
+
+int vsys_im2col_patch(const void* z_f32, int64_t Bz, void* out, int64_t B, int64_t F, int64_t Cin, int64_t H, int64_t W,
+                      int64_t p, void* stream) {
+  if (!z_f32 || !out) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(F) || !fits_int(Cin) || !fits_int(H) || !fits_int(W) || !fits_int(p) || !fits_int(Bz)) return VSYS_ERR_SHAPE;
+  if ((Cin * p * p) % 8) return VSYS_ERR_SHAPE;
+  return launch_im2col_patch(reinterpret_cast<const float*>(z_f32), (int)Bz, B16(out), (int)B, (int)F, (int)Cin, (int)H, (int)W,
+                             (int)p, S(stream));
+}
+
+int vsys_unpatchify_cvx(const void* x, int64_t ldx, void* out_f32, int64_t B, int64_t F, int64_t Hp, int64_t Wp, int64_t Cout,
+                        int64_t p, void* stream) {
+  if (!x || !out_f32) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(F) || !fits_int(Hp) || !fits_int(Wp) || !fits_int(Cout) || !fits_int(p)) return VSYS_ERR_SHAPE;
+  return launch_unpatchify_cvx(B16(x), ldx, reinterpret_cast<float*>(out_f32), (int)B, (int)F, (int)Hp, (int)Wp, (int)Cout,
+                               (int)p, S(stream));
+}
+
+int vsys_attn_prep_kv64(const void* k, int64_t k_stride, const void* v, int64_t v_stride, const void* ln_w, const void* ln_b,
+                        const void* rope_cos_f32, const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, void* kp,
+                        void* vt, int64_t batch, int64_t heads, int64_t kv_len, int64_t kv_pad, float eps, void* stream) {
+  if (!k || !v || !kp || !vt) return VSYS_ERR_ARG;
+  if ((ln_w == nullptr) != (ln_b == nullptr)) return VSYS_ERR_ARG;
+  if (!fits_int(batch) || !fits_int(heads) || !fits_int(kv_len) || !fits_int(kv_pad) || !fits_int(rope_start) || !fits_int(rope_len))
+    return VSYS_ERR_SHAPE;
+  return launch_attn_prep_kv64(B16(k), k_stride, B16(v), v_stride, B16(ln_w), B16(ln_b),
+                               reinterpret_cast<const float*>(rope_cos_f32), reinterpret_cast<const float*>(rope_sin_f32),
+                               (int)rope_start, (int)rope_len, B16(kp), B16(vt), (int)batch, (int)heads, (int)kv_len, (int)kv_pad,
+                               eps, S(stream));
+}
+
+int vsys_flash_attn_d64(const void* q, int64_t q_stride, const void* ln_w, const void* ln_b, const void* rope_cos_f32,
+                        const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, const void* kp, const void* vt, void* out,
+                        int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad, float eps,
+                        void* stream) {
+  if (!q || !kp || !vt || !out) return VSYS_ERR_ARG;
+  if ((ln_w == nullptr) != (ln_b == nullptr)) return VSYS_ERR_ARG;
+  if (!fits_int(batch) || !fits_int(heads) || !fits_int(q_len) || !fits_int(kv_len) || !fits_int(kv_pad) || !fits_int(rope_start) ||
+      !fits_int(rope_len))
+    return VSYS_ERR_SHAPE;
+  return launch_flash_attn_d64(B16(q), q_stride, B16(ln_w), B16(ln_b), reinterpret_cast<const float*>(rope_cos_f32),
+                               reinterpret_cast<const float*>(rope_sin_f32), (int)rope_start, (int)rope_len, B16(kp), B16(vt),
+                               B16(out), out_stride, (int)batch, (int)heads, (int)q_len, (int)kv_len, (int)kv_pad, eps, S(stream));
 }
 
 int vsys_linear_small(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,

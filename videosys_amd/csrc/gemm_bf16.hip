@@ -387,7 +387,9 @@ __global__ __launch_bounds__(Geo<BM_>::NT, 2) void gemm_kernel(GemmParams p) {
       if (p.gate != nullptr) {
         int grow = row0 + wm * 64 + m_local;
         grow = grow < p.M ? grow : p.M - 1;
-        const bf16_t* gate_row = p.gate + (int64_t)(grow / p.rows_per_sample) * p.gate_stride + ncol0 + 4 * hi;
+        const int sample = grow / p.rows_per_sample;
+        const bf16_t* gate_row = p.gate + (int64_t)sample * p.gate_stride + ncol0 + 4 * hi;
+        if (p.seg_split > 0 && grow - sample * p.rows_per_sample < p.seg_split) gate_row += p.gate_alt;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll

@@ -76,6 +76,129 @@ __global__ __launch_bounds__(256) void adaln_modulate_kernel(const bf16_t* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// General LayerNorm + modulate for the CogVideoX blocks (modules/normalization.py:36-60 CogVideoXLayerNormZero, :62-114
+// AdaLayerNorm, nn.LayerNorm norm_final): y = (LN(x) * w + b) * (1 + scale) + shift with optional affine (w, b), optional
+// modulation (shift/scale NULL = plain LayerNorm) and TWO row segments per sample: rows whose position inside the sample
+// is < seg_split (the text tokens of the joint [text | video] sequence) read their shift/scale mod_alt elements further on.
+// ---------------------------------------------------------------------------------------------------------
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ ln_w,
+                                                          const bf16_t* __restrict__ ln_b, const bf16_t* __restrict__ shift,
+                                                          const bf16_t* __restrict__ scale, bf16_t* __restrict__ y, int64_t rows,
+                                                          int C, int64_t rows_per_sample, int64_t mod_stride, int64_t seg_split,
+                                                          int64_t mod_alt, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nchunk = C >> 3;
+  const bf16_t* xr = x + row * C;
+  float v[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[i][e];
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const int64_t b = row / rows_per_sample;
+  const int64_t alt = (seg_split > 0 && row - b * rows_per_sample < seg_split) ? mod_alt : 0;
+  bf16_t* yr = y + row * C;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nchunk) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (v[i][e] - mean) * rstd;
+      if (ln_w != nullptr) {
+        float w[8], bb[8];
+        unpack8(*reinterpret_cast<const uint4*>(ln_w + c * 8), w);
+        unpack8(*reinterpret_cast<const uint4*>(ln_b + c * 8), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * w[e] + bb[e];
+      }
+      if (shift != nullptr) {
+        float a[8], m[8];
+        unpack8(*reinterpret_cast<const uint4*>(shift + b * mod_stride + alt + c * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(scale + b * mod_stride + alt + c * 8), m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * (1.0f + m[e]) + a[e];
+      }
+      *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+    }
+  }
+}
+
+// x[r] += gate[sample(r)] * y[r]   (CogVideoX PAB: the cached un-gated attention output is re-gated every step,
+// cogvideox_transformer_3d.py:288-289); two gate segments per sample like ln_modulate.
+__global__ void gate_add_rows_kernel(bf16_t* __restrict__ x, const bf16_t* __restrict__ y, const bf16_t* __restrict__ gate,
+                                     int64_t rows, int C8, int64_t rows_per_sample, int64_t gate_stride, int64_t seg_split,
+                                     int64_t gate_alt) {
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / C8;
+    const int c = (int)(i - r * C8);
+    const int64_t b = r / rows_per_sample;
+    const int64_t alt = (seg_split > 0 && r - b * rows_per_sample < seg_split) ? gate_alt : 0;
+    float a[8], v[8], g[8];
+    unpack8(reinterpret_cast<const uint4*>(x)[i], a);
+    unpack8(reinterpret_cast<const uint4*>(y)[i], v);
+    unpack8(*reinterpret_cast<const uint4*>(gate + b * gate_stride + alt + c * 8), g);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] += bf2f(f2bf(g[k] * v[k]));
+    reinterpret_cast<uint4*>(x)[i] = pack8(a);
+  }
+}
+
+// CogVideoXPatchEmbed's Conv2d(k = s = p) as a GEMM operand (modules/embeddings.py:14-51): out[(b, f, hp, wp)][(c, dy, dx)]
+// = bf16(z[b % Bz][f][c][hp*p + dy][wp*p + dx]), z fp32 [Bz, F, Cin, H, W]; the weight [C, Cin, p, p] flattens to the same
+// (c, dy, dx) order.  K = Cin*p*p must be a multiple of 8 (64 for CogVideoX).
+__global__ void im2col_patch_kernel(const float* __restrict__ z, int Bz, bf16_t* __restrict__ out, int B, int F, int Cin, int H,
+                                    int W, int p) {
+  const int Hp = H / p, Wp = W / p, K = Cin * p * p;
+  const int64_t total = (int64_t)B * F * Hp * Wp * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % K);
+    const int64_t tok = i / K;
+    const int wp = (int)(tok % Wp), hp = (int)((tok / Wp) % Hp), f = (int)((tok / ((int64_t)Wp * Hp)) % F);
+    const int b = (int)(tok / ((int64_t)Wp * Hp * F));
+    const int dx = k % p, dy = (k / p) % p, c = k / (p * p);
+    out[i] = f2bf(z[((((int64_t)(b % Bz) * F + f) * Cin + c) * H + hp * p + dy) * W + wp * p + dx]);
+  }
+}
+
+// CogVideoX unpatchify (cogvideox_transformer_3d.py:581-583): x [(b, f, hp, wp)][>= Cout*p*p] bf16, channel order (c, dy, dx)
+// -> out fp32 [B, F, Cout, Hp*p, Wp*p]
+__global__ void unpatchify_cvx_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ out, int B, int F, int Hp,
+                                      int Wp, int Cout, int p) {
+  const int H = Hp * p, W = Wp * p;
+  const int64_t total = (int64_t)B * F * Cout * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)((i / ((int64_t)W * H)) % Cout);
+    const int64_t bf = i / ((int64_t)W * H * Cout);
+    const int64_t tok = (bf * Hp + h / p) * Wp + w / p;
+    out[i] = bf2f(x[tok * ldx + (c * p + h % p) * p + w % p]);
+  }
+}
+
 // mod[blk][b][6][C] = bf16(table[blk][6][C] + t_mlp[b][6*C])   (bf16 add, as the reference's bf16 tensors do)
 __global__ void mod_table_kernel(const bf16_t* __restrict__ table, const bf16_t* __restrict__ t_mlp, bf16_t* __restrict__ out,
                                  int nblk, int B, int C6) {
@@ -355,6 +478,55 @@ int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* sc
   else
     hipLaunchKernelGGL(adaln_modulate_kernel<4>, dim3(grid), dim3(256), 0, stream, x, shift, scale, y, rows, C,
                        rows_per_sample, mod_stride, eps);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_ln_modulate(const bf16_t* x, const bf16_t* ln_w, const bf16_t* ln_b, const bf16_t* shift, const bf16_t* scale,
+                       bf16_t* y, int64_t rows, int C, int64_t rows_per_sample, int64_t mod_stride, int64_t seg_split,
+                       int64_t mod_alt, float eps, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (C % 8 != 0 || C > 64 * 8 * 6 || rows_per_sample <= 0 || (mod_stride % 8) || (mod_alt % 8)) return VSYS_ERR_SHAPE;
+  if ((ln_w == nullptr) != (ln_b == nullptr) || (shift == nullptr) != (scale == nullptr)) return VSYS_ERR_ARG;
+  const unsigned grid = (unsigned)((rows + 3) / 4);
+#define VSYS_LNMOD(V)                                                                                                      \
+  hipLaunchKernelGGL(ln_modulate_kernel<V>, dim3(grid), dim3(256), 0, stream, x, ln_w, ln_b, shift, scale, y, rows, C,       \
+                     rows_per_sample, mod_stride, seg_split, mod_alt, eps)
+  if (C <= 64 * 8 * 2) VSYS_LNMOD(2);
+  else if (C <= 64 * 8 * 3) VSYS_LNMOD(3);
+  else if (C <= 64 * 8 * 4) VSYS_LNMOD(4);
+  else VSYS_LNMOD(6);
+#undef VSYS_LNMOD
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_gate_add_rows(bf16_t* x, const bf16_t* y, const bf16_t* gate, int64_t rows, int C, int64_t rows_per_sample,
+                         int64_t gate_stride, int64_t seg_split, int64_t gate_alt, hipStream_t stream) {
+  if (rows <= 0) return 0;
+  if (C % 8 || rows_per_sample <= 0 || (gate_stride % 8) || (gate_alt % 8)) return VSYS_ERR_SHAPE;
+  int64_t grid = (rows * (C / 8) + 255) / 256;
+  if (grid > 2048 * 4) grid = 2048 * 4;
+  hipLaunchKernelGGL(gate_add_rows_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, y, gate, rows, C / 8, rows_per_sample,
+                     gate_stride, seg_split, gate_alt);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_im2col_patch(const float* z, int Bz, bf16_t* out, int B, int F, int Cin, int H, int W, int p, hipStream_t stream) {
+  if (p <= 0 || H % p || W % p || Bz <= 0) return VSYS_ERR_SHAPE;
+  const int64_t total = (int64_t)B * F * (H / p) * (W / p) * Cin * p * p;
+  if (total <= 0) return 0;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 2048 * 8) grid = 2048 * 8;
+  hipLaunchKernelGGL(im2col_patch_kernel, dim3((unsigned)grid), dim3(256), 0, stream, z, Bz, out, B, F, Cin, H, W, p);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_unpatchify_cvx(const bf16_t* x, int64_t ldx, float* out, int B, int F, int Hp, int Wp, int Cout, int p,
+                          hipStream_t stream) {
+  const int64_t total = (int64_t)B * F * Cout * Hp * p * Wp * p;
+  if (total <= 0) return 0;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 2048 * 8) grid = 2048 * 8;
+  hipLaunchKernelGGL(unpatchify_cvx_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, ldx, out, B, F, Hp, Wp, Cout, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

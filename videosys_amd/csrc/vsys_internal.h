@@ -22,6 +22,9 @@ struct GemmParams {
   const bf16_t* res; int64_t ldr;           // residual [M, N] or null
   bf16_t* aux; int64_t ldaux;               // optional copy of gate*(acc+bias) (PAB cache slab) or null
   int rows_per_sample;
+  // CogVideoX joint [text | video] rows: rows whose position inside the sample is < seg_split take their gate vector
+  // gate_alt elements further on (enc_gate vs gate of CogVideoXLayerNormZero); 0 = one gate per sample
+  int seg_split; int64_t gate_alt;
 };
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
@@ -53,6 +56,21 @@ int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int6
 int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt,
                           bf16_t* out, int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad,
                           float eps, hipStream_t stream);
+int launch_attn_prep_kv64(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* ln_w,
+                          const bf16_t* ln_b, const float* rope_cos, const float* rope_sin, int rope_start, int rope_len,
+                          bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps, hipStream_t stream);
+int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
+                          const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
+                          int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps,
+                          hipStream_t stream);
+int launch_ln_modulate(const bf16_t* x, const bf16_t* ln_w, const bf16_t* ln_b, const bf16_t* shift, const bf16_t* scale,
+                       bf16_t* y, int64_t rows, int C, int64_t rows_per_sample, int64_t mod_stride, int64_t seg_split,
+                       int64_t mod_alt, float eps, hipStream_t stream);
+int launch_gate_add_rows(bf16_t* x, const bf16_t* y, const bf16_t* gate, int64_t rows, int C, int64_t rows_per_sample,
+                         int64_t gate_stride, int64_t seg_split, int64_t gate_alt, hipStream_t stream);
+int launch_unpatchify_cvx(const bf16_t* x, int64_t ldx, float* out, int B, int F, int Hp, int Wp, int Cout, int p,
+                          hipStream_t stream);
+int launch_im2col_patch(const float* z, int Bz, bf16_t* out, int B, int F, int Cin, int H, int W, int p, hipStream_t stream);
 int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
                              const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T,
                              int S, int heads, float eps, hipStream_t stream);

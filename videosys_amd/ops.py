@@ -242,3 +242,97 @@ def attn_temporal(qkv, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, B, T, S, 
     _lib.check(lib.vsys_attn_temporal_d72(_p(qkv), qkv.stride(0), C, _p(q_norm_w), _p(k_norm_w), _p(rope_cos), _p(rope_sin),
                                           _p(out), out.stride(0), B, T, S, heads, eps, _stream()), "vsys_attn_temporal_d72")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ CogVideoX (head_dim 64)
+def gemm_gate2(x, w, bias, gate, gate_stride, rows_per_sample, seg_split, gate_alt, res, out, aux=None):
+    """EPI_GATE_RES with two gate vectors per sample (text rows: gate + gate_alt)."""
+    _chk(x, w, bias, gate, res, aux, out)
+    _bf16(x, w, bias, gate, res, aux, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1 and out.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    lib = _lib.load()
+    _lib.check(lib.vsys_gemm_bf16_gate2(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(gate),
+                                        gate_stride, rows_per_sample, seg_split, gate_alt, _p(res),
+                                        res.stride(0) if res is not None else 0, _p(aux),
+                                        aux.stride(0) if aux is not None else 0, _stream()), "vsys_gemm_bf16_gate2")
+    return out
+
+
+def ln_modulate(x, ln_w, ln_b, shift, scale, rows_per_sample, mod_stride=0, seg_split=0, mod_alt=0, eps=1e-5, out=None):
+    _chk(x, ln_w, ln_b, shift, scale, out)
+    _bf16(x, ln_w, ln_b, shift, scale, out)
+    assert x.is_contiguous()
+    rows, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    lib = _lib.load()
+    _lib.check(lib.vsys_ln_modulate(_p(x), _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(out), rows, C, rows_per_sample, mod_stride,
+                                    seg_split, mod_alt, eps, _stream()), "vsys_ln_modulate")
+    return out
+
+
+def gate_add_rows(x, y, gate, rows_per_sample, gate_stride, seg_split=0, gate_alt=0):
+    _chk(x, y, gate)
+    _bf16(x, y, gate)
+    assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
+    rows, C = x.shape
+    lib = _lib.load()
+    _lib.check(lib.vsys_gate_add_rows(_p(x), _p(y), _p(gate), rows, C, rows_per_sample, gate_stride, seg_split, gate_alt, _stream()),
+               "vsys_gate_add_rows")
+    return x
+
+
+def im2col_patch(z_f32, B, p):
+    """z fp32 [Bz, F, Cin, H, W] -> bf16 [B*F*(H/p)*(W/p), Cin*p*p]"""
+    _chk(z_f32)
+    assert z_f32.dtype == torch.float32 and z_f32.is_contiguous()
+    Bz, F, Cin, H, W = z_f32.shape
+    out = torch.empty(B * F * (H // p) * (W // p), Cin * p * p, dtype=torch.bfloat16, device=z_f32.device)
+    lib = _lib.load()
+    _lib.check(lib.vsys_im2col_patch(_p(z_f32), Bz, _p(out), B, F, Cin, H, W, p, _stream()), "vsys_im2col_patch")
+    return out
+
+
+def unpatchify_cvx(x, B, F, Hp, Wp, Cout, p):
+    _chk(x)
+    _bf16(x)
+    assert x.stride(1) == 1
+    out = torch.empty(B, F, Cout, Hp * p, Wp * p, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.vsys_unpatchify_cvx(_p(x), x.stride(0), _p(out), B, F, Hp, Wp, Cout, p, _stream()), "vsys_unpatchify_cvx")
+    return out
+
+
+def alloc_kv_buffers64(batch, heads, kv_len, device):
+    kv_pad = kv_pad_len(kv_len)
+    kp = torch.zeros(batch, heads, kv_pad, 64, dtype=torch.bfloat16, device=device)
+    vt = torch.zeros(batch, heads, 64, kv_pad, dtype=torch.bfloat16, device=device)
+    return kp, vt
+
+
+def attn_prep_kv64(k, v, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, batch, heads, kv_len, eps=1e-6):
+    _chk(k, v, ln_w, ln_b, rope_cos, rope_sin, kp, vt)
+    _bf16(k, v, ln_w, ln_b, kp, vt)
+    assert k.stride(1) == 1 and v.stride(1) == 1 and kp.is_contiguous() and vt.is_contiguous()
+    rope_len = 0
+    if rope_cos is not None:
+        assert rope_cos.dtype == torch.float32 and rope_cos.is_contiguous() and rope_sin.is_contiguous() and rope_cos.shape[1] == 64
+        rope_len = rope_cos.shape[0]
+    lib = _lib.load()
+    _lib.check(lib.vsys_attn_prep_kv64(_p(k), k.stride(0), _p(v), v.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin),
+                                       rope_start, rope_len, _p(kp), _p(vt), batch, heads, kv_len, kp.shape[2], eps, _stream()),
+               "vsys_attn_prep_kv64")
+
+
+def flash_attn64(q, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
+    _chk(q, ln_w, ln_b, rope_cos, rope_sin, kp, vt, out)
+    _bf16(q, ln_w, ln_b, kp, vt, out)
+    assert q.stride(1) == 1 and out.stride(1) == 1
+    rope_len = 0 if rope_cos is None else rope_cos.shape[0]
+    lib = _lib.load()
+    _lib.check(lib.vsys_flash_attn_d64(_p(q), q.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin), rope_start, rope_len,
+                                       _p(kp), _p(vt), _p(out), out.stride(0), batch, heads, q_len, kv_len, kp.shape[2], eps,
+                                       _stream()), "vsys_flash_attn_d64")
+    return out
