@@ -118,15 +118,21 @@ class ApproximateGELU(nn.Module):
 
 # ----------------------------------------------------------------------------------------------- attention
 class Attention(nn.Module):
-    """diffusers.models.attention_processor.Attention with AttnProcessor2_0 (the default under torch >= 2):
+    """diffusers.models.attention_processor.Attention.  Default forward = AttnProcessor2_0 (torch >= 2); when a
+    ``processor`` object is passed (CogVideoXAttnProcessor2_0 of the reference) forward delegates to it, as diffusers does.
+    qk_norm="layer_norm" adds norm_q / norm_k = nn.LayerNorm(dim_head, eps=eps) (affine).  Default path:
     q = to_q(x), k = to_k(ctx), v = to_v(ctx), heads split as view(B, L, H, D).transpose(1, 2),
     F.scaled_dot_product_attention(q, k, v, attn_mask=additive mask [B, H, Lq|1, Lk]), to_out[0] (Linear), to_out[1]
     (Dropout).  qk_norm / added projections are not used by the Latte blocks."""
 
     def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
-                 upcast_attention=False, out_bias=True, **unused):
+                 upcast_attention=False, out_bias=True, qk_norm=None, eps=1e-5, processor=None, **unused):
         super().__init__()
         inner = heads * dim_head
+        self.processor = processor
+        self.norm_q = nn.LayerNorm(dim_head, eps=eps) if qk_norm == "layer_norm" else None
+        self.norm_k = nn.LayerNorm(dim_head, eps=eps) if qk_norm == "layer_norm" else None
+        assert qk_norm in (None, "layer_norm")
         self.heads = heads
         self.inner_dim = inner
         self.is_cross_attention = cross_attention_dim is not None
@@ -142,7 +148,10 @@ class Attention(nn.Module):
         # [B, 1, Lk] -> [B*H, 1, Lk] (repeat_interleave over heads), as diffusers does for the SDPA processor
         return attention_mask.repeat_interleave(self.heads, dim=0)
 
-    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **unused):
+    def forward(self, hidden_states, encoder_hidden_states=None, attention_mask=None, **kwargs):
+        if self.processor is not None:
+            return self.processor(self, hidden_states, encoder_hidden_states=encoder_hidden_states,
+                                  attention_mask=attention_mask, **kwargs)
         B, Lq, _ = hidden_states.shape
         ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
         Lk = ctx.shape[1]
@@ -245,11 +254,12 @@ class Timesteps(nn.Module):
 class TimestepEmbedding(nn.Module):
     def __init__(self, in_channels, time_embed_dim, act_fn="silu"):
         super().__init__()
+        assert act_fn == "silu"
         self.linear_1 = nn.Linear(in_channels, time_embed_dim)
         self.act = nn.SiLU()
         self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
 
-    def forward(self, sample):
+    def forward(self, sample, condition=None):
         return self.linear_2(self.act(self.linear_1(sample)))
 
 
@@ -275,6 +285,47 @@ class PixArtAlphaTextProjection(nn.Module):
 
     def forward(self, caption):
         return self.linear_2(self.act_1(self.linear_1(caption)))
+
+
+class FeedForward(nn.Module):
+    """diffusers.models.attention.FeedForward (0.30.0) for activation_fn="gelu-approximate"."""
+
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu", final_dropout=False, inner_dim=None,
+                 bias=True):
+        super().__init__()
+        assert activation_fn == "gelu-approximate"
+        inner_dim = int(dim * mult) if inner_dim is None else inner_dim
+        dim_out = dim_out if dim_out is not None else dim
+        self.net = nn.ModuleList([GELU(dim, inner_dim, approximate="tanh", bias=bias), nn.Dropout(dropout),
+                                  nn.Linear(inner_dim, dim_out, bias=bias)])
+        if final_dropout:
+            self.net.append(nn.Dropout(dropout))
+
+    def forward(self, hidden_states, *args, **kwargs):
+        for m in self.net:
+            hidden_states = m(hidden_states)
+        return hidden_states
+
+
+def get_3d_sincos_pos_embed(embed_dim, spatial_size, temporal_size, spatial_interpolation_scale=1.0,
+                            temporal_interpolation_scale=1.0):
+    """diffusers.models.embeddings.get_3d_sincos_pos_embed (0.30.0): [T, H*W, D] = [temporal D/4 | spatial 3D/4]."""
+    if isinstance(spatial_size, int):
+        spatial_size = (spatial_size, spatial_size)
+    ds, dt = 3 * embed_dim // 4, embed_dim // 4
+    grid_h = np.arange(spatial_size[1], dtype=np.float32) / spatial_interpolation_scale
+    grid_w = np.arange(spatial_size[0], dtype=np.float32) / spatial_interpolation_scale
+    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, spatial_size[1], spatial_size[0]])
+    pos_s = get_2d_sincos_pos_embed_from_grid(ds, grid)
+    grid_t = np.arange(temporal_size, dtype=np.float32) / temporal_interpolation_scale
+    pos_t = get_1d_sincos_pos_embed_from_grid(dt, grid_t)
+    pos_s = np.repeat(pos_s[np.newaxis], temporal_size, axis=0)
+    pos_t = np.repeat(pos_t[:, np.newaxis], spatial_size[0] * spatial_size[1], axis=1)
+    return np.concatenate([pos_t, pos_s], axis=-1)
+
+
+class SchedulerMixin:
+    pass
 
 
 class _Unused(nn.Module):
@@ -345,16 +396,21 @@ def install():
     models.__dict__.setdefault("__path__", [])
     _mod("diffusers.models.activations", GEGLU=GEGLU, GELU=GELU, ApproximateGELU=ApproximateGELU)
     ap = _mod("diffusers.models.attention_processor", Attention=Attention, AttnProcessor=object)
-    sys.modules["diffusers.models.attention"] = _mod("diffusers.models.attention", Attention=Attention)
+    sys.modules["diffusers.models.attention"] = _mod("diffusers.models.attention", Attention=Attention, FeedForward=FeedForward)
+    _mod("diffusers.models.modeling_outputs", Transformer2DModelOutput=BaseOutput)
+    _mod("diffusers.schedulers.scheduling_utils", KarrasDiffusionSchedulers=[], SchedulerMixin=SchedulerMixin)
     _mod("diffusers.models.embeddings", ImagePositionalEmbeddings=_Unused, PatchEmbed=PatchEmbed,
          PixArtAlphaCombinedTimestepSizeEmbeddings=PixArtAlphaCombinedTimestepSizeEmbeddings,
          PixArtAlphaTextProjection=PixArtAlphaTextProjection, SinusoidalPositionalEmbedding=_Unused,
          get_1d_sincos_pos_embed_from_grid=get_1d_sincos_pos_embed_from_grid, Timesteps=Timesteps,
-         TimestepEmbedding=TimestepEmbedding, get_2d_sincos_pos_embed=get_2d_sincos_pos_embed)
+         TimestepEmbedding=TimestepEmbedding, get_2d_sincos_pos_embed=get_2d_sincos_pos_embed,
+         get_3d_sincos_pos_embed=get_3d_sincos_pos_embed)
     _mod("diffusers.models.lora", LoRACompatibleConv=LoRACompatibleConv, LoRACompatibleLinear=LoRACompatibleLinear)
     _mod("diffusers.models.modeling_utils", ModelMixin=ModelMixin)
     _mod("diffusers.models.normalization", AdaLayerNorm=_Unused, AdaLayerNormContinuous=_Unused, AdaLayerNormZero=_Unused)
-    _mod("diffusers.utils", USE_PEFT_BACKEND=False, BaseOutput=BaseOutput, deprecate=deprecate)
+    _mod("diffusers.utils", USE_PEFT_BACKEND=False, BaseOutput=BaseOutput, deprecate=deprecate,
+         is_torch_version=lambda *a, **k: True)
     _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=maybe_allow_in_graph)
-    _mod("diffusers.schedulers", DDIMScheduler=DDIMScheduler)
+    sch = _mod("diffusers.schedulers", DDIMScheduler=DDIMScheduler)
+    sch.__dict__["__path__"] = []
     return ap

@@ -184,3 +184,38 @@ def build_reference_latte(cfg_kwargs: dict, state_dict=None, dtype=torch.float32
         assert not unexpected, unexpected
         assert all("pos_embed.pos_embed" in k or "temp_pos_embed" in k for k in missing), missing
     return model.to(dtype).eval()
+
+
+# ---------------------------------------------------------------------------------------------------- CogVideoX
+def build_reference_cogvideox(cfg_kwargs: dict, state_dict=None, dtype=torch.float32):
+    """Instantiate the reference CogVideoXTransformer3DModel (cogvideox_transformer_3d.py:315-589) on CPU over the
+    restated diffusers leaves, sp = cp = 1."""
+    install_stubs()
+    from oracle import diffusers_stub
+
+    diffusers_stub.install()
+    import importlib
+
+    m = importlib.import_module("videosys.models.transformers.cogvideox_transformer_3d")
+    model = m.CogVideoXTransformer3DModel(**cfg_kwargs)
+    model.parallel_manager = _SPStub()
+    for blk in model.transformer_blocks:
+        blk.attn1.parallel_manager = _SPStub()
+    if state_dict is not None:
+        missing, unexpected = model.load_state_dict(state_dict, strict=False)
+        assert not unexpected, unexpected
+        assert all("pos_embedding" in k for k in missing), missing
+    return model.to(dtype).eval()
+
+
+def load_reference_cogvideox_scheduler(**kwargs):
+    """The in-tree CogVideoXDDIMScheduler (schedulers/scheduling_ddim_cogvideox.py:118-395)."""
+    install_stubs()
+    from oracle import diffusers_stub
+
+    diffusers_stub.install()
+    import importlib
+
+    m = importlib.import_module("videosys.schedulers.scheduling_ddim_cogvideox")
+    s = m.CogVideoXDDIMScheduler(**kwargs)
+    return s

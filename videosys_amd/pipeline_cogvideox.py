@@ -1,0 +1,219 @@
+"""CogVideoX pipeline plug-in — host mirror of videosys/pipelines/cogvideox/pipeline_cogvideox.py (CogVideoXPABConfig
+:33-45, CogVideoXConfig :48-118, CogVideoXPipeline :121-755) for the denoising hot path: text embeddings + noise ->
+latents.  ``CogVideoXConfig`` / ``CogVideoXPABConfig`` take the same kwargs with the same defaults and drop into
+``VideoSysEngine``.  T5 and the causal 3-D VAE (tiled decode) are pluggable callables (no weights offline; the VAE decode
+kernels are a later row of SURVEY.md §8f).
+
+Scheduler: host restatement of schedulers/scheduling_ddim_cogvideox.py (scaled-linear betas, SNR shift, zero terminal
+SNR, "trailing" spacing, v-prediction, eta = 0) whose per-step CFG combine + update is one HIP kernel
+(vsys_cfg_linear_step); the dynamic-CFG guidance (:702-705) is a host scalar per step.
+"""
+from __future__ import annotations
+
+import math
+import os
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+
+from . import ops, pab
+from .cogvideox import CogVideoXTransformer3DModel, synth_state_dict
+from .pab import PABConfig
+from .pipeline_open_sora import VideoSysPipelineOutput
+
+
+class CogVideoXPABConfig(PABConfig):
+    """pipeline_cogvideox.py:33-45 — identical defaults (spatial broadcast only)."""
+
+    def __init__(self, spatial_broadcast: bool = True, spatial_threshold: list = [100, 850], spatial_range: int = 2):
+        super().__init__(spatial_broadcast=spatial_broadcast, spatial_threshold=spatial_threshold, spatial_range=spatial_range)
+
+
+class CogVideoXConfig:
+    """pipeline_cogvideox.py:48-118 — identical kwargs/defaults."""
+
+    def __init__(self, model_path: str = "THUDM/CogVideoX-2b", num_gpus: int = 1, cpu_offload: bool = False,
+                 vae_tiling: bool = True, enable_pab: bool = False, pab_config=None, **extra):
+        self.model_path = model_path
+        self.pipeline_cls = CogVideoXPipeline
+        self.num_gpus = num_gpus
+        self.cpu_offload = cpu_offload
+        self.vae_tiling = vae_tiling
+        self.enable_pab = enable_pab
+        self.pab_config = pab_config if pab_config is not None else CogVideoXPABConfig()
+        self.transformer_config = extra.pop("transformer_config", None)  # extension: geometry override for tests
+        if extra:
+            raise TypeError(f"unexpected CogVideoXConfig kwargs: {sorted(extra)}")
+
+
+# geometry of the two published checkpoints (HF transformer/config.json; the code defaults are the 2B values)
+_GEOMETRY = {
+    "THUDM/CogVideoX-2b": dict(num_attention_heads=30, num_layers=30, use_rotary_positional_embeddings=False),
+    "THUDM/CogVideoX-5b": dict(num_attention_heads=48, num_layers=42, use_rotary_positional_embeddings=True),
+}
+
+
+class CogVideoXDDIMScheduler:
+    """schedulers/scheduling_ddim_cogvideox.py:118-393 with the values of the checkpoints' scheduler_config.json
+    (v_prediction, trailing spacing, zero terminal SNR, snr_shift_scale 3.0 for 2b / 1.0 for 5b)."""
+
+    order = 1
+    init_noise_sigma = 1.0
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                 set_alpha_to_one=True, steps_offset=0, prediction_type="v_prediction", timestep_spacing="trailing",
+                 rescale_betas_zero_snr=True, snr_shift_scale=3.0):
+        if beta_schedule != "scaled_linear" or prediction_type != "v_prediction":
+            raise NotImplementedError("CogVideoX uses scaled_linear betas with v-prediction")
+        self.num_train_timesteps = num_train_timesteps
+        betas = torch.linspace(beta_start**0.5, beta_end**0.5, num_train_timesteps, dtype=torch.float64) ** 2
+        ac = torch.cumprod(1.0 - betas, dim=0)
+        ac = ac / (snr_shift_scale + (1 - snr_shift_scale) * ac)
+        if rescale_betas_zero_snr:  # :87-115
+            s = ac.sqrt()
+            s0, sT = s[0].clone(), s[-1].clone()
+            ac = ((s - sT) * (s0 / (s0 - sT))) ** 2
+        self.alphas_cumprod = ac
+        self.final_alpha_cumprod = 1.0 if set_alpha_to_one else float(ac[0])
+        self.timestep_spacing, self.steps_offset = timestep_spacing, steps_offset
+        self.num_inference_steps = None
+        self.timesteps: List[int] = []
+
+    def set_timesteps(self, num_inference_steps: int, device=None):
+        self.num_inference_steps = num_inference_steps
+        n = self.num_train_timesteps
+        if self.timestep_spacing == "trailing":
+            ts = np.round(np.arange(n, 0, -n / num_inference_steps)).astype(np.int64) - 1
+        elif self.timestep_spacing == "leading":
+            ts = (np.arange(0, num_inference_steps) * (n // num_inference_steps)).round()[::-1].astype(np.int64) + self.steps_offset
+        else:
+            ts = np.linspace(0, n - 1, num_inference_steps).round()[::-1].astype(np.int64)
+        self.timesteps = [int(v) for v in ts]
+
+    def coeffs(self, t: int):
+        """prev_sample = c_z * sample + c_v * v_pred (:358-388)."""
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        a_t = float(self.alphas_cumprod[t])
+        a_prev = float(self.alphas_cumprod[prev_t]) if prev_t >= 0 else self.final_alpha_cumprod
+        a_coef = math.sqrt((1 - a_prev) / (1 - a_t))
+        b = math.sqrt(a_prev) - math.sqrt(a_t) * a_coef
+        return a_coef + b * math.sqrt(a_t), -b * math.sqrt(1 - a_t)
+
+
+def get_resize_crop_region_for_grid(src, tgt_width, tgt_height):
+    """pipeline_cogvideox.py:757-775."""
+    h, w = src
+    if h / w > tgt_height / tgt_width:
+        rh, rw = tgt_height, int(round(tgt_height / h * w))
+    else:
+        rw, rh = tgt_width, int(round(tgt_width / w * h))
+    top, left = int(round((tgt_height - rh) / 2.0)), int(round((tgt_width - rw) / 2.0))
+    return (top, left), (top + rh, left + rw)
+
+
+def get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size, theta: float = 10000.0):
+    """modules/embeddings.py:283-355 (use_real): constant cos / sin tables [T*H*W, embed_dim], built once on the host."""
+    (s0, s1), (e0, e1) = crops_coords
+    gh = torch.from_numpy(np.linspace(s0, e0, grid_size[0], endpoint=False, dtype=np.float32))
+    gw = torch.from_numpy(np.linspace(s1, e1, grid_size[1], endpoint=False, dtype=np.float32))
+    gt = torch.from_numpy(np.linspace(0, temporal_size, temporal_size, endpoint=False, dtype=np.float32))
+    dt, dh, dw = embed_dim // 4, embed_dim // 8 * 3, embed_dim // 8 * 3
+
+    def axis(grid, d):
+        f = 1.0 / (theta ** (torch.arange(0, d, 2).float() / d))
+        return torch.einsum("n,f->nf", grid, f).repeat_interleave(2, dim=-1)
+
+    ft, fh, fw = axis(gt, dt), axis(gh, dh), axis(gw, dw)
+    T, H, W = temporal_size, grid_size[0], grid_size[1]
+    freqs = torch.cat([ft[:, None, None, :].expand(T, H, W, dt), fh[None, :, None, :].expand(T, H, W, dh),
+                       fw[None, None, :, :].expand(T, H, W, dw)], dim=-1).reshape(T * H * W, -1)
+    return freqs.cos().contiguous(), freqs.sin().contiguous()
+
+
+class CogVideoXPipeline:
+    vae_scale_factor_spatial = 8
+    vae_scale_factor_temporal = 4
+
+    def __init__(self, config: CogVideoXConfig, device=None, text_encoder: Optional[Callable] = None,
+                 vae_decoder: Optional[Callable] = None):
+        self._config = config
+        if device is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("CogVideoXPipeline needs a HIP device (videosys_amd has no CPU execution path)")
+            device = torch.device("cuda", torch.cuda.current_device())
+        self._device = torch.device(device)
+        name = config.model_path
+        base = name.split("@", 1)[0] if isinstance(name, str) else ""
+        tcfg = dict(_GEOMETRY.get(base, {}))
+        tcfg.update(config.transformer_config or {})
+        self.transformer = CogVideoXTransformer3DModel(**tcfg, device=self._device)
+        st = os.path.join(name, "transformer", "diffusion_pytorch_model.safetensors") if isinstance(name, str) else ""
+        if st and os.path.exists(st):
+            from safetensors.torch import load_file
+
+            sd = load_file(st)
+        else:
+            seed = int(name.rsplit(":", 1)[1]) if isinstance(name, str) and ":" in name and name.rsplit(":", 1)[1].isdigit() else 777
+            c = self.transformer.config
+            sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.text_embed_dim, c.in_channels,
+                                  c.out_channels, c.time_embed_dim, c.patch_size, seed=seed)
+        self.transformer.load_state_dict(sd)
+        self.scheduler = CogVideoXDDIMScheduler(snr_shift_scale=1.0 if base.endswith("5b") else 3.0)
+        self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
+        pab.set_pab_manager(config.pab_config if config.enable_pab else None)
+
+    def _prepare_rotary_positional_embeddings(self, height: int, width: int, num_frames: int):
+        """pipeline_cogvideox.py:449-474."""
+        c = self.transformer.config
+        gh = height // (self.vae_scale_factor_spatial * c.patch_size)
+        gw = width // (self.vae_scale_factor_spatial * c.patch_size)
+        crops = get_resize_crop_region_for_grid((gh, gw), 720 // (self.vae_scale_factor_spatial * c.patch_size),
+                                                480 // (self.vae_scale_factor_spatial * c.patch_size))
+        return get_3d_rotary_pos_embed(c.attention_head_dim, crops, (gh, gw), num_frames)
+
+    @torch.no_grad()
+    def generate(self, prompt=None, negative_prompt=None, height: int = 480, width: int = 720, num_frames: int = 49,
+                 num_inference_steps: int = 50, guidance_scale: float = 6, use_dynamic_cfg: bool = False, seed: int = -1,
+                 verbose: bool = False, *, prompt_embeds: Optional[torch.Tensor] = None,
+                 negative_prompt_embeds: Optional[torch.Tensor] = None, latents: Optional[torch.Tensor] = None,
+                 output_type: str = "auto"):
+        """pipeline_cogvideox.py:498-755 for text-to-video (CFG batch [negative | prompt], eta = 0)."""
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, 226, 4096]")
+            prompt_embeds = self.text_encoder(prompt)
+            negative_prompt_embeds = self.text_encoder(negative_prompt or "")
+        if guidance_scale <= 1.0:
+            raise NotImplementedError("the MI355X path runs the classifier-free-guidance batch (guidance_scale > 1)")
+        pab.update_steps(num_inference_steps)
+        self.transformer.reset_pab_state()
+        B = prompt_embeds.shape[0]
+        emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        self.scheduler.set_timesteps(num_inference_steps)
+        c = self.transformer.config
+        lat_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
+        if latents is None:
+            g = torch.Generator(device="cpu").manual_seed(seed if seed >= 0 else 0)
+            latents = torch.randn(B, lat_frames, c.in_channels, height // self.vae_scale_factor_spatial,
+                                  width // self.vae_scale_factor_spatial, generator=g, dtype=torch.float32)
+        z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
+        rope = self._prepare_rotary_positional_embeddings(height, width, z.shape[1]) if c.use_rotary_positional_embeddings else None
+        zf = z.view(B, 1, -1)  # the step kernel sees [Bz, Cin = 1, thw]: CogVideoX predicts all 16 channels (no sigma half)
+        for t in self.scheduler.timesteps:
+            out = self.transformer(z, emb, torch.full((2 * B,), t, dtype=torch.int64), image_rotary_emb=rope,
+                                   return_dict=False)[0]
+            g_t = guidance_scale
+            if use_dynamic_cfg:  # :702-705
+                g_t = 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
+            c_z, c_v = self.scheduler.coeffs(t)
+            ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, c_z, c_v, cond_first=False)
+            z.copy_(z.to(torch.bfloat16).float())  # latents = latents.to(prompt_embeds.dtype) (:723)
+        if self.vae_decoder is None or output_type in ("latent", "latents"):
+            return VideoSysPipelineOutput(video=z)
+        return VideoSysPipelineOutput(video=self.vae_decoder(z))
+
+    def save_video(self, video, output_path):
+        from .utils import save_video
+
+        save_video(video, output_path)
