@@ -169,10 +169,19 @@ def main():
             a[1] += f
             a[2] += 1
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM/fabric bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same
+        # kernels and shapes, tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json), config-2 launch mix
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
+        if os.path.exists(tpath) and world == 1:
+            with open(tpath) as fh:
+                traffic = round(json.load(fh)["avg_bytes_per_launch_config2_mix"])
         roof = {
             "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> (256x192x64 tile, bf16 MFMA 32x32x16, all epilogues)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits; algorithmic "
+                            "operand + output (+ residual) bytes per launch: 305e6)",
             "launches_per_step": n // nrep, "avg_launch_ms": round(tot_ms / n, 4),
             "algorithmic_gflop_per_launch": round(tot_fl / n / 1e9, 2),
             "gemm_ms_per_step": round(tot_ms / nrep, 2),

@@ -24,6 +24,8 @@ x, h = rnd(N, C), rnd(N, 4 * C)
 mod = rnd(2, 6 * C, scale=0.3)
 resid = rnd(N, C)
 shapes = [("qkv", 3 * C, C, 0), ("fc2", C, 4 * C, 2)]
+if os.environ.get("VSYS_GEMM_ALL_SHAPES"):  # dispatch order = qkv, proj, fc1, fc2 (3 launches each) per variant
+    shapes = [("qkv", 3 * C, C, 0), ("proj", C, C, 2), ("fc1", 4 * C, C, 1), ("fc2", C, 4 * C, 2)]
 bufs = {name: (rnd(n, k, scale=1 / math.sqrt(k)), rnd(n, scale=0.1), torch.empty(N, n, dtype=torch.bfloat16, device=dev))
         for name, n, k, epi in shapes}
 for variant in [int(v) for v in os.environ.get("VSYS_GEMM_VARIANTS", "6,8").split(",")]:

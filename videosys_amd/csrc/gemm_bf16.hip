@@ -55,7 +55,7 @@ struct Geo {
 // ABL (lab builds only): 1 = no epilogue (accumulators kept alive), 2 = no LDS-DMA inside the loop, 3 = every tile reads
 // the A rows of tile 0 (A becomes L2-resident: separates HBM-miss latency from DMA issue / LDS-write cost), 4 = epilogue
 // arithmetic without the HBM stores, 5 = streaming (nt) stores.
-template <int EPI, int PIPE, int BM_>
+template <int EPI, int PIPE, int BM_, int RASTER = 1>
 __global__ __launch_bounds__(Geo<BM_>::NT, 2) void gemm_kernel(GemmParams p) {
 #if __HIP_DEVICE_COMPILE__  // the buffer-resource type below exists in the device pass only; the host pass needs just the stub
   using G = Geo<BM_>;
@@ -68,7 +68,39 @@ __global__ __launch_bounds__(Geo<BM_>::NT, 2) void gemm_kernel(GemmParams p) {
 
   const int nbn = p.N / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  const int bm = tile / nbn, bn = tile - bm * nbn;
+  // Raster (RASTER = 1): the row panels are split into 8 contiguous groups, one per XCD chunk of the remap; inside a group
+  // the order is column-GROUP major (GW = 6 column tiles = 2.65 MB of W at K = 1152): for g: for panel: for j.  The 32
+  // tiles an XCD runs at once are then ~5 row panels x 6 column tiles, so the W slab of the group stays in the XCD's
+  // 4 MiB L2 for the whole sweep over the group's panels (W is the operand with the ONE-tile DMA lead) while A, the
+  // operand with the two-tile lead, is re-read once per column group from L2 / MALL.  With plain row-major order every
+  // wave of tiles re-reads all of W (8-10.6 MB > L2) from the fabric: 586 MB fetched for 98 MB of operands at qkv shape.
+  int bm, bn;
+  if (RASTER && nbn > 6) {
+    const int nbm = (p.M + BM_ - 1) / BM_;
+    const int q = nbm / 8, r = nbm - q * 8;
+    const int big = r * (q + 1) * nbn;
+    int off, np, p0;
+    if (tile < big) {
+      const int xg = tile / ((q + 1) * nbn);
+      off = tile - xg * (q + 1) * nbn; np = q + 1; p0 = xg * (q + 1);
+    } else {
+      const int t2 = tile - big;
+      const int xg = t2 / (q * nbn);
+      off = t2 - xg * q * nbn; np = q; p0 = r * (q + 1) + xg * q;
+    }
+    constexpr int GW = 6;
+    const int ng = (nbn + GW - 1) / GW;
+    int g = off / (np * GW);
+    g = g < ng - 1 ? g : ng - 1;
+    const int off2 = off - g * np * GW;
+    const int width = g < ng - 1 ? GW : nbn - (ng - 1) * GW;
+    const int pm = off2 / width;
+    bm = p0 + pm;
+    bn = g * GW + (off2 - pm * width);
+  } else {
+    bm = tile / nbn;
+    bn = tile - bm * nbn;
+  }
   const int row0 = bm * BM_, col0 = bn * BN;
 
   // ---- LDS-DMA staging assignment.  global_load_lds writes lane l of a wave to  M0_base + 16*l  (lane-linear), so each
@@ -529,7 +561,7 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 static int g_gemm_variant = 8;
 void set_gemm_variant(int v) { g_gemm_variant = v > 0 ? v : 8; }
 
-template <int PIPE, int BM_>
+template <int PIPE, int BM_, int RASTER = 1>
 static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   using G = Geo<BM_>;
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
@@ -537,15 +569,15 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   const size_t lds = (PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER>), dim3(grid), dim3(G::NT), lds, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -564,6 +596,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     case 48: return launch_gemm_t<48, 256>(p, epi, stream);
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 3: return launch_gemm_t<3, 256>(p, epi, stream);
+    case 9: return launch_gemm_t<8, 256, 0>(p, epi, stream);  // schedule 8, plain row-major tile order
     default: return launch_gemm_t<8, 256>(p, epi, stream);
   }
 }
