@@ -41,3 +41,15 @@ def test_hot_kernels_have_no_scratch(src, pattern, max_vgpr):
         assert res.get("ScratchSize", 0) == 0, f"{name} uses scratch: {res}"
         assert res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) == 0, f"{name} spills: {res}"
         assert res.get("VGPRs", 0) <= max_vgpr, f"{name}: {res.get('VGPRs')} VGPRs"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_two_workgroup_gemm_fits_two_per_cu():
+    """gemm2_bf16.hip is dispatched for the store-only epilogues (bias, bias+GELU): those instantiations must run without
+    scratch in 256 VGPRs (2 waves per SIMD) and in half the LDS of a CU."""
+    u = _usage("gemm2_bf16.hip")
+    hits = {k: v for k, v in u.items() if "gemm2_kernelILi0E" in k or "gemm2_kernelILi1E" in k}
+    assert len(hits) >= 2, list(u)
+    for name, res in hits.items():
+        assert res.get("ScratchSize", 0) == 0, f"{name} uses scratch: {res}"
+        assert res.get("VGPRs", 0) <= 256, f"{name}: {res.get('VGPRs')} VGPRs"

@@ -1,0 +1,340 @@
+// bf16 MFMA GEMM, "two workgroups per CU" geometry (variant 20 of vsys_tune_gemm_variant).
+//
+// Same contract, tile (256 x 192) and epilogues as gemm_bf16.hip; what changes is who shares a SIMD.  In the 8-wave kernel
+// the two waves of a SIMD belong to ONE workgroup: they reach the tile barrier, the prologue and the epilogue together, and
+// the matrix pipe idles through all three (ablations at config 2: the epilogue + relaunch + first-tile latency are 16-30 %
+// of the K = 1152 GEMMs).  Here a workgroup is 4 waves (2 x 2), every wave owns a 128 x 96 output tile = 4 x 3
+// v_mfma_f32_32x32x16_bf16 accumulators (192 VGPRs), the K step is 32 so the staging footprint is 72 KiB, and TWO
+// independent workgroups are resident per CU (144 KiB of LDS, 2 waves per SIMD, one from each).  While one workgroup
+// converts, stores, relaunches or waits for its first operand tile, the other one has the whole matrix pipe.
+//
+// LDS per workgroup: three A slots (256 rows x 64 B) + two W slots (192 rows x 64 B).  64-byte rows: four rows per
+// 256-byte bank row; 16-byte chunk c of row r is stored at chunk c ^ ((r>>2)&3), so the 16 rows a ds_read_b128 lane group
+// touches hit 16 distinct slots.  The swizzle sits on the source side of the LDS-DMA (buffer_load_dwordx4 ... lds).
+// Pipeline: A(t+2) and W(t+1) are issued during stage t, W first; the wait in front of the stage barrier is vmcnt(4).
+#include "common.h"
+#include "vsys_internal.h"
+
+namespace vsys {
+namespace {
+
+constexpr int BM = 256, BN = 192, BK = 32;
+constexpr int A_SLOT = BM * BK * 2;   // 16384
+constexpr int W_SLOT = BN * BK * 2;   // 12288
+constexpr int W_BASE = 3 * A_SLOT;    // 49152
+constexpr int LDS_BYTES = W_BASE + 2 * W_SLOT;  // 73728
+constexpr int OUT_ROW_BYTES = 96 * 2 + 16;
+constexpr int OUT_WAVE_BYTES = 64 * OUT_ROW_BYTES;  // 13312 per wave and pass
+static_assert(4 * OUT_WAVE_BYTES <= LDS_BYTES, "epilogue image must fit in the staging buffers");
+
+template <int EPI, int PRIO>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
+#if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  // The two waves of a SIMD come from two different workgroups.  Left alone they drift INTO phase (the one that reaches its
+  // epilogue first hands the whole matrix pipe to the other, which then catches up), and in phase both epilogues idle the
+  // pipe together.  A static priority by hardware wave slot breaks the symmetry: the odd slot owns the pipe whenever it has
+  // MFMAs, the even slot fills its gaps (epilogue, relaunch, first-tile latency, barrier and DMA waits).
+  if (PRIO) {
+    const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u;  // HW_REG_HW_ID[3:0] = wave slot in its SIMD
+    if (__builtin_amdgcn_readfirstlane(slot)) __builtin_amdgcn_s_setprio(2);
+  }
+
+  // tile order: same W-resident raster as gemm_bf16.hip (column groups of 6 inside 8 row-panel groups)
+  const int nbn = p.N / BN;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int bm, bn;
+  if (nbn > 6) {
+    const int nbm = (p.M + BM - 1) / BM;
+    const int q = nbm / 8, r = nbm - q * 8;
+    const int big = r * (q + 1) * nbn;
+    int off, np, p0;
+    if (tile < big) {
+      const int xg = tile / ((q + 1) * nbn);
+      off = tile - xg * (q + 1) * nbn; np = q + 1; p0 = xg * (q + 1);
+    } else {
+      const int t2 = tile - big;
+      const int xg = t2 / (q * nbn);
+      off = t2 - xg * q * nbn; np = q; p0 = r * (q + 1) + xg * q;
+    }
+    constexpr int GW = 6;
+    const int ng = (nbn + GW - 1) / GW;
+    int g = off / (np * GW);
+    g = g < ng - 1 ? g : ng - 1;
+    const int off2 = off - g * np * GW;
+    const int width = g < ng - 1 ? GW : nbn - (ng - 1) * GW;
+    const int pm = off2 / width;
+    bm = p0 + pm;
+    bn = g * GW + (off2 - pm * width);
+  } else {
+    bm = tile / nbn;
+    bn = tile - bm * nbn;
+  }
+  const int row0 = bm * BM, col0 = bn * BN;
+
+  // ---- LDS-DMA assignment: a piece = 1 KiB = 16 rows x 64 B; lane l -> row (l>>2), physical chunk l&3, which holds
+  // logical chunk (l&3) ^ ((row>>2)&3) = (l&3) ^ ((l>>4)&3) (piece bases are multiples of 16 rows).
+  // wave w stages A rows [64w, 64w+64) (4 pieces) and W rows [48w, 48w+48) (3 pieces) of every stage.
+  const int dchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+  int a_off[4], b_off[3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wave_u * 64 + i * 16 + (lane >> 2);
+    const int rl = row0 + r < p.M ? r : p.M - 1 - row0;  // rows past M re-read the last row (never stored)
+    a_off[i] = rl * (int)p.lda * 2 + dchunk;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) b_off[i] = (wave_u * 48 + i * 16 + (lane >> 2)) * (int)p.ldw * 2 + dchunk;
+  const int64_t a_bytes = ((int64_t)(p.M - 1 - row0) * p.lda + p.K) * 2, b_bytes = ((int64_t)(p.N - 1 - col0) * p.ldw + p.K) * 2;
+  const auto rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)(p.A + (int64_t)row0 * p.lda), 0,
+                                                        (int)(a_bytes < 0x7fffffff ? a_bytes : 0x7fffffff), 0x00020000);
+  const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)col0 * p.ldw), 0,
+                                                        (int)(b_bytes < 0x7fffffff ? b_bytes : 0x7fffffff), 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  auto dma_a = [&](int i, int t, int slot) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(smem + slot * A_SLOT + (wave_u * 64 + i * 16) * 64), 16, a_off[i],
+                                             t * (BK * 2), 0, 0);
+  };
+  auto dma_w = [&](int i, int t, int slot) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(smem + W_BASE + slot * W_SLOT + (wave_u * 48 + i * 16) * 64), 16,
+                                             b_off[i], t * (BK * 2), 0, 0);
+  };
+
+  // ---- fragment read offsets: row r, k-step ks: logical chunk 2ks + hi at physical chunk ^ ((r>>2)&3); all fragment rows of
+  // a lane are l31 + a multiple of 32, so (r>>2)&3 = (l31>>2)&3 and the k-step is an XOR of bit 5
+  const int fsw = ((hi ^ ((l31 >> 2) & 3)) << 4);
+  const int xo = (wm * 128 + l31) * 64 + fsw;           // + i*2048 for m-block i
+  const int wo = W_BASE + (wn * 96 + l31) * 64 + fsw;   // + j*2048 for n-block j
+
+  f32x16 acc[4][3];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nt = p.K / BK;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dma_a(i, 0, 0);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) dma_w(i, 0, 0);
+  if (nt > 1) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dma_a(i, 1, 1);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+
+  int sa = 0, sw = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1, sw1 = sw ^ 1;
+    const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
+    const char* ab = smem + sa * A_SLOT;
+    const char* wb = smem + sw * W_SLOT;
+    bf16x8 x0, x1, x2, x3, w0, w1, w2, v0, v1, v2;  // x: A fragments of the current k-step; w / v: W fragments of k-step 0 / 1
+    x0 = *reinterpret_cast<const bf16x8*>(ab + xo);
+    w0 = *reinterpret_cast<const bf16x8*>(wb + wo);
+    w1 = *reinterpret_cast<const bf16x8*>(wb + wo + 2048);
+    w2 = *reinterpret_cast<const bf16x8*>(wb + wo + 4096);
+    x1 = *reinterpret_cast<const bf16x8*>(ab + xo + 2048);
+    x2 = *reinterpret_cast<const bf16x8*>(ab + xo + 4096);
+    x3 = *reinterpret_cast<const bf16x8*>(ab + xo + 6144);
+    v0 = *reinterpret_cast<const bf16x8*>(wb + (wo ^ 32));
+    v1 = *reinterpret_cast<const bf16x8*>(wb + (wo ^ 32) + 2048);
+    v2 = *reinterpret_cast<const bf16x8*>(wb + (wo ^ 32) + 4096);
+    __builtin_amdgcn_sched_barrier(0);
+#define G2_ROW(i_, X_, W0_, W1_, W2_)                                                                  \
+  acc[i_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0_, X_, acc[i_][0], 0, 0, 0);                  \
+  acc[i_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1_, X_, acc[i_][1], 0, 0, 0);                  \
+  acc[i_][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W2_, X_, acc[i_][2], 0, 0, 0)
+    // k-step 0: after each m-block's three MFMAs its A fragment register is reloaded with the k-step-1 fragment; the
+    // DMA pieces of the next stages are slotted in between the m-blocks (behind MFMAs of this wave)
+    G2_ROW(0, x0, w0, w1, w2);
+    __builtin_amdgcn_sched_barrier(0);
+    x0 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32));
+    if (n1) { dma_w(0, t + 1, sw1); dma_w(1, t + 1, sw1); }
+    __builtin_amdgcn_sched_barrier(0);
+    G2_ROW(1, x1, w0, w1, w2);
+    __builtin_amdgcn_sched_barrier(0);
+    x1 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32) + 2048);
+    if (n1) dma_w(2, t + 1, sw1);
+    if (n2) dma_a(0, t + 2, sa2);
+    __builtin_amdgcn_sched_barrier(0);
+    G2_ROW(2, x2, w0, w1, w2);
+    __builtin_amdgcn_sched_barrier(0);
+    x2 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32) + 4096);
+    if (n2) { dma_a(1, t + 2, sa2); dma_a(2, t + 2, sa2); }
+    __builtin_amdgcn_sched_barrier(0);
+    G2_ROW(3, x3, w0, w1, w2);
+    __builtin_amdgcn_sched_barrier(0);
+    x3 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32) + 6144);
+    if (n2) dma_a(3, t + 2, sa2);
+    __builtin_amdgcn_sched_barrier(0);
+    // k-step 1
+    G2_ROW(0, x0, v0, v1, v2);
+    G2_ROW(1, x1, v0, v1, v2);
+    G2_ROW(2, x2, v0, v1, v2);
+    G2_ROW(3, x3, v0, v1, v2);
+#undef G2_ROW
+    __builtin_amdgcn_sched_barrier(0);
+    if (n2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // stage t+1 has landed everywhere; nobody reads the slots of stage t any more
+    __builtin_amdgcn_sched_barrier(0);
+    sa = sa1;
+    sw = sw1;
+  }
+
+  // ---- epilogue in two passes of 64 rows per wave (m-blocks {0,1}, then {2,3}); the per-wave LDS image is private to the
+  // wave, so only wave-local ordering is needed between its writes and reads (the barrier above covers the staging reads)
+  char* st = smem + wave * OUT_WAVE_BYTES;
+  const int ncol0 = col0 + wn * 96;
+  uint2 bb[3][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bb[j][g] = make_uint2(0, 0);
+  if (p.bias != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) bb[j][g] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * hi);
+  }
+  const bool full = row0 + BM <= p.M;
+#pragma unroll
+  for (int ih = 0; ih < 2; ++ih) {
+    const int wrow0 = row0 + wm * 128 + ih * 64;
+#pragma unroll
+    for (int i2 = 0; i2 < 2; ++i2) {
+      const int i = ih * 2 + i2;
+      const int m_local = i2 * 32 + l31;
+      const bf16_t* gate_row = nullptr;
+      if (EPI == EPI_GATE_RES && p.gate != nullptr) {
+        int grow = wrow0 + m_local;
+        grow = grow < p.M ? grow : p.M - 1;
+        const int sample = grow / p.rows_per_sample;
+        gate_row = p.gate + (int64_t)sample * p.gate_stride + ncol0 + 4 * hi;
+        if (p.seg_split > 0 && grow - sample * p.rows_per_sample < p.seg_split) gate_row += p.gate_alt;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        uint2 gg[4];  // gate of this 32-column block only (register budget: 192 accumulators are live)
+        if (EPI == EPI_GATE_RES) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) gg[g] = make_uint2(0x3f803f80u, 0x3f803f80u);  // bf16 1.0 pairs
+          if (gate_row != nullptr) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gg[g] = *reinterpret_cast<const uint2*>(gate_row + j * 32 + 8 * g);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n_local = j * 32 + 8 * g + 4 * hi;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][j][4 * g + r];
+          v[0] += bflo(bb[j][g].x); v[1] += bfhi(bb[j][g].x); v[2] += bflo(bb[j][g].y); v[3] += bfhi(bb[j][g].y);
+          if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+          }
+          if (EPI == EPI_GATE_RES) {
+            v[0] *= bflo(gg[g].x); v[1] *= bfhi(gg[g].x); v[2] *= bflo(gg[g].y); v[3] *= bfhi(gg[g].y);
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2) = o;
+        }
+      }
+    }
+    // residual rows are fetched only now: the accumulators of this pass are dead, so the 48 registers are free (the
+    // other workgroup of the CU covers the latency)
+    uint4 rres[12];
+    if (EPI == EPI_GATE_RES) {
+#pragma unroll
+      for (int it = 0; it < 12; ++it) rres[it] = make_uint4(0, 0, 0, 0);
+      if (p.res != nullptr) {
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+          const int q = lane + 64 * it;
+          const int m_local = q / 12, c = q - m_local * 12;
+          int grow = wrow0 + m_local;
+          grow = grow < p.M ? grow : p.M - 1;
+          rres[it] = *reinterpret_cast<const uint4*>(p.res + (int64_t)grow * p.ldr + ncol0 + c * 8);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    uint4 val[12];
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int q = lane + 64 * it;
+      const int m_local = q / 12, c = q - m_local * 12;
+      val[it] = *reinterpret_cast<const uint4*>(st + m_local * OUT_ROW_BYTES + c * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int q = lane + 64 * it;
+      const int m_local = q / 12, c = q - m_local * 12;
+      const int64_t grow = wrow0 + m_local;
+      const int gcol = ncol0 + c * 8;
+      const bool ok = full || grow < p.M;
+      uint4 v = val[it];
+      if (EPI == EPI_GATE_RES) {
+        if (p.aux != nullptr && ok) *reinterpret_cast<uint4*>(p.aux + grow * p.ldaux + gcol) = v;
+        if (p.res != nullptr) {
+          float a[8], b[8];
+          unpack8(v, a);
+          unpack8(rres[it], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          v = pack8(a);
+        }
+      }
+      if (ok) *reinterpret_cast<uint4*>(p.out + grow * p.ldo + gcol) = v;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // image reads done before the next pass overwrites it
+    __builtin_amdgcn_wave_barrier();
+  }
+#endif
+}
+
+}  // namespace
+
+template <int PRIO>
+static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+  const int grid = nbm * nbn;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  switch (epi) {
+    case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, PRIO>), dim3(grid), dim3(256), LDS_BYTES, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, PRIO>), dim3(grid), dim3(256), LDS_BYTES, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, PRIO>), dim3(grid), dim3(256), LDS_BYTES, stream, p); break;
+    default: return VSYS_ERR_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_gemm2(const GemmParams& p, int epi, int prio, hipStream_t stream) {
+  return prio ? launch_gemm2_t<1>(p, epi, stream) : launch_gemm2_t<0>(p, epi, stream);
+}
+
+}  // namespace vsys

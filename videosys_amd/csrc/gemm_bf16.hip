@@ -558,8 +558,8 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 
 // Variant id understood by set_gemm_variant / vsys_tune_gemm_variant:  PIPE (+ 100 for the 128-row, two-workgroups-per-CU
 // geometry).  0 = the shipped default.
-static int g_gemm_variant = 8;
-void set_gemm_variant(int v) { g_gemm_variant = v > 0 ? v : 8; }
+static int g_gemm_variant = 0;
+void set_gemm_variant(int v) { g_gemm_variant = v > 0 ? v : 0; }  // 0 = shape dispatch (default)
 
 template <int PIPE, int BM_, int RASTER = 1>
 static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
@@ -595,9 +595,17 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     case 18: return launch_gemm_t<18, 256>(p, epi, stream);
     case 48: return launch_gemm_t<48, 256>(p, epi, stream);
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
+    case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
+    case 21: return launch_gemm2(p, epi, 1, stream);  // ... with static priority by wave slot (lab: no gain measured)
+    case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
     case 3: return launch_gemm_t<3, 256>(p, epi, stream);
     case 9: return launch_gemm_t<8, 256, 0>(p, epi, stream);  // schedule 8, plain row-major tile order
-    default: return launch_gemm_t<8, 256>(p, epi, stream);
+    default:
+      // Shape dispatch (config-2 A/B, tools/kernel_bench.py --variants 8,20): with a short K loop and a store-only epilogue
+      // the two-workgroups-per-CU geometry wins (qkv 1152->3456 -3 %, fc1 1152->4608 -7 %); with K = 4608 or the
+      // gate+residual epilogue the 8-wave kernel is 10-18 % faster.  Both produce identical bits.
+      if (epi != EPI_GATE_RES && p.K <= 1536 && p.N >= 2304) return launch_gemm2(p, epi, 0, stream);
+      return launch_gemm_t<8, 256>(p, epi, stream);
   }
 }
 

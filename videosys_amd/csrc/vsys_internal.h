@@ -28,6 +28,7 @@ struct GemmParams {
 };
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
+int launch_gemm2(const GemmParams& p, int epi, int prio, hipStream_t stream);
 void set_gemm_variant(int v);
 void set_flash_variant(int v);
 void set_flash_debug_buffer(void* p);
