@@ -195,6 +195,48 @@ int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const
                            const void* rope_cos_f32, const void* rope_sin_f32, void* out, int64_t out_stride, int64_t B,
                            int64_t T, int64_t S, int64_t heads, float eps, void* stream);
 
+/* ---- VAE decode (VideoAutoencoderPipeline.decode, autoencoder_kl_open_sora.py:672-695) --------------
+ * Activations are channels-last bf16 row matrices over a grid; a grid is described by int64 g[6] = {T, H, W, pad, tf,
+ * sample_rows}: sample n, frame t, pixel (h, w) is row n*sample_rows + ((t + tf)*(H + 2 pad) + h + pad)*(W + 2 pad) + w + pad.
+ * Borders (pad = 1) and front frames (tf) of conv INPUT buffers are zero and never written by these entry points. */
+
+/* Implicit-GEMM convolution (replaces nn.Conv3d inside CausalConv3d, autoencoder_kl_open_sora.py:89-124, and the Conv2d /
+ * Linear layers of the diffusers 0.30.0 AutoencoderKL decoder): out[r, n] = bias[n] + sum_{tap, c} a[r + delta(tap), c] *
+ * w[n, tap*cin + c] (+ res[r, n] after rounding to bf16), tap = (a, b, c) in kt x kh x kw, delta = a*plane_pitch +
+ * b*row_pitch + c rows.  `a` points at the row tap (0,0,0) reads for output row 0; rows up to M - 1 + delta(last tap) must
+ * be readable.  kt*kh*kw == 1 is a plain GEMM with any K = cin (multiple of 32); otherwise cin/32 must be a power of two.
+ * N % 128 == 0.  Exactly one of out (bf16) / out_f32 (fp32, scaled by out_scale, no bias/res) is non-NULL.  batch > 1
+ * repeats the product with operand strides batch_a / batch_w / batch_o (elements). */
+int vsys_conv_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* bias, const void* res, int64_t ldr,
+                   void* out, void* out_f32, int64_t ldo, int64_t M, int64_t N, int64_t cin, int64_t kt, int64_t kh, int64_t kw,
+                   int64_t row_pitch, int64_t plane_pitch, int64_t batch, int64_t batch_a, int64_t batch_w, int64_t batch_o,
+                   float out_scale, void* stream);
+
+/* nn.GroupNorm statistics over the interior of every sample (autoencoder_kl_open_sora.py:145,147,343; diffusers ResnetBlock2D
+ * norm1/norm2): stats_f32[n][group] = (mean, 1/sqrt(var + eps)).  partial_f32 is scratch of N*nblk*(C/4)*2 floats. */
+int vsys_gn_stats(const void* x, const int64_t* grid, int64_t N, int64_t C, int64_t groups, float eps, void* partial_f32,
+                  int64_t nblk, void* stats_f32, void* stream);
+/* y = act(bf16((x - mean) * rstd * gamma + beta)), act = VSYS_ACT_NONE | VSYS_ACT_SILU, interior rows of grid_dst only. */
+int vsys_gn_apply(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t groups,
+                  const void* stats_f32, const void* gamma, const void* beta, int act, void* stream);
+/* grid-to-grid copy of the interior; up = 1: nearest-neighbour 2x upsampling (diffusers Upsample2D before its conv). */
+int vsys_regrid(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t up,
+                void* stream);
+/* temporal depth-to-space "B (C ts) T H W -> B C (T ts) H W", ts = 2 (autoencoder_kl_open_sora.py:362-368): x has 2*Cout channels. */
+int vsys_d2s_time(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t Cout, void* stream);
+/* First decoder layer: planar bf16 latent z[4][F][H][W] -> z*scale + shift -> 1x1 post_quant_conv -> im2col rows
+ * [F*H*W, kcols] (column = tap*4 + channel, zero padding; kt = 3: causal, two virtual zero frames in front).
+ * params (HOST floats): scale[4], shift[4], pq_w[4][4], pq_b[4]. */
+int vsys_vae_first_im2col(const void* z, int64_t F, int64_t H, int64_t W, int64_t kt, int64_t kcols, const float* params,
+                          void* out, void* stream);
+/* Last decoder layer: the first nc (<= 4) channels of rows [*, ldx] -> planar bf16 out[c][f0 + frame - tskip][h][w], frames
+ * below tskip dropped (VAE_Temporal.decode's x[:, :, time_padding:], autoencoder_kl_open_sora.py:461). */
+int vsys_extract_planar(const void* x, const int64_t* grid, int64_t N, int64_t ldx, int64_t nc, int64_t tskip, void* out,
+                        int64_t Ftot, int64_t f0, void* stream);
+/* row softmax over the first n of ld columns, fp32 [rows, ld] -> bf16 [rows, ld] with zeros in columns n..ld-1 (mid-block
+ * attention of the 2-D decoder, keys padded to the 128-column tile; n % 4 == 0, ld % 4 == 0, ld <= 8192). */
+int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64_t ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -14,6 +14,8 @@ reference code) on CPU; only the leaves below are restated from the published di
   diffusers.models.lora.LoRACompatibleLinear / LoRACompatibleConv (plain Linear / Conv2d taking an ignored ``scale``)
   diffusers.configuration_utils.ConfigMixin / register_to_config, diffusers.models.modeling_utils.ModelMixin
   diffusers.schedulers.DDIMScheduler (set_timesteps "leading", step with eta = 0, epsilon prediction)
+  diffusers.models.AutoencoderKL — decode side only (post_quant_conv + vae.Decoder: ResnetBlock2D, UNetMidBlock2D with the
+      single-head Attention, UpDecoderBlock2D, Upsample2D) at the SDXL-VAE config the Open-Sora pipeline loads
 
 Parity status: the reference holds no test that pins these leaves, so the Latte goldens are "reference block code over
 restated diffusers leaves" (parity unpinned for the leaves, stated in DESIGN.md).
@@ -379,6 +381,136 @@ class DDIMScheduler:
         return (prev,)
 
 
+
+# ----------------------------------------------------------------------------------------------- AutoencoderKL (decode side)
+class _VaeResnetBlock2D(nn.Module):
+    """diffusers.models.resnet.ResnetBlock2D with temb_channels=None, time_embedding_norm="default", output_scale_factor=1:
+    norm1 -> SiLU -> conv1 -> norm2 -> SiLU -> dropout(0) -> conv2; 1x1 ``conv_shortcut`` when the channel count changes."""
+
+    def __init__(self, in_channels, out_channels, groups=32, eps=1e-6):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, in_channels, eps=eps, affine=True)
+        self.conv1 = nn.Conv2d(in_channels, out_channels, 3, stride=1, padding=1)
+        self.norm2 = nn.GroupNorm(groups, out_channels, eps=eps, affine=True)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, 3, stride=1, padding=1)
+        self.nonlinearity = nn.SiLU()
+        self.conv_shortcut = nn.Conv2d(in_channels, out_channels, 1) if in_channels != out_channels else None
+
+    def forward(self, x, temb=None):
+        h = self.conv1(self.nonlinearity(self.norm1(x)))
+        h = self.conv2(self.nonlinearity(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class _VaeAttention(nn.Module):
+    """diffusers Attention as UNetMidBlock2D builds it for the VAE (heads = C // attention_head_dim = 1, norm_num_groups=32,
+    eps=1e-6, residual_connection=True, bias=True, rescale_output_factor=1) run by AttnProcessor2_0 on a 4-D input."""
+
+    def __init__(self, channels, groups=32, eps=1e-6):
+        super().__init__()
+        self.group_norm = nn.GroupNorm(groups, channels, eps=eps, affine=True)
+        self.to_q = nn.Linear(channels, channels, bias=True)
+        self.to_k = nn.Linear(channels, channels, bias=True)
+        self.to_v = nn.Linear(channels, channels, bias=True)
+        self.to_out = nn.ModuleList([nn.Linear(channels, channels, bias=True), nn.Dropout(0.0)])
+
+    def forward(self, x, temb=None):
+        b, c, h, w = x.shape
+        res = x
+        t = x.view(b, c, h * w).transpose(1, 2)
+        t = self.group_norm(t.transpose(1, 2)).transpose(1, 2)
+        q, k, v = self.to_q(t), self.to_k(t), self.to_v(t)
+        o = F.scaled_dot_product_attention(q.unsqueeze(1), k.unsqueeze(1), v.unsqueeze(1)).squeeze(1)
+        o = self.to_out[0](o)
+        return o.transpose(-1, -2).reshape(b, c, h, w) + res
+
+
+class _VaeMidBlock(nn.Module):
+    def __init__(self, channels):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VaeResnetBlock2D(channels, channels), _VaeResnetBlock2D(channels, channels)])
+        self.attentions = nn.ModuleList([_VaeAttention(channels)])
+
+    def forward(self, x):
+        x = self.resnets[0](x)
+        x = self.attentions[0](x)
+        return self.resnets[1](x)
+
+
+class _VaeUpsample2D(nn.Module):
+    """Upsample2D(use_conv=True): F.interpolate(scale_factor=2, mode="nearest") then a 3x3 conv."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class _VaeUpDecoderBlock2D(nn.Module):
+    def __init__(self, in_channels, out_channels, num_layers, add_upsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VaeResnetBlock2D(in_channels if i == 0 else out_channels, out_channels)
+                                      for i in range(num_layers)])
+        self.upsamplers = nn.ModuleList([_VaeUpsample2D(out_channels)]) if add_upsample else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.upsamplers is not None:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class _VaeDecoder(nn.Module):
+    """diffusers.models.autoencoders.vae.Decoder: conv_in -> mid_block -> up_blocks (reversed block_out_channels,
+    layers_per_block + 1 resnets each, upsample on all but the last) -> conv_norm_out -> SiLU -> conv_out."""
+
+    def __init__(self, in_channels=4, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2):
+        super().__init__()
+        rev = list(reversed(block_out_channels))
+        self.conv_in = nn.Conv2d(in_channels, rev[0], 3, padding=1)
+        self.mid_block = _VaeMidBlock(rev[0])
+        self.up_blocks = nn.ModuleList()
+        out_ch = rev[0]
+        for i, ch in enumerate(rev):
+            prev, out_ch = out_ch, ch
+            self.up_blocks.append(_VaeUpDecoderBlock2D(prev, out_ch, layers_per_block + 1, i != len(rev) - 1))
+        self.conv_norm_out = nn.GroupNorm(32, block_out_channels[0], eps=1e-6)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(block_out_channels[0], out_channels, 3, padding=1)
+
+    def forward(self, z):
+        x = self.mid_block(self.conv_in(z))
+        for b in self.up_blocks:
+            x = b(x)
+        return self.conv_out(self.conv_act(self.conv_norm_out(x)))
+
+
+class AutoencoderKL(nn.Module):
+    """Decode side of diffusers.models.AutoencoderKL at the SDXL-VAE config the reference loads
+    ("PixArt-alpha/pixart_sigma_sdxlvae_T5_diffusers", subfolder "vae": block_out_channels (128, 256, 512, 512),
+    layers_per_block 2, latent_channels 4, norm_num_groups 32): decode(z) = decoder(post_quant_conv(z)).  The encoder is not
+    restated (the hot path never encodes).  ``from_pretrained`` returns randomly initialised weights (no network here)."""
+
+    def __init__(self, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4):
+        super().__init__()
+        self.config = SimpleNamespace(latent_channels=latent_channels, block_out_channels=tuple(block_out_channels),
+                                      layers_per_block=layers_per_block, scaling_factor=0.13025)
+        self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
+        self.decoder = _VaeDecoder(latent_channels, 3, block_out_channels, layers_per_block)
+
+    @classmethod
+    def from_pretrained(cls, *args, **kwargs):
+        return cls()
+
+    def decode(self, z, return_dict=True):
+        return SimpleNamespace(sample=self.decoder(self.post_quant_conv(z)))
+
+
 # ----------------------------------------------------------------------------------------------- installation
 def _mod(name, **attrs):
     m = types.ModuleType(name)
@@ -394,6 +526,8 @@ def install():
     _mod("diffusers.configuration_utils", ConfigMixin=ConfigMixin, register_to_config=register_to_config)
     models = sys.modules.get("diffusers.models") or _mod("diffusers.models")
     models.__dict__.setdefault("__path__", [])
+    models.__dict__["AutoencoderKL"] = AutoencoderKL
+    models.__dict__["AutoencoderKLTemporalDecoder"] = _Unused
     _mod("diffusers.models.activations", GEGLU=GEGLU, GELU=GELU, ApproximateGELU=ApproximateGELU)
     ap = _mod("diffusers.models.attention_processor", Attention=Attention, AttnProcessor=object)
     sys.modules["diffusers.models.attention"] = _mod("diffusers.models.attention", Attention=Attention, FeedForward=FeedForward)

@@ -219,3 +219,27 @@ def load_reference_cogvideox_scheduler(**kwargs):
     m = importlib.import_module("videosys.schedulers.scheduling_ddim_cogvideox")
     s = m.CogVideoXDDIMScheduler(**kwargs)
     return s
+
+
+# ---------------------------------------------------------------------------------------------------- Open-Sora VAE
+def build_reference_opensora_vae(state_dict=None, dtype=torch.float32, micro_frame_size=17, micro_batch_size=4):
+    """Instantiate the reference VideoAutoencoderPipeline (autoencoder_kl_open_sora.py:620-735) on CPU: the temporal VAE
+    (VAE_Temporal_SD, reference code) over the restated diffusers AutoencoderKL decoder of oracle/diffusers_stub.py, with the
+    OpenSoraVAE_V1_2 normalisation constants (:738-761).  Random init unless ``state_dict`` is given."""
+    install_stubs()
+    from oracle import diffusers_stub
+
+    diffusers_stub.install()
+    import importlib
+
+    m = importlib.import_module("videosys.models.autoencoders.autoencoder_kl_open_sora")
+    cfg = m.VideoAutoencoderPipelineConfig(
+        vae_2d=dict(type="VideoAutoencoderKL", from_pretrained="stub", subfolder="vae", micro_batch_size=micro_batch_size),
+        vae_temporal=dict(type="VAE_Temporal_SD", from_pretrained=None), freeze_vae_2d=False, cal_loss=False,
+        micro_frame_size=micro_frame_size, shift=(-0.10, 0.34, 0.27, 0.98), scale=(3.85, 2.32, 2.33, 3.06))
+    model = m.VideoAutoencoderPipeline(cfg)
+    if state_dict is not None:
+        missing, unexpected = model.load_state_dict(state_dict, strict=False)
+        assert not unexpected, unexpected
+        assert all("encoder" in k or "quant_conv" in k or k in ("scale", "shift") for k in missing), missing
+    return model.to(dtype).eval()

@@ -1,0 +1,193 @@
+"""GPU: the VAE-decode kernels (tap-shifted implicit-GEMM conv, GroupNorm, regrid/upsample, depth-to-space, first/last layer,
+softmax) against plain torch fp32 on bf16-rounded inputs (per-op tolerance max|err| <= 2^-7 max|ref|), and the full
+OpenSoraVAE.decode against the golden minted from the reference's VideoAutoencoderPipeline (tests/golden/opensora_vae_small.pt):
+rel-rms error vs the fp32 reference <= 1.5x the error of the reference's own bf16 run + cosine >= 0.999."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def check(out, ref, rel=2 ** -7, what=""):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    err = (out - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= rel * scale, f"{what}: max|err| {err:.4e} vs max|ref| {scale:.3f}"
+
+
+def bfr(t):
+    return t.to(torch.bfloat16).float()
+
+
+def to_rows(x, g, zero=True):
+    """x [n, C, T, H, W] fp32 -> (storage, rows) bf16 over grid g on the GPU (borders / front frames zero or NaN-free junk)."""
+    n, C, T, H, W = x.shape
+    buf, rows = g.alloc(C, dev(), zero=True)
+    if not zero:
+        buf.fill_(3.0)  # junk that must never be read as padding
+    v = rows.view(n, g.sample_rows, C)[:, :(T + g.tf) * g.plane].view(n, T + g.tf, g.Hp, g.Wp, C)
+    v[:, g.tf:, g.pad:g.pad + H, g.pad:g.pad + W] = x.permute(0, 2, 3, 4, 1).to(torch.bfloat16).to(dev())
+    return buf, rows
+
+
+def from_rows(rows, g, C):
+    n = g.n
+    v = rows.view(n, g.sample_rows, -1)[:, :(g.T + g.tf) * g.plane].view(n, g.T + g.tf, g.Hp, g.Wp, -1)
+    return v[:, g.tf:, g.pad:g.pad + g.H, g.pad:g.pad + g.W, :C].permute(0, 4, 1, 2, 3).float().cpu()
+
+
+@pytest.mark.parametrize("n,T,H,W,cin,cout,kt,res", [(1, 3, 6, 5, 128, 256, 3, True), (3, 1, 9, 7, 256, 128, 1, False),
+                                                     (1, 5, 12, 8, 512, 512, 3, False), (2, 1, 16, 16, 128, 128, 1, True)])
+def test_conv_tap_shift_matches_torch(n, T, H, W, cin, cout, kt, res):
+    from videosys_amd import ops
+    from videosys_amd.vae_open_sora import _conv_w
+
+    g = torch.Generator().manual_seed(n * 1000 + T * 100 + cin)
+    x = bfr(torch.randn(n, cin, T, H, W, generator=g))
+    w = bfr(torch.randn(cout, cin, kt, 3, 3, generator=g) / math.sqrt(cin * kt * 9))
+    b = bfr(torch.randn(cout, generator=g) * 0.1)
+    r = bfr(torch.randn(n, cout, T, H, W, generator=g)) if res else None
+    ref = F.conv3d(F.pad(x, (1, 1, 1, 1, kt - 1, 0)), w, b)
+    if res:
+        ref = bfr(ref) + r
+    grid = ops.VaeGrid(n, T, H, W, 1, kt - 1)
+    _, rows = to_rows(x, grid)
+    og = grid.conv_out()
+    rr = to_rows(r, og, zero=False)[1] if res else None
+    wm = _conv_w(w.to(dev()) if kt == 3 else w[:, :, 0].to(dev()))
+    out = ops.conv(rows, grid, wm, b.to(torch.bfloat16).to(dev()), cin, kt, 3, res=rr)
+    check(from_rows(out, og, cout), ref, what=f"conv {cin}->{cout} kt={kt}")
+
+
+def test_gemm128_plain_batched_and_f32():
+    from videosys_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 700, 384, 160
+    a = bfr(torch.randn(M, K, generator=g)); w = bfr(torch.randn(N, K, generator=g) / math.sqrt(K)); b = bfr(torch.randn(N, generator=g))
+    r = bfr(torch.randn(M, N, generator=g))
+    out = ops.gemm128(a.to(torch.bfloat16).to(dev()), w.to(torch.bfloat16).to(dev()), b.to(torch.bfloat16).to(dev()),
+                      res=r.to(torch.bfloat16).to(dev()))
+    check(out, bfr(a @ w.t() + b) + r, what="gemm128 bias+res")
+    # batched fp32 scores with a scale
+    nb, L, C = 3, 256, 64
+    q = bfr(torch.randn(nb, L, C, generator=g)); k = bfr(torch.randn(nb, L, C, generator=g))
+    s = torch.empty(nb, L, L, dtype=torch.float32, device=dev())
+    ops.gemm128(q.to(torch.bfloat16).to(dev()), k.to(torch.bfloat16).to(dev()), out_f32=s, out_scale=0.125, batch=nb, batch_a=L * C,
+                batch_w=L * C, batch_o=L * L, M=L)
+    ref = torch.einsum("bqc,bkc->bqk", q, k) * 0.125
+    assert (s.cpu() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    # broadcast A (batch_a = 0): V^T = W_v X^T
+    wv = bfr(torch.randn(128, C, generator=g))
+    vt = torch.empty(nb, 128, L, dtype=torch.bfloat16, device=dev())
+    ops.gemm128(wv.to(torch.bfloat16).to(dev()), k.to(torch.bfloat16).to(dev()), out=vt, batch=nb, batch_a=0, batch_w=L * C,
+                batch_o=128 * L, M=128)
+    check(vt, torch.einsum("dc,bkc->bdk", wv, k), what="batched transposed value product")
+
+
+@pytest.mark.parametrize("n,T,H,W,C,silu,src_pad,dense", [(2, 1, 10, 6, 128, True, 1, False), (1, 4, 5, 7, 512, True, 0, False),
+                                                          (3, 1, 8, 8, 256, False, 1, True), (1, 3, 6, 6, 1024, True, 1, False)])
+def test_group_norm_matches_torch(n, T, H, W, C, silu, src_pad, dense):
+    from videosys_amd import ops
+
+    g = torch.Generator().manual_seed(C + T)
+    x = bfr(torch.randn(n, C, T, H, W, generator=g) * 1.5 + 0.7)
+    gamma = bfr(1 + 0.1 * torch.randn(C, generator=g)); beta = bfr(0.1 * torch.randn(C, generator=g))
+    ref = bfr(F.group_norm(x, 32, gamma, beta, 1e-6))
+    if silu:
+        ref = F.silu(ref)
+    gs = ops.VaeGrid(n, T, H, W, src_pad, 0)
+    _, rows = to_rows(x, gs, zero=False)
+    gd = ops.VaeGrid(n, T, H, W, 0, 0, sample_rows=T * H * W + 5) if dense else ops.VaeGrid(n, T, H, W, 1, 2)
+    ybuf, y = gd.alloc(C, dev(), zero=True)
+    ops.group_norm(rows, gs, y, gd, C, gamma.to(torch.bfloat16).to(dev()), beta.to(torch.bfloat16).to(dev()), 1e-6, silu)
+    check(from_rows(y, gd, C), ref, rel=2 ** -6, what="group norm")
+    # borders / front frames / slack rows untouched (still zero)
+    total = ybuf.float().abs().sum().item()
+    inner = from_rows(y, gd, C).abs().sum().item()
+    assert abs(total - inner) <= 1e-3 * max(inner, 1.0)
+
+
+def test_regrid_upsample_d2s_extract_softmax_first_layer():
+    from videosys_amd import ops
+
+    g = torch.Generator().manual_seed(17)
+    n, T, H, W, C = 2, 1, 5, 6, 128
+    x = bfr(torch.randn(n, C, T, H, W, generator=g))
+    gs = ops.VaeGrid(n, T, H, W, 1, 0)
+    _, rows = to_rows(x, gs, zero=False)
+    gd = ops.VaeGrid(n, T, 2 * H, 2 * W, 1, 0)
+    _, y = gd.alloc(C, dev(), zero=True)
+    ops.regrid(rows, gs, y, gd, C, up=1)
+    ref = F.interpolate(x[:, :, 0], scale_factor=2.0, mode="nearest")[:, :, None]
+    assert torch.equal(from_rows(y, gd, C), ref)
+    # temporal depth-to-space
+    T2, Co = 3, 64
+    x2 = bfr(torch.randn(1, 2 * Co, T2, H, W, generator=g))
+    g1 = ops.VaeGrid(1, T2, H, W, 1, 0)
+    _, r2 = to_rows(x2, g1, zero=False)
+    g2 = ops.VaeGrid(1, 2 * T2, H, W, 1, 0)
+    _, y2 = g2.alloc(Co, dev(), zero=True)
+    ops.d2s_time(r2, g1, y2, g2, Co)
+    ref2 = x2.view(1, Co, 2, T2, H, W).permute(0, 1, 3, 2, 4, 5).reshape(1, Co, 2 * T2, H, W)
+    assert torch.equal(from_rows(y2, g2, Co), ref2)
+    # planar extraction with a frame skip
+    x3 = bfr(torch.randn(1, 128, 4, H, W, generator=g))
+    g3 = ops.VaeGrid(1, 4, H, W, 1, 0)
+    _, r3 = to_rows(x3, g3, zero=False)
+    out = torch.zeros(4, 6, H, W, dtype=torch.bfloat16, device=dev())
+    ops.extract_planar(r3, g3, 4, 1, out, 2)
+    assert torch.equal(out[:, 2:5].float().cpu(), x3[0, :4, 1:]) and out[:, :2].abs().sum().item() == 0 and out[:, 5:].abs().sum().item() == 0
+    # masked row softmax
+    s = torch.randn(37, 256, generator=g) * 3
+    p = ops.softmax_rows(s.to(dev()), n=200)
+    ref = torch.softmax(s[:, :200], -1)
+    assert (p[:, :200].float().cpu() - ref).abs().max().item() <= 2 ** -8 and p[:, 200:].abs().sum().item() == 0
+    # first layer: affine -> 1x1 conv -> im2col
+    Fz, Hz, Wz = 3, 4, 5
+    z = bfr(torch.randn(4, Fz, Hz, Wz, generator=g))
+    scale, shift = [3.85, 2.32, 2.33, 3.06], [-0.10, 0.34, 0.27, 0.98]
+    pw = torch.randn(4, 4, generator=g) * 0.5; pb = torch.randn(4, generator=g) * 0.1
+    for kt, kcols in ((3, 128), (1, 64)):
+        a = ops.vae_first_im2col(z.to(torch.bfloat16).to(dev()), kt, kcols, scale + shift + pw.flatten().tolist() + pb.tolist())
+        v = bfr(z * torch.tensor(scale)[:, None, None, None] + torch.tensor(shift)[:, None, None, None])
+        u = bfr(torch.einsum("oc,cfhw->ofhw", pw, v) + pb[:, None, None, None])
+        up = F.pad(u, (1, 1, 1, 1, kt - 1, 0))
+        cols = []
+        for a_ in range(kt):
+            for b_ in range(3):
+                for c_ in range(3):
+                    cols.append(up[:, a_:a_ + Fz, b_:b_ + Hz, c_:c_ + Wz])
+        ref = torch.stack(cols, 0).permute(2, 3, 4, 0, 1).reshape(Fz * Hz * Wz, kt * 36)
+        got = a.float().cpu()
+        assert (got[:, :kt * 36] - ref).abs().max().item() <= 2 ** -7 * ref.abs().max().item()
+        assert got[:, kt * 36:].abs().sum().item() == 0
+
+
+def test_opensora_vae_decode_matches_reference_golden():
+    from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict
+
+    gold = load_golden("opensora_vae_small.pt")
+    vae = OpenSoraVAE(synth_state_dict(gold["seed"]), device=dev(), frames_per_launch=8)
+    out = vae.decode(gold["z"].to(dev()), gold["num_frames"]).float().cpu()
+    ref = gold["out_fp32"].float()
+    assert out.shape == ref.shape
+    assert torch.isfinite(out).all()
+    rms = lambda t: t.pow(2).mean().sqrt().item()
+    floor = rms(gold["out_bf16"].float() - ref) / rms(ref)
+    mine = rms(out - ref) / rms(ref)
+    cos = F.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+    assert mine <= 1.5 * floor + 1e-3, f"rel rms {mine:.4f} vs reference-bf16 floor {floor:.4f}"
+    assert cos >= 0.999, cos
+    # second call reuses the zero-bordered buffers: must give the same bits
+    out2 = vae.decode(gold["z"].to(dev()), gold["num_frames"]).float().cpu()
+    assert torch.equal(out, out2)

@@ -249,4 +249,99 @@ int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const
                                   B16(out), out_stride, (int)B, (int)T, (int)S_, (int)heads, eps, S(stream));
 }
 
+namespace {
+inline bool to_grid(const int64_t* g, VaeGrid& o) {
+  if (!g) return false;
+  for (int i = 0; i < 5; ++i) if (!fits_int(g[i])) return false;
+  o.T = (int)g[0]; o.H = (int)g[1]; o.W = (int)g[2]; o.pad = (int)g[3]; o.tf = (int)g[4]; o.sample_rows = g[5];
+  return g[5] >= 0;
+}
+}  // namespace
+
+int vsys_conv_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* bias, const void* res, int64_t ldr,
+                   void* out, void* out_f32, int64_t ldo, int64_t M, int64_t N, int64_t cin, int64_t kt, int64_t kh, int64_t kw,
+                   int64_t row_pitch, int64_t plane_pitch, int64_t batch, int64_t batch_a, int64_t batch_w, int64_t batch_o,
+                   float out_scale, void* stream) {
+  if (!a || !w || ((out == nullptr) == (out_f32 == nullptr))) return VSYS_ERR_ARG;
+  if (out_f32 && (bias || res)) return VSYS_ERR_ARG;
+  if (!fits_int(M) || !fits_int(N) || !fits_int(cin) || !fits_int(row_pitch) || !fits_int(plane_pitch) || !fits_int(batch))
+    return VSYS_ERR_SHAPE;
+  if (kt < 1 || kt > 3 || kh < 1 || kh > 3 || kw < 1 || kw > 3 || kh != kw || cin <= 0) return VSYS_ERR_SHAPE;
+  ConvParams p;
+  p.A = B16(a); p.lda = lda; p.W = B16(w); p.ldw = ldw; p.bias = B16(bias); p.res = B16(res); p.ldr = ldr;
+  p.out = B16(out); p.out32 = reinterpret_cast<float*>(out_f32); p.ldo = ldo;
+  p.M = (int)M; p.N = (int)N; p.cin = (int)cin; p.taps = (int)(kt * kh * kw);
+  const int64_t K = cin * p.taps;
+  if (!fits_int(K)) return VSYS_ERR_SHAPE;
+  p.K = (int)K;
+  p.taps_hw = (int)(kh * kw); p.kw = (int)kw; p.row_pitch = (int)row_pitch; p.plane_pitch = (int)plane_pitch;
+  const int64_t mtr = (kt - 1) * plane_pitch + (kh - 1) * row_pitch + (kw - 1);
+  if (!fits_int(mtr)) return VSYS_ERR_SHAPE;
+  p.max_tap_rows = (int)mtr;
+  if (p.taps == 1) {
+    p.cshift = 30;  // k-tile index never reaches the next tap
+  } else {
+    int sh = 0;
+    while ((32 << sh) < cin) ++sh;
+    p.cshift = sh;  // launch_conv checks cin == 32 << sh
+  }
+  p.batch = (int)batch; p.batch_a = batch_a; p.batch_w = batch_w; p.batch_o = batch_o; p.out_scale = out_scale;
+  return launch_conv(p, S(stream));
+}
+
+int vsys_gn_stats(const void* x, const int64_t* grid, int64_t N, int64_t C, int64_t groups, float eps, void* partial_f32,
+                  int64_t nblk, void* stats_f32, void* stream) {
+  VaeGrid g;
+  if (!x || !partial_f32 || !stats_f32 || !to_grid(grid, g)) return VSYS_ERR_ARG;
+  if (!fits_int(N) || !fits_int(C) || !fits_int(groups) || !fits_int(nblk)) return VSYS_ERR_SHAPE;
+  return launch_gn_stats(B16(x), g, (int)N, (int)C, (int)groups, eps, reinterpret_cast<float*>(partial_f32), (int)nblk,
+                         reinterpret_cast<float*>(stats_f32), S(stream));
+}
+
+int vsys_gn_apply(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t groups,
+                  const void* stats_f32, const void* gamma, const void* beta, int act, void* stream) {
+  VaeGrid gs, gd;
+  if (!x || !y || !stats_f32 || !gamma || !beta || !to_grid(grid_src, gs) || !to_grid(grid_dst, gd)) return VSYS_ERR_ARG;
+  if (!fits_int(N) || !fits_int(C) || !fits_int(groups)) return VSYS_ERR_SHAPE;
+  return launch_gn_apply(B16(x), gs, B16(y), gd, (int)N, (int)C, (int)groups, reinterpret_cast<const float*>(stats_f32), B16(gamma),
+                         B16(beta), act, S(stream));
+}
+
+int vsys_regrid(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t up,
+                void* stream) {
+  VaeGrid gs, gd;
+  if (!x || !y || !to_grid(grid_src, gs) || !to_grid(grid_dst, gd)) return VSYS_ERR_ARG;
+  if (!fits_int(N) || !fits_int(C) || !fits_int(up)) return VSYS_ERR_SHAPE;
+  return launch_regrid(B16(x), gs, B16(y), gd, (int)N, (int)C, (int)up, S(stream));
+}
+
+int vsys_d2s_time(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t Cout, void* stream) {
+  VaeGrid gs, gd;
+  if (!x || !y || !to_grid(grid_src, gs) || !to_grid(grid_dst, gd)) return VSYS_ERR_ARG;
+  if (!fits_int(N) || !fits_int(Cout)) return VSYS_ERR_SHAPE;
+  return launch_d2s_time(B16(x), gs, B16(y), gd, (int)N, (int)Cout, S(stream));
+}
+
+int vsys_vae_first_im2col(const void* z, int64_t F, int64_t H, int64_t W, int64_t kt, int64_t kcols, const float* params,
+                          void* out, void* stream) {
+  if (!z || !out || !params) return VSYS_ERR_ARG;
+  if (!fits_int(F) || !fits_int(H) || !fits_int(W) || !fits_int(kt) || !fits_int(kcols)) return VSYS_ERR_SHAPE;
+  return launch_vae_first_im2col(B16(z), (int)F, (int)H, (int)W, (int)kt, (int)kcols, params, params + 4, params + 8, params + 24,
+                                 B16(out), S(stream));
+}
+
+int vsys_extract_planar(const void* x, const int64_t* grid, int64_t N, int64_t ldx, int64_t nc, int64_t tskip, void* out,
+                        int64_t Ftot, int64_t f0, void* stream) {
+  VaeGrid g;
+  if (!x || !out || !to_grid(grid, g)) return VSYS_ERR_ARG;
+  if (!fits_int(N) || !fits_int(ldx) || !fits_int(nc) || !fits_int(tskip) || !fits_int(f0) || Ftot <= 0) return VSYS_ERR_SHAPE;
+  return launch_extract_planar(B16(x), g, (int)N, (int)ldx, (int)nc, (int)tskip, B16(out), Ftot, (int)f0, S(stream));
+}
+
+int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64_t ld, void* stream) {
+  if (!s_f32 || !p) return VSYS_ERR_ARG;
+  if (!fits_int(n) || !fits_int(ld)) return VSYS_ERR_SHAPE;
+  return launch_softmax_rows(reinterpret_cast<const float*>(s_f32), B16(p), rows, (int)n, (int)ld, S(stream));
+}
+
 }  // extern "C"

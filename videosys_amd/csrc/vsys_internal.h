@@ -27,6 +27,37 @@ struct GemmParams {
   int seg_split; int64_t gate_alt;
 };
 
+// implicit-GEMM convolution / 128-column GEMM (conv_bf16.hip).  A points at the row that tap (0,0,0) reads for output row 0.
+struct ConvParams {
+  const bf16_t* A; int64_t lda;   // activation rows [*, cin]
+  const bf16_t* W; int64_t ldw;   // [N, taps*cin], k = tap*cin + channel
+  const bf16_t* bias;             // [N] or null
+  const bf16_t* res; int64_t ldr; // residual rows [M, N] added after rounding, or null
+  bf16_t* out; float* out32; int64_t ldo;  // exactly one of out / out32
+  int M, N, K;
+  int cin, taps, cshift, taps_hw, kw, row_pitch, plane_pitch, max_tap_rows;
+  int batch; int64_t batch_a, batch_w, batch_o;  // gridDim.y operand strides in elements
+  float out_scale;                // fp32 output only
+};
+int launch_conv(const ConvParams& p, hipStream_t stream);
+
+// activation grid of the VAE kernels (vae_ops.hip): row(n,t,h,w) = n*sample_rows + ((t+tf)*(H+2pad) + h+pad)*(W+2pad) + w+pad
+struct VaeGrid {
+  int T, H, W, pad, tf;
+  int64_t sample_rows;
+};
+int launch_gn_stats(const bf16_t* x, const VaeGrid& g, int N, int C, int groups, float eps, float* partial, int nblk, float* stats,
+                    hipStream_t stream);
+int launch_gn_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int groups, const float* stats,
+                    const bf16_t* gamma, const bf16_t* beta, int act, hipStream_t stream);
+int launch_regrid(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int up, hipStream_t stream);
+int launch_d2s_time(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int Cout, hipStream_t stream);
+int launch_vae_first_im2col(const bf16_t* z, int F, int H, int W, int kt, int kcols, const float* scale, const float* shift,
+                            const float* pq_w, const float* pq_b, bf16_t* out, hipStream_t stream);
+int launch_extract_planar(const bf16_t* x, const VaeGrid& g, int N, int ldx, int nc, int tskip, bf16_t* out, int64_t Ftot, int f0,
+                          hipStream_t stream);
+int launch_softmax_rows(const float* s, bf16_t* p, int64_t rows, int n, int ld, hipStream_t stream);
+
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm2(const GemmParams& p, int epi, int prio, hipStream_t stream);
 void set_gemm_variant(int v);

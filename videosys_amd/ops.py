@@ -336,3 +336,139 @@ def flash_attn64(q, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, out, bat
                                        _p(kp), _p(vt), _p(out), out.stride(0), batch, heads, q_len, kv_len, kp.shape[2], eps,
                                        _stream()), "vsys_flash_attn_d64")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ VAE decode (row a14)
+import ctypes as _ct
+
+
+class VaeGrid:
+    """Activation grid of the VAE kernels (include/videosys_amd.h): ``n`` samples of (T, H, W) with a spatial zero border of
+    ``pad`` pixels and ``tf`` zero frames in front; rows are channels-last.  ``guard`` rows of slack precede and follow the
+    grid in the allocation so tap-shifted conv reads stay inside it."""
+
+    def __init__(self, n, T, H, W, pad=0, tf=0, sample_rows=None):
+        self.n, self.T, self.H, self.W, self.pad, self.tf = n, T, H, W, pad, tf
+        self.Hp, self.Wp = H + 2 * pad, W + 2 * pad
+        self.plane = self.Hp * self.Wp
+        self.sample_rows = (T + tf) * self.plane if sample_rows is None else sample_rows
+        assert self.sample_rows >= (T + tf) * self.plane
+        self.rows = n * self.sample_rows
+        self.guard = (self.Wp + 1) if pad else 0
+        self._c = (_ct.c_int64 * 6)(T, H, W, pad, tf, self.sample_rows)
+
+    def alloc(self, C, device, zero=False):
+        """[guard + rows + guard, C] bf16; returns (storage, view of the grid rows)."""
+        total = self.rows + 2 * self.guard
+        buf = (torch.zeros if zero else torch.empty)(total, C, dtype=torch.bfloat16, device=device)
+        return buf, buf[self.guard:self.guard + self.rows]
+
+    def conv_out(self):
+        """Grid of a conv's output when this grid is its (padded) input: same rows minus the front frames."""
+        return VaeGrid(self.n, self.T, self.H, self.W, self.pad, 0)
+
+
+def conv(a, grid: VaeGrid, w, bias, cin, kt, ks, out=None, res=None):
+    """Tap-shifted implicit-GEMM conv over the padded grid ``grid`` whose rows are the 2-D tensor ``a`` (a view that has
+    grid.guard rows of slack on both sides in its storage).  ks = spatial kernel (1 or 3), kt = temporal taps (needs
+    grid.tf == kt - 1).  Returns rows of grid.conv_out() [M, N]."""
+    _chk(a, w, bias, res, out)
+    _bf16(a, w, bias, res, out)
+    assert grid.tf == kt - 1 and (ks == 1 or grid.pad == 1) and a.shape[0] == grid.rows and a.stride(1) == 1
+    og = grid.conv_out()
+    M, N = og.rows, w.shape[0]
+    assert w.shape[1] == cin * kt * ks * ks and a.shape[1] >= cin
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    shift_rows = (grid.Wp + 1) if ks == 3 else 0
+    a_ptr = a.data_ptr() - shift_rows * a.stride(0) * 2
+    lib = _lib.load()
+    _lib.check(lib.vsys_conv_bf16(a_ptr, a.stride(0), _p(w), w.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
+                                  _p(out), None, out.stride(0), M, N, cin, kt, ks, ks, grid.Wp, grid.plane, 1, 0, 0, 0, 1.0,
+                                  _stream()), "vsys_conv_bf16")
+    return out
+
+
+def gemm128(a, w, bias=None, res=None, out=None, out_f32=None, out_scale=1.0, batch=1, batch_a=0, batch_w=0, batch_o=0, M=None):
+    """Plain C = A W^T (+ bias, + res) on the 128-column tile kernel; batch > 1 strides the operands (elements)."""
+    _chk(a, w, bias, res, out, out_f32)
+    _bf16(a, w, bias, res, out)
+    M = a.shape[0] if M is None else M
+    N, K = w.shape[0] if batch == 1 else w.shape[-2], a.shape[-1]
+    if out is None and out_f32 is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    o = out if out is not None else out_f32
+    lib = _lib.load()
+    _lib.check(lib.vsys_conv_bf16(_p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(res), res.stride(-2) if res is not None else 0,
+                                  _p(out), _p(out_f32), o.stride(-2), M, N, K, 1, 1, 1, 0, 0, batch, batch_a, batch_w, batch_o,
+                                  float(out_scale), _stream()), "vsys_conv_bf16")
+    return o
+
+
+_GN_NBLK = 128
+
+
+def group_norm(x, gs: VaeGrid, y, gd: VaeGrid, C, gamma, beta, eps, silu_act, groups=32):
+    """y[interior of gd] = act(GroupNorm(x[interior of gs])); statistics per sample over (T, H, W) and the group's channels."""
+    _chk(x, y, gamma, beta)
+    _bf16(x, y, gamma, beta)
+    assert x.shape[0] == gs.rows and y.shape[0] == gd.rows and x.shape[1] == C and y.shape[1] == C
+    assert x.is_contiguous() and y.is_contiguous()
+    lib = _lib.load()
+    partial = torch.empty(gs.n * _GN_NBLK * (C // 4) * 2, dtype=torch.float32, device=x.device)
+    stats = torch.empty(gs.n * groups * 2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vsys_gn_stats(_p(x), gs._c, gs.n, C, groups, float(eps), _p(partial), _GN_NBLK, _p(stats), _stream()), "vsys_gn_stats")
+    _lib.check(lib.vsys_gn_apply(_p(x), gs._c, _p(y), gd._c, gs.n, C, groups, _p(stats), _p(gamma), _p(beta),
+                                 ACT_SILU if silu_act else ACT_NONE, _stream()), "vsys_gn_apply")
+    return y
+
+
+def regrid(x, gs: VaeGrid, y, gd: VaeGrid, C, up=0):
+    _chk(x, y)
+    _bf16(x, y)
+    assert x.shape[0] == gs.rows and y.shape[0] == gd.rows and x.is_contiguous() and y.is_contiguous()
+    _lib.check(_lib.load().vsys_regrid(_p(x), gs._c, _p(y), gd._c, gs.n, C, up, _stream()), "vsys_regrid")
+    return y
+
+
+def d2s_time(x, gs: VaeGrid, y, gd: VaeGrid, Cout):
+    _chk(x, y)
+    _bf16(x, y)
+    assert x.shape == (gs.rows, 2 * Cout) and y.shape == (gd.rows, Cout) and x.is_contiguous() and y.is_contiguous()
+    _lib.check(_lib.load().vsys_d2s_time(_p(x), gs._c, _p(y), gd._c, gs.n, Cout, _stream()), "vsys_d2s_time")
+    return y
+
+
+def vae_first_im2col(z, kt, kcols, params):
+    """z bf16 planar [4, F, H, W] -> [F*H*W, kcols]; params = 28 host floats (scale, shift, pq_w row-major, pq_b)."""
+    _chk(z)
+    _bf16(z)
+    assert z.dim() == 4 and z.shape[0] == 4 and z.is_contiguous() and len(params) == 28
+    _, F, H, W = z.shape
+    out = torch.empty(F * H * W, kcols, dtype=torch.bfloat16, device=z.device)
+    arr = (_ct.c_float * 28)(*[float(v) for v in params])
+    _lib.check(_lib.load().vsys_vae_first_im2col(_p(z), F, H, W, kt, kcols, arr, _p(out), _stream()), "vsys_vae_first_im2col")
+    return out
+
+
+def extract_planar(x, g: VaeGrid, nc, tskip, out, f0):
+    """first nc channels of the rows of grid g -> out[c, f0 + frame - tskip, h, w] (planar bf16 [nc, Ftot, H, W])."""
+    _chk(x, out)
+    _bf16(x, out)
+    assert x.shape[0] == g.rows and out.is_contiguous() and out.shape[0] == nc and tuple(out.shape[2:]) == (g.H, g.W)
+    _lib.check(_lib.load().vsys_extract_planar(_p(x), g._c, g.n, x.stride(0), nc, tskip, _p(out), out.shape[1], f0, _stream()),
+               "vsys_extract_planar")
+    return out
+
+
+def softmax_rows(s_f32, n=None, out=None):
+    """softmax over the first n columns of every row of s_f32 [..., ld]; columns n.. of the bf16 result are zero."""
+    _chk(s_f32, out)
+    assert s_f32.dtype == torch.float32 and s_f32.is_contiguous()
+    ld = s_f32.shape[-1]
+    n = ld if n is None else n
+    rows = s_f32.numel() // ld
+    if out is None:
+        out = torch.empty(s_f32.shape, dtype=torch.bfloat16, device=s_f32.device)
+    _lib.check(_lib.load().vsys_softmax_rows(_p(s_f32), _p(out), rows, n, ld, _stream()), "vsys_softmax_rows")
+    return out
