@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--depth", type=int, default=28, help="debug only; the reported config is depth 28")
     ap.add_argument("--pab", action="store_true", help="BASELINE config 3: attention-only PAB (reported as a separate workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--text-len", type=int, default=300)
     return ap.parse_args()
 
@@ -177,7 +178,7 @@ def main():
             with open(tpath) as fh:
                 traffic = round(json.load(fh)["avg_bytes_per_launch_config2_mix"])
         roof = {
-            "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> (256x192x64 tile, bf16 MFMA 32x32x16, all epilogues)",
+            "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> + vsys::gemm2_kernel<EPI> (256x192 tile, bf16 MFMA 32x32x16, shape-dispatched, all epilogues)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits; algorithmic "
@@ -195,6 +196,23 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pab:
         cpu = cpu_baseline(cfg, T, Hl, Wl, L)
 
+    # ---- VAE decode of the final latent (rank 0, N == 1; outside the timed region; row a14): one warm-up + one timed call
+    vae = None
+    if rank == 0 and world == 1 and not args.no_vae:
+        from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict as vae_synth
+
+        dec = OpenSoraVAE(vae_synth(0), device=dev)
+        zb = z[:1].to(torch.bfloat16)
+        dec.decode(zb, frames)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        vid = dec.decode(zb, frames)
+        torch.cuda.synchronize()
+        vae_s = time.perf_counter() - t0
+        vae = {"sec_per_video": round(vae_s, 4), "output": list(vid.shape),
+               "videos_per_min_dit_plus_vae": round(60.0 / (STEPS_PER_VIDEO * step_s + vae_s), 4)}
+        del dec, vid
+
     if rank == 0:
         vpm = 60.0 / (STEPS_PER_VIDEO * step_s)
         line = {
@@ -206,11 +224,11 @@ def main():
                 "workload": ("open-sora-v1.2 STDiT3-XL/2 512x512x64f, latent [4,19,64,64], CFG batch 2 = 38912 token rows, "
                              f"{L} text tokens, depth {args.depth}" + (", PAB attention-only (config 3)" if args.pab else "")),
                 "steps_per_video": STEPS_PER_VIDEO, "parallelism": f"dsp{world}",
-                "not_included": "T5 text encode, VAE decode (SURVEY.md 8f next rows)",
+                "not_included": "T5 text encode (value is DiT denoising only; vae_decode reports the decode term beside it)",
                 "algorithmic_tflop_per_step": 89.4 if args.depth == 28 and L == 300 else None,
             },
             "step_tflops": round(89.4 / step_s, 1) if args.depth == 28 and L == 300 and not args.pab else None,
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "vae_decode": vae,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

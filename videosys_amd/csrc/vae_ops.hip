@@ -55,56 +55,67 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
   }
 }
 
-// pass 2: one thread per (n, group): fold the block partials in double, emit mean and 1/sqrt(var + eps)
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int groups, int64_t count_per_channel,
-                                   float eps, float* __restrict__ stats, int total) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+// pass 2: one wave per (n, group): fold the block partials in double (fixed lane assignment + butterfly: deterministic),
+// emit mean and 1/sqrt(var + eps)
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int groups,
+                                                         int64_t count_per_channel, float eps, float* __restrict__ stats) {
+  const int idx = blockIdx.x;
   const int n = idx / groups, grp = idx - n * groups;
   const int hpg = (C / groups) >> 2;  // 4-channel half chunks per group
   double s = 0.0, q = 0.0;
-  for (int b = 0; b < nblk; ++b) {
-    const float* pp = partial + (((int64_t)n * nblk + b) * (C >> 2) + grp * hpg) * 2;
-    for (int k = 0; k < hpg; ++k) { s += pp[2 * k]; q += pp[2 * k + 1]; }
+  for (int i = threadIdx.x; i < nblk * hpg; i += 64) {
+    const int b = i / hpg, k = i - b * hpg;
+    const float2 v = *reinterpret_cast<const float2*>(partial + (((int64_t)n * nblk + b) * (C >> 2) + grp * hpg + k) * 2);
+    s += v.x; q += v.y;
   }
-  const double cnt = (double)count_per_channel * (C / groups);
-  const double mean = s / cnt;
-  double var = q / cnt - mean * mean;
-  var = var > 0.0 ? var : 0.0;
-  stats[2 * idx] = (float)mean;
-  stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
+  if (threadIdx.x == 0) {
+    const double cnt = (double)count_per_channel * (C / groups);
+    const double mean = s / cnt;
+    double var = q / cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[2 * idx] = (float)mean;
+    stats[2 * idx + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
 }
 
 // normalise + affine (+ SiLU) from grid gs to grid gd (same T, H, W).  The reference rounds the GroupNorm output to bf16
-// before the activation (two modules), so do we.
+// before the activation (two modules), so do we.  Block = one image row (n, t, h): W x C/8 16-byte items, 32-bit index math;
+// a chunk of 8 channels lies in one group (C/groups >= 8) or two (C/groups = 4), so two stat pairs per item are enough.
 template <int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, VaeGrid gs, bf16_t* __restrict__ y, VaeGrid gd,
                                                        int C, int groups, const float* __restrict__ stats,
                                                        const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta, int N) {
   const int nch = C >> 3;
-  const int64_t total = (int64_t)N * gs.T * gs.H * gs.W * nch;
   const int cg = C / groups;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int ch = (int)(i % nch);
-    int64_t pos = i / nch;
-    const int w = (int)(pos % gs.W); pos /= gs.W;
-    const int h = (int)(pos % gs.H); pos /= gs.H;
-    const int t = (int)(pos % gs.T);
-    const int n = (int)(pos / gs.T);
-    const uint4 v = *reinterpret_cast<const uint4*>(x + grid_row(gs, n, t, h, w) * C + ch * 8);
-    const uint4 gm = *reinterpret_cast<const uint4*>(gamma + ch * 8);
-    const uint4 bt = *reinterpret_cast<const uint4*>(beta + ch * 8);
-    float f[8], ga[8], be[8];
-    unpack8(v, f); unpack8(gm, ga); unpack8(bt, be);
+  const int64_t nrows = (int64_t)N * gs.T * gs.H;
+  for (int64_t br = blockIdx.x; br < nrows; br += gridDim.x) {
+    const int h = (int)(br % gs.H);
+    const int64_t r1 = br / gs.H;
+    const int t = (int)(r1 % gs.T), n = (int)(r1 / gs.T);
+    const bf16_t* xr = x + grid_row(gs, n, t, h, 0) * C;
+    bf16_t* yr = y + grid_row(gd, n, t, h, 0) * C;
+    const float* st = stats + 2 * n * groups;
+    const int items = gs.W * nch;
+    for (int i = threadIdx.x; i < items; i += 256) {
+      const int w = i / nch, ch = i - w * nch;
+      const uint4 v = *reinterpret_cast<const uint4*>(xr + (int64_t)w * C + ch * 8);
+      const uint4 gm = *reinterpret_cast<const uint4*>(gamma + ch * 8);
+      const uint4 bt = *reinterpret_cast<const uint4*>(beta + ch * 8);
+      const int g0 = (ch * 8) / cg, g1 = (ch * 8 + 4) / cg;
+      const float2 s0 = *reinterpret_cast<const float2*>(st + 2 * g0), s1 = *reinterpret_cast<const float2*>(st + 2 * g1);
+      float f[8], ga[8], be[8];
+      unpack8(v, f); unpack8(gm, ga); unpack8(bt, be);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int grp = (ch * 8 + e) / cg;
-      const float mean = stats[2 * (n * groups + grp)], rstd = stats[2 * (n * groups + grp) + 1];
-      float o = bf2f(f2bf((f[e] - mean) * rstd * ga[e] + be[e]));
-      if (ACT) o = silu(o);
-      f[e] = o;
+      for (int e = 0; e < 8; ++e) {
+        const float mean = e < 4 ? s0.x : s1.x, rstd = e < 4 ? s0.y : s1.y;
+        float o = bf2f(f2bf((f[e] - mean) * rstd * ga[e] + be[e]));
+        if (ACT) o = silu(o);
+        f[e] = o;
+      }
+      *reinterpret_cast<uint4*>(yr + (int64_t)w * C + ch * 8) = pack8(f);
     }
-    *reinterpret_cast<uint4*>(y + grid_row(gd, n, t, h, w) * C + ch * 8) = pack8(f);
   }
 }
 
@@ -269,9 +280,8 @@ int launch_gn_stats(const bf16_t* x, const VaeGrid& g, int N, int C, int groups,
   if (!grid_ok(g) || C % 8 != 0 || C > 2048 || groups <= 0 || C % groups != 0 || (C / groups) % 4 != 0 || nblk <= 0 || N > 65535)
     return VSYS_ERR_SHAPE;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk, N), dim3(256), 0, stream, x, g, C, partial);
-  const int total = N * groups;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((total + 63) / 64), dim3(64), 0, stream, partial, nblk, C, groups,
-                     (int64_t)g.T * g.H * g.W, eps, stats, total);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N * groups), dim3(64), 0, stream, partial, nblk, C, groups,
+                     (int64_t)g.T * g.H * g.W, eps, stats);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
@@ -280,7 +290,9 @@ int launch_gn_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid
   if (N <= 0) return 0;
   if (!grid_ok(gs) || !grid_ok(gd) || gs.T != gd.T || gs.H != gd.H || gs.W != gd.W || C % 8 != 0 || groups <= 0 || C % groups != 0)
     return VSYS_ERR_SHAPE;
-  const unsigned grid = grid_for((int64_t)N * gs.T * gs.H * gs.W * (C >> 3));
+  if ((C / groups) % 4 != 0) return VSYS_ERR_SHAPE;
+  const int64_t nrows = (int64_t)N * gs.T * gs.H;
+  const unsigned grid = (unsigned)(nrows < 65536 ? nrows : 65536);
   if (act == ACT_SILU) hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(grid), dim3(256), 0, stream, x, gs, y, gd, C, groups, stats, gamma, beta, N);
   else if (act == ACT_NONE) hipLaunchKernelGGL(gn_apply_kernel<0>, dim3(grid), dim3(256), 0, stream, x, gs, y, gd, C, groups, stats, gamma, beta, N);
   else return VSYS_ERR_ARG;

@@ -140,12 +140,27 @@ class OpenSoraPipeline:
         self.scheduler = RFLOW(num_sampling_steps=config.num_sampling_steps, cfg_scale=config.cfg_scale,
                                use_timestep_transform=True)
         self.text_encoder = text_encoder
+        if vae_decoder is None:
+            vae_decoder = self._load_vae(config.vae)
         self.vae_decoder = vae_decoder
         if config.enable_pab:
             pab.set_pab_manager(config.pab_config)
         else:
             pab.set_pab_manager(None)
         self._set_parallel()
+
+    def _load_vae(self, name):
+        """OpenSoraVAE_V1_2 (autoencoder_kl_open_sora.py:738-761): a local checkpoint directory (model.safetensors with the
+        reference's keys) or "synthetic:<seed>"; a hub id cannot be fetched here, so it leaves the pipeline latent-only."""
+        from .vae_open_sora import OpenSoraVAE, synth_state_dict as vae_synth
+
+        if isinstance(name, str) and name.startswith("synthetic:"):
+            return OpenSoraVAE(vae_synth(int(name.split(":", 1)[1])), device=self._device)
+        if isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "model.safetensors")):
+            from safetensors.torch import load_file
+
+            return OpenSoraVAE(load_file(os.path.join(name, "model.safetensors")), device=self._device)
+        return None
 
     def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: bool = False):
         """pipeline_open_sora.py:253-267: dp=1, sp=world."""
