@@ -1,0 +1,210 @@
+"""GPU: the model-level sequence-parallel paths end to end on real hardware.  The GPU box has ONE device, so the two ranks
+share cuda:0 and talk over gloo (which stages CUDA tensors through the host); everything else — the HIP pack/unpack kernels,
+the padded layouts, the per-rank shapes of every kernel launch — is the product path that runs under RCCL on an 8-GPU node.
+The sharded result must equal the single-process result bit for bit (the partition is over whole attention problems)."""
+import os
+import socket
+import tempfile
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _stdit3_worker(rank, world, port, outdir, T, HW):
+    import traceback
+
+    import torch.distributed as dist
+
+    try:
+        from oracle import stdit3_oracle as O
+        from videosys_amd import dsp
+        from videosys_amd.stdit3 import STDiT3, STDiT3Config
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        cfg = dict(depth=2, hidden_size=576, num_heads=8, caption_channels=64, model_max_length=16)
+        sd = O.synth_state_dict(**cfg, seed=31)
+        sd = {k: (v if k == "rope.freqs" else v.to(torch.bfloat16).float()) for k, v in sd.items()}
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(2, 4, T, HW, HW, generator=g).to(torch.bfloat16).float()
+        y = torch.randn(2, 1, 16, 64, generator=g).to(torch.bfloat16).float()
+        mask = torch.zeros(1, 16, dtype=torch.long)
+        mask[:, :11] = 1
+        kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([float(HW * 8)] * 2),
+                  width=torch.tensor([float(HW * 8)] * 2))
+        t = torch.tensor([500.0, 500.0])
+        model = STDiT3(STDiT3Config(**cfg), device="cuda:0")
+        model.load_state_dict(sd)
+        ref = model(x, t, y, **kw).float().cpu()
+        model.enable_parallel(1, world, False)
+        out = model(x, t, y, **kw).float().cpu()
+        out2 = model(x, t, y, **kw).float().cpu()
+        torch.cuda.synchronize()
+        ok = torch.equal(out, ref) and torch.equal(out, out2)
+        err = (out - ref).abs().max().item()
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write("ok" if ok else f"mismatch max|diff| {err} of {ref.abs().max().item()}")
+    except Exception:
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def _run(worker, args, world=2, timeout=300):
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as d:
+        procs = [ctx.Process(target=worker, args=(r, world, port, d) + args) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=timeout)
+        for p in procs:
+            if p.is_alive():
+                p.kill()
+        res = []
+        for r in range(world):
+            fn = os.path.join(d, f"r{r}.txt")
+            res.append(open(fn).read() if os.path.exists(fn) else "no result (crashed or timed out)")
+    for r, s in enumerate(res):
+        assert s == "ok", f"rank {r}: {s}"
+
+
+def _latte_worker(rank, world, port, outdir):
+    import traceback
+
+    import torch.distributed as dist
+
+    try:
+        from conftest import load_golden
+        from oracle import latte_oracle as LO
+        from videosys_amd import pab
+        from videosys_amd.latte import LatteT2V
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        pab.set_pab_manager(None)
+        fx = load_golden("latte_fwd_small.pt")
+        cfg = fx["cfg"]
+        sd = LO.synth_state_dict(cfg["num_layers"], cfg["num_attention_heads"], cfg["attention_head_dim"],
+                                 caption_channels=cfg["caption_channels"], seed=fx["seed"])
+        sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+        m = LatteT2V(**cfg, device="cuda:0")
+        m.load_state_dict(sd)
+        g = torch.Generator().manual_seed(4)
+        res = []
+        for frames in (4, 3):   # 3 frames over 2 ranks: one zero-padded frame on the last rank
+            x = fx["x"][:, :, :frames].contiguous()
+            call = lambda: m(x, timestep=fx["t"], encoder_hidden_states=fx["y"].clone(), encoder_attention_mask=fx["mask"],
+                             return_dict=False)[0].float().cpu()
+            m._sp = None            # single-process path
+            ref = call()
+            m.enable_parallel(1, world, False)
+            out = call()
+            res.append((frames, torch.equal(out, ref), (out - ref).abs().max().item(), ref.abs().max().item()))
+        torch.cuda.synchronize()
+        bad = [r for r in res if not r[1]]
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write("ok" if not bad else f"mismatch (frames, equal, max|diff|, max|ref|): {bad}")
+    except Exception:
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_latte_sp_two_ranks_equals_single():
+    """Latte frame-sharded sequence parallelism (latte_transformer_3d.py:826-843,1300-1308,1428-1429,1469-1482)."""
+    _run(_latte_worker, ())
+
+
+def _cogvideox_worker(rank, world, port, outdir):
+    import traceback
+
+    import torch.distributed as dist
+
+    try:
+        from conftest import load_golden
+        from oracle import cogvideox_oracle as CO
+        from videosys_amd import pab
+        from videosys_amd.cogvideox import CogVideoXTransformer3DModel
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        pab.set_pab_manager(None)
+        fx = load_golden("cogvideox_fwd_small.pt")
+        res = []
+        for key in ("sincos", "rope"):
+            cfg = dict(fx[key]["cfg"], num_attention_heads=6)   # 6 heads: 3 per rank
+            sd = {k: v.to(torch.bfloat16).float() for k, v in CO.synth_state_dict(
+                cfg["num_layers"], cfg["num_attention_heads"], text_embed_dim=cfg["text_embed_dim"], seed=fx["seed"]).items()}
+            m = CogVideoXTransformer3DModel(**cfg, device="cuda:0")
+            m.load_state_dict(sd)
+            if key == "rope":
+                # 3 frames x (3 x 5) patches = 45 video tokens: 23 + 22 over two ranks, one zero-padded row on the last
+                x = fx["x"][:, :, :, :6, :10].contiguous()
+                rope = CO.rope_3d(64, CO.crop_region((3, 5), 45, 30), (3, 5), 3)
+            else:
+                x, rope = fx["x"], None
+            call = lambda: m(x, fx["y"], fx["t"], image_rotary_emb=rope, return_dict=False)[0].float().cpu()
+            ref = call()
+            m.enable_parallel(1, world, False)
+            out = call()
+            res.append((key, torch.equal(out, ref), (out - ref).abs().max().item(), ref.abs().max().item()))
+        torch.cuda.synchronize()
+        bad = [r for r in res if not r[1]]
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write("ok" if not bad else f"mismatch (scheme, equal, max|diff|, max|ref|): {bad}")
+    except Exception:
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_cogvideox_ulysses_two_ranks_equals_single():
+    """CogVideoX Ulysses (cogvideox_transformer_3d.py:45-86,112-123,160-165,530-532,569-570): heads split 2 ways, the video rows
+    sharded at rest with the text rows replicated."""
+    _run(_cogvideox_worker, ())
+
+
+@pytest.mark.parametrize("T,HW", [(5, 16), (4, 12)])
+def test_stdit3_dsp_two_ranks_equals_single(T, HW):
+    """Open-Sora DSP (open_sora_transformer_3d.py:288-315,598-619): T = 5 needs the temporal zero-pad (5 -> 6 over 2 ranks),
+    HW = 12 -> S = 36 tokens per frame split 18 / 18."""
+    _run(_stdit3_worker, (T, HW))
+
+
+def test_bench_two_ranks_dry_run():
+    """bench.py's N > 1 path (rank-0 build, barriers, DSP model, max-over-ranks timing, one JSON line from rank 0), launched the
+    way the driver launches it, with both ranks on the one GPU of the test box over gloo (VSYS_BENCH_ONE_GPU=1), depth 2."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = dict(os.environ, VSYS_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--depth", "2", "--no-cpu-baseline", "--no-vae"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
+    assert j["roofline"]["frac"] > 0

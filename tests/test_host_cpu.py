@@ -186,3 +186,57 @@ def test_dsp_two_ranks_gloo(T, S):
         p.join(timeout=60)
     for rank, status in res:
         assert status == "ok", f"rank {rank}: {status}"
+
+
+# ------------------------------------------------------------------------------------------------ Ulysses over gloo
+def _ulysses_worker(rank, world, port, B, Lt, Lv, C, ret):
+    try:
+        from videosys_amd import dsp
+
+        dsp.initialize(rank=rank, world_size=world, init_method=f"tcp://127.0.0.1:{port}", backend="gloo")
+        pm = dsp.ParallelManager(1, 1, world)
+        up = dsp.UlyssesParallel(pm.sp_group, copy_executor=torch_copy_executor)
+        Lvl = up.shard_len(Lv)
+        hw = C // world
+        g = torch.Generator().manual_seed(321)
+        full = torch.randn(B, Lt + Lv, 3 * C, generator=g).to(torch.bfloat16)      # q | k | v of the whole sequence
+        attn = torch.randn(B, Lt + Lv, C, generator=g).to(torch.bfloat16)          # attention output, all heads
+
+        def local_rows(t):  # [text | this rank's video shard, zero padded] as the model holds them at rest
+            out = torch.zeros(B, Lt + Lvl, t.shape[-1], dtype=t.dtype)
+            out[:, :Lt] = t[:, :Lt]
+            nv = max(0, min(Lvl, Lv - rank * Lvl))
+            out[:, Lt:Lt + nv] = t[:, Lt + rank * Lvl: Lt + rank * Lvl + nv]
+            return out
+
+        # what the reference computes: all_to_all_comm(scatter heads, gather sequence) + _remove_extra_encoder
+        # (cogvideox_transformer_3d.py:45-62,112-123) == the rank's head slice of q, k, v over the whole un-padded sequence
+        want = torch.cat([full[..., i * C + rank * hw: i * C + (rank + 1) * hw] for i in range(3)], -1)
+        got = up.scatter_heads(local_rows(full).view(-1, 3 * C), B, Lt, Lv, C)
+        assert torch.equal(got.view(B, Lt + Lv, 3 * hw), want), "scatter_heads"
+        # way back: _add_extra_encoder + all_to_all_comm(scatter sequence, gather heads) (:64-86,160-165)
+        back = up.gather_heads(attn[..., rank * hw:(rank + 1) * hw].contiguous().view(-1, hw), B, Lt, Lv, C)
+        assert torch.equal(back.view(B, Lt + Lvl, C), local_rows(attn)), "gather_heads"
+        ret.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+
+        ret.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("Lt,Lv", [(3, 10), (5, 7)])
+def test_ulysses_two_ranks_gloo(Lt, Lv):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ulysses_worker, args=(r, 2, port, 2, Lt, Lv, 32, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [ret.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in res:
+        assert status == "ok", f"rank {rank}: {status}"

@@ -141,9 +141,20 @@ class CogVideoXTransformer3DModel:
         self.w["_proj_out.weight"], self.w["_proj_out.bias"] = dev(po), dev(pb)
         return self
 
-    def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None):
-        if (sp_size or 1) > 1:
-            raise NotImplementedError("CogVideoX Ulysses sequence parallelism is not built in this round")
+    def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None, parallel_mgr=None, copy_executor=None):
+        """cogvideox_transformer_3d.py:466-477.  Video tokens are sharded at rest (text rows replicated, :530-532); attention
+        exchanges sequence for heads (Ulysses, :112-123,160-165).  cp (CFG batch split) is not built: accepted and ignored."""
+        from . import dsp
+
+        self.parallel_manager = parallel_mgr if parallel_mgr is not None else dsp.ParallelManager(dp_size or 1, 1, sp_size or 1)
+        P = self.parallel_manager.sp_size
+        if P > 1:
+            if self.H % P:
+                raise ValueError(f"Number of heads {self.H} must be divisible by sequence parallel size {P}")
+            kw = {} if copy_executor is None else {"copy_executor": copy_executor}
+            self._sp = dsp.UlyssesParallel(self.parallel_manager.sp_group, **kw)
+        else:
+            self._sp = None
 
     def reset_pab_state(self):
         self.attn_count = [0] * self.L
@@ -180,7 +191,13 @@ class CogVideoXTransformer3DModel:
             raise ValueError("batch sizes of latents and encoder_hidden_states do not agree")
         Hp, Wp = Hh // p, Ww // p
         Lv = Fr * Hp * Wp
-        L = Lt + Lv
+        L = Lt + Lv          # rows of a sample in the attention
+        sp = getattr(self, "_sp", None)
+        Lvl = Lv if sp is None else sp.shard_len(Lv)   # video rows of a sample held by this rank
+        v0 = 0 if sp is None else sp.rank * Lvl
+        nv = max(0, min(Lvl, Lv - v0))                # ... of which real (the rest is set_pad("pad") zero padding, :531)
+        Ll = Lt + Lvl        # rows of a sample at rest
+        Hl = H if sp is None else H // sp.P
         dev = self.device
         # 1. time embedding and every modulation row of the step
         ts_host = torch.as_tensor(timestep).detach().to("cpu").float().reshape(-1)
@@ -192,20 +209,25 @@ class CogVideoXTransformer3DModel:
         mod = ops.linear_small(emb, w["_mod.weight"], w["_mod.bias"], act_in=ops.ACT_SILU)  # [B, (2L + 1) * 6C]
         ms = mod.shape[1]
         # 2. patch embedding straight into the joint buffer [B, Lt + Lv, C]
-        x = self._buf("x", (B * L, C))
+        x = self._buf("x", (B * Ll, C))
         txt = encoder_hidden_states.to(device=dev, dtype=self.dtype).reshape(B * Lt, -1).contiguous()
         cols = ops.im2col_patch(hidden_states.to(device=dev, dtype=torch.float32).contiguous(), B, p)
+        if nv < Lvl:
+            x.view(B, Ll, C)[:, Lt + nv:].zero_()
         for b in range(B):
             ops.gemm(txt[b * Lt:(b + 1) * Lt], w["patch_embed.text_proj.weight"], w["patch_embed.text_proj.bias"],
-                     out=x[b * L: b * L + Lt])
-            ops.gemm(cols[b * Lv:(b + 1) * Lv], w["patch_embed.proj.weight"], w["patch_embed.proj.bias"], out=x[b * L + Lt:(b + 1) * L])
-            if not cfgm.use_rotary_positional_embeddings:
-                ops.add_bcast_rows(x[b * L + Lt:(b + 1) * L], self._pos3d, 1, Lv)
+                     out=x[b * Ll: b * Ll + Lt])
+            if nv:
+                ops.gemm(cols[b * Lv + v0: b * Lv + v0 + nv], w["patch_embed.proj.weight"], w["patch_embed.proj.bias"],
+                         out=x[b * Ll + Lt: b * Ll + Lt + nv])
+                if not cfgm.use_rotary_positional_embeddings:
+                    ops.add_bcast_rows(x[b * Ll + Lt: b * Ll + Lt + nv], self._pos3d[v0:v0 + nv], 1, nv)
         cos, sin = self._rope(image_rotary_emb if cfgm.use_rotary_positional_embeddings else None)
         use_pab = pab.enable_pab()
         timestep_int = int(ts_host[0]) if use_pab else None
-        kp, vt = self._kv(B, L)
+        kp, vt = self._kv(B, L, Hl)
         C6 = 6 * C
+        hw = Hl * 64
         for i in range(self.L):
             pre = f"transformer_blocks.{i}"
             m1 = mod[:, (2 * i) * C6:(2 * i + 1) * C6]  # shift, scale, gate, enc_shift, enc_scale, enc_gate
@@ -214,39 +236,49 @@ class CogVideoXTransformer3DModel:
             if use_pab:
                 bc, self.attn_count[i] = pab.if_broadcast_spatial(timestep_int, self.attn_count[i])
             if not bc:
-                xm = ops.ln_modulate(x, w[pre + ".norm1.norm.weight"], w[pre + ".norm1.norm.bias"], m1[0, 0:C], m1[0, C:2 * C], L,
-                                     mod_stride=ms, seg_split=Lt, mod_alt=3 * C, eps=cfgm.norm_eps, out=self._buf("xm", (B * L, C)))
-                qkv = ops.gemm(xm, w[pre + ".attn1.qkv.weight"], w[pre + ".attn1.qkv.bias"], out=self._buf("qkv", (B * L, 3 * C)))
-                ops.attn_prep_kv64(qkv[:, C:2 * C], qkv[:, 2 * C:], w[pre + ".attn1.norm_k.weight"], w[pre + ".attn1.norm_k.bias"],
-                                   cos, sin, Lt, kp, vt, B, H, L)
-                ao = self._buf("attn_out", (B * L, C))
-                ops.flash_attn64(qkv[:, :C], w[pre + ".attn1.norm_q.weight"], w[pre + ".attn1.norm_q.bias"], cos, sin, Lt, kp, vt,
-                                 ao, B, H, L, L)
+                xm = ops.ln_modulate(x, w[pre + ".norm1.norm.weight"], w[pre + ".norm1.norm.bias"], m1[0, 0:C], m1[0, C:2 * C], Ll,
+                                     mod_stride=ms, seg_split=Lt, mod_alt=3 * C, eps=cfgm.norm_eps, out=self._buf("xm", (B * Ll, C)))
+                qkv = ops.gemm(xm, w[pre + ".attn1.qkv.weight"], w[pre + ".attn1.qkv.bias"], out=self._buf("qkv", (B * Ll, 3 * C)))
+                if sp is not None:  # sequence -> heads: this rank's H/P heads over the whole [text | video] sequence
+                    qkv = sp.scatter_heads(qkv, B, Lt, Lv, C, out=self._buf("qkv_h", (B, L, 3 * hw)))
+                ops.attn_prep_kv64(qkv[:, hw:2 * hw], qkv[:, 2 * hw:], w[pre + ".attn1.norm_k.weight"], w[pre + ".attn1.norm_k.bias"],
+                                   cos, sin, Lt, kp, vt, B, Hl, L)
+                ao = self._buf("attn_out_h" if sp is not None else "attn_out", (B * L, hw))
+                ops.flash_attn64(qkv[:, :hw], w[pre + ".attn1.norm_q.weight"], w[pre + ".attn1.norm_q.bias"], cos, sin, Lt, kp, vt,
+                                 ao, B, Hl, L, L)
+                if sp is not None:  # heads -> sequence
+                    ao = sp.gather_heads(ao, B, Lt, Lv, C, out=self._buf("attn_out", (B, Ll, C)))
             if use_pab:
                 # the cache holds the UN-gated attention output (:284-286); it is re-gated with this step's gate (:288-289)
                 if not bc:
                     if self.last_attn[i] is None or self.last_attn[i].shape != x.shape:
                         self.last_attn[i] = torch.empty_like(x)
                     ops.gemm(ao, w[pre + ".attn1.to_out.0.weight"], w[pre + ".attn1.to_out.0.bias"], out=self.last_attn[i])
-                ops.gate_add_rows(x, self.last_attn[i], m1[0, 2 * C:3 * C], L, ms, Lt, 3 * C)
+                ops.gate_add_rows(x, self.last_attn[i], m1[0, 2 * C:3 * C], Ll, ms, Lt, 3 * C)
             else:
-                ops.gemm_gate2(ao, w[pre + ".attn1.to_out.0.weight"], w[pre + ".attn1.to_out.0.bias"], m1[0, 2 * C:3 * C], ms, L, Lt,
+                ops.gemm_gate2(ao, w[pre + ".attn1.to_out.0.weight"], w[pre + ".attn1.to_out.0.bias"], m1[0, 2 * C:3 * C], ms, Ll, Lt,
                                3 * C, res=x, out=x)
-            xm = ops.ln_modulate(x, w[pre + ".norm2.norm.weight"], w[pre + ".norm2.norm.bias"], m2[0, 0:C], m2[0, C:2 * C], L,
-                                 mod_stride=ms, seg_split=Lt, mod_alt=3 * C, eps=cfgm.norm_eps, out=self._buf("xm", (B * L, C)))
+            xm = ops.ln_modulate(x, w[pre + ".norm2.norm.weight"], w[pre + ".norm2.norm.bias"], m2[0, 0:C], m2[0, C:2 * C], Ll,
+                                 mod_stride=ms, seg_split=Lt, mod_alt=3 * C, eps=cfgm.norm_eps, out=self._buf("xm", (B * Ll, C)))
             hb = ops.gemm(xm, w[pre + ".ff.net.0.proj.weight"], w[pre + ".ff.net.0.proj.bias"], epilogue=ops.EPI_BIAS_GELU,
-                          out=self._buf("mlp_h", (B * L, w[pre + ".ff.net.0.proj.weight"].shape[0])))
-            ops.gemm_gate2(hb, w[pre + ".ff.net.2.weight"], w[pre + ".ff.net.2.bias"], m2[0, 2 * C:3 * C], ms, L, Lt, 3 * C, res=x,
+                          out=self._buf("mlp_h", (B * Ll, w[pre + ".ff.net.0.proj.weight"].shape[0])))
+            ops.gemm_gate2(hb, w[pre + ".ff.net.2.weight"], w[pre + ".ff.net.2.bias"], m2[0, 2 * C:3 * C], ms, Ll, Lt, 3 * C, res=x,
                            out=x)
         # 3. norm_final -> norm_out (AdaLayerNorm, chunk_dim=1: shift, scale) -> proj_out -> unpatchify, video rows only
         mo = mod[:, 2 * self.L * C6:]
-        xv = self._buf("xm", (B * Lv, C))
+        xv = self._buf("xm", (B * Lvl, C))
         for b in range(B):
-            ops.ln_modulate(x[b * L + Lt:(b + 1) * L], w["norm_final.weight"], w["norm_final.bias"], None, None, Lv,
-                            eps=cfgm.norm_eps, out=xv[b * Lv:(b + 1) * Lv])
-        xo = ops.ln_modulate(xv, w["norm_out.norm.weight"], w["norm_out.norm.bias"], mo[0, 0:C], mo[0, C:2 * C], Lv, mod_stride=ms,
-                             eps=cfgm.norm_eps, out=self._buf("attn_out", (B * Lv, C)))
-        po = ops.gemm(xo, w["_proj_out.weight"], w["_proj_out.bias"], out=self._buf("proj", (B * Lv, 192)))
+            ops.ln_modulate(x[b * Ll + Lt:(b + 1) * Ll], w["norm_final.weight"], w["norm_final.bias"], None, None, Lvl,
+                            eps=cfgm.norm_eps, out=xv[b * Lvl:(b + 1) * Lvl])
+        xo = ops.ln_modulate(xv, w["norm_out.norm.weight"], w["norm_out.norm.bias"], mo[0, 0:C], mo[0, C:2 * C], Lvl, mod_stride=ms,
+                             eps=cfgm.norm_eps, out=self._buf("attn_out", (B * Lvl, C)))
+        po = ops.gemm(xo, w["_proj_out.weight"], w["_proj_out.bias"], out=self._buf("proj", (B * Lvl, 192)))
+        if sp is not None:  # gather_sequence (:569-570) on the projected rows (192 columns instead of C), padding dropped
+            import torch.distributed as dist
+
+            parts = torch.empty(sp.P, B, Lvl, 192, dtype=po.dtype, device=dev)
+            dist.all_gather_into_tensor(parts.view(sp.P * B, Lvl, 192), po.view(B, Lvl, 192).contiguous(), group=sp.group)
+            po = parts.permute(1, 0, 2, 3).reshape(B, sp.P * Lvl, 192)[:, :Lv].reshape(B * Lv, 192).contiguous()
         out = ops.unpatchify_cvx(po, B, Fr, Hp, Wp, cfgm.out_channels, p)
         if not return_dict:
             return (out,)
@@ -254,10 +286,11 @@ class CogVideoXTransformer3DModel:
 
     __call__ = forward
 
-    def _kv(self, batch, kv_len):
-        key = ("kv", batch, kv_len)
+    def _kv(self, batch, kv_len, heads=None):
+        heads = heads or self.H
+        key = ("kv", batch, kv_len, heads)
         if key not in self._ws:
-            self._ws[key] = ops.alloc_kv_buffers64(batch, self.H, kv_len, self.device)
+            self._ws[key] = ops.alloc_kv_buffers64(batch, heads, kv_len, self.device)
         return self._ws[key]
 
 

@@ -215,3 +215,86 @@ class SequenceParallel:
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, unpack)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Ulysses head/sequence exchange for CogVideoX's joint [text | video] attention
+# (cogvideox_transformer_3d.py:45-86 _remove/_add_extra_encoder, :112-123 and :160-165 all_to_all_comm).
+# At rest a rank holds rows [text Lt | its video shard Lvl] of every sample; attention needs the FULL sequence for H/P heads.
+# The reference sends the (replicated) text rows through the all-to-all and drops P-1 copies afterwards; here the text rows of
+# q, k, v never travel (every rank already has them for all heads) and travel once on the way back (a rank computed the
+# attention of the text rows for its own heads only).
+# ---------------------------------------------------------------------------------------------------------
+def plan_heads_scatter(B, Lt, Lvl, Lv, C, P, rank):
+    """qkv local [B, Lt+Lvl, 3C] -> send [P][B][Lvl][3][C/P]; recv (same shape, indexed by source) + local text ->
+    qkv_h [B, Lt+Lv, 3*C/P] (q | k | v column blocks of this rank's heads, full sequence, padding rows dropped)."""
+    hw = C // P
+    Ll, L = Lt + Lvl, Lt + Lv
+    pack = [CopyOp(Lt * 3 * C + r * hw, r * B * Lvl * 3 * hw, B, Lvl, 3, hw, (Ll * 3 * C, 3 * C, C), (Lvl * 3 * hw, 3 * hw, hw), Lvl, 3)
+            for r in range(P)]
+    unpack = [CopyOp(rank * hw, 0, B, Lt, 3, hw, (Ll * 3 * C, 3 * C, C), (L * 3 * hw, 3 * hw, hw), Lt, 3)]  # from the LOCAL qkv
+    unpack_recv = []
+    for s in range(P):
+        valid = max(0, min(Lvl, Lv - s * Lvl))
+        if valid > 0:
+            unpack_recv.append(CopyOp(s * B * Lvl * 3 * hw, (Lt + s * Lvl) * 3 * hw, B, valid, 1, 3 * hw, (Lvl * 3 * hw, 3 * hw, 3 * hw),
+                                      (L * 3 * hw, 3 * hw, 3 * hw), valid, 1))
+    return pack, unpack, unpack_recv, (P, B, Lvl, 3, hw), (B, L, 3 * hw)
+
+
+def plan_heads_gather(B, Lt, Lvl, Lv, C, P):
+    """attention output of this rank's heads [B, Lt+Lv, C/P] -> send [P][B][Lt+Lvl][C/P] (text rows to everyone, video rows
+    to their owner, zero rows past Lv); recv -> local [B, Lt+Lvl, C] (column block s from source s)."""
+    hw = C // P
+    Ll, L = Lt + Lvl, Lt + Lv
+    pack = []
+    for r in range(P):
+        base = r * B * Ll * hw
+        pack.append(CopyOp(0, base, B, Lt, 1, hw, (L * hw, hw, hw), (Ll * hw, hw, hw), Lt, 1))
+        valid = max(0, min(Lvl, Lv - r * Lvl))
+        pack.append(CopyOp((Lt + r * Lvl) * hw if valid > 0 else 0, base + Lt * hw, B, Lvl, 1, hw, (L * hw, hw, hw), (Ll * hw, hw, hw), valid, 1))
+    unpack = [CopyOp(s * B * Ll * hw, s * hw, B, Ll, 1, hw, (Ll * hw, hw, hw), (Ll * C, C, C), Ll, 1) for s in range(P)]
+    return pack, unpack, (P, B, Ll, hw), (B, Ll, C)
+
+
+class UlyssesParallel:
+    """Head <-> sequence exchange of one rank (packed buffers + all_to_all_single, like SequenceParallel)."""
+
+    def __init__(self, group, copy_executor: Callable = hip_copy_executor):
+        self.group = group
+        self.P = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.exec = copy_executor
+        self._bufs = {}
+
+    _buf = SequenceParallel._buf
+
+    def shard_len(self, Lv):
+        return -(-Lv // self.P)
+
+    def scatter_heads(self, qkv, B, Lt, Lv, C, out=None):
+        """qkv [B*(Lt+Lvl), 3C] (local rows) -> [B*(Lt+Lv), 3C/P] (this rank's heads, whole sequence)."""
+        Lvl = self.shard_len(Lv)
+        pack, unpack_local, unpack_recv, sshape, oshape = plan_heads_scatter(B, Lt, Lvl, Lv, C, self.P, self.rank)
+        send = self._buf("u_send", sshape, qkv)
+        recv = self._buf("u_recv", sshape, qkv)
+        self.exec(qkv, send, pack)
+        dist.all_to_all_single(recv, send, group=self.group)
+        if out is None:
+            out = torch.empty(oshape, dtype=qkv.dtype, device=qkv.device)
+        self.exec(qkv, out, unpack_local)
+        self.exec(recv, out, unpack_recv)
+        return out.view(oshape[0] * oshape[1], oshape[2])
+
+    def gather_heads(self, ao, B, Lt, Lv, C, out=None):
+        """ao [B*(Lt+Lv), C/P] -> [B*(Lt+Lvl), C] (all heads, local rows)."""
+        Lvl = self.shard_len(Lv)
+        pack, unpack, sshape, oshape = plan_heads_gather(B, Lt, Lvl, Lv, C, self.P)
+        send = self._buf("g_send", sshape, ao)
+        recv = self._buf("g_recv", sshape, ao)
+        self.exec(ao, send, pack)
+        dist.all_to_all_single(recv, send, group=self.group)
+        if out is None:
+            out = torch.empty(oshape, dtype=ao.dtype, device=ao.device)
+        self.exec(recv, out, unpack)
+        return out.view(oshape[0] * oshape[1], oshape[2])

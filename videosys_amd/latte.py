@@ -27,7 +27,7 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
-from . import ops, pab
+from . import dsp, ops, pab
 
 
 def _sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
@@ -83,6 +83,7 @@ class LatteT2V:
         self.device, self.dtype = torch.device(device), dtype
         self.w: Dict[str, torch.Tensor] = {}
         self.parallel_manager = SimpleNamespace(sp_size=1, cp_size=1, dp_size=1, dp_rank=0, sp_group=None, cp_group=None)
+        self._sp = None
         self.states = [_BlockState(i // 2, bool(i % 2)) for i in range(2 * num_layers)]
         self._pos_cache, self._ws = {}, {}
         self._text_cache = None
@@ -131,9 +132,16 @@ class LatteT2V:
         self._text_cache = None
         return self
 
-    def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None):
-        if (sp_size or 1) > 1:
-            raise NotImplementedError("Latte sequence parallelism is not built in this round (Open-Sora DSP is)")
+    def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None, parallel_mgr=None, copy_executor=None):
+        """latte_transformer_3d.py:1127-1140.  Frames are sharded at rest (split_from_second_dim :1469-1475): spatial blocks
+        and cross-attention need no exchange; each temporal block switches to the pixel shard around its attention
+        (dynamic_switch :826-843).  cp (CFG batch split) is not built: enable_cp is accepted and ignored."""
+        self.parallel_manager = parallel_mgr if parallel_mgr is not None else dsp.ParallelManager(dp_size or 1, 1, sp_size or 1)
+        if self.parallel_manager.sp_size > 1:
+            kw = {} if copy_executor is None else {"copy_executor": copy_executor}
+            self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
+        else:
+            self._sp = None
 
     # ------------------------------------------------------------------ helpers
     def _buf(self, name, shape):
@@ -214,8 +222,24 @@ class LatteT2V:
             self._pos_cache[pkey] = latte_pos_embed_2d(C, gh, gw, self.config.sample_size // p, interp).to(
                 device=dev, dtype=self.dtype).contiguous()
         # (b f) frames of one sample are consecutive, exactly the [B, T, S, C] layout of the patch-embed kernel
-        xz = hidden_states.to(device=dev, dtype=torch.float32).contiguous()
-        x = ops.patch_embed(xz, w["pos_embed.proj.weight"], w["pos_embed.proj.bias"], self._pos_cache[pkey], B, (1, p, p), C)
+        xz = hidden_states.to(device=dev, dtype=torch.float32)
+        sp = self._sp
+        Fa, f0 = Fr, 0          # frames in the (temporal) attention / first frame of this rank
+        tpe = self.temp_pos_embed
+        if sp is not None:
+            # frame shard at rest: rank r owns frames [r*Tl, (r+1)*Tl), zero latents past the end (set_pad("temporal") :1301)
+            Tl = -(-Fr // sp.P)
+            f0 = sp.rank * Tl
+            loc = torch.zeros(Bz, cin, Tl, Hh, Ww, dtype=torch.float32, device=dev)
+            nv = max(0, min(Tl, Fr - f0))
+            if nv:
+                loc[:, :, :nv] = xz[:, :, f0:f0 + nv]
+                tl = torch.zeros(Tl, C, dtype=tpe.dtype, device=dev)
+                tl[:nv] = tpe[f0:f0 + nv]
+            else:
+                tl = torch.zeros(Tl, C, dtype=tpe.dtype, device=dev)
+            xz, tpe, Fr = loc, tl, Tl
+        x = ops.patch_embed(xz.contiguous(), w["pos_embed.proj.weight"], w["pos_embed.proj.bias"], self._pos_cache[pkey], B, (1, p, p), C)
         x = x.view(B * Fr * S, C)
 
         timestep_int = int(ts_host[0]) if pab.enable_pab() else None
@@ -223,27 +247,49 @@ class LatteT2V:
         for d in range(self.L):
             x = self._spatial_block(2 * d, x, mod[2 * d], txt, B, Fr, S, timestep_int, ats)
             if enable_temporal_attentions:
-                if d == 0 and Fr > 1:
-                    ops.add_bcast_rows(x, self.temp_pos_embed, S, Fr)  # hidden + temp_pos_embed (:1410-1411)
-                x = self._temporal_block(2 * d + 1, x, mod[2 * d + 1], B, Fr, S, timestep_int, ats)
+                if d == 0 and Fa > 1:
+                    ops.add_bcast_rows(x, tpe, S, Fr)  # hidden + temp_pos_embed (:1410-1411)
+                x = self._temporal_block(2 * d + 1, x, mod[2 * d + 1], B, Fr, S, timestep_int, ats, Fa)
         out = ops.final_layer(x, w["scale_shift_table"], emb, w["proj_out.weight"], w["proj_out.bias"], B, Fr, gh, gw, Hh, Ww,
                               (1, p, p), self.out_channels)
+        if sp is not None:  # gather_from_second_dim (:1477-1482): frames of all ranks, time padding dropped
+            import torch.distributed as dist
+
+            parts = torch.empty(sp.P, *out.shape, dtype=out.dtype, device=dev)
+            dist.all_gather_into_tensor(parts.view(sp.P * out.shape[0], *out.shape[1:]), out.contiguous(), group=sp.group)
+            out = parts.permute(1, 2, 0, 3, 4, 5).reshape(B, self.out_channels, sp.P * Fr, Hh, Ww)[:, :, :Fa].contiguous()
         if not return_dict:
             return (out,)
         return SimpleNamespace(sample=out)
 
     __call__ = forward
 
-    def _self_attn_out(self, i, x, mod_i, B, Fr, S, st, use_pab, temporal):
-        """norm1 + modulate, attn1, gate, residual (+ PAB slab).  x: [B*Fr*S, C] rows ordered (b, f, s)."""
+    def _self_attn_out(self, i, x, mod_i, B, Fr, S, st, use_pab, temporal, Fa=None):
+        """norm1 + modulate, attn1, gate, residual (+ PAB slab).  x: [B*Fr*S, C] rows ordered (b, f, s).  Under sequence
+        parallelism Fr is the local frame count and Fa the global one: the temporal attention runs on the pixel shard."""
         w, C, H = self.w, self.C, self.H
         p = self.block_prefix(i)
         N, C6 = B * Fr * S, 6 * C
         shift, scale, gate = mod_i[0, 0:C], mod_i[0, C:2 * C], mod_i[0, 2 * C:3 * C]
         xm = ops.adaln_modulate(x, shift, scale, Fr * S, C6, eps=self.config.norm_eps, out=self._buf("xm", (N, C)))
-        qkv = self._gemm(xm, p + ".attn1.qkv", out=self._buf("qkv", (N, 3 * C)))
-        ao = self._buf("attn_out", (N, C))
-        if temporal:
+        if temporal and self._sp is not None:
+            # [B, Tl, S, C] -> all-to-all -> [B, Fa, Sl, C]: every frame of 1/P of the pixels (the modulated activations travel,
+            # one C-wide tensor instead of q, k and v), attention, and back
+            sp = self._sp
+            Sl = -(-S // sp.P)
+            xs = sp.to_spatial_shard(xm.view(B, Fr, S, C), Fa, Sl, out=self._buf("sp_x", (B, Fa, Sl, C)))
+            Ns = B * Fa * Sl
+            qkv = self._gemm(xs.view(Ns, C), p + ".attn1.qkv", out=self._buf("qkv", (Ns, 3 * C)))
+            aos = self._buf("sp_ao", (Ns, C))
+            ops.attn_temporal(qkv, C, None, None, None, None, aos, B, Fa, Sl, H)
+            ao = sp.to_temporal_shard(aos.view(B, Fa, Sl, C), S, out=self._buf("attn_out", (B, Fr, S, C))).view(N, C)
+            qkv = None
+        else:
+            qkv = self._gemm(xm, p + ".attn1.qkv", out=self._buf("qkv", (N, 3 * C)))
+            ao = self._buf("attn_out", (N, C))
+        if temporal and qkv is None:
+            pass
+        elif temporal:
             ops.attn_temporal(qkv, C, None, None, None, None, ao, B, Fr, S, H)
         else:
             key = ("kv_spatial", B * Fr, S)
@@ -319,7 +365,7 @@ class LatteT2V:
         self._ff(i, x, mod_i, B, Fr, S, st, timestep_int, ats, temporal=False)
         return x
 
-    def _temporal_block(self, i, x, mod_i, B, Fr, S, timestep_int, ats):
+    def _temporal_block(self, i, x, mod_i, B, Fr, S, timestep_int, ats, Fa=None):
         """BasicTransformerBlock_.forward (latte_transformer_3d.py:680-824) on the (b, f, s)-ordered rows."""
         st = self.states[i]
         use_pab = pab.enable_pab()
@@ -329,7 +375,7 @@ class LatteT2V:
         if bc:
             ops.add_rows(x, st.last_attn)
         else:
-            self._self_attn_out(i, x, mod_i, B, Fr, S, st, use_pab, temporal=True)
+            self._self_attn_out(i, x, mod_i, B, Fr, S, st, use_pab, temporal=True, Fa=Fa)
         self._ff(i, x, mod_i, B, Fr, S, st, timestep_int, ats, temporal=True)
         return x
 
