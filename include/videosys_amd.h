@@ -195,6 +195,11 @@ int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const
                            const void* rope_cos_f32, const void* rope_sin_f32, void* out, int64_t out_stride, int64_t B,
                            int64_t T, int64_t S, int64_t heads, float eps, void* stream);
 
+/* Up to 16 vsys_copy_4d problems over one (src, dst) pair in a single launch: the per-peer pack (or unpack) pieces of a DSP /
+ * Ulysses all-to-all (comm.py:104-108,282-304; cogvideox_transformer_3d.py:45-86).  desc (HOST) holds nops x 14 int64:
+ * src_off, dst_off, n0, n1, n2, run, ss0, ss1, ss2, ds0, ds1, ds2, n1_valid, n2_valid (elements; run % 8 == 0). */
+int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* desc, void* stream);
+
 /* ---- VAE decode (VideoAutoencoderPipeline.decode, autoencoder_kl_open_sora.py:672-695) --------------
  * Activations are channels-last bf16 row matrices over a grid; a grid is described by int64 g[6] = {T, H, W, pad, tf,
  * sample_rows}: sample n, frame t, pixel (h, w) is row n*sample_rows + ((t + tf)*(H + 2 pad) + h + pad)*(W + 2 pad) + w + pad.

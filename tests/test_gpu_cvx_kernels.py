@@ -85,7 +85,18 @@ def test_ln_modulate_two_segments_and_plain():
     check(y3, torch.nn.functional.layer_norm(xs.float(), (1920,), None, None, 1e-6), what="LayerNorm no affine")
 
 
-def test_gemm_gate2_and_gate_add_rows():
+@pytest.mark.parametrize("variant", [0, 8, 20])
+def test_gemm_gate2_and_gate_add_rows(variant):
+    from videosys_amd import _lib
+
+    _lib.load().vsys_tune_gemm_variant(variant)
+    try:
+        _gemm_gate2_and_gate_add_rows()
+    finally:
+        _lib.load().vsys_tune_gemm_variant(0)
+
+
+def _gemm_gate2_and_gate_add_rows():
     from videosys_amd import ops
 
     B, Lt, Lv, C, K = 2, 30, 500, 576, 192

@@ -47,8 +47,19 @@ def ops():
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("variant", [0, 8, 20])
 @pytest.mark.parametrize("M,N,K", [(300, 192, 64), (1000, 576, 576), (257, 384, 128), (2048, 1152, 1152)])
-def test_gemm_bias(ops, M, N, K):
+def test_gemm_bias(ops, M, N, K, variant):
+    from videosys_amd import _lib
+
+    _lib.load().vsys_tune_gemm_variant(variant)
+    try:
+        _gemm_bias(ops, M, N, K)
+    finally:
+        _lib.load().vsys_tune_gemm_variant(0)
+
+
+def _gemm_bias(ops, M, N, K):
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
@@ -102,7 +113,20 @@ def test_gemm_is_transpose_exact(ops):
     assert torch.equal(out, x[:, perm])
 
 
-def test_gemm_gate_residual_aux(ops):
+@pytest.mark.parametrize("variant", [0, 8, 20, 103])
+def test_gemm_gate_residual_aux(ops, variant):
+    """variant 0 = the shape dispatch (small problems take the 128-row geometry); 8 / 20 / 103 force each kernel family
+    through the gate + residual + aux epilogue."""
+    from videosys_amd import _lib
+
+    _lib.load().vsys_tune_gemm_variant(variant)
+    try:
+        _gate_residual_aux(ops)
+    finally:
+        _lib.load().vsys_tune_gemm_variant(0)
+
+
+def _gate_residual_aux(ops):
     M, N, K, rps = 1100, 576, 1152, 400  # 3 samples, tiles straddle sample boundaries
     g = torch.Generator().manual_seed(11)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16)

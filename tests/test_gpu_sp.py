@@ -208,3 +208,32 @@ def test_bench_two_ranks_dry_run():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
     assert j["roofline"]["frac"] > 0
+
+
+def test_batched_copy_executor_matches_plan_semantics():
+    """hip_copy_executor (one vsys_copy_4d_batch launch per plan) against the element-wise definition of a copy plan, on the
+    pack / unpack plans of a 4-way DSP switch and of the Ulysses exchange (padding on the last shard in both)."""
+    from test_host_cpu import torch_copy_executor
+    from videosys_amd import dsp
+
+    g = torch.Generator().manual_seed(2)
+    B, T, S, C, P = 2, 5, 10, 16, 4
+    Sl = -(-S // P)
+    pack, unpack, sshape, oshape = dsp.plan_switch_to_temporal_shard(B, T, Sl, S, C, P)
+    x = torch.randn(B, T, Sl, C, generator=g).to(torch.bfloat16)
+    for plan, src_shape, dst_shape in ((pack, (B, T, Sl, C), sshape), (unpack, sshape, oshape)):
+        src = torch.randn(src_shape, generator=g).to(torch.bfloat16)
+        want = torch.full(dst_shape, 7.0, dtype=torch.bfloat16)
+        torch_copy_executor(src, want, plan)
+        got = torch.full(dst_shape, 7.0, dtype=torch.bfloat16, device="cuda:0")
+        dsp.hip_copy_executor(src.to("cuda:0"), got, plan)
+        assert torch.equal(got.cpu(), want)
+    Lt, Lv, Cc = 3, 9, 64
+    Lvl = -(-Lv // P)
+    pk, ul, ur, sshape, oshape = dsp.plan_heads_scatter(B, Lt, Lvl, Lv, Cc, P, 1)
+    src = torch.randn(B, Lt + Lvl, 3 * Cc, generator=g).to(torch.bfloat16)
+    want = torch.zeros(sshape, dtype=torch.bfloat16)
+    torch_copy_executor(src, want, pk)
+    got = torch.zeros(sshape, dtype=torch.bfloat16, device="cuda:0")
+    dsp.hip_copy_executor(src.to("cuda:0"), got, pk)
+    assert torch.equal(got.cpu(), want)

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--variants", default="0", help="comma list of GEMM pipeline variants to A/B (interleaved); 0 = default")
     ap.add_argument("--flash-variants", default="0")
     ap.add_argument("--only", default="", help="'gemm' = skip the non-GEMM kernels")
+    ap.add_argument("--rows", type=int, default=38912, help="token rows (38912 = config 2; 4864 = one rank of 8-way DSP)")
     args = ap.parse_args()
     import __graft_entry__ as ge
 
@@ -43,7 +44,7 @@ def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    N, C, H = 38912, 1152, 16
+    N, C, H = args.rows, 1152, 16
     res = {}
 
     def rnd(*shape, scale=1.0):

@@ -258,6 +258,22 @@ inline bool to_grid(const int64_t* g, VaeGrid& o) {
 }
 }  // namespace
 
+int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* desc, void* stream) {
+  if (!src || !dst || (nops > 0 && !desc)) return VSYS_ERR_ARG;
+  if (nops < 0 || nops > VSYS_COPY_BATCH_MAX) return VSYS_ERR_SHAPE;
+  CopyDesc ops[VSYS_COPY_BATCH_MAX];
+  for (int i = 0; i < (int)nops; ++i) {
+    const int64_t* d = desc + 14 * i;
+    for (int k = 2; k < 6; ++k) if (!fits_int(d[k])) return VSYS_ERR_SHAPE;
+    if (!fits_int(d[12]) || !fits_int(d[13]) || d[0] < 0 || d[1] < 0) return VSYS_ERR_SHAPE;
+    ops[i].src_off = d[0]; ops[i].dst_off = d[1];
+    ops[i].n0 = (int)d[2]; ops[i].n1 = (int)d[3]; ops[i].n2 = (int)d[4]; ops[i].C = (int)d[5];
+    ops[i].ss0 = d[6]; ops[i].ss1 = d[7]; ops[i].ss2 = d[8]; ops[i].ds0 = d[9]; ops[i].ds1 = d[10]; ops[i].ds2 = d[11];
+    ops[i].n1_valid = (int)d[12]; ops[i].n2_valid = (int)d[13];
+  }
+  return launch_copy_4d_batch(B16(src), B16(dst), ops, (int)nops, S(stream));
+}
+
 int vsys_conv_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* bias, const void* res, int64_t ldr,
                    void* out, void* out_f32, int64_t ldo, int64_t M, int64_t N, int64_t cin, int64_t kt, int64_t kh, int64_t kw,
                    int64_t row_pitch, int64_t plane_pitch, int64_t batch, int64_t batch_a, int64_t batch_w, int64_t batch_o,

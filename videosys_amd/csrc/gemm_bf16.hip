@@ -604,6 +604,10 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
       // Shape dispatch (config-2 A/B, tools/kernel_bench.py --variants 8,20): with a short K loop and a store-only epilogue
       // the two-workgroups-per-CU geometry wins (qkv 1152->3456 -3 %, fc1 1152->4608 -7 %); with K = 4608 or the
       // gate+residual epilogue the 8-wave kernel is 10-18 % faster.  Both produce identical bits.
+      // Few tiles (one rank of an 8-way DSP run has M = 4864: 114 tiles of 256 rows for the N = 1152 GEMMs on 256 CUs): the
+      // 128-row geometry (two 4-wave workgroups per CU, 512 slots) fills the chip; measured at M = 4864 against schedule 8:
+      // qkv -7 %, proj -15 %, fc2 -16 %, fc1 -2 % (tools/kernel_bench.py --rows 4864 --variants 8,20,103).
+      if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
       if (epi != EPI_GATE_RES && p.K <= 1536 && p.N >= 2304) return launch_gemm2(p, epi, 0, stream);
       return launch_gemm_t<8, 256>(p, epi, stream);
   }

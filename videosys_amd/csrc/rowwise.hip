@@ -462,7 +462,51 @@ __global__ void copy_4d_kernel(const bf16_t* __restrict__ src, bf16_t* __restric
   }
 }
 
+// several copy_4d problems over the same (src, dst) pair in ONE launch (blockIdx.y = problem): the P pack (or unpack) pieces
+// of a DSP / Ulysses all-to-all
+struct CopyBatch {
+  int nops;
+  CopyDesc d[VSYS_COPY_BATCH_MAX];
+};
+__global__ void copy_4d_batch_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, CopyBatch b) {
+  const CopyDesc& o = b.d[blockIdx.y];
+  const int cch = o.C >> 3;
+  const int64_t total = (int64_t)o.n0 * o.n1 * o.n2 * cch;
+  const bf16_t* s = src + o.src_off;
+  bf16_t* d = dst + o.dst_off;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cch);
+    int64_t r = i / cch;
+    const int i2 = (int)(r % o.n2);
+    r /= o.n2;
+    const int i1 = (int)(r % o.n1);
+    const int i0 = (int)(r / o.n1);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i1 < o.n1_valid && i2 < o.n2_valid) v = *reinterpret_cast<const uint4*>(s + i0 * o.ss0 + i1 * o.ss1 + i2 * o.ss2 + c * 8);
+    *reinterpret_cast<uint4*>(d + i0 * o.ds0 + i1 * o.ds1 + i2 * o.ds2 + c * 8) = v;
+  }
+}
+
 }  // namespace
+
+int launch_copy_4d_batch(const bf16_t* src, bf16_t* dst, const CopyDesc* ops, int nops, hipStream_t stream) {
+  if (nops <= 0) return 0;
+  if (nops > VSYS_COPY_BATCH_MAX) return VSYS_ERR_SHAPE;
+  CopyBatch b;
+  b.nops = nops;
+  int64_t most = 0;
+  for (int i = 0; i < nops; ++i) {
+    if (ops[i].C % 8 || ops[i].n0 < 0 || ops[i].n1 < 0 || ops[i].n2 < 0) return VSYS_ERR_SHAPE;
+    b.d[i] = ops[i];
+    const int64_t t = (int64_t)ops[i].n0 * ops[i].n1 * ops[i].n2 * (ops[i].C / 8);
+    most = t > most ? t : most;
+  }
+  if (most <= 0) return 0;
+  int64_t grid = (most + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(copy_4d_batch_kernel, dim3((unsigned)grid, (unsigned)nops), dim3(256), 0, stream, src, dst, b);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
 
 int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* scale, bf16_t* y, int64_t rows, int C,
                           int64_t rows_per_sample, int64_t mod_stride, float eps, hipStream_t stream) {

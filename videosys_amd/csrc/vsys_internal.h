@@ -82,6 +82,14 @@ int launch_add_bcast_rows(bf16_t* x, const bf16_t* e, int64_t rows, int C, int64
 int launch_add_rows(bf16_t* x, const bf16_t* y, int64_t n, hipStream_t stream);
 int launch_copy_4d(const bf16_t* src, bf16_t* dst, int n0, int n1, int n2, int C, int64_t ss0, int64_t ss1, int64_t ss2,
                    int64_t ds0, int64_t ds1, int64_t ds2, int n1_valid, int n2_valid, hipStream_t stream);
+constexpr int VSYS_COPY_BATCH_MAX = 16;
+struct CopyDesc {  // one copy_4d problem relative to a common (src, dst) pair; offsets and strides in elements
+  int64_t src_off, dst_off;
+  int n0, n1, n2, C;
+  int64_t ss0, ss1, ss2, ds0, ds1, ds2;
+  int n1_valid, n2_valid;
+};
+int launch_copy_4d_batch(const bf16_t* src, bf16_t* dst, const CopyDesc* ops, int nops, hipStream_t stream);
 int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* k_norm_w,
                         bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps,
                         hipStream_t stream);

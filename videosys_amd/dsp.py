@@ -148,12 +148,13 @@ def plan_gather(B, T, Sl, S, C, P):
 
 
 def hip_copy_executor(src: torch.Tensor, dst: torch.Tensor, ops: List[CopyOp]):
-    """The product executor: one vsys_copy_4d launch per op (device tensors only)."""
+    """The product executor: ONE vsys_copy_4d_batch launch for the whole plan (device tensors only)."""
     from . import ops as vops
 
-    s, d = src.view(-1), dst.view(-1)
-    for o in ops:
-        vops.copy_4d(s[o.src_off:], d[o.dst_off:], o.n0, o.n1, o.n2, o.run, o.sstr, o.dstr, o.n1_valid, o.n2_valid)
+    if not ops:
+        return
+    vops.copy_4d_batch(src.view(-1), dst.view(-1), [(o.src_off, o.dst_off, o.n0, o.n1, o.n2, o.run, *o.sstr, *o.dstr, o.n1_valid,
+                                                      o.n2_valid) for o in ops])
 
 
 class SequenceParallel:

@@ -195,6 +195,20 @@ def copy_4d(src, dst, n0, n1, n2, C, sstr, dstr, n1_valid=None, n2_valid=None):
     return dst
 
 
+def copy_4d_batch(src, dst, descs):
+    """descs: list of 14-tuples (src_off, dst_off, n0, n1, n2, run, ss0, ss1, ss2, ds0, ds1, ds2, n1_valid, n2_valid)."""
+    import ctypes
+
+    _chk(src, dst)
+    _bf16(src, dst)
+    lib = _lib.load()
+    for i in range(0, len(descs), 16):
+        part = descs[i:i + 16]
+        flat = [int(v) for d in part for v in d]
+        arr = (ctypes.c_int64 * len(flat))(*flat)
+        _lib.check(lib.vsys_copy_4d_batch(_p(src), _p(dst), len(part), arr, _stream()), "vsys_copy_4d_batch")
+
+
 def kv_pad_len(kv_len: int) -> int:
     return (kv_len + 63) // 64 * 64
 

@@ -162,6 +162,21 @@ class CogVideoXPipeline:
         self.scheduler = CogVideoXDDIMScheduler(snr_shift_scale=1.0 if base.endswith("5b") else 3.0)
         self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
+        self._set_parallel()
+
+    def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: Optional[bool] = False):
+        """pipeline_cogvideox.py:195-209: sp = world size unless given (then dp = world / sp)."""
+        import torch.distributed as dist
+
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        if world == 1:
+            return
+        if sp_size is None:
+            sp_size, dp_size = world, 1
+        else:
+            assert world % sp_size == 0, f"world_size {world} must be divisible by sp_size"
+            dp_size = world // sp_size
+        self.transformer.enable_parallel(dp_size, sp_size, enable_cp)
 
     def _prepare_rotary_positional_embeddings(self, height: int, width: int, num_frames: int):
         """pipeline_cogvideox.py:449-474."""
