@@ -200,6 +200,20 @@ int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const
  * src_off, dst_off, n0, n1, n2, run, ss0, ss1, ss2, ds0, ds1, ds2, n1_valid, n2_valid (elements; run % 8 == 0). */
 int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* desc, void* stream);
 
+/* ---- T5 text encoder (T5EncoderModel of transformers, third-party; called once per prompt at pipeline_open_sora.py:269-287,
+ * pipeline_cogvideox.py:211-247, pipeline_latte.py) — the linears are vsys_conv_bf16 with one tap. */
+/* out[i, :] = table[ids[i], :] (nn.Embedding; ids int64 on the device, clamped to [0, vocab)). */
+int vsys_gather_rows(const void* table, const void* ids_i64, void* out, int64_t n, int64_t C, int64_t vocab, void* stream);
+/* T5LayerNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)), fp32 statistics, C <= 8192. */
+int vsys_rms_norm_rows(const void* x, const void* w, void* y, int64_t rows, int64_t C, float eps, void* stream);
+/* T5DenseGatedActDense: out[r, f] = bf16(gelu_new(h[r, f])) * h[r, F + f], h = [wi_0 x | wi_1 x] of 2F columns. */
+int vsys_geglu(const void* h, void* out, int64_t rows, int64_t F, void* stream);
+/* T5Attention (encoder self-attention, d_kv = 64, no score scaling): softmax_j(q_i k_j + relbias[h][j - i + L - 1]) v over the
+ * first klen[b] keys.  qkv rows (b, l) of row_stride elements, q | k | v at column 0 | inner | 2 inner, head h at h*64;
+ * relbias fp32 [heads, 2L-1]; klen int32 [B] on the device; L <= 512. */
+int vsys_t5_attention(const void* qkv, int64_t row_stride, int64_t inner, const void* relbias_f32, const void* klen_i32, void* out,
+                      int64_t out_stride, int64_t B, int64_t L, int64_t heads, void* stream);
+
 /* ---- VAE decode (VideoAutoencoderPipeline.decode, autoencoder_kl_open_sora.py:672-695) --------------
  * Activations are channels-last bf16 row matrices over a grid; a grid is described by int64 g[6] = {T, H, W, pad, tf,
  * sample_rows}: sample n, frame t, pixel (h, w) is row n*sample_rows + ((t + tf)*(H + 2 pad) + h + pad)*(W + 2 pad) + w + pad.

@@ -1,0 +1,52 @@
+"""CPU: the T5-encoder oracle against the golden minted from the real transformers.T5EncoderModel (oracle/make_golden_t5.py) and
+against the live class (transformers is part of the image, here and on the GPU box); the host-side bucket function."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_t5_oracle_matches_transformers_golden():
+    from oracle import t5_oracle as TO
+    from videosys_amd.t5 import synth_state_dict
+
+    gold = load_golden("t5_small.pt")
+    cfg = gold["cfg"]
+    sd = synth_state_dict(seed=gold["seed"], **cfg)
+    out = TO.encode(sd, gold["ids"], gold["mask"], cfg["num_layers"], cfg["num_heads"])
+    assert (out - gold["out_fp32"]).abs().max().item() < 1e-4
+
+
+def test_t5_oracle_matches_live_transformers():
+    transformers = pytest.importorskip("transformers")
+    from oracle import make_golden_t5 as MG
+    from oracle import t5_oracle as TO
+    from videosys_amd.t5 import synth_state_dict
+
+    sd = synth_state_dict(seed=9, **MG.CFG)
+    g = torch.Generator().manual_seed(1)
+    ids = torch.randint(0, MG.CFG["vocab_size"], (1, 40), generator=g)
+    mask = torch.ones(1, 40, dtype=torch.long)
+    mask[0, 33:] = 0
+    with torch.no_grad():
+        ref = MG.hf_model(sd)(input_ids=ids, attention_mask=mask)["last_hidden_state"]
+    out = TO.encode(sd, ids, mask, MG.CFG["num_layers"], MG.CFG["num_heads"])
+    assert (out - ref).abs().max().item() < 1e-4
+
+
+def test_relative_position_bucket_matches_transformers():
+    pytest.importorskip("transformers")
+    from transformers.models.t5.modeling_t5 import T5Attention
+
+    from videosys_amd.t5 import relative_position_bucket
+
+    rel = torch.arange(-511, 512, dtype=torch.long)
+    want = T5Attention._relative_position_bucket(rel, bidirectional=True, num_buckets=32, max_distance=128)
+    assert torch.equal(relative_position_bucket(rel, 32, 128), want)
+
+
+def test_t5_needs_gpu():
+    from videosys_amd.t5 import T5Encoder
+
+    with pytest.raises(RuntimeError):
+        T5Encoder(device="cpu")

@@ -258,6 +258,32 @@ inline bool to_grid(const int64_t* g, VaeGrid& o) {
 }
 }  // namespace
 
+int vsys_gather_rows(const void* table, const void* ids_i64, void* out, int64_t n, int64_t C, int64_t vocab, void* stream) {
+  if (!table || !ids_i64 || !out) return VSYS_ERR_ARG;
+  if (!fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_gather_rows(B16(table), reinterpret_cast<const int64_t*>(ids_i64), B16(out), n, (int)C, vocab, S(stream));
+}
+
+int vsys_rms_norm_rows(const void* x, const void* w, void* y, int64_t rows, int64_t C, float eps, void* stream) {
+  if (!x || !w || !y) return VSYS_ERR_ARG;
+  if (!fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_rms_norm_rows(B16(x), B16(w), B16(y), rows, (int)C, eps, S(stream));
+}
+
+int vsys_geglu(const void* h, void* out, int64_t rows, int64_t F, void* stream) {
+  if (!h || !out) return VSYS_ERR_ARG;
+  if (!fits_int(F)) return VSYS_ERR_SHAPE;
+  return launch_geglu(B16(h), B16(out), rows, (int)F, S(stream));
+}
+
+int vsys_t5_attention(const void* qkv, int64_t row_stride, int64_t inner, const void* relbias_f32, const void* klen_i32, void* out,
+                      int64_t out_stride, int64_t B, int64_t L, int64_t heads, void* stream) {
+  if (!qkv || !relbias_f32 || !klen_i32 || !out) return VSYS_ERR_ARG;
+  if (!fits_int(inner) || !fits_int(B) || !fits_int(L) || !fits_int(heads)) return VSYS_ERR_SHAPE;
+  return launch_t5_attention(B16(qkv), row_stride, (int)inner, reinterpret_cast<const float*>(relbias_f32),
+                             reinterpret_cast<const int*>(klen_i32), B16(out), out_stride, (int)B, (int)L, (int)heads, S(stream));
+}
+
 int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* desc, void* stream) {
   if (!src || !dst || (nops > 0 && !desc)) return VSYS_ERR_ARG;
   if (nops < 0 || nops > VSYS_COPY_BATCH_MAX) return VSYS_ERR_SHAPE;

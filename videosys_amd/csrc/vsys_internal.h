@@ -58,6 +58,13 @@ int launch_extract_planar(const bf16_t* x, const VaeGrid& g, int N, int ldx, int
                           hipStream_t stream);
 int launch_softmax_rows(const float* s, bf16_t* p, int64_t rows, int n, int ld, hipStream_t stream);
 
+// T5 encoder pieces (t5_ops.hip)
+int launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int64_t n, int C, int64_t vocab, hipStream_t stream);
+int launch_rms_norm_rows(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t rows, int C, float eps, hipStream_t stream);
+int launch_geglu(const bf16_t* h, bf16_t* out, int64_t rows, int F, hipStream_t stream);
+int launch_t5_attention(const bf16_t* qkv, int64_t row_stride, int inner, const float* relbias, const int* klen, bf16_t* out,
+                        int64_t out_stride, int B, int L, int heads, hipStream_t stream);
+
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm2(const GemmParams& p, int epi, int prio, hipStream_t stream);
 void set_gemm_variant(int v);

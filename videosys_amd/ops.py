@@ -486,3 +486,48 @@ def softmax_rows(s_f32, n=None, out=None):
         out = torch.empty(s_f32.shape, dtype=torch.bfloat16, device=s_f32.device)
     _lib.check(_lib.load().vsys_softmax_rows(_p(s_f32), _p(out), rows, n, ld, _stream()), "vsys_softmax_rows")
     return out
+
+
+# ------------------------------------------------------------------------------------------------ T5 encoder
+def gather_rows(table, ids):
+    _chk(table, ids)
+    _bf16(table)
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and table.is_contiguous()
+    n, C = ids.numel(), table.shape[1]
+    out = torch.empty(n, C, dtype=torch.bfloat16, device=table.device)
+    _lib.check(_lib.load().vsys_gather_rows(_p(table), _p(ids), _p(out), n, C, table.shape[0], _stream()), "vsys_gather_rows")
+    return out
+
+
+def rms_norm_rows(x, w, eps=1e-6, out=None):
+    _chk(x, w, out)
+    _bf16(x, w, out)
+    assert x.is_contiguous() and x.dim() == 2
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(_lib.load().vsys_rms_norm_rows(_p(x), _p(w), _p(out), x.shape[0], x.shape[1], float(eps), _stream()), "vsys_rms_norm_rows")
+    return out
+
+
+def geglu(h, out=None):
+    _chk(h, out)
+    _bf16(h, out)
+    assert h.is_contiguous() and h.shape[1] % 2 == 0
+    F = h.shape[1] // 2
+    if out is None:
+        out = torch.empty(h.shape[0], F, dtype=torch.bfloat16, device=h.device)
+    _lib.check(_lib.load().vsys_geglu(_p(h), _p(out), h.shape[0], F, _stream()), "vsys_geglu")
+    return out
+
+
+def t5_attention(qkv, relbias, klen, B, L, heads, out=None):
+    _chk(qkv, relbias, klen, out)
+    _bf16(qkv, out)
+    inner = heads * 64
+    assert qkv.shape == (B * L, 3 * inner) and qkv.stride(1) == 1 and relbias.dtype == torch.float32 and klen.dtype == torch.int32
+    assert relbias.shape == (heads, 2 * L - 1) and relbias.is_contiguous() and klen.numel() == B
+    if out is None:
+        out = torch.empty(B * L, inner, dtype=torch.bfloat16, device=qkv.device)
+    _lib.check(_lib.load().vsys_t5_attention(_p(qkv), qkv.stride(0), inner, _p(relbias), _p(klen), _p(out), out.stride(0), B, L, heads,
+                                             _stream()), "vsys_t5_attention")
+    return out
