@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--pab", action="store_true", help="BASELINE config 3: attention-only PAB (reported as a separate workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
+    ap.add_argument("--no-t5", action="store_true", help="skip the (untimed-region) T5 encode measurement")
     ap.add_argument("--text-len", type=int, default=300)
     return ap.parse_args()
 
@@ -220,6 +221,25 @@ def main():
                "videos_per_min_dit_plus_vae": round(60.0 / (STEPS_PER_VIDEO * step_s + vae_s), 4)}
         del dec, vid
 
+    # ---- T5-v1.1-XXL prompt encode (rank 0, N == 1; outside the timed region): 300-token prompt, device-generated weights
+    t5 = None
+    if rank == 0 and world == 1 and not args.no_t5:
+        from videosys_amd.t5 import T5Encoder
+
+        enc = T5Encoder(device=dev).init_random_(0)
+        ids = torch.randint(0, enc.config.vocab_size, (1, 300), generator=torch.Generator().manual_seed(0))
+        tmask = torch.zeros(1, 300, dtype=torch.long)
+        tmask[:, :120] = 1
+        enc(ids, tmask)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        enc(ids, tmask)
+        torch.cuda.synchronize()
+        t5 = {"sec_per_prompt": round(time.perf_counter() - t0, 5), "model": "T5-v1.1-XXL encoder geometry, 300 tokens"}
+        del enc
+        if vae is not None:
+            vae["videos_per_min_t5_dit_vae"] = round(60.0 / (STEPS_PER_VIDEO * step_s + vae["sec_per_video"] + t5["sec_per_prompt"]), 4)
+
     if rank == 0:
         vpm = 60.0 / (STEPS_PER_VIDEO * step_s)
         line = {
@@ -231,11 +251,11 @@ def main():
                 "workload": ("open-sora-v1.2 STDiT3-XL/2 512x512x64f, latent [4,19,64,64], CFG batch 2 = 38912 token rows, "
                              f"{L} text tokens, depth {args.depth}" + (", PAB attention-only (config 3)" if args.pab else "")),
                 "steps_per_video": STEPS_PER_VIDEO, "parallelism": f"dsp{world}",
-                "not_included": "T5 text encode (value is DiT denoising only; vae_decode reports the decode term beside it)",
+                "not_included": "value is DiT denoising only; vae_decode / t5_encode report the other two terms of the metric beside it",
                 "algorithmic_tflop_per_step": 89.4 if args.depth == 28 and L == 300 else None,
             },
             "step_tflops": round(89.4 / step_s, 1) if args.depth == 28 and L == 300 and not args.pab else None,
-            "roofline": roof, "cpu_baseline": cpu, "vae_decode": vae,
+            "roofline": roof, "cpu_baseline": cpu, "vae_decode": vae, "t5_encode": t5,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -200,7 +200,7 @@ def test_bench_two_ranks_dry_run():
     env = dict(os.environ, VSYS_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--depth", "2", "--no-cpu-baseline", "--no-vae"]
+           "--depth", "2", "--no-cpu-baseline", "--no-vae", "--no-t5"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -191,3 +191,26 @@ def test_opensora_vae_decode_matches_reference_golden():
     # second call reuses the zero-bordered buffers: must give the same bits
     out2 = vae.decode(gold["z"].to(dev()), gold["num_frames"]).float().cpu()
     assert torch.equal(out, out2)
+
+
+def test_open_sora_pipeline_latents_to_uint8_video():
+    """OpenSoraPipeline.generate end to end on the GPU: prompt embeddings -> RFLOW denoising (small STDiT3) -> OpenSoraVAE decode ->
+    uint8 [B, T, H, W, C] on the CPU (pipeline_open_sora.py:638-656), and the same latents decoded directly give the same video."""
+    from videosys_amd import OpenSoraConfig, OpenSoraPipeline
+    from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict
+
+    tcfg = dict(depth=1, hidden_size=576, num_heads=8, caption_channels=64, model_max_length=16)
+    pipe = OpenSoraPipeline(OpenSoraConfig(transformer="synthetic:3", vae="synthetic:7", num_sampling_steps=2, transformer_config=tcfg),
+                            device=dev())
+    assert isinstance(pipe.vae_decoder, OpenSoraVAE)
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn(1, 1, 16, 64, generator=g).to(torch.bfloat16)
+    mask = torch.ones(1, 16, dtype=torch.long)
+    video = pipe.generate(prompt_embeds=emb, prompt_mask=mask, height=64, width=96, num_frames=21, seed=1).video
+    assert video.dtype == torch.uint8 and tuple(video.shape) == (1, 21, 64, 96, 3) and video.device.type == "cpu"
+    lat = pipe.generate(prompt_embeds=emb, prompt_mask=mask, height=64, width=96, num_frames=21, seed=1, output_type="latent").video
+    assert tuple(lat.shape) == (1, 4, 6, 8, 12)  # 17 frames -> 5 latent frames, the 4 left over -> 1
+    ref = OpenSoraVAE(synth_state_dict(7), device=dev()).decode(lat.to(torch.bfloat16), 21)
+    ref = (ref.clamp(-1, 1) * 0.5 + 0.5).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
+    assert torch.equal(video, ref)
+    assert video.float().std().item() > 1.0  # not a constant image

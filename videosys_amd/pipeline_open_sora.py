@@ -139,6 +139,8 @@ class OpenSoraPipeline:
         self.transformer.load_state_dict(sd)
         self.scheduler = RFLOW(num_sampling_steps=config.num_sampling_steps, cfg_scale=config.cfg_scale,
                                use_timestep_transform=True)
+        if text_encoder is None:
+            text_encoder = self._load_text_encoder(config.text_encoder)
         self.text_encoder = text_encoder
         if vae_decoder is None:
             vae_decoder = self._load_vae(config.vae)
@@ -148,6 +150,32 @@ class OpenSoraPipeline:
         else:
             pab.set_pab_manager(None)
         self._set_parallel()
+
+    def _load_text_encoder(self, name):
+        """pipeline_open_sora.py:211-214: T5EncoderModel + AutoTokenizer from ``config.text_encoder`` — here a LOCAL directory
+        holding the HF checkpoint (config.json, *.safetensors, tokenizer files); a hub id cannot be fetched, so the pipeline then
+        expects ``prompt_embeds``."""
+        import glob
+        import json
+
+        if not (isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "config.json"))):
+            return None
+        from safetensors.torch import load_file
+        from transformers import AutoTokenizer
+
+        from .t5 import T5Encoder, T5TextEncoder
+
+        with open(os.path.join(name, "config.json")) as fh:
+            c = json.load(fh)
+        enc = T5Encoder(d_model=c["d_model"], d_kv=c["d_kv"], d_ff=c["d_ff"], num_layers=c["num_layers"], num_heads=c["num_heads"],
+                        vocab_size=c["vocab_size"], relative_attention_num_buckets=c.get("relative_attention_num_buckets", 32),
+                        relative_attention_max_distance=c.get("relative_attention_max_distance", 128),
+                        layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-6), device=self._device)
+        sd = {}
+        for f in sorted(glob.glob(os.path.join(name, "*.safetensors"))):
+            sd.update(load_file(f))
+        enc.load_state_dict(sd)
+        return T5TextEncoder(enc, AutoTokenizer.from_pretrained(name), max_length=300)
 
     def _load_vae(self, name):
         """OpenSoraVAE_V1_2 (autoencoder_kl_open_sora.py:738-761): a local checkpoint directory (model.safetensors with the

@@ -71,6 +71,26 @@ class T5Encoder:
         self._bias_cache.clear()
         return self
 
+    def init_random_(self, seed: int = 0):
+        """Random weights generated ON the device (benchmarks at the XXL size: 4.8 B parameters are slow to draw on the host)."""
+        c, dev = self.config, self.device
+        g = torch.Generator(device=dev).manual_seed(seed)
+        r = lambda *s, scale=1.0: (torch.randn(*s, generator=g, device=dev) * scale).to(self.dtype)
+        inner = c.num_heads * c.d_kv
+        ones = lambda n: torch.ones(n, dtype=self.dtype, device=dev)
+        self.w["emb"] = r(c.vocab_size, c.d_model)
+        for i in range(c.num_layers):
+            self.w[f"{i}.qkv"] = torch.cat([r(inner, c.d_model, scale=(c.d_model * c.d_kv) ** -0.5),
+                                            r(2 * inner, c.d_model, scale=c.d_model ** -0.5)], 0)
+            self.w[f"{i}.o"] = r(c.d_model, inner, scale=inner ** -0.5)
+            self.w[f"{i}.wi"] = r(2 * c.d_ff, c.d_model, scale=c.d_model ** -0.5)
+            self.w[f"{i}.wo"] = r(c.d_model, c.d_ff, scale=c.d_ff ** -0.5)
+            self.w[f"{i}.ln0"], self.w[f"{i}.ln1"] = ones(c.d_model), ones(c.d_model)
+        self.w["ln_f"] = ones(c.d_model)
+        self._rel = (torch.randn(c.relative_attention_num_buckets, c.num_heads, generator=torch.Generator().manual_seed(seed)) * 0.5)
+        self._bias_cache.clear()
+        return self
+
     def _relbias(self, L: int) -> torch.Tensor:
         """[heads, 2L-1] fp32: bias of relative position d = j - i at column d + L - 1 (T5Attention.compute_bias)."""
         t = self._bias_cache.get(L)
