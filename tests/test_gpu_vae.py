@@ -214,3 +214,22 @@ def test_open_sora_pipeline_latents_to_uint8_video():
     ref = (ref.clamp(-1, 1) * 0.5 + 0.5).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
     assert torch.equal(video, ref)
     assert video.float().std().item() > 1.0  # not a constant image
+
+
+def test_autoencoder_kl_decoder_matches_oracle():
+    """AutoencoderKLDecoder (Latte's non-temporal VAE branch, pipeline_latte.py:916-927) against the 2-D part of the oracle."""
+    from oracle import vae_oracle as VO
+    from videosys_amd.vae_open_sora import AutoencoderKLDecoder, synth_state_dict
+
+    sd = synth_state_dict(3)
+    pre = "spatial_vae.module."
+    sd2 = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    g = torch.Generator().manual_seed(8)
+    lat = (torch.randn(1, 4, 3, 8, 12, generator=g) * 0.18215 * 3).to(torch.bfloat16).float()
+    ref = VO.spatial_decode(sd, lat[0].permute(1, 0, 2, 3) / 0.18215)                       # [F, 3, 64, 96]
+    want = ((ref / 2.0 + 0.5).clamp(0, 1) * 255).permute(0, 2, 3, 1)[None]                   # [1, F, h, w, c] float
+    dec = AutoencoderKLDecoder(sd2, device=dev())
+    got = dec.decode_latents(lat.to(dev()))
+    assert got.dtype == torch.uint8 and tuple(got.shape) == (1, 3, 64, 96, 3)
+    diff = (got.float() - want).abs()
+    assert diff.mean().item() < 1.5 and (diff > 12).float().mean().item() < 1e-3, (diff.mean().item(), diff.max().item())

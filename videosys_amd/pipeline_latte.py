@@ -118,9 +118,31 @@ class LattePipeline:
         self.transformer.load_state_dict(sd)
         self.scheduler = DDIMScheduler(beta_start=config.beta_start, beta_end=config.beta_end,
                                        beta_schedule=config.beta_schedule, variance_type=config.variance_type)
+        if vae_decoder is None:
+            vae_decoder = self._load_vae(config)
         self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
         self._set_parallel()
+
+    def _load_vae(self, config):
+        """pipeline_latte.py:211-217.  Built here: the plain ``AutoencoderKL`` branch (``enable_vae_temporal_decoder=False``) from a
+        local ``<model_path>/vae/diffusion_pytorch_model.safetensors`` or ``"synthetic:<seed>"``; the SVD temporal decoder
+        (AutoencoderKLTemporalDecoder, the reference default) is not built: pass ``vae_decoder=`` or read latents."""
+        from .vae_open_sora import AutoencoderKLDecoder, synth_state_dict as vae_synth
+
+        name = config.model_path
+        if config.enable_vae_temporal_decoder or not isinstance(name, str):
+            return None
+        if name.startswith("synthetic:"):
+            pre = "spatial_vae.module."
+            sd = {k[len(pre):]: v for k, v in vae_synth(int(name.split(":", 1)[1])).items() if k.startswith(pre)}
+            return AutoencoderKLDecoder(sd, device=self._device)
+        st = os.path.join(name, "vae", "diffusion_pytorch_model.safetensors")
+        if os.path.exists(st):
+            from safetensors.torch import load_file
+
+            return AutoencoderKLDecoder(load_file(st), device=self._device)
+        return None
 
     def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: Optional[bool] = False):
         """pipeline_latte.py:236-250: sp = world size unless given (then dp = world / sp)."""

@@ -107,7 +107,11 @@ class OpenSoraVAE:
         self.micro_batch_size = micro_batch_size   # kept for API parity; frames are independent in the 2-D decoder
         self.frames_per_launch = frames_per_launch
         self.micro_z_frame_size = self.get_temporal_latent_size(micro_frame_size)
-        sd = state_dict
+        self._padded: Dict[tuple, tuple] = {}
+        self._init_temporal(state_dict, dev)
+        self._init_spatial(state_dict, dev, "spatial_vae.module.")
+
+    def _init_temporal(self, sd, dev):
         # ---- temporal VAE (VAE_Temporal_SD: filters 128, multipliers (1,2,2,4), 4 res blocks, temporal up (F,T,T))
         t = "temporal_vae."
         self.t_pq = (sd[t + "post_quant_conv.conv.weight"].float().reshape(4, 4).cpu(), sd[t + "post_quant_conv.conv.bias"].float().cpu())
@@ -120,8 +124,9 @@ class OpenSoraVAE:
         self.t_up = {i: _Conv(sd, f"{d}conv_blocks.{i}.conv", dev) for i in range(3) if f"{d}conv_blocks.{i}.conv.weight" in sd}
         self.t_norm = _Norm(sd, d + "norm1", dev, 1e-5)
         self.t_out = _Conv(sd, d + "conv_out.conv", dev, n_pad=128)
-        # ---- 2-D SDXL decoder
-        s = "spatial_vae.module."
+
+    def _init_spatial(self, sd, dev, s):
+        """2-D SD / SDXL decoder (diffusers AutoencoderKL decode side) under key prefix ``s``."""
         self.s_pq = (sd[s + "post_quant_conv.weight"].float().reshape(4, 4).cpu(), sd[s + "post_quant_conv.bias"].float().cpu())
         d = s + "decoder."
         self.s_conv_in_w = _conv_w(sd[d + "conv_in.weight"].to(dev), None, 64)   # K = 9 * 4 = 36 -> 64
@@ -145,7 +150,6 @@ class OpenSoraVAE:
             self.s_up.append((res, _Conv(sd, upk, dev) if (upk + ".weight") in sd else None))
         self.s_norm = _Norm(sd, d + "conv_norm_out", dev, 1e-6)
         self.s_out = _Conv(sd, d + "conv_out", dev, n_pad=128)
-        self._padded: Dict[tuple, tuple] = {}
 
     # ------------------------------------------------------------------------------------------------ sizes
     def get_temporal_latent_size(self, t: int) -> int:
@@ -258,10 +262,10 @@ class OpenSoraVAE:
                         batch_o=Lp * C, M=Lp)
         return ops.gemm128(o, self.a_wo, self.a_bo, res=xd), gdn
 
-    def _spatial_decode(self, xz: torch.Tensor, out: torch.Tensor, f0: int):
+    def _spatial_decode(self, xz: torch.Tensor, out: torch.Tensor, f0: int, in_scale: float = 1.0 / _SD_SCALE):
         """xz planar bf16 [4, F, H, W] -> out[3, f0:f0+F, 8H, 8W].  VideoAutoencoderKL.decode :522-538 + diffusers Decoder."""
         _, F, H, W = xz.shape
-        params = [1.0 / _SD_SCALE] * 4 + [0.0] * 4 + self.s_pq[0].flatten().tolist() + self.s_pq[1].tolist()
+        params = [in_scale] * 4 + [0.0] * 4 + self.s_pq[0].flatten().tolist() + self.s_pq[1].tolist()
         a = ops.vae_first_im2col(xz, 1, 64, params)
         g = VaeGrid(F, 1, H, W, 0, 0)
         x = ops.gemm128(a, self.s_conv_in_w, self.s_conv_in_b)
@@ -308,6 +312,46 @@ class OpenSoraVAE:
         return torch.stack(outs, 0)
 
     __call__ = decode
+
+
+class AutoencoderKLDecoder(OpenSoraVAE):
+    """Per-frame decode with a diffusers ``AutoencoderKL`` (SD / SDXL VAE geometry, state-dict keys ``decoder.*``,
+    ``post_quant_conv.*``) — what LattePipeline.decode_latents does with ``enable_vae_temporal_decoder=False``
+    (pipeline_latte.py:916-927: latents / scaling_factor, every frame through ``vae.decode``, ``(x / 2 + 0.5).clamp(0, 1) * 255``
+    as uint8 [b, f, h, w, c]).  The 2-D decoder kernels are the ones of OpenSoraVAE."""
+
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda", scaling_factor: float = 0.18215, frames_per_launch: int = 16):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("videosys_amd.AutoencoderKLDecoder needs a HIP device (no CPU path)")
+        self.device = dev
+        self.frames_per_launch = frames_per_launch
+        self.scaling_factor = scaling_factor
+        self._padded = {}
+        self._init_spatial(state_dict, dev, "")
+
+    @torch.no_grad()
+    def decode(self, latents: torch.Tensor) -> torch.Tensor:
+        """latents [B, 4, F, H, W] -> sample [B, 3, F, 8H, 8W] bf16 (before the pipeline's /2 + 0.5)."""
+        if not latents.is_cuda:
+            raise RuntimeError("AutoencoderKLDecoder.decode needs a HIP device tensor (no CPU path)")
+        B, C, Fr, H, W = latents.shape
+        outs = []
+        for b in range(B):
+            xz = latents[b].to(torch.bfloat16).contiguous()
+            vid = torch.empty(3, Fr, 8 * H, 8 * W, dtype=torch.bfloat16, device=self.device)
+            for f in range(0, Fr, self.frames_per_launch):
+                m = min(self.frames_per_launch, Fr - f)
+                self._spatial_decode(xz[:, f:f + m].contiguous(), vid, f, 1.0 / self.scaling_factor)
+            outs.append(vid)
+        return torch.stack(outs, 0)
+
+    def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        """pipeline_latte.py:916-927 -> uint8 [b, f, h, w, c] on the CPU."""
+        v = self.decode(latents).float()
+        return ((v / 2.0 + 0.5).clamp(0, 1) * 255).permute(0, 2, 3, 4, 1).to(dtype=torch.uint8).cpu().contiguous()
+
+    __call__ = decode_latents
 
 
 # ---------------------------------------------------------------------------------------------------- synthetic weights
