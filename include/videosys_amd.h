@@ -238,9 +238,21 @@ int vsys_gn_stats(const void* x, const int64_t* grid, int64_t N, int64_t C, int6
 /* y = act(bf16((x - mean) * rstd * gamma + beta)), act = VSYS_ACT_NONE | VSYS_ACT_SILU, interior rows of grid_dst only. */
 int vsys_gn_apply(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t groups,
                   const void* stats_f32, const void* gamma, const void* beta, int act, void* stream);
-/* grid-to-grid copy of the interior; up = 1: nearest-neighbour 2x upsampling (diffusers Upsample2D before its conv). */
+/* grid-to-grid copy of the interior; up = 1: nearest-neighbour 2x upsampling in H and W (diffusers Upsample2D before its conv).
+ * tmode 0: same frame count; 1: destination frame t reads source frame t/2; 2: CogVideoXUpsample3D with an odd frame count
+ * (modules/upsampling.py:42-49): 2T-1 frames, frame 0 stays single. */
 int vsys_regrid(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t up,
-                void* stream);
+                int64_t tmode, void* stream);
+/* CogVideoXSpatialNorm3D + SiLU (autoencoder_kl_cogvideox.py:165-178,275-276): y = silu(GN(x) * Y + B); yb = [conv_y(zq) |
+ * conv_b(zq)] computed at LATENT resolution, rows (n, zt, zh, zw) of 2C columns; the latent voxel of (t, h, w) follows
+ * F.interpolate(zq, size=f.shape) including the first-frame split for odd frame counts.  stats from vsys_gn_stats. */
+int vsys_spatial_norm_apply(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C,
+                            int64_t groups, const void* stats_f32, const void* gamma, const void* beta, const void* yb, int64_t zT,
+                            int64_t zH, int64_t zW, void* stream);
+/* tiled_decode's blend_v (axis 0) / blend_h (axis 1) (autoencoder_kl_cogvideox.py:1145-1159) on planar bf16 tiles
+ * a [outer, Ha, Wa], b [outer, Hb, Wb], in place on b: the first ext rows (columns) of b fade in from the last ext of a. */
+int vsys_blend_edge(const void* a, void* b, int64_t outer, int64_t Ha, int64_t Wa, int64_t Hb, int64_t Wb, int64_t ext, int64_t axis,
+                    void* stream);
 /* temporal depth-to-space "B (C ts) T H W -> B C (T ts) H W", ts = 2 (autoencoder_kl_open_sora.py:362-368): x has 2*Cout channels. */
 int vsys_d2s_time(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t Cout, void* stream);
 /* First decoder layer: planar bf16 latent z[4][F][H][W] -> z*scale + shift -> 1x1 post_quant_conv -> im2col rows

@@ -511,6 +511,18 @@ class AutoencoderKL(nn.Module):
         return SimpleNamespace(sample=self.decoder(self.post_quant_conv(z)))
 
 
+def get_activation(name):
+    """diffusers.models.activations.get_activation for the names the reference uses."""
+    return {"swish": nn.SiLU, "silu": nn.SiLU, "mish": nn.Mish, "gelu": nn.GELU, "relu": nn.ReLU}[name.lower()]()
+
+
+class DecoderOutput:
+    """diffusers.models.autoencoders.vae.DecoderOutput (a dataclass with one field)."""
+
+    def __init__(self, sample):
+        self.sample = sample
+
+
 # ----------------------------------------------------------------------------------------------- installation
 def _mod(name, **attrs):
     m = types.ModuleType(name)
@@ -545,6 +557,18 @@ def install():
     _mod("diffusers.utils", USE_PEFT_BACKEND=False, BaseOutput=BaseOutput, deprecate=deprecate,
          is_torch_version=lambda *a, **k: True)
     _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=maybe_allow_in_graph)
+    # what videosys/models/autoencoders/autoencoder_kl_cogvideox.py imports (:18-24): no arithmetic except get_activation
+    loaders = sys.modules.get("diffusers.loaders") or _mod("diffusers.loaders")
+    loaders.__dict__.setdefault("__path__", [])
+    _mod("diffusers.loaders.single_file_model", FromOriginalModelMixin=type("FromOriginalModelMixin", (), {}))
+    sys.modules["diffusers.models.activations"].__dict__["get_activation"] = get_activation
+    ae = sys.modules.get("diffusers.models.autoencoders") or _mod("diffusers.models.autoencoders")
+    ae.__dict__.setdefault("__path__", [])
+    _mod("diffusers.models.autoencoders.vae", DecoderOutput=DecoderOutput, DiagonalGaussianDistribution=_Unused)
+    sys.modules["diffusers.models.modeling_outputs"].__dict__["AutoencoderKLOutput"] = BaseOutput
+    utils = sys.modules["diffusers.utils"]
+    utils.__dict__.setdefault("__path__", [])
+    _mod("diffusers.utils.accelerate_utils", apply_forward_hook=lambda f: f)
     sch = _mod("diffusers.schedulers", DDIMScheduler=DDIMScheduler)
     sch.__dict__["__path__"] = []
     return ap

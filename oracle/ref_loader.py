@@ -243,3 +243,23 @@ def build_reference_opensora_vae(state_dict=None, dtype=torch.float32, micro_fra
         assert not unexpected, unexpected
         assert all("encoder" in k or "quant_conv" in k or k in ("scale", "shift") for k in missing), missing
     return model.to(dtype).eval()
+
+
+# ---------------------------------------------------------------------------------------------------- CogVideoX VAE
+def build_reference_cogvideox_vae(state_dict=None, dtype=torch.float32, **cfg):
+    """Instantiate the reference AutoencoderKLCogVideoX (autoencoder_kl_cogvideox.py:872-1257; in-tree code: causal convs with
+    conv_cache, spatial norm, 3-D upsampling, frame batching, tiled decode) on CPU.  Only import-level diffusers names are
+    stubbed (mixins, DecoderOutput, get_activation)."""
+    install_stubs()
+    from oracle import diffusers_stub
+
+    diffusers_stub.install()
+    import importlib
+
+    m = importlib.import_module("videosys.models.autoencoders.autoencoder_kl_cogvideox")
+    model = m.AutoencoderKLCogVideoX(**cfg)
+    if state_dict is not None:
+        missing, unexpected = model.load_state_dict(state_dict, strict=False)
+        assert not unexpected, unexpected
+        assert all(k.startswith("encoder.") for k in missing), missing
+    return model.to(dtype).eval()

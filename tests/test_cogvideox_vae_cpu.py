@@ -1,0 +1,43 @@
+"""CPU: the CogVideoX-VAE oracle against the golden minted from the reference's AutoencoderKLCogVideoX (plain, even-frame and tiled
+decodes), the parameter inventory against the reference class, and the tile geometry at the published sample size."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+
+def test_cogvideox_vae_oracle_matches_reference_golden():
+    from oracle import cogvideox_vae_oracle as CV
+    from oracle.make_golden import sd_checksum
+    from videosys_amd.vae_cogvideox import synth_state_dict
+
+    gold = load_golden("cogvideox_vae_small.pt")
+    sd = synth_state_dict(gold["seed"])
+    assert sd_checksum(sd) == gold["sd_checksum"]
+    sh, sw = gold["sample"]
+    for key, z, tiling in (("even", gold["z_even"], False), ("tiled", gold["z"], True)):
+        out = CV.decode(sd, z, sh, sw, tiling=tiling)
+        assert (out - gold[key].float()).abs().max().item() < 3e-3, key   # fixture stored as fp16
+
+
+def test_cogvideox_vae_param_inventory_matches_reference():
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present on this box")
+    from videosys_amd.vae_cogvideox import decoder_param_shapes
+
+    m = ref_loader.build_reference_cogvideox_vae()
+    ref = {k: tuple(v.shape) for k, v in m.state_dict().items() if k.startswith("decoder.")}
+    assert decoder_param_shapes() == ref
+
+
+def test_tile_geometry_at_published_size():
+    """480 x 720 samples (autoencoder_kl_cogvideox.py:983-995,1183-1189): latent tiles 30 x 45, strides 25 x 36, cross-fades
+    40 x 72 pixels, kept 200 x 288 pixels per tile -> 3 x 3 tiles for the 60 x 90 latent of config 5."""
+    from oracle import cogvideox_vae_oracle as CV
+
+    g = CV.tile_geometry(480, 720)
+    assert (g["tl_h"], g["tl_w"], g["ov_h"], g["ov_w"], g["be_h"], g["be_w"], g["lim_h"], g["lim_w"]) == (30, 45, 25, 36, 40, 72, 200, 288)
+    assert len(range(0, 60, g["ov_h"])) == 3 and len(range(0, 90, g["ov_w"])) == 3
+    assert CV._frame_batches(13) == [(0, 3), (3, 5), (5, 7), (7, 9), (9, 11), (11, 13)]

@@ -350,11 +350,28 @@ int vsys_gn_apply(const void* x, const int64_t* grid_src, void* y, const int64_t
 }
 
 int vsys_regrid(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t up,
-                void* stream) {
+                int64_t tmode, void* stream) {
   VaeGrid gs, gd;
   if (!x || !y || !to_grid(grid_src, gs) || !to_grid(grid_dst, gd)) return VSYS_ERR_ARG;
-  if (!fits_int(N) || !fits_int(C) || !fits_int(up)) return VSYS_ERR_SHAPE;
-  return launch_regrid(B16(x), gs, B16(y), gd, (int)N, (int)C, (int)up, S(stream));
+  if (!fits_int(N) || !fits_int(C) || !fits_int(up) || !fits_int(tmode)) return VSYS_ERR_SHAPE;
+  return launch_regrid(B16(x), gs, B16(y), gd, (int)N, (int)C, (int)up, (int)tmode, S(stream));
+}
+
+int vsys_spatial_norm_apply(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C,
+                            int64_t groups, const void* stats_f32, const void* gamma, const void* beta, const void* yb, int64_t zT,
+                            int64_t zH, int64_t zW, void* stream) {
+  VaeGrid gs, gd;
+  if (!x || !y || !stats_f32 || !gamma || !beta || !yb || !to_grid(grid_src, gs) || !to_grid(grid_dst, gd)) return VSYS_ERR_ARG;
+  if (!fits_int(N) || !fits_int(C) || !fits_int(groups) || !fits_int(zT) || !fits_int(zH) || !fits_int(zW)) return VSYS_ERR_SHAPE;
+  return launch_spatial_norm_apply(B16(x), gs, B16(y), gd, (int)N, (int)C, (int)groups, reinterpret_cast<const float*>(stats_f32),
+                                   B16(gamma), B16(beta), B16(yb), (int)zT, (int)zH, (int)zW, S(stream));
+}
+
+int vsys_blend_edge(const void* a, void* b, int64_t outer, int64_t Ha, int64_t Wa, int64_t Hb, int64_t Wb, int64_t ext, int64_t axis,
+                    void* stream) {
+  if (!a || !b) return VSYS_ERR_ARG;
+  if (!fits_int(Ha) || !fits_int(Wa) || !fits_int(Hb) || !fits_int(Wb) || !fits_int(ext) || !fits_int(axis)) return VSYS_ERR_SHAPE;
+  return launch_blend_edge(B16(a), B16(b), outer, (int)Ha, (int)Wa, (int)Hb, (int)Wb, (int)ext, (int)axis, S(stream));
 }
 
 int vsys_d2s_time(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t Cout, void* stream) {

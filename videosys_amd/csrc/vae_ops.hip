@@ -119,9 +119,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
-// grid-to-grid copy; (H, W) of the destination are (H << up, W << up) of the source: up = 1 is F.interpolate(nearest, 2x)
+// grid-to-grid copy; (H, W) of the destination are (H << up, W << up) of the source: up = 1 is F.interpolate(nearest, 2x).
+// tmode: 0 = same frame; 1 = destination frame t reads source frame t/2 (nearest 2x in time); 2 = CogVideoXUpsample3D with an
+// odd frame count (modules/upsampling.py:42-49): frame 0 stays single, frame t >= 1 reads source frame 1 + (t-1)/2.
 __global__ __launch_bounds__(256) void regrid_kernel(const bf16_t* __restrict__ x, VaeGrid gs, bf16_t* __restrict__ y, VaeGrid gd,
-                                                     int C, int up, int N) {
+                                                     int C, int up, int tmode, int N) {
   const int nch = C >> 3;
   const int64_t total = (int64_t)N * gd.T * gd.H * gd.W * nch;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -131,8 +133,9 @@ __global__ __launch_bounds__(256) void regrid_kernel(const bf16_t* __restrict__ 
     const int h = (int)(pos % gd.H); pos /= gd.H;
     const int t = (int)(pos % gd.T);
     const int n = (int)(pos / gd.T);
+    const int ts = tmode == 0 ? t : (tmode == 1 ? (t >> 1) : (t == 0 ? 0 : 1 + ((t - 1) >> 1)));
     *reinterpret_cast<uint4*>(y + grid_row(gd, n, t, h, w) * C + ch * 8) =
-        *reinterpret_cast<const uint4*>(x + grid_row(gs, n, t, h >> up, w >> up) * C + ch * 8);
+        *reinterpret_cast<const uint4*>(x + grid_row(gs, n, ts, h >> up, w >> up) * C + ch * 8);
   }
 }
 
@@ -264,6 +267,78 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// CogVideoXSpatialNorm3D + SiLU (autoencoder_kl_cogvideox.py:165-178, :275-276): y = silu(GN(x) * Y[z] + B[z]) where [Y | B] =
+// [conv_y(zq) | conv_b(zq)] were computed at LATENT resolution (1x1x1 convs commute with nearest-neighbour interpolation) as rows
+// (zt, zh, zw) of 2C columns, and z = the latent voxel F.interpolate(zq, size=f.shape) maps (t, h, w) to — with the reference's
+// first-frame split when the frame count is odd.  Every intermediate is rounded to bf16 like the reference's tensors.
+__global__ __launch_bounds__(256) void spatial_norm_apply_kernel(const bf16_t* __restrict__ x, VaeGrid gs, bf16_t* __restrict__ y, VaeGrid gd,
+                                                                 int C, int groups, const float* __restrict__ stats,
+                                                                 const bf16_t* __restrict__ gamma, const bf16_t* __restrict__ beta,
+                                                                 const bf16_t* __restrict__ yb, int zT, int zH, int zW, int N) {
+  const int nch = C >> 3;
+  const int cg = C / groups;
+  const int T = gs.T;
+  const bool split = T > 1 && (T & 1);
+  const int64_t nrows = (int64_t)N * T * gs.H;
+  for (int64_t br = blockIdx.x; br < nrows; br += gridDim.x) {
+    const int h = (int)(br % gs.H);
+    const int64_t r1 = br / gs.H;
+    const int t = (int)(r1 % T), n = (int)(r1 / T);
+    const int zt = split ? (t == 0 ? 0 : 1 + (int)(((int64_t)(t - 1) * (zT - 1)) / (T - 1))) : (int)(((int64_t)t * zT) / T);
+    const int zh = (int)(((int64_t)h * zH) / gs.H);
+    const bf16_t* xr = x + grid_row(gs, n, t, h, 0) * C;
+    bf16_t* yr = y + grid_row(gd, n, t, h, 0) * C;
+    const bf16_t* zr = yb + (((int64_t)n * zT + zt) * zH + zh) * zW * (2 * C);
+    const float* st = stats + 2 * n * groups;
+    const int items = gs.W * nch;
+    for (int i = threadIdx.x; i < items; i += 256) {
+      const int w = i / nch, ch = i - w * nch;
+      const int zw = (int)(((int64_t)w * zW) / gs.W);
+      const uint4 v = *reinterpret_cast<const uint4*>(xr + (int64_t)w * C + ch * 8);
+      const uint4 gm = *reinterpret_cast<const uint4*>(gamma + ch * 8);
+      const uint4 bt = *reinterpret_cast<const uint4*>(beta + ch * 8);
+      const uint4 yy = *reinterpret_cast<const uint4*>(zr + (int64_t)zw * 2 * C + ch * 8);
+      const uint4 bb = *reinterpret_cast<const uint4*>(zr + (int64_t)zw * 2 * C + C + ch * 8);
+      const int g0 = (ch * 8) / cg, g1 = (ch * 8 + 4) / cg;
+      const float2 s0 = *reinterpret_cast<const float2*>(st + 2 * g0), s1 = *reinterpret_cast<const float2*>(st + 2 * g1);
+      float f[8], ga[8], be[8], fy[8], fb[8];
+      unpack8(v, f); unpack8(gm, ga); unpack8(bt, be); unpack8(yy, fy); unpack8(bb, fb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float mean = e < 4 ? s0.x : s1.x, rstd = e < 4 ? s0.y : s1.y;
+        const float nf = bf2f(f2bf((f[e] - mean) * rstd * ga[e] + be[e]));
+        const float q = bf2f(f2bf(bf2f(f2bf(nf * fy[e])) + fb[e]));
+        f[e] = silu(q);
+      }
+      *reinterpret_cast<uint4*>(yr + (int64_t)w * C + ch * 8) = pack8(f);
+    }
+  }
+}
+
+// tiled_decode's blend_v / blend_h (autoencoder_kl_cogvideox.py:1145-1159) on planar bf16 tiles [outer, H, W]:
+// b[o, y, x] = bf16(bf16(a[o, Ha - ext + y, x] * (1 - y/ext)) + bf16(b[o, y, x] * (y/ext))) for y < ext (axis 0; axis 1: columns).
+__global__ __launch_bounds__(256) void blend_edge_kernel(const bf16_t* __restrict__ a, bf16_t* __restrict__ b, int64_t outer, int Ha,
+                                                         int Wa, int Hb, int Wb, int ext, int axis) {
+  const int64_t per = axis == 0 ? (int64_t)ext * Wb : (int64_t)Hb * ext;
+  const int64_t total = outer * per;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t o = i / per;
+    const int64_t r = i - o * per;
+    int yy, xx, k;
+    int64_t ia;
+    if (axis == 0) {
+      yy = (int)(r / Wb); xx = (int)(r - (int64_t)yy * Wb); k = yy;
+      ia = (o * Ha + (Ha - ext + yy)) * Wa + xx;
+    } else {
+      yy = (int)(r / ext); xx = (int)(r - (int64_t)yy * ext); k = xx;
+      ia = (o * Ha + yy) * Wa + (Wa - ext + xx);
+    }
+    const int64_t ib = (o * Hb + yy) * Wb + xx;
+    const float w1 = (float)(1.0 - (double)k / (double)ext), w2 = (float)((double)k / (double)ext);
+    b[ib] = f2bf(bf2f(f2bf(bf2f(a[ia]) * w1)) + bf2f(f2bf(bf2f(b[ib]) * w2)));
+  }
+}
+
 inline unsigned grid_for(int64_t work_items) {
   int64_t b = (work_items + 255) / 256;
   const int64_t cap = 256 * 32;  // grid-stride: 32 blocks per CU are plenty for streaming kernels
@@ -299,11 +374,36 @@ int launch_gn_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
-int launch_regrid(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int up, hipStream_t stream) {
+int launch_regrid(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int up, int tmode, hipStream_t stream) {
   if (N <= 0) return 0;
-  if (!grid_ok(gs) || !grid_ok(gd) || up < 0 || up > 1 || gs.T != gd.T || (gs.H << up) != gd.H || (gs.W << up) != gd.W || C % 8 != 0)
+  const int want_t = tmode == 0 ? gs.T : (tmode == 1 ? 2 * gs.T : 2 * gs.T - 1);
+  if (!grid_ok(gs) || !grid_ok(gd) || up < 0 || up > 1 || tmode < 0 || tmode > 2 || gd.T != want_t || (gs.H << up) != gd.H ||
+      (gs.W << up) != gd.W || C % 8 != 0)
     return VSYS_ERR_SHAPE;
-  hipLaunchKernelGGL(regrid_kernel, dim3(grid_for((int64_t)N * gd.T * gd.H * gd.W * (C >> 3))), dim3(256), 0, stream, x, gs, y, gd, C, up, N);
+  hipLaunchKernelGGL(regrid_kernel, dim3(grid_for((int64_t)N * gd.T * gd.H * gd.W * (C >> 3))), dim3(256), 0, stream, x, gs, y, gd, C, up,
+                     tmode, N);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_spatial_norm_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int groups,
+                              const float* stats, const bf16_t* gamma, const bf16_t* beta, const bf16_t* yb, int zT, int zH, int zW,
+                              hipStream_t stream) {
+  if (N <= 0) return 0;
+  if (!grid_ok(gs) || !grid_ok(gd) || gs.T != gd.T || gs.H != gd.H || gs.W != gd.W || C % 8 != 0 || groups <= 0 || C % groups != 0 ||
+      (C / groups) % 4 != 0 || zT <= 0 || zH <= 0 || zW <= 0)
+    return VSYS_ERR_SHAPE;
+  const int64_t nrows = (int64_t)N * gs.T * gs.H;
+  hipLaunchKernelGGL(spatial_norm_apply_kernel, dim3((unsigned)(nrows < 65536 ? nrows : 65536)), dim3(256), 0, stream, x, gs, y, gd, C,
+                     groups, stats, gamma, beta, yb, zT, zH, zW, N);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_blend_edge(const bf16_t* a, bf16_t* b, int64_t outer, int Ha, int Wa, int Hb, int Wb, int ext, int axis, hipStream_t stream) {
+  if (outer <= 0 || ext <= 0) return 0;
+  if (axis < 0 || axis > 1 || Ha <= 0 || Wa <= 0 || Hb <= 0 || Wb <= 0) return VSYS_ERR_SHAPE;
+  if (axis == 0 ? (ext > Ha || ext > Hb || Wa != Wb) : (ext > Wa || ext > Wb || Ha != Hb)) return VSYS_ERR_SHAPE;
+  const int64_t total = outer * (axis == 0 ? (int64_t)ext * Wb : (int64_t)Hb * ext);
+  hipLaunchKernelGGL(blend_edge_kernel, dim3(grid_for(total)), dim3(256), 0, stream, a, b, outer, Ha, Wa, Hb, Wb, ext, axis);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

@@ -50,7 +50,11 @@ int launch_gn_stats(const bf16_t* x, const VaeGrid& g, int N, int C, int groups,
                     hipStream_t stream);
 int launch_gn_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int groups, const float* stats,
                     const bf16_t* gamma, const bf16_t* beta, int act, hipStream_t stream);
-int launch_regrid(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int up, hipStream_t stream);
+int launch_regrid(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int up, int tmode, hipStream_t stream);
+int launch_spatial_norm_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int groups,
+                              const float* stats, const bf16_t* gamma, const bf16_t* beta, const bf16_t* yb, int zT, int zH, int zW,
+                              hipStream_t stream);
+int launch_blend_edge(const bf16_t* a, bf16_t* b, int64_t outer, int Ha, int Wa, int Hb, int Wb, int ext, int axis, hipStream_t stream);
 int launch_d2s_time(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int Cout, hipStream_t stream);
 int launch_vae_first_im2col(const bf16_t* z, int F, int H, int W, int kt, int kcols, const float* scale, const float* shift,
                             const float* pq_w, const float* pq_b, bf16_t* out, hipStream_t stream);

@@ -437,12 +437,39 @@ def group_norm(x, gs: VaeGrid, y, gd: VaeGrid, C, gamma, beta, eps, silu_act, gr
     return y
 
 
-def regrid(x, gs: VaeGrid, y, gd: VaeGrid, C, up=0):
+def regrid(x, gs: VaeGrid, y, gd: VaeGrid, C, up=0, tmode=0):
     _chk(x, y)
     _bf16(x, y)
     assert x.shape[0] == gs.rows and y.shape[0] == gd.rows and x.is_contiguous() and y.is_contiguous()
-    _lib.check(_lib.load().vsys_regrid(_p(x), gs._c, _p(y), gd._c, gs.n, C, up, _stream()), "vsys_regrid")
+    _lib.check(_lib.load().vsys_regrid(_p(x), gs._c, _p(y), gd._c, gs.n, C, up, tmode, _stream()), "vsys_regrid")
     return y
+
+
+def spatial_norm_silu(x, gs: VaeGrid, y, gd: VaeGrid, C, gamma, beta, yb, zdims, eps=1e-6, groups=32):
+    """y[interior of gd] = silu(GroupNorm(x) * Y + B) with [Y | B] = yb rows over the latent grid zdims = (zT, zH, zW)."""
+    _chk(x, y, gamma, beta, yb)
+    _bf16(x, y, gamma, beta, yb)
+    zT, zH, zW = zdims
+    assert x.shape == (gs.rows, C) and y.shape == (gd.rows, C) and x.is_contiguous() and y.is_contiguous()
+    assert yb.shape == (gs.n * zT * zH * zW, 2 * C) and yb.is_contiguous()
+    lib = _lib.load()
+    partial = torch.empty(gs.n * _GN_NBLK * (C // 4) * 2, dtype=torch.float32, device=x.device)
+    stats = torch.empty(gs.n * groups * 2, dtype=torch.float32, device=x.device)
+    _lib.check(lib.vsys_gn_stats(_p(x), gs._c, gs.n, C, groups, float(eps), _p(partial), _GN_NBLK, _p(stats), _stream()), "vsys_gn_stats")
+    _lib.check(lib.vsys_spatial_norm_apply(_p(x), gs._c, _p(y), gd._c, gs.n, C, groups, _p(stats), _p(gamma), _p(beta), _p(yb), zT, zH, zW,
+                                           _stream()), "vsys_spatial_norm_apply")
+    return y
+
+
+def blend_edge(a, b, ext, axis):
+    """a, b planar bf16 [..., H, W] (contiguous); in place on b (blend_v: axis 0, blend_h: axis 1)."""
+    _chk(a, b)
+    _bf16(a, b)
+    assert a.is_contiguous() and b.is_contiguous() and a.shape[:-2] == b.shape[:-2]
+    outer = a.numel() // (a.shape[-2] * a.shape[-1])
+    _lib.check(_lib.load().vsys_blend_edge(_p(a), _p(b), outer, a.shape[-2], a.shape[-1], b.shape[-2], b.shape[-1], ext, axis, _stream()),
+               "vsys_blend_edge")
+    return b
 
 
 def d2s_time(x, gs: VaeGrid, y, gd: VaeGrid, Cout):
