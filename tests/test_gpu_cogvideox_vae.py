@@ -115,3 +115,22 @@ def test_cogvideox_vae_decode_matches_reference_golden():
     fr = vae.decode_latents(lat.to(dev())).float().cpu()
     assert fr.shape == gold["tiled"].shape
     assert F.cosine_similarity(fr.flatten(), ref_t.flatten(), dim=0).item() >= 0.998
+
+
+def test_cogvideox_pipeline_latents_to_uint8_video():
+    """CogVideoXPipeline.generate end to end: embeddings -> DDIM denoising (small transformer) -> CogVideoXVAE -> uint8 video."""
+    from videosys_amd import CogVideoXConfig, CogVideoXPipeline
+    from videosys_amd.vae_cogvideox import CogVideoXVAE
+
+    fx = load_golden("cogvideox_sample_small.pt")
+    pipe = CogVideoXPipeline(CogVideoXConfig(model_path=f"THUDM/CogVideoX-5b@synthetic:{fx['seed']}", transformer_config=fx["cfg"]),
+                             device=dev())
+    assert isinstance(pipe.vae_decoder, CogVideoXVAE) and pipe.vae_decoder.config.scaling_factor == 0.7
+    kw = dict(prompt_embeds=fx["pos"], negative_prompt_embeds=fx["neg"], latents=fx["latents"], height=64, width=96, num_frames=9,
+              num_inference_steps=2, guidance_scale=fx["guidance"], use_dynamic_cfg=True)
+    video = pipe.generate(**kw).video
+    assert video.dtype == torch.uint8 and tuple(video.shape) == (1, 9, 64, 96, 3) and video.device.type == "cpu"
+    lat = pipe.generate(output_type="latent", **kw).video
+    fr = pipe.vae_decoder(lat.to(torch.bfloat16))
+    ref = ((fr.float() / 2.0 + 0.5).clamp(0, 1) * 255).round().permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
+    assert torch.equal(video, ref) and video.float().std().item() > 1.0

@@ -160,9 +160,28 @@ class CogVideoXPipeline:
                                   c.out_channels, c.time_embed_dim, c.patch_size, seed=seed)
         self.transformer.load_state_dict(sd)
         self.scheduler = CogVideoXDDIMScheduler(snr_shift_scale=1.0 if base.endswith("5b") else 3.0)
+        if vae_decoder is None:
+            vae_decoder = self._load_vae(config, base)
         self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
         self._set_parallel()
+
+    def _load_vae(self, config, base):
+        """pipeline_cogvideox.py:146-147,170-172: AutoencoderKLCogVideoX from ``<model_path>/vae`` (local safetensors) or
+        ``...@synthetic:<seed>`` random weights; tiling per ``config.vae_tiling``.  scaling_factor as published: 1.15258426 (2B),
+        0.7 (5B)."""
+        from .vae_cogvideox import CogVideoXVAE, synth_state_dict as vae_synth
+
+        name = config.model_path
+        sf = 0.7 if base.endswith("5b") else 1.15258426
+        if isinstance(name, str) and "@synthetic:" in name:
+            return CogVideoXVAE(vae_synth(int(name.rsplit(":", 1)[1])), device=self._device, scaling_factor=sf, use_tiling=config.vae_tiling)
+        st = os.path.join(name, "vae", "diffusion_pytorch_model.safetensors") if isinstance(name, str) else ""
+        if st and os.path.exists(st):
+            from safetensors.torch import load_file
+
+            return CogVideoXVAE(load_file(st), device=self._device, scaling_factor=sf, use_tiling=config.vae_tiling)
+        return None
 
     def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: Optional[bool] = False):
         """pipeline_cogvideox.py:195-209: sp = world size unless given (then dp = world / sp)."""
@@ -226,7 +245,12 @@ class CogVideoXPipeline:
             z.copy_(z.to(torch.bfloat16).float())  # latents = latents.to(prompt_embeds.dtype) (:723)
         if self.vae_decoder is None or output_type in ("latent", "latents"):
             return VideoSysPipelineOutput(video=z)
-        return VideoSysPipelineOutput(video=self.vae_decoder(z))
+        frames = self.vae_decoder(z.to(torch.bfloat16))   # decode_latents (:359-364) -> [B, 3, T, H, W]
+        if not torch.is_tensor(frames) or frames.dtype == torch.uint8:
+            return VideoSysPipelineOutput(video=frames)
+        # VideoProcessor.postprocess_video (diffusers, third-party) denormalises to [0, 1]; here: uint8 [B, T, H, W, C] on the CPU
+        video = ((frames.float() / 2.0 + 0.5).clamp(0, 1) * 255).round().permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
+        return VideoSysPipelineOutput(video=video)
 
     def save_video(self, video, output_path):
         from .utils import save_video
