@@ -55,8 +55,12 @@ struct Geo {
 // ABL (lab builds only): 1 = no epilogue (accumulators kept alive), 2 = no LDS-DMA inside the loop, 3 = every tile reads
 // the A rows of tile 0 (A becomes L2-resident: separates HBM-miss latency from DMA issue / LDS-write cost), 4 = epilogue
 // arithmetic without the HBM stores, 5 = streaming (nt) stores.
-template <int EPI, int PIPE, int BM_, int RASTER = 1>
-__global__ __launch_bounds__(Geo<BM_>::NT, 2) void gemm_kernel(GemmParams p) {
+// PROD = 1 (schedule 8 only, variant 28): four extra PRODUCER waves (one per SIMD) issue every LDS-DMA piece; the eight consumer
+// waves only read fragments and issue MFMAs.  A piece costs its issuing wave 60-185 cycles (MI355X_MICROARCH.md), 7 pieces per
+// wave and tile against 24 MFMAs = 768 cycles: with the DMA on a third wave of the SIMD that time no longer comes out of an
+// MFMA-issuing wave.  Needs <= 168 VGPRs (three waves per SIMD), which the store-only epilogues meet (165).
+template <int EPI, int PIPE, int BM_, int RASTER = 1, int PROD = 0>
+__global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_kernel(GemmParams p) {
 #if __HIP_DEVICE_COMPILE__  // the buffer-resource type below exists in the device pass only; the host pass needs just the stub
   using G = Geo<BM_>;
   constexpr int BASE = PIPE % 10, ABL = PIPE / 10;
@@ -241,17 +245,89 @@ __global__ __launch_bounds__(Geo<BM_>::NT, 2) void gemm_kernel(GemmParams p) {
     acc[1][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(S##w2, S##x1, acc[1][2], 0, 0, 0);      \
     V8_SB();                                                                                    \
   } while (0)
-    const bool dma_on = (ABL != 2);
+    const bool dma_on = (ABL != 2) && !PROD;
+    if constexpr (PROD) {
+      if (wave >= G::NW) {
+        // ---- producer wave pw stages the rows the consumer waves 2 pw and 2 pw + 1 would have staged: 8 A + 6 W pieces / tile
+        const int pw = wave_u - G::NW;
+        int pa_off[2][NA], pb_off[2][NB], pa_lds[2][NA], pb_lds[2][NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) dma_a(i, 0, 0);
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const int cw = 2 * pw + s_;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) dma_w(i, 0, 0);
-    if (nt > 1) {
+          for (int i = 0; i < NA; ++i) {
+            const int r = cw * (NA * 8) + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            pa_lds[s_][i] = (cw * (NA * 8) + i * 8) * 128;
+            const int rl = row0 + r < p.M ? r : p.M - 1 - row0;
+            pa_off[s_][i] = (rl * (int)p.lda + c * 8) * 2;
+          }
 #pragma unroll
-      for (int i = 0; i < NA; ++i) dma_a(i, 1, 1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          for (int i = 0; i < NB; ++i) {
+            const int r = cw * (NB * 8) + i * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            pb_lds[s_][i] = (cw * (NB * 8) + i * 8) * 128;
+            pb_off[s_][i] = (r * (int)p.ldw + c * 8) * 2;
+          }
+        }
+        auto pdma_a = [&](int kt_, int slot) {
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(smem + slot * A_BYTES + pa_lds[s_][i]), 16, pa_off[s_][i],
+                                                       kt_ * (BK * 2), 0, 0);
+        };
+        auto pdma_w = [&](int kt_, int slot) {
+#pragma unroll
+          for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(smem + W_BASE + slot * B_BYTES + pb_lds[s_][i]), 16,
+                                                       pb_off[s_][i], kt_ * (BK * 2), 0, 0);
+        };
+        pdma_a(0, 0);
+        pdma_w(0, 0);
+        if (nt > 1) {
+          pdma_a(1, 1);
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        V8_SB();
+        __builtin_amdgcn_s_barrier();
+        V8_SB();
+        int psa = 0, psw = 0;
+        for (int t = 0; t < nt; ++t) {
+          const int sa1 = psa == 2 ? 0 : psa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1, sw1 = psw ^ 1;
+          if (t + 1 < nt) pdma_w(t + 1, sw1);   // slot of tile t-1: free since barrier t-1
+          if (t + 2 < nt) {
+            pdma_a(t + 2, sa2);
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // all but A(t+2): A(t+1) and W(t+1) have landed
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          V8_SB();
+          __builtin_amdgcn_s_barrier();
+          V8_SB();
+          psa = sa1;
+          psw = sw1;
+        }
+        __syncthreads();
+        return;
+      }
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < NA; ++i) dma_a(i, 0, 0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) dma_w(i, 0, 0);
+      if (nt > 1) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) dma_a(i, 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
     }
     V8_SB();
     __builtin_amdgcn_s_barrier();
@@ -561,23 +637,25 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 static int g_gemm_variant = 0;
 void set_gemm_variant(int v) { g_gemm_variant = v > 0 ? v : 0; }  // 0 = shape dispatch (default)
 
-template <int PIPE, int BM_, int RASTER = 1>
+template <int PIPE, int BM_, int RASTER = 1, int PROD = 0>
 static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   using G = Geo<BM_>;
+  if (PROD && epi == EPI_GATE_RES) return launch_gemm_t<PIPE, BM_, RASTER, 0>(p, epi, stream);  // 208 VGPRs: no third wave
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
   const int grid = nbm * nbn;
   const size_t lds = (PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
+  constexpr int NTH = G::NT + PROD * 256;
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>), dim3(grid), dim3(NTH), lds, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>), dim3(grid), dim3(NTH), lds, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -598,6 +676,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
     case 21: return launch_gemm2(p, epi, 1, stream);  // ... with static priority by wave slot (lab: no gain measured)
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
+    case 28: return launch_gemm_t<8, 256, 1, 1>(p, epi, stream);  // schedule 8 + four producer waves (store-only epilogues)
     case 3: return launch_gemm_t<3, 256>(p, epi, stream);
     case 9: return launch_gemm_t<8, 256, 0>(p, epi, stream);  // schedule 8, plain row-major tile order
     default:
