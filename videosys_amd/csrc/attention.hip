@@ -523,6 +523,166 @@ __global__ void attn_temporal_d72_kernel(const bf16_t* __restrict__ qkv, int64_t
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// attn_temporal_d72_v2: same contract and lane mapping as attn_temporal_d72_kernel, restructured after its profile
+// (1.86 TB/s, VALU-heavy): (i) q, k and v rows are fetched in ONE round trip; (ii) T <= TK keys: all scores are kept in
+// registers and the softmax is two-pass (exact max, no per-key rescale of the 24 accumulators: 24 FMAs per key instead of
+// 24 mul + 24 FMA + 2 exp); (iii) dot products and accumulation on float2 vectors (v_pk_fma_f32).
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int TK>
+__global__ __launch_bounds__(256) void attn_temporal_d72_v2_kernel(const bf16_t* __restrict__ qkv, int64_t row_stride, int C,
+                                                                   const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
+                                                                   const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
+                                                                   bf16_t* __restrict__ out, int64_t out_stride, int B, int T, int S,
+                                                                   int heads, int wpb, float eps, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int hgroups = (heads + wpb - 1) / wpb;
+  const int hg = blockIdx.x % hgroups;
+  const int64_t bs = blockIdx.x / hgroups;
+  const int s = (int)(bs % S), b = (int)(bs / S);
+  const int h = hg * wpb + wave;
+  if (h >= heads) return;  // no block-level barrier is used below
+  float* ks = reinterpret_cast<float*>(smem) + (size_t)wave * 2 * T * HD;
+  float* vs = ks + (size_t)T * HD;
+  const int g = lane / 3, part = lane - g * 3;
+  const bool lane_ok = lane < 63;
+  const int npass = (T + 20) / 21;
+  const int base = g * 3;
+
+  auto norm_rope = [&](float* x, const bf16_t* w, int t) {
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 24; ++e) ss += x[e] * x[e];
+    const float tot = __shfl(ss, base, 64) + __shfl(ss, base + 1, 64) + __shfl(ss, base + 2, 64);
+    const float rstd = rsqrtf(tot / (float)HD + eps);
+    if (w != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 24; ++e) x[e] = bf2f(f2bf(bf2f(f2bf(x[e] * rstd)) * bf2f(w[part * 24 + e])));
+    }
+    if (rope_cos != nullptr) {
+      const float* cs = rope_cos + (int64_t)t * HD + part * 24;
+      const float* sn = rope_sin + (int64_t)t * HD + part * 24;
+#pragma unroll
+      for (int e = 0; e < 24; e += 2) {
+        const float a = x[e], bb = x[e + 1];
+        x[e] = bf2f(f2bf(a * cs[e] - bb * sn[e]));
+        x[e + 1] = bf2f(f2bf(bb * cs[e + 1] + a * sn[e + 1]));
+      }
+    }
+  };
+
+  // ---- one round trip: q, k, v of this lane's frame (first pass) are all requested before anything is consumed
+  uint4 rq[3], rk[3], rv[3];
+  {
+    const int tt = g < T ? g : T - 1;
+    const bf16_t* row = qkv + (((int64_t)b * T + tt) * S + s) * row_stride + h * HD + part * 24;
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      rk[cc] = *reinterpret_cast<const uint4*>(row + C + cc * 8);
+      rv[cc] = *reinterpret_cast<const uint4*>(row + 2 * C + cc * 8);
+      rq[cc] = *reinterpret_cast<const uint4*>(row + cc * 8);
+    }
+  }
+  for (int pss = 0; pss < npass; ++pss) {
+    const int t = pss * 21 + g;
+    const bool act = lane_ok && t < T;
+    const int tt = t < T ? t : T - 1;
+    if (pss > 0) {
+      const bf16_t* row = qkv + (((int64_t)b * T + tt) * S + s) * row_stride + h * HD + part * 24;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        rk[cc] = *reinterpret_cast<const uint4*>(row + C + cc * 8);
+        rv[cc] = *reinterpret_cast<const uint4*>(row + 2 * C + cc * 8);
+      }
+    }
+    float kx[24], vx[24];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      unpack8(rk[cc], kx + cc * 8);
+      unpack8(rv[cc], vx + cc * 8);
+    }
+    norm_rope(kx, k_norm_w, tt);
+    if (act) {
+#pragma unroll
+      for (int e = 0; e < 24; e += 4) {
+        *reinterpret_cast<float4*>(ks + t * HD + part * 24 + e) = make_float4(kx[e], kx[e + 1], kx[e + 2], kx[e + 3]);
+        *reinterpret_cast<float4*>(vs + t * HD + part * 24 + e) = make_float4(vx[e], vx[e + 1], vx[e + 2], vx[e + 3]);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+  for (int pss = 0; pss < npass; ++pss) {
+    const int t = pss * 21 + g;
+    const bool act = lane_ok && t < T;
+    const int tt = t < T ? t : T - 1;
+    if (pss > 0) {
+      const bf16_t* row = qkv + (((int64_t)b * T + tt) * S + s) * row_stride + h * HD + part * 24;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) rq[cc] = *reinterpret_cast<const uint4*>(row + cc * 8);
+    }
+    float qx[24];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) unpack8(rq[cc], qx + cc * 8);
+    norm_rope(qx, q_norm_w, tt);
+    f32x2 q2[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) q2[e] = f32x2{qx[2 * e] * scale, qx[2 * e + 1] * scale};  // fold the softmax scale into q
+    float sc[TK];
+    float m = NEG_BIG;
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      sc[j] = NEG_BIG;
+      if (j < T) {
+        const float* kr = ks + j * HD + part * 24;
+        f32x2 d2 = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 24; e += 4) {
+          const float4 kk = *reinterpret_cast<const float4*>(kr + e);
+          d2 = __builtin_elementwise_fma(q2[e / 2], f32x2{kk.x, kk.y}, d2);
+          d2 = __builtin_elementwise_fma(q2[e / 2 + 1], f32x2{kk.z, kk.w}, d2);
+        }
+        const float d = d2.x + d2.y;
+        sc[j] = __shfl(d, base, 64) + __shfl(d, base + 1, 64) + __shfl(d, base + 2, 64);
+        m = fmaxf(m, sc[j]);
+      }
+    }
+    f32x2 acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = f32x2{0.f, 0.f};
+    float l = 0.f;
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      if (j < T) {
+        const float pj = __expf(sc[j] - m);
+        l += pj;
+        const f32x2 p2 = f32x2{pj, pj};
+        const float* vr = vs + j * HD + part * 24;
+#pragma unroll
+        for (int e = 0; e < 24; e += 4) {
+          const float4 vv = *reinterpret_cast<const float4*>(vr + e);
+          acc[e / 2] = __builtin_elementwise_fma(p2, f32x2{vv.x, vv.y}, acc[e / 2]);
+          acc[e / 2 + 1] = __builtin_elementwise_fma(p2, f32x2{vv.z, vv.w}, acc[e / 2 + 1]);
+        }
+      }
+    }
+    if (act) {
+      const float inv = 1.0f / l;
+      float o[24];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) { o[2 * e] = acc[e].x * inv; o[2 * e + 1] = acc[e].y * inv; }
+      bf16_t* orow = out + (((int64_t)b * T + t) * S + s) * out_stride + h * HD + part * 24;
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) *reinterpret_cast<uint4*>(orow + cc * 8) = pack8(o + cc * 8);
+    }
+  }
+}
+
 }  // namespace
 
 static int g_flash_variant = 0;
@@ -575,10 +735,19 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
   const int64_t grid = (int64_t)B * S * hgroups;
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = per_wave * wpb;
-  if (lds > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)attn_temporal_d72_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(attn_temporal_d72_kernel, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
-                     k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, 0.11785113019775793f);
+  const float scale = 0.11785113019775793f;
+  if (T <= 20 && g_flash_variant != 9) {
+    hipLaunchKernelGGL(attn_temporal_d72_v2_kernel<20>, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
+                       k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, scale);
+  } else if (T <= 40 && g_flash_variant != 9) {
+    hipLaunchKernelGGL(attn_temporal_d72_v2_kernel<40>, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
+                       k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, scale);
+  } else {  // long sequences (or lab variant 9): the online-softmax kernel
+    if (lds > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(attn_temporal_d72_kernel, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
+                       k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, scale);
+  }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
