@@ -53,3 +53,19 @@ def test_two_workgroup_gemm_fits_two_per_cu():
     for name, res in hits.items():
         assert res.get("ScratchSize", 0) == 0, f"{name} uses scratch: {res}"
         assert res.get("VGPRs", 0) <= 256, f"{name}: {res.get('VGPRs')} VGPRs"
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_conv_and_producer_gemm_resources():
+    """conv_bf16.hip runs two workgroups per CU (<= 256 VGPRs, no scratch); the producer-wave GEMM variant needs three waves per
+    SIMD (<= 168 VGPRs) for its store-only epilogues."""
+    u = _usage("conv_bf16.hip")
+    hits = {k: v for k, v in u.items() if "conv_kernel" in k}
+    assert len(hits) == 2
+    for name, res in hits.items():
+        assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs", 0) <= 256, f"{name}: {res}"
+    g = _usage("gemm_bf16.hip")
+    prod = {k: v for k, v in g.items() if "ELi8ELi256ELi1ELi1E" in k}
+    assert len(prod) >= 2, list(g)
+    for name, res in prod.items():
+        assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs", 0) <= 168, f"{name}: {res}"
