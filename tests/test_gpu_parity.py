@@ -71,7 +71,7 @@ def _gemm_bias(ops, M, N, K):
     check(out, O.gelu_tanh(ref), what="gemm+gelu")
 
 
-@pytest.mark.parametrize("variant", [3, 6, 8, 20, 28, 103])
+@pytest.mark.parametrize("variant", [3, 6, 8, 20, 28, 30, 103])
 def test_gemm_pipeline_variants(ops, variant):
     """Every main-loop schedule of the GEMM (LDS-DMA burst / interleaved, 2-stage / 3+2-slot, 8-wave / 4-wave geometry)
     must give the same result;
@@ -82,7 +82,7 @@ def test_gemm_pipeline_variants(ops, variant):
     g = torch.Generator().manual_seed(40 + variant)
     try:
         lib.vsys_tune_gemm_variant(variant)
-        for M, N, K in ((515, 192, 64), (300, 384, 128), (1000, 576, 1152), (777, 576, 192)):
+        for M, N, K in ((515, 192, 64), (300, 384, 128), (1000, 576, 1152), (777, 576, 192), (600, 1152, 320)):
             x = torch.randn(M, K, generator=g).to(torch.bfloat16)
             w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
             b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16)

@@ -18,32 +18,41 @@
 namespace vsys {
 namespace {
 
-constexpr int BM = 256, BN = 192, BK = 32;
+constexpr int BM = 256, BK = 32;
 constexpr int A_SLOT = BM * BK * 2;   // 16384
-constexpr int W_SLOT = BN * BK * 2;   // 12288
 constexpr int W_BASE = 3 * A_SLOT;    // 49152
-constexpr int LDS_BYTES = W_BASE + 2 * W_SLOT;  // 73728
 constexpr int OUT_ROW_BYTES = 96 * 2 + 16;
 constexpr int OUT_WAVE_BYTES = 64 * OUT_ROW_BYTES;  // 13312 per wave and pass
-static_assert(4 * OUT_WAVE_BYTES <= LDS_BYTES, "epilogue image must fit in the staging buffers");
 
-template <int EPI, int PRIO>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
+// NWN = waves along N.  2: 4 waves, tile 256 x 192, 72 KiB, TWO workgroups per CU (variant 20).  4: 8 waves, tile 256 x 384,
+// one workgroup per CU (variant 30): the loop needs (256 + 384) / (256 * 384) = 0.0065 operand bytes per flop instead of 0.0091,
+// and 384 still divides every N of the denoise path (1152 = 3, 3456 = 9, 4608 = 12 tiles).
+template <int NWN>
+struct G2 {
+  static constexpr int NW = 2 * NWN;
+  static constexpr int NT = 64 * NW;
+  static constexpr int BN = 96 * NWN;
+  static constexpr int NA = 16 / NW;             // A pieces (16 rows x 64 B) per wave and stage: 4 or 2
+  static constexpr int W_SLOT = BN * BK * 2;     // 12288 or 24576
+  // W prefetch distance in stages.  An LDS-DMA piece lands ~1.1 us after issue (MI355X_MICROARCH.md, ldsdma-fill) but a stage
+  // is only ~0.65 us of MFMAs, so a one-stage lead leaves every stage barrier waiting for W; the wide tile has the LDS for a
+  // third W slot (3 x 16 + 3 x 24 = 120 KiB) and prefetches BOTH operands two stages ahead.
+  static constexpr int WLEAD = NWN == 4 ? 2 : 1;
+  static constexpr int NWSLOT = WLEAD + 1;
+  static constexpr int STAGING = W_BASE + NWSLOT * W_SLOT;
+  static constexpr int LDS_BYTES = STAGING > NW * OUT_WAVE_BYTES ? STAGING : NW * OUT_WAVE_BYTES;  // 73728 or 106496
+};
+
+template <int EPI, int NWN>
+__global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
+  using G = G2<NWN>;
+  constexpr int BN = G::BN, NA = G::NA, W_SLOT = G::W_SLOT, WLEAD = G::WLEAD;
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int l31 = lane & 31, hi = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  // The two waves of a SIMD come from two different workgroups.  Left alone they drift INTO phase (the one that reaches its
-  // epilogue first hands the whole matrix pipe to the other, which then catches up), and in phase both epilogues idle the
-  // pipe together.  A static priority by hardware wave slot breaks the symmetry: the odd slot owns the pipe whenever it has
-  // MFMAs, the even slot fills its gaps (epilogue, relaunch, first-tile latency, barrier and DMA waits).
-  if (PRIO) {
-    const unsigned slot = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) & 1u;  // HW_REG_HW_ID[3:0] = wave slot in its SIMD
-    if (__builtin_amdgcn_readfirstlane(slot)) __builtin_amdgcn_s_setprio(2);
-  }
-
   // tile order: same W-resident raster as gemm_bf16.hip (column groups of 6 inside 8 row-panel groups)
   const int nbn = p.N / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -80,10 +89,10 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
   // logical chunk (l&3) ^ ((row>>2)&3) = (l&3) ^ ((l>>4)&3) (piece bases are multiples of 16 rows).
   // wave w stages A rows [64w, 64w+64) (4 pieces) and W rows [48w, 48w+48) (3 pieces) of every stage.
   const int dchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
-  int a_off[4], b_off[3];
+  int a_off[NA], b_off[3];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int r = wave_u * 64 + i * 16 + (lane >> 2);
+  for (int i = 0; i < NA; ++i) {
+    const int r = wave_u * (16 * NA) + i * 16 + (lane >> 2);
     const int rl = row0 + r < p.M ? r : p.M - 1 - row0;  // rows past M re-read the last row (never stored)
     a_off[i] = rl * (int)p.lda * 2 + dchunk;
   }
@@ -96,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
                                                         (int)(b_bytes < 0x7fffffff ? b_bytes : 0x7fffffff), 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   auto dma_a = [&](int i, int t, int slot) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(smem + slot * A_SLOT + (wave_u * 64 + i * 16) * 64), 16, a_off[i],
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(smem + slot * A_SLOT + (wave_u * (16 * NA) + i * 16) * 64), 16, a_off[i],
                                              t * (BK * 2), 0, 0);
   };
   auto dma_w = [&](int i, int t, int slot) {
@@ -120,13 +129,21 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
 
   const int nt = p.K / BK;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dma_a(i, 0, 0);
+  for (int i = 0; i < NA; ++i) dma_a(i, 0, 0);
 #pragma unroll
   for (int i = 0; i < 3; ++i) dma_w(i, 0, 0);
   if (nt > 1) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dma_a(i, 1, 1);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    for (int i = 0; i < NA; ++i) dma_a(i, 1, 1);
+    if constexpr (WLEAD == 2) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) dma_w(i, 1, 1);
+      asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // stage 1 (2 A + 3 W pieces) may still be in flight
+    } else if constexpr (NA == 4) {
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
@@ -136,8 +153,12 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
 
   int sa = 0, sw = 0;
   for (int t = 0; t < nt; ++t) {
-    const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1, sw1 = sw ^ 1;
-    const bool n1 = t + 1 < nt, n2 = t + 2 < nt;
+    const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
+    const int sw1 = WLEAD == 2 ? sa1 : (sw ^ 1);          // with the two-stage lead W uses the same 3-slot ring as A
+    const int swn = WLEAD == 2 ? sa2 : sw1;               // slot the W pieces issued in this stage go to
+    const int tw = t + WLEAD;                             // ... and their stage
+    const bool n2 = t + 2 < nt;
+    const bool n1 = WLEAD == 2 ? n2 : (t + 1 < nt);       // "W pieces are issued in this stage"
     const char* ab = smem + sa * A_SLOT;
     const char* wb = smem + sw * W_SLOT;
     bf16x8 x0, x1, x2, x3, w0, w1, w2, v0, v1, v2;  // x: A fragments of the current k-step; w / v: W fragments of k-step 0 / 1
@@ -161,23 +182,28 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
     G2_ROW(0, x0, w0, w1, w2);
     __builtin_amdgcn_sched_barrier(0);
     x0 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32));
-    if (n1) { dma_w(0, t + 1, sw1); dma_w(1, t + 1, sw1); }
+    if (n1) { dma_w(0, tw, swn); dma_w(1, tw, swn); }
     __builtin_amdgcn_sched_barrier(0);
     G2_ROW(1, x1, w0, w1, w2);
     __builtin_amdgcn_sched_barrier(0);
     x1 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32) + 2048);
-    if (n1) dma_w(2, t + 1, sw1);
+    if (n1) dma_w(2, tw, swn);
     if (n2) dma_a(0, t + 2, sa2);
     __builtin_amdgcn_sched_barrier(0);
     G2_ROW(2, x2, w0, w1, w2);
     __builtin_amdgcn_sched_barrier(0);
     x2 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32) + 4096);
-    if (n2) { dma_a(1, t + 2, sa2); dma_a(2, t + 2, sa2); }
+    if (n2) {
+      dma_a(1, t + 2, sa2);
+      if constexpr (NA > 2) dma_a(2 < NA ? 2 : 0, t + 2, sa2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     G2_ROW(3, x3, w0, w1, w2);
     __builtin_amdgcn_sched_barrier(0);
     x3 = *reinterpret_cast<const bf16x8*>(ab + (xo ^ 32) + 6144);
-    if (n2) dma_a(3, t + 2, sa2);
+    if constexpr (NA > 3) {
+      if (n2) dma_a(3 < NA ? 3 : 0, t + 2, sa2);
+    }
     __builtin_amdgcn_sched_barrier(0);
     // k-step 1
     G2_ROW(0, x0, v0, v1, v2);
@@ -186,8 +212,13 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
     G2_ROW(3, x3, v0, v1, v2);
 #undef G2_ROW
     __builtin_amdgcn_sched_barrier(0);
-    if (n2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (n2) {
+      if constexpr (WLEAD == 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else if constexpr (NA == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();  // stage t+1 has landed everywhere; nobody reads the slots of stage t any more
     __builtin_amdgcn_sched_barrier(0);
@@ -313,28 +344,31 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(GemmParams p) {
 
 }  // namespace
 
-template <int PRIO>
+template <int NWN>
 static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
-  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / BN;
+  using G = G2<NWN>;
+  if (p.N % G::BN != 0) return VSYS_ERR_SHAPE;
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / G::BN;
   const int grid = nbm * nbn;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     attr_set = true;
   }
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, PRIO>), dim3(grid), dim3(256), LDS_BYTES, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, PRIO>), dim3(grid), dim3(256), LDS_BYTES, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, PRIO>), dim3(grid), dim3(256), LDS_BYTES, stream, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
-int launch_gemm2(const GemmParams& p, int epi, int prio, hipStream_t stream) {
-  return prio ? launch_gemm2_t<1>(p, epi, stream) : launch_gemm2_t<0>(p, epi, stream);
+// wide = 0: 256 x 192 tile, two workgroups per CU (variant 20); wide = 1: 256 x 384 tile, one 8-wave workgroup per CU (variant 30)
+int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream) {
+  return wide ? launch_gemm2_t<4>(p, epi, stream) : launch_gemm2_t<2>(p, epi, stream);
 }
 
 }  // namespace vsys
