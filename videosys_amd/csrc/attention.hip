@@ -689,6 +689,7 @@ static int g_flash_variant = 0;
 static unsigned long long* g_flash_dbg = nullptr;
 void set_flash_variant(int v) { g_flash_variant = v; }
 void set_flash_debug_buffer(void* p) { g_flash_dbg = reinterpret_cast<unsigned long long*>(p); }
+void* get_lab_debug_buffer() { return g_flash_dbg; }
 
 int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* k_norm_w,
                         bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps,

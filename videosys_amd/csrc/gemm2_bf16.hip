@@ -43,7 +43,9 @@ struct G2 {
   static constexpr int LDS_BYTES = STAGING > NW * OUT_WAVE_BYTES ? STAGING : NW * OUT_WAVE_BYTES;  // 73728 or 106496
 };
 
-template <int EPI, int NWN>
+// STAMP = 1 (lab, variant 31): s_memtime stamps around the four phases of every stage (fragment reads landed / MFMA block issued /
+// counted waits / barrier), summed per wave into p.aux viewed as int64[blocks][waves][8] — the cycle accounting of one stage.
+template <int EPI, int NWN, int STAMP = 0>
 __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   using G = G2<NWN>;
   constexpr int BN = G::BN, NA = G::NA, W_SLOT = G::W_SLOT, WLEAD = G::WLEAD;
@@ -152,6 +154,8 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   __builtin_amdgcn_sched_barrier(0);
 
   int sa = 0, sw = 0;
+  uint64_t st_read = 0, st_mfma = 0, st_wait = 0, st_bar = 0, st_t0 = 0, st_begin = 0;
+  if constexpr (STAMP) { st_begin = __builtin_amdgcn_s_memtime(); st_t0 = st_begin; }
   for (int t = 0; t < nt; ++t) {
     const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1;
     const int sw1 = WLEAD == 2 ? sa1 : (sw ^ 1);          // with the two-stage lead W uses the same 3-slot ring as A
@@ -173,6 +177,12 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     v1 = *reinterpret_cast<const bf16x8*>(wb + (wo ^ 32) + 2048);
     v2 = *reinterpret_cast<const bf16x8*>(wb + (wo ^ 32) + 4096);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAMP) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      st_read += now - st_t0; st_t0 = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #define G2_ROW(i_, X_, W0_, W1_, W2_)                                                                  \
   acc[i_][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W0_, X_, acc[i_][0], 0, 0, 0);                  \
   acc[i_][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W1_, X_, acc[i_][1], 0, 0, 0);                  \
@@ -212,6 +222,11 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     G2_ROW(3, x3, v0, v1, v2);
 #undef G2_ROW
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAMP) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      st_mfma += now - st_t0; st_t0 = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if (n2) {
       if constexpr (WLEAD == 2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
       else if constexpr (NA == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
@@ -220,8 +235,18 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAMP) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      st_wait += now - st_t0; st_t0 = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     __builtin_amdgcn_s_barrier();  // stage t+1 has landed everywhere; nobody reads the slots of stage t any more
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (STAMP) {
+      const uint64_t now = __builtin_amdgcn_s_memtime();
+      st_bar += now - st_t0; st_t0 = now;
+      __builtin_amdgcn_sched_barrier(0);
+    }
     sa = sa1;
     sw = sw1;
   }
@@ -339,6 +364,14 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // image reads done before the next pass overwrites it
     __builtin_amdgcn_wave_barrier();
   }
+  if constexpr (STAMP) {
+    if (lane == 0 && p.aux != nullptr) {
+      int64_t* d = reinterpret_cast<int64_t*>(p.aux) + ((int64_t)blockIdx.x * G::NW + wave) * 8;
+      const uint64_t end = __builtin_amdgcn_s_memtime();
+      d[0] = (int64_t)st_read; d[1] = (int64_t)st_mfma; d[2] = (int64_t)st_wait; d[3] = (int64_t)st_bar;
+      d[4] = (int64_t)(st_t0 - st_begin); d[5] = (int64_t)(end - st_t0); d[6] = (int64_t)st_begin; d[7] = nt;
+    }
+  }
 #endif
 }
 
@@ -363,6 +396,17 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
     case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_gemm2_stamp(const GemmParams& p_, hipStream_t stream) {
+  using G = G2<4>;
+  GemmParams p = p_;
+  p.aux = reinterpret_cast<bf16_t*>(get_lab_debug_buffer());  // set with vsys_lab_flash_debug_buffer: int64[blocks * 8 * 8]
+  if (p.N % G::BN != 0 || p.aux == nullptr) return VSYS_ERR_SHAPE;
+  const int grid = ((p.M + BM - 1) / BM) * (p.N / G::BN);
+  (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+  hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, 4, 1>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

@@ -70,10 +70,12 @@ int launch_t5_attention(const bf16_t* qkv, int64_t row_stride, int inner, const 
                         int64_t out_stride, int B, int L, int heads, hipStream_t stream);
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
-int launch_gemm2(const GemmParams& p, int epi, int prio, hipStream_t stream);
+int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream);
+int launch_gemm2_stamp(const GemmParams& p, hipStream_t stream);  // lab: per-stage cycle stamps into p.aux (int64)
 void set_gemm_variant(int v);
 void set_flash_variant(int v);
 void set_flash_debug_buffer(void* p);
+void* get_lab_debug_buffer();
 int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,
                         int64_t ldo, int M, int N, int K, int act_in, int act_out, hipStream_t stream);
 int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* scale, bf16_t* y, int64_t rows, int C,
