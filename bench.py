@@ -189,6 +189,9 @@ def main():
             "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> + vsys::gemm2_kernel<EPI> (256x192 tile, bf16 MFMA 32x32x16, shape-dispatched, all epilogues)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "power_limited_mfma_ceiling_tflops": 1816.0,
+            "power_note": "measured (profiles/r01_mfma_power_ceiling.json): a bare MFMA loop with operands changing every instruction "
+                          "sustains 1816 TFLOP/s at the 1400 W cap (2465 with constant operands); the GEMMs run at that cap, 1.76-1.98 GHz",
             "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits; algorithmic "
                             "operand + output (+ residual) bytes per launch: 305e6)",
             "launches_per_step": n // nrep, "avg_launch_ms": round(tot_ms / n, 4),

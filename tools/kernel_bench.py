@@ -73,7 +73,7 @@ def main():
                 ms = timeit(fn, args.reps)
                 tf = 2.0 * N * n * k / (ms * 1e-3) / 1e12
                 res.setdefault(f"gemm_{name}_pipe{variant}", []).append((ms, tf))
-                if rd == 0 and (variant % 100 < 10 or variant in (20, 28, 30)):  # schedules must not change results: same k order, same MFMA
+                if rd == 0 and (variant % 100 < 10 or variant in (20, 28, 30, 40)):  # schedules must not change results: same k order, same MFMA
                     got = out.clone()
                     lib.vsys_tune_gemm_variant(0)
                     fn()

@@ -674,6 +674,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     case 48: return launch_gemm_t<48, 256>(p, epi, stream);
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
+    case 40: return launch_gemm3(p, epi, stream);  // 5-slot ring, fragments always one k-step ahead (gemm3_bf16.hip)
     case 31: return (epi == EPI_BIAS && p.N % 384 == 0) ? launch_gemm2_stamp(p, stream) : VSYS_ERR_ARG;  // lab: cycle stamps
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape

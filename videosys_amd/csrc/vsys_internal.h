@@ -71,6 +71,7 @@ int launch_t5_attention(const bf16_t* qkv, int64_t row_stride, int inner, const 
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream);
+int launch_gemm3(const GemmParams& p, int epi, hipStream_t stream);  // continuous k-step pipeline (gemm3_bf16.hip)
 int launch_gemm2_stamp(const GemmParams& p, hipStream_t stream);  // lab: per-stage cycle stamps into p.aux (int64)
 void set_gemm_variant(int v);
 void set_flash_variant(int v);
