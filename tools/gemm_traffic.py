@@ -13,7 +13,7 @@ NAMES = ["qkv", "proj", "fc1", "fc2"]
 def per_dispatch(db, counter):
     cur = sqlite3.connect(db).cursor()
     rows = cur.execute("select dispatch_id, sum(value) from counters_collection where counter_name = ? and kernel_name like "
-                       "'%gemm_kernel%' group by dispatch_id order by dispatch_id", (counter,)).fetchall()
+                       "'%gemm%kernel%' group by dispatch_id order by dispatch_id", (counter,)).fetchall()
     return [v for _, v in rows]
 
 
