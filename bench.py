@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--no-t5", action="store_true", help="skip the (untimed-region) T5 encode measurement")
     ap.add_argument("--text-len", type=int, default=300)
+    ap.add_argument("--gemm-variant", type=int, default=0, help="lab: vsys_tune_gemm_variant id (0 = shipped shape dispatch)")
     return ap.parse_args()
 
 
@@ -79,7 +80,10 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         dist.barrier()
 
-    from videosys_amd import ops, pab
+    from videosys_amd import _lib, ops, pab
+
+    if args.gemm_variant:
+        _lib.load().vsys_tune_gemm_variant(args.gemm_variant)
     from videosys_amd.pipeline_open_sora import OpenSoraPABConfig, get_latent_size
     from videosys_amd.rflow import RFLOW
     from videosys_amd.stdit3 import STDiT3, STDiT3Config, synth_state_dict

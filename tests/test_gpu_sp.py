@@ -48,8 +48,13 @@ def _stdit3_worker(rank, world, port, outdir, T, HW):
         model.enable_parallel(1, world, False)
         out = model(x, t, y, **kw).float().cpu()
         out2 = model(x, t, y, **kw).float().cpu()
+        # opt-in comm/compute overlap: the two CFG samples on two side streams, collectives issued A1, B1, A2, B2
+        model.enable_parallel(1, world, False, overlap=True)
+        assert model._overlap and model._side is not None
+        out3 = model(x, t, y, **kw).float().cpu()
+        out4 = model(x, t, y, **kw).float().cpu()
         torch.cuda.synchronize()
-        ok = torch.equal(out, ref) and torch.equal(out, out2)
+        ok = torch.equal(out, ref) and torch.equal(out, out2) and torch.equal(out3, ref) and torch.equal(out4, ref)
         err = (out - ref).abs().max().item()
         with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
             f.write("ok" if ok else f"mismatch max|diff| {err} of {ref.abs().max().item()}")

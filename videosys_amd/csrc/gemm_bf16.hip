@@ -668,7 +668,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   if (epi == EPI_GATE_RES && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;
   // tile-relative operand offsets are 32-bit (buffer addressing)
   if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 384 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
-  switch (g_gemm_variant) {
+  switch (g_gemm_variant == 50 ? 0 : g_gemm_variant) {
     case 6: return launch_gemm_t<6, 256>(p, epi, stream);
     case 18: return launch_gemm_t<18, 256>(p, epi, stream);
     case 48: return launch_gemm_t<48, 256>(p, epi, stream);
@@ -690,6 +690,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
       // qkv -7 %, proj -15 %, fc2 -16 %, fc1 -2 % (tools/kernel_bench.py --rows 4864 --variants 8,20,103).
       if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
       if (epi != EPI_GATE_RES && p.K <= 1536 && p.N >= 2304) return launch_gemm2(p, epi, 0, stream);
+      if (g_gemm_variant == 50 && p.K >= 2304 && p.N % 384 == 0) return launch_gemm2(p, epi, 1, stream);  // lab: long-K on the wide tile
       return launch_gemm_t<8, 256>(p, epi, stream);
   }
 }

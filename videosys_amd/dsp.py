@@ -191,12 +191,13 @@ class SequenceParallel:
         self.exec(recv, out, ops)
         return out
 
-    def to_temporal_shard(self, x, S, out=None):
-        """[B,T,Sl,C] -> [B,Tp,S,C]  (before spatial attention)."""
+    def to_temporal_shard(self, x, S, out=None, tag=""):
+        """[B,T,Sl,C] -> [B,Tp,S,C]  (before spatial attention).  ``tag`` selects a private pair of staging buffers (two
+        switches in flight on different streams must not share them)."""
         B, T, Sl, C = x.shape
         pack, unpack, sshape, oshape = plan_switch_to_temporal_shard(B, T, Sl, S, C, self.P)
-        send = self._buf("a2a_send", sshape, x)
-        recv = self._buf("a2a_recv", sshape, x)
+        send = self._buf(f"a2a_send{tag}", sshape, x)
+        recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
         dist.all_to_all_single(recv, send, group=self.group)
         if out is None:
@@ -204,12 +205,12 @@ class SequenceParallel:
         self.exec(recv, out, unpack)
         return out
 
-    def to_spatial_shard(self, x, T, Sl, out=None):
+    def to_spatial_shard(self, x, T, Sl, out=None, tag=""):
         """[B,Tp,S,C] -> [B,T,Sl,C]  (after spatial attention)."""
         B, Tp, S, C = x.shape
         pack, unpack, sshape, oshape = plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, self.P)
-        send = self._buf("a2a_send", sshape, x)
-        recv = self._buf("a2a_recv", sshape, x)
+        send = self._buf(f"a2a_send{tag}", sshape, x)
+        recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
         dist.all_to_all_single(recv, send, group=self.group)
         if out is None:

@@ -20,6 +20,7 @@ Differences from the reference that do not change results (SURVEY.md §7 "hard p
 from __future__ import annotations
 
 import math
+import os
 from types import SimpleNamespace
 from typing import Dict, Optional
 
@@ -190,7 +191,7 @@ class STDiT3:
         return sd
 
     # ------------------------------------------------------------------ parallel
-    def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None, parallel_mgr=None, copy_executor=None):
+    def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None, parallel_mgr=None, copy_executor=None, overlap=None):
         """open_sora_transformer_3d.py:466-482.  cp (CFG batch split) is not built in this round: enable_cp is accepted
         and ignored exactly like the reference's default (pipeline_open_sora.py:254 passes False)."""
         if parallel_mgr is not None:
@@ -202,6 +203,12 @@ class STDiT3:
             self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
         else:
             self._sp = None
+        # comm/compute overlap of the two CFG samples around the spatial attention (opt-in: VSYS_DSP_OVERLAP=1 or overlap=True;
+        # validated bit-exact with two ranks on one GPU, not yet timed on a multi-GPU node)
+        if overlap is None:
+            overlap = os.environ.get("VSYS_DSP_OVERLAP", "0") == "1"
+        self._overlap = bool(overlap) and self._sp is not None
+        self._side = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)] if self._overlap else None
 
     # ------------------------------------------------------------------ helpers
     def get_dynamic_size(self, x):
@@ -374,7 +381,10 @@ class STDiT3:
                 cos, sin = self._rope(T)
                 ops.attn_temporal(qkv, C, w[p + ".attn.q_norm.weight"], w[p + ".attn.k_norm.weight"], cos, sin, ao, B, T, S, H)
             else:
-                if sp is not None and T > 1:
+                if sp is not None and T > 1 and B == 2 and getattr(self, "_overlap", False):
+                    ao = self._spatial_attn_overlapped(p, xm, B, T, S, S_full)
+                    xa = None
+                elif sp is not None and T > 1:
                     xt = sp.to_temporal_shard(xm.view(B, T, S, C), S_full)  # [B, Tp, S_full, C]
                     Tp = xt.shape[1]
                     xa, Ta, Sa = xt.view(B * Tp * S_full, C), Tp, S_full
@@ -382,14 +392,15 @@ class STDiT3:
                     raise NotImplementedError("DSP image case (T == 1, batch scatter) is not built")
                 else:
                     xa, Ta, Sa = xm, T, S
-                Na = B * Ta * Sa
-                qkv = ops.gemm(xa, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (Na, 3 * C)))
-                kp, vt = self._kv_spatial(B * Ta, Sa)
-                ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * Ta, H, Sa)
-                ao = self._buf("attn_out", (Na, C))
-                ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * Ta, H, Sa, Sa)
-                if sp is not None:
-                    ao = sp.to_spatial_shard(ao.view(B, Ta, Sa, C), T, S, out=self._buf("attn_back", (B, T, S, C))).view(N, C)
+                if xa is not None:
+                    Na = B * Ta * Sa
+                    qkv = ops.gemm(xa, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (Na, 3 * C)))
+                    kp, vt = self._kv_spatial(B * Ta, Sa)
+                    ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * Ta, H, Sa)
+                    ao = self._buf("attn_out", (Na, C))
+                    ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * Ta, H, Sa, Sa)
+                    if sp is not None:
+                        ao = sp.to_spatial_shard(ao.view(B, Ta, Sa, C), T, S, out=self._buf("attn_back", (B, T, S, C))).view(N, C)
             ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
                      gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
 
@@ -422,6 +433,38 @@ class STDiT3:
         ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
                  gate_stride=C6, rows_per_sample=T * S, res=x, out=x)
         return x
+
+    def _spatial_attn_overlapped(self, p, xm, B, T, S, S_full):
+        """The DSP section of a spatial block (modulated activations -> all-to-all -> qkv -> attention -> all-to-all) with the
+        two CFG samples on two side streams.  The collectives are ISSUED in the order A1, B1, A2, B2 (RCCL runs the collectives of
+        a communicator in issue order), so sample B's first exchange travels while sample A computes and A's second exchange
+        travels while B computes.  Every op is per-sample independent, so the result equals the batched path bit for bit."""
+        w, C, H, sp = self.w, self.hidden_size, self.num_heads, self._sp
+        main = torch.cuda.current_stream()
+        ev_in = main.record_event()
+        xm4 = xm.view(B, T, S, C)
+        back = self._buf("attn_back", (B, T, S, C))
+        xts = [None, None]
+        for i in range(2):   # phase 1: both first exchanges
+            with torch.cuda.stream(self._side[i]):
+                self._side[i].wait_event(ev_in)
+                xts[i] = sp.to_temporal_shard(xm4[i:i + 1], S_full, tag=f"_{i}", out=self._buf(f"sp_xt{i}", (1, -(-T // sp.P), S_full, C)))
+        for i in range(2):   # phase 2: per-sample attention, then the exchange back
+            with torch.cuda.stream(self._side[i]):
+                xt = xts[i]
+                Tp = xt.shape[1]
+                Na = Tp * S_full
+                qkv = ops.gemm(xt.view(Na, C), w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf(f"qkv_o{i}", (Na, 3 * C)))
+                key = ("kv_spatial_o", i, Tp, S_full)
+                if key not in self._ws:
+                    self._ws[key] = ops.alloc_kv_buffers(Tp, H, S_full, self.device)
+                kp, vt = self._ws[key]
+                ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, Tp, H, S_full)
+                ao = self._buf(f"attn_out_o{i}", (Na, C))
+                ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, Tp, H, S_full, S_full)
+                sp.to_spatial_shard(ao.view(1, Tp, S_full, C), T, S, out=back[i:i + 1], tag=f"_{i}")
+                main.wait_event(self._side[i].record_event())
+        return back.view(B * T * S, C)
 
     def _kv_spatial(self, batch, kv_len):
         key = ("kv_spatial", batch, kv_len)
