@@ -54,7 +54,13 @@ def _stdit3_worker(rank, world, port, outdir, T, HW):
         out3 = model(x, t, y, **kw).float().cpu()
         out4 = model(x, t, y, **kw).float().cpu()
         torch.cuda.synchronize()
-        ok = torch.equal(out, ref) and torch.equal(out, out2) and torch.equal(out3, ref) and torch.equal(out4, ref)
+        # enable_cp: the CFG pair split over the two ranks (cp = 2, sp = 1), outputs gathered along the batch
+        model.enable_parallel(1, world, True)
+        assert model.parallel_manager.cp_size == 2 and model.parallel_manager.sp_size == 1 and model._sp is None
+        out5 = model(x, t, y, **kw).float().cpu()
+        torch.cuda.synchronize()
+        ok = (torch.equal(out, ref) and torch.equal(out, out2) and torch.equal(out3, ref) and torch.equal(out4, ref)
+              and torch.equal(out5, ref))
         err = (out - ref).abs().max().item()
         with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
             f.write("ok" if ok else f"mismatch max|diff| {err} of {ref.abs().max().item()}")

@@ -192,12 +192,15 @@ class STDiT3:
 
     # ------------------------------------------------------------------ parallel
     def enable_parallel(self, dp_size=None, sp_size=None, enable_cp=None, parallel_mgr=None, copy_executor=None, overlap=None):
-        """open_sora_transformer_3d.py:466-482.  cp (CFG batch split) is not built in this round: enable_cp is accepted
-        and ignored exactly like the reference's default (pipeline_open_sora.py:254 passes False)."""
+        """open_sora_transformer_3d.py:466-482, incl. enable_cp: with an even sp_size the CFG batch is split over cp = 2 rank
+        groups (each runs DSP over sp_size / 2 ranks on ONE sample) and the outputs are gathered along the batch (:546-557,621)."""
         if parallel_mgr is not None:
             self.parallel_manager = parallel_mgr
         else:
-            self.parallel_manager = dsp.ParallelManager(dp_size or 1, 1, sp_size or 1)
+            sp_size, cp_size = sp_size or 1, 1
+            if enable_cp and sp_size % 2 == 0:   # "update cfg parallel" (:470-475): the CFG pair goes to two rank groups
+                sp_size, cp_size = sp_size // 2, 2
+            self.parallel_manager = dsp.ParallelManager(dp_size or 1, cp_size, sp_size)
         if self.parallel_manager.sp_size > 1:
             kw = {} if copy_executor is None else {"copy_executor": copy_executor}
             self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
@@ -296,6 +299,17 @@ class STDiT3:
         if x_mask is not None:
             raise NotImplementedError("x_mask (reference/mask conditioning) is outside the MI355X hot path")
         w, C, H = self.w, self.hidden_size, self.num_heads
+        # === Split batch === (:545-557): rank group cp_rank keeps its rows of every per-sample input
+        pm = self.parallel_manager
+        cp = getattr(pm, "cp_size", 1) or 1
+        if cp > 1:
+            Bfull = x.shape[0]
+            if Bfull % cp:
+                raise ValueError(f"batch {Bfull} is not divisible by cp_size {cp}")
+            Bl = Bfull // cp
+            sl = slice(pm.cp_rank * Bl, (pm.cp_rank + 1) * Bl)
+            rows = lambda v: v[sl] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == Bfull) else v
+            x, timestep, y, fps, height, width, mask = (rows(v) for v in (x, timestep, y, fps, height, width, mask))
         B, _, Tx, Hx, Wx = x.shape
         T, Hp, Wp = self.get_dynamic_size(x)
         S = Hp * Wp
@@ -344,6 +358,12 @@ class STDiT3:
 
         out = ops.final_layer(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
                               w["final_layer.linear.bias"], B, T, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
+        if cp > 1:  # gather_sequence(x, cp_group, dim=0) (:621)
+            import torch.distributed as dist
+
+            parts = torch.empty(cp * B, *out.shape[1:], dtype=out.dtype, device=dev)
+            dist.all_gather_into_tensor(parts, out.contiguous(), group=pm.cp_group)
+            out = parts
         return out
 
     __call__ = forward
