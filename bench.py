@@ -209,43 +209,52 @@ def main():
     # ---- CPU baseline (rank 0, N == 1 only): oracle = fp32 port of the reference path, bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.pab:
-        cpu = cpu_baseline(cfg, T, Hl, Wl, L)
+        try:
+            cpu = cpu_baseline(cfg, T, Hl, Wl, L)
+        except Exception as e:  # a reported baseline, never a reason to lose the measurement
+            cpu = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- VAE decode of the final latent (rank 0, N == 1; outside the timed region; row a14): one warm-up + one timed call
     vae = None
     if rank == 0 and world == 1 and not args.no_vae:
-        from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict as vae_synth
+        try:
+            from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict as vae_synth
 
-        dec = OpenSoraVAE(vae_synth(0), device=dev)
-        zb = z[:1].to(torch.bfloat16)
-        dec.decode(zb, frames)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        vid = dec.decode(zb, frames)
-        torch.cuda.synchronize()
-        vae_s = time.perf_counter() - t0
-        vae = {"sec_per_video": round(vae_s, 4), "output": list(vid.shape),
-               "videos_per_min_dit_plus_vae": round(60.0 / (STEPS_PER_VIDEO * step_s + vae_s), 4)}
-        del dec, vid
+            dec = OpenSoraVAE(vae_synth(0), device=dev)
+            zb = z[:1].to(torch.bfloat16)
+            dec.decode(zb, frames)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            vid = dec.decode(zb, frames)
+            torch.cuda.synchronize()
+            vae_s = time.perf_counter() - t0
+            vae = {"sec_per_video": round(vae_s, 4), "output": list(vid.shape),
+                   "videos_per_min_dit_plus_vae": round(60.0 / (STEPS_PER_VIDEO * step_s + vae_s), 4)}
+            del dec, vid
+        except Exception as e:  # the extra terms must never cost the bench line
+            vae = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     # ---- T5-v1.1-XXL prompt encode (rank 0, N == 1; outside the timed region): 300-token prompt, device-generated weights
     t5 = None
     if rank == 0 and world == 1 and not args.no_t5:
-        from videosys_amd.t5 import T5Encoder
+        try:
+            from videosys_amd.t5 import T5Encoder
 
-        enc = T5Encoder(device=dev).init_random_(0)
-        ids = torch.randint(0, enc.config.vocab_size, (1, 300), generator=torch.Generator().manual_seed(0))
-        tmask = torch.zeros(1, 300, dtype=torch.long)
-        tmask[:, :120] = 1
-        enc(ids, tmask)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        enc(ids, tmask)
-        torch.cuda.synchronize()
-        t5 = {"sec_per_prompt": round(time.perf_counter() - t0, 5), "model": "T5-v1.1-XXL encoder geometry, 300 tokens"}
-        del enc
-        if vae is not None:
-            vae["videos_per_min_t5_dit_vae"] = round(60.0 / (STEPS_PER_VIDEO * step_s + vae["sec_per_video"] + t5["sec_per_prompt"]), 4)
+            enc = T5Encoder(device=dev).init_random_(0)
+            ids = torch.randint(0, enc.config.vocab_size, (1, 300), generator=torch.Generator().manual_seed(0))
+            tmask = torch.zeros(1, 300, dtype=torch.long)
+            tmask[:, :120] = 1
+            enc(ids, tmask)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            enc(ids, tmask)
+            torch.cuda.synchronize()
+            t5 = {"sec_per_prompt": round(time.perf_counter() - t0, 5), "model": "T5-v1.1-XXL encoder geometry, 300 tokens"}
+            del enc
+            if vae is not None and "sec_per_video" in vae:
+                vae["videos_per_min_t5_dit_vae"] = round(60.0 / (STEPS_PER_VIDEO * step_s + vae["sec_per_video"] + t5["sec_per_prompt"]), 4)
+        except Exception as e:
+            t5 = {"error": f"{type(e).__name__}: {e}"[:300]}
 
     if rank == 0:
         vpm = 60.0 / (STEPS_PER_VIDEO * step_s)
