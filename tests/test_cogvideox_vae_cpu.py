@@ -41,3 +41,29 @@ def test_tile_geometry_at_published_size():
     assert (g["tl_h"], g["tl_w"], g["ov_h"], g["ov_w"], g["be_h"], g["be_w"], g["lim_h"], g["lim_w"]) == (30, 45, 25, 36, 40, 72, 200, 288)
     assert len(range(0, 60, g["ov_h"])) == 3 and len(range(0, 90, g["ov_w"])) == 3
     assert CV._frame_batches(13) == [(0, 3), (3, 5), (5, 7), (7, 9), (9, 11), (11, 13)]
+
+
+def test_host_frame_batching_matches_reference_decode_shapes():
+    """CogVideoXVAE's host-side frame batching / output frame count (no GPU needed) against the shapes the reference produced in
+    the golden: 5 latent frames -> 17, 4 -> 16; and the published 13 -> 49."""
+    from videosys_amd.vae_cogvideox import CogVideoXVAE
+
+    v = CogVideoXVAE.__new__(CogVideoXVAE)
+    gold = load_golden("cogvideox_vae_small.pt")
+    assert v._batches(5) == [(0, 3), (3, 5)] and v._out_frames(5) == gold["plain"].shape[2] == 17
+    assert v._batches(4) == [(0, 2), (2, 4)] and v._out_frames(4) == gold["even"].shape[2] == 16
+    assert v._out_frames(13) == 49
+
+
+def test_vae_grid_arithmetic():
+    """ops.VaeGrid: rows, guards and the conv-output grid of a padded causal input (pure host arithmetic)."""
+    from videosys_amd.ops import VaeGrid
+
+    g = VaeGrid(2, 5, 12, 8, pad=1, tf=2)
+    assert (g.Hp, g.Wp, g.plane, g.sample_rows, g.rows, g.guard) == (14, 10, 140, 7 * 140, 2 * 7 * 140, 11)
+    o = g.conv_out()
+    assert (o.T, o.tf, o.pad, o.rows) == (5, 0, 1, 2 * 5 * 140)
+    d = VaeGrid(3, 1, 4, 4, sample_rows=128)
+    assert d.rows == 384 and d.guard == 0
+    with pytest.raises(AssertionError):
+        VaeGrid(1, 1, 4, 4, sample_rows=8)

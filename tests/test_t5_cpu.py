@@ -50,3 +50,20 @@ def test_t5_needs_gpu():
 
     with pytest.raises(RuntimeError):
         T5Encoder(device="cpu")
+
+
+def test_relative_bias_table_matches_transformers_compute_bias():
+    """The [heads, 2L-1] table the attention kernel indexes with j - i holds exactly T5Attention.compute_bias's [1, H, L, L]."""
+    pytest.importorskip("transformers")
+    from oracle import make_golden_t5 as MG
+    from videosys_amd.t5 import relative_bias_table, synth_state_dict
+
+    sd = synth_state_dict(seed=2, **MG.CFG)
+    m = MG.hf_model(sd)
+    att = m.encoder.block[0].layer[0].SelfAttention
+    L = 77
+    with torch.no_grad():
+        want = att.compute_bias(L, L)[0]                                    # [H, L, L]
+    tab = relative_bias_table(sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], L)
+    idx = (torch.arange(L)[None, :] - torch.arange(L)[:, None]) + L - 1      # j - i + L - 1
+    assert torch.equal(tab[:, idx], want)

@@ -32,6 +32,14 @@ def relative_position_bucket(rel: torch.Tensor, num_buckets: int = 32, max_dista
     return out + torch.where(is_small, rel, large)
 
 
+def relative_bias_table(rel_weight: torch.Tensor, L: int, num_buckets: int = 32, max_distance: int = 128) -> torch.Tensor:
+    """[heads, 2L-1] fp32: the bias of relative position d = j - i (memory - query) at column d + L - 1, i.e.
+    T5Attention.compute_bias(L, L)[0, h, i, j] == table[h, j - i + L - 1].  rel_weight: the [num_buckets, heads] embedding."""
+    rel = torch.arange(-(L - 1), L, dtype=torch.long)
+    bucket = relative_position_bucket(rel, num_buckets, max_distance)
+    return rel_weight.float()[bucket].t().contiguous()
+
+
 class T5Encoder:
     def __init__(self, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64, vocab_size=32128,
                  relative_attention_num_buckets=32, relative_attention_max_distance=128, layer_norm_epsilon=1e-6, device="cuda"):
@@ -92,13 +100,10 @@ class T5Encoder:
         return self
 
     def _relbias(self, L: int) -> torch.Tensor:
-        """[heads, 2L-1] fp32: bias of relative position d = j - i at column d + L - 1 (T5Attention.compute_bias)."""
         t = self._bias_cache.get(L)
         if t is None:
             c = self.config
-            rel = torch.arange(-(L - 1), L, dtype=torch.long)
-            bucket = relative_position_bucket(rel, c.relative_attention_num_buckets, c.relative_attention_max_distance)
-            t = self._rel[bucket].t().contiguous().to(self.device)
+            t = relative_bias_table(self._rel, L, c.relative_attention_num_buckets, c.relative_attention_max_distance).to(self.device)
             self._bias_cache[L] = t
         return t
 
