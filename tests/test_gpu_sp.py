@@ -192,10 +192,10 @@ def test_cogvideox_ulysses_two_ranks_equals_single():
     _run(_cogvideox_worker, ())
 
 
-@pytest.mark.parametrize("T,HW", [(5, 16), (4, 12)])
+@pytest.mark.parametrize("T,HW", [(5, 16), (4, 12), (1, 12)])
 def test_stdit3_dsp_two_ranks_equals_single(T, HW):
     """Open-Sora DSP (open_sora_transformer_3d.py:288-315,598-619): T = 5 needs the temporal zero-pad (5 -> 6 over 2 ranks),
-    HW = 12 -> S = 36 tokens per frame split 18 / 18."""
+    HW = 12 -> S = 36 tokens per frame split 18 / 18; T = 1 is the image case (the CFG batch is scattered instead of the frame)."""
     _run(_stdit3_worker, (T, HW))
 
 

@@ -409,17 +409,24 @@ class STDiT3:
                     Tp = xt.shape[1]
                     xa, Ta, Sa = xt.view(B * Tp * S_full, C), Tp, S_full
                 elif sp is not None:
-                    raise NotImplementedError("DSP image case (T == 1, batch scatter) is not built")
+                    # image case (dynamic_switch is_image, :288-303): the batch is scattered instead of the single frame —
+                    # [B, 1, S/P, C] is the same memory as [1, B, S/P, C], so it is the same switch with "frames" = samples
+                    xt = sp.to_temporal_shard(xm.view(1, B, S, C), S_full)  # [1, ceil(B/P), S_full, C]
+                    xa, Ta, Sa = xt.view(-1, C), xt.shape[1], S_full
                 else:
                     xa, Ta, Sa = xm, T, S
                 if xa is not None:
-                    Na = B * Ta * Sa
+                    image = sp is not None and T == 1
+                    nf = Ta if image else B * Ta          # attention problems (frames) on this rank
+                    Na = nf * Sa
                     qkv = ops.gemm(xa, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (Na, 3 * C)))
-                    kp, vt = self._kv_spatial(B * Ta, Sa)
-                    ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * Ta, H, Sa)
+                    kp, vt = self._kv_spatial(nf, Sa)
+                    ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, nf, H, Sa)
                     ao = self._buf("attn_out", (Na, C))
-                    ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * Ta, H, Sa, Sa)
-                    if sp is not None:
+                    ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, nf, H, Sa, Sa)
+                    if image:
+                        ao = sp.to_spatial_shard(ao.view(1, Ta, Sa, C), B, S, out=self._buf("attn_back", (1, B, S, C))).view(N, C)
+                    elif sp is not None:
                         ao = sp.to_spatial_shard(ao.view(B, Ta, Sa, C), T, S, out=self._buf("attn_back", (B, T, S, C))).view(N, C)
             ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
                      gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
