@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--flash-variants", default="0")
     ap.add_argument("--only", default="", help="'gemm' = skip the non-GEMM kernels")
     ap.add_argument("--rows", type=int, default=38912, help="token rows (38912 = config 2; 4864 = one rank of 8-way DSP)")
+    ap.add_argument("--vendor", action="store_true", help="also time torch.nn.functional.linear (hipBLASLt / rocBLAS) on the four "
+                    "GEMM shapes: a yardstick only, never on the product path")
     args = ap.parse_args()
     import __graft_entry__ as ge
 
@@ -81,6 +83,14 @@ def main():
                     same = torch.equal(got, out)
                     print(f"  check gemm_{name} variant {variant} == default: {same}", flush=True)
     lib.vsys_tune_gemm_variant(0)
+    if args.vendor:  # yardstick: the vendor library's plain GEMM + bias (no GELU / gate / residual fusion) on the same operands
+        import torch.nn.functional as F
+
+        for name, n, k, epi in shapes:
+            w, b, _ = bufs[name]
+            a = h if k == 4 * C else x
+            ms = timeit(lambda: F.linear(a, w, b), args.reps)
+            res[f"vendor_linear_{name}"] = [(ms, 2.0 * N * n * k / (ms * 1e-3) / 1e12)]
     if args.only == "gemm":
         return report(res)
 
