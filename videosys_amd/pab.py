@@ -1,133 +1,129 @@
 """Pyramid Attention Broadcast policy — host mirror of videosys/core/pab/pab_mgr.py (reference :6-232).
 
-Same names, arguments and decisions as the reference module so configs drop in unchanged.  The cache itself lives in
-pre-allocated HBM slabs owned by the transformer blocks (``videosys_amd/stdit3.py``); this module only decides.
-The timestep handed to the decision functions is a Python int that the sampler already has on the host
-(``all_timesteps``), so no device->host sync happens per block (the reference does ``int(timestep[0])`` per block,
+Same public names, arguments and decisions as the reference module so configs drop in unchanged (pinned call for call against
+the reference module in tests/test_pab_cpu.py).  The caches themselves are pre-allocated HBM slabs owned by the transformer
+blocks; this module only decides.  The timestep handed to the decision functions is a Python int the sampler already has on the
+host (``all_timesteps``), so no device->host sync happens per block (the reference does ``int(timestep[0])`` per block,
 open_sora_transformer_3d.py:188,190,232,244).
+
+Structure (differs from the reference on purpose): the three attention policies are one table-driven rule; the MLP policy is
+expressed as *windows* — a window opens at a configured timestep ``k`` (the block computes and stores its MLP output) and covers
+the next ``skip_count`` timesteps of the schedule (the block replays the stored output; the entry is dropped at the window's end).
 """
 from __future__ import annotations
 
 import logging
+from typing import Dict, Optional, Sequence, Tuple
 
 PAB_MANAGER = None
 
+_ATTN_KINDS = ("cross", "spatial", "temporal")
+_FIELDS = tuple(f"{k}_{s}" for k in _ATTN_KINDS for s in ("broadcast", "threshold", "range")) + (
+    "mlp_broadcast", "mlp_spatial_broadcast_config", "mlp_temporal_broadcast_config")
+
 
 class PABConfig:
-    """pab_mgr.py:6-41 — identical kwargs/defaults."""
+    """pab_mgr.py:6-41 — identical kwargs/defaults; ``steps`` is filled in by ``update_steps``."""
 
-    def __init__(
-        self,
-        cross_broadcast: bool = False,
-        cross_threshold: list = None,
-        cross_range: int = None,
-        spatial_broadcast: bool = False,
-        spatial_threshold: list = None,
-        spatial_range: int = None,
-        temporal_broadcast: bool = False,
-        temporal_threshold: list = None,
-        temporal_range: int = None,
-        mlp_broadcast: bool = False,
-        mlp_spatial_broadcast_config: dict = None,
-        mlp_temporal_broadcast_config: dict = None,
-    ):
+    def __init__(self, cross_broadcast: bool = False, cross_threshold: list = None, cross_range: int = None,
+                 spatial_broadcast: bool = False, spatial_threshold: list = None, spatial_range: int = None,
+                 temporal_broadcast: bool = False, temporal_threshold: list = None, temporal_range: int = None,
+                 mlp_broadcast: bool = False, mlp_spatial_broadcast_config: dict = None, mlp_temporal_broadcast_config: dict = None):
+        given = locals()
+        for name in _FIELDS:
+            setattr(self, name, given[name])
         self.steps = None
-        self.cross_broadcast = cross_broadcast
-        self.cross_threshold = cross_threshold
-        self.cross_range = cross_range
-        self.spatial_broadcast = spatial_broadcast
-        self.spatial_threshold = spatial_threshold
-        self.spatial_range = spatial_range
-        self.temporal_broadcast = temporal_broadcast
-        self.temporal_threshold = temporal_threshold
-        self.temporal_range = temporal_range
-        self.mlp_broadcast = mlp_broadcast
-        self.mlp_spatial_broadcast_config = mlp_spatial_broadcast_config
-        self.mlp_temporal_broadcast_config = mlp_temporal_broadcast_config
-        self.mlp_temporal_outputs = {}
-        self.mlp_spatial_outputs = {}
+        self.mlp_spatial_outputs: Dict[Tuple[int, int], object] = {}
+        self.mlp_temporal_outputs: Dict[Tuple[int, int], object] = {}
+
+    def attn_rule(self, kind: str):
+        return getattr(self, kind + "_broadcast"), getattr(self, kind + "_range"), getattr(self, kind + "_threshold")
+
+    def mlp_rule(self, is_temporal: bool):
+        return self.mlp_temporal_broadcast_config if is_temporal else self.mlp_spatial_broadcast_config
+
+    def mlp_store(self, is_temporal: bool):
+        return self.mlp_temporal_outputs if is_temporal else self.mlp_spatial_outputs
+
+
+def _mlp_window(schedule: Sequence[int], t, rule: dict) -> Optional[Tuple[int, int]]:
+    """The (first, last) timesteps of the first configured window of ``rule`` that contains ``t`` (pab_mgr.py:93-106: a window is
+    the configured timestep plus the ``skip_count`` schedule entries after it; keys missing from the schedule are ignored; a
+    window reaching past the schedule's end still matches its existing entries but cannot be named, as in the reference, which
+    raises IndexError there)."""
+    for first in rule:
+        if first not in schedule:
+            continue
+        at = schedule.index(first)
+        n = int(rule[first]["skip_count"])
+        if t in schedule[at:at + 1 + n]:
+            return schedule[at], schedule[at + n]
+    return None
 
 
 class PABManager:
-    """pab_mgr.py:43-181 (attention/cross decisions; the MLP-broadcast branch is kept for API parity, see
-    if_skip_mlp)."""
+    """pab_mgr.py:43-181."""
 
     def __init__(self, config: PABConfig):
         self.config: PABConfig = config
-        logging.info(
-            "Init Pyramid Attention Broadcast. spatial: %s/%s/%s temporal: %s/%s/%s cross: %s/%s/%s mlp: %s",
-            config.spatial_broadcast, config.spatial_range, config.spatial_threshold,
-            config.temporal_broadcast, config.temporal_range, config.temporal_threshold,
-            config.cross_broadcast, config.cross_range, config.cross_threshold, config.mlp_broadcast,
-        )
+        logging.info("Init Pyramid Attention Broadcast. " + " ".join(
+            "%s: %s/%s/%s" % ((k,) + config.attn_rule(k)) for k in ("spatial", "temporal", "cross")) + f" mlp: {config.mlp_broadcast}")
 
-    def _decide(self, enabled, rng, thr, timestep, count):
-        flag = bool(enabled and (timestep is not None) and (count % rng != 0) and (thr[0] < timestep < thr[1]))
-        return flag, (count + 1) % self.config.steps
+    # ---- attention policies: inside the threshold window, recompute every ``range``-th call and broadcast in between
+    def _attn(self, kind: str, timestep, count: int):
+        on, every, (lo, hi) = self._rule(kind)
+        reuse = bool(on) and timestep is not None and count % every != 0 and lo < timestep < hi
+        return reuse, (count + 1) % self.config.steps
+
+    def _rule(self, kind):
+        on, every, thr = self.config.attn_rule(kind)
+        return on, every, (thr if thr is not None else (0, 0))
 
     def if_broadcast_cross(self, timestep: int, count: int):
-        c = self.config
-        return self._decide(c.cross_broadcast, c.cross_range, c.cross_threshold, timestep, count)
+        return self._attn("cross", timestep, count)
 
     def if_broadcast_temporal(self, timestep: int, count: int):
-        c = self.config
-        return self._decide(c.temporal_broadcast, c.temporal_range, c.temporal_threshold, timestep, count)
+        return self._attn("temporal", timestep, count)
 
     def if_broadcast_spatial(self, timestep: int, count: int):
-        c = self.config
-        return self._decide(c.spatial_broadcast, c.spatial_range, c.spatial_threshold, timestep, count)
+        return self._attn("spatial", timestep, count)
 
-    @staticmethod
-    def _is_t_in_skip_config(all_timesteps, timestep, config):
-        """pab_mgr.py:93-106."""
-        is_t_in_skip_config = False
-        skip_range = None
-        for key in config:
-            if key not in all_timesteps:
-                continue
-            index = all_timesteps.index(key)
-            skip_range = all_timesteps[index : index + 1 + int(config[key]["skip_count"])]
-            if timestep in skip_range:
-                is_t_in_skip_config = True
-                skip_range = [all_timesteps[index], all_timesteps[index + int(config[key]["skip_count"])]]
-                break
-        return is_t_in_skip_config, skip_range
-
+    # ---- MLP policy (pab_mgr.py:108-141).  Unlike the reference's STDiT3.forward (which never hands ``all_timesteps`` to its
+    # blocks and therefore raises TypeError whenever mlp_broadcast=True) the callers here pass it through.
     def if_skip_mlp(self, timestep: int, count: int, block_idx: int, all_timesteps, is_temporal=False):
-        """pab_mgr.py:108-141.  Unlike the reference's STDiT3.forward (which never forwards ``all_timesteps`` to
-        the blocks and therefore raises TypeError whenever mlp_broadcast=True — SURVEY.md §0.9), this build passes
-        ``all_timesteps`` through, so the documented behaviour is reachable."""
         if not self.config.mlp_broadcast:
             return False, None, False, None
-        cur_config = self.config.mlp_temporal_broadcast_config if is_temporal else self.config.mlp_spatial_broadcast_config
-        is_t_in_skip_config, skip_range = self._is_t_in_skip_config(all_timesteps, timestep, cur_config)
-        next_flag = False
-        if (timestep is not None) and (timestep in cur_config) and (block_idx in cur_config[timestep]["block"]):
-            flag = False
-            next_flag = True
-            count = count + 1
-        elif (timestep is not None) and is_t_in_skip_config and (block_idx in cur_config[skip_range[0]]["block"]):
-            flag = True
-            count = 0
-        else:
-            flag = False
-        return flag, count, next_flag, skip_range
+        rule = self.config.mlp_rule(is_temporal)
+        window = _mlp_window(all_timesteps, timestep, rule)
+        skip_range = list(window) if window is not None else self._last_seen_range(all_timesteps, rule)
+        if timestep is None:
+            return False, count, False, skip_range
+        opens_here = timestep in rule and block_idx in rule[timestep]["block"]
+        if opens_here:                       # compute now, keep the output for the window
+            return False, count + 1, True, skip_range
+        if window is not None and block_idx in rule[window[0]]["block"]:
+            return True, 0, False, skip_range   # replay the stored output
+        return False, count, False, skip_range
+
+    @staticmethod
+    def _last_seen_range(schedule, rule):
+        """What the reference's loop leaves in ``skip_range`` when no window matches: the schedule slice of the LAST configured
+        timestep that is on the schedule (or None) — returned verbatim so callers see the same 4-tuple."""
+        last = None
+        for first in rule:
+            if first in schedule:
+                at = schedule.index(first)
+                last = schedule[at:at + 1 + int(rule[first]["skip_count"])]
+        return last
 
     def save_skip_output(self, timestep, block_idx, ff_output, is_temporal=False):
-        d = self.config.mlp_temporal_outputs if is_temporal else self.config.mlp_spatial_outputs
-        d[(timestep, block_idx)] = ff_output
+        self.config.mlp_store(is_temporal)[(timestep, block_idx)] = ff_output
 
     def get_mlp_output(self, skip_range, timestep, block_idx, is_temporal=False):
-        d = self.config.mlp_temporal_outputs if is_temporal else self.config.mlp_spatial_outputs
-        skip_start_t = skip_range[0]
-        skip_output = d.get((skip_start_t, block_idx), None)
-        if skip_output is None:
-            raise ValueError(
-                f"No stored MLP output found | t {timestep} |[{skip_range[0]}, {skip_range[-1]}] | block {block_idx}"
-            )
-        if timestep == skip_range[-1]:
-            del d[(skip_start_t, block_idx)]
-        return skip_output
+        store, key = self.config.mlp_store(is_temporal), (skip_range[0], block_idx)
+        if store.get(key) is None:
+            raise ValueError(f"No stored MLP output found | t {timestep} |[{skip_range[0]}, {skip_range[-1]}] | block {block_idx}")
+        return store.pop(key) if timestep == skip_range[-1] else store[key]
 
 
 def set_pab_manager(config: PABConfig):
@@ -135,11 +131,9 @@ def set_pab_manager(config: PABConfig):
     PAB_MANAGER = PABManager(config) if config is not None else None
 
 
-def enable_pab():
-    if PAB_MANAGER is None:
-        return False
-    c = PAB_MANAGER.config
-    return bool(c.cross_broadcast or c.spatial_broadcast or c.temporal_broadcast)
+def enable_pab() -> bool:
+    c = PAB_MANAGER.config if PAB_MANAGER is not None else None
+    return c is not None and any(bool(c.attn_rule(k)[0]) for k in _ATTN_KINDS)
 
 
 def update_steps(steps: int):
@@ -147,22 +141,18 @@ def update_steps(steps: int):
         PAB_MANAGER.config.steps = steps
 
 
-def if_broadcast_cross(timestep: int, count: int):
-    if not enable_pab():
-        return False, count
-    return PAB_MANAGER.if_broadcast_cross(timestep, count)
+def _attn_entry(kind):
+    def decide(timestep: int, count: int):
+        return getattr(PAB_MANAGER, "if_broadcast_" + kind)(timestep, count) if enable_pab() else (False, count)
+
+    decide.__name__ = "if_broadcast_" + kind
+    decide.__doc__ = f"pab_mgr.py module-level if_broadcast_{kind}: (broadcast?, next counter)."
+    return decide
 
 
-def if_broadcast_temporal(timestep: int, count: int):
-    if not enable_pab():
-        return False, count
-    return PAB_MANAGER.if_broadcast_temporal(timestep, count)
-
-
-def if_broadcast_spatial(timestep: int, count: int):
-    if not enable_pab():
-        return False, count
-    return PAB_MANAGER.if_broadcast_spatial(timestep, count)
+if_broadcast_cross = _attn_entry("cross")
+if_broadcast_temporal = _attn_entry("temporal")
+if_broadcast_spatial = _attn_entry("spatial")
 
 
 def if_broadcast_mlp(timestep: int, count: int, block_idx: int, all_timesteps, is_temporal=False):
