@@ -11,18 +11,15 @@ from . import ops
 
 
 def timestep_transform(t, model_kwargs, base_resolution=512 * 512, base_num_frames=1, scale=1.0, num_timesteps=1):
-    """scheduling_rflow_open_sora.py:47-70 (host scalars/tensors)."""
-    t = t / num_timesteps
-    resolution = model_kwargs["height"] * model_kwargs["width"]
-    ratio_space = (resolution / base_resolution).sqrt()
-    if model_kwargs["num_frames"][0] == 1:
-        num_frames = torch.ones_like(model_kwargs["num_frames"])
-    else:
-        num_frames = model_kwargs["num_frames"] // 17 * 5
-    ratio_time = (num_frames / base_num_frames).sqrt()
-    ratio = ratio_space * ratio_time * scale
-    new_t = ratio * t / (1 + (ratio - 1) * t)
-    return new_t * num_timesteps
+    """Resolution / duration dependent time warp (scheduling_rflow_open_sora.py:47-70), on host tensors.
+
+    With u = t / num_timesteps and r = scale * sqrt(H*W / base_resolution) * sqrt(F' / base_num_frames), where F' = 1 for an
+    image and (num_frames // 17) * 5 latent frames for a video, the warped time is u' = r u / (1 + (r - 1) u)."""
+    frames = model_kwargs["num_frames"]
+    latent_frames = torch.ones_like(frames) if frames[0] == 1 else frames // 17 * 5
+    r = scale * (model_kwargs["height"] * model_kwargs["width"] / base_resolution).sqrt() * (latent_frames / base_num_frames).sqrt()
+    u = t / num_timesteps
+    return num_timesteps * (r * u / (1 + (r - 1) * u))
 
 
 class RFLOW:
@@ -36,14 +33,15 @@ class RFLOW:
 
     def prepare_timesteps(self, batch, model_args):
         """:208-213 — host tensors [batch] per step."""
-        ts = [(1.0 - i / self.num_sampling_steps) * self.num_timesteps for i in range(self.num_sampling_steps)]
+        n, full = self.num_sampling_steps, self.num_timesteps
+        grid = [(1.0 - k / n) * full for k in range(n)]          # 1000, 1000 (1 - 1/n), ... (uniform in flow time)
         if self.use_discrete_timesteps:
-            ts = [int(round(t)) for t in ts]
-        ts = [torch.tensor([t] * batch, dtype=torch.float32) for t in ts]
-        if self.use_timestep_transform:
-            host_args = {k: model_args[k].detach().to("cpu").float() for k in ("height", "width", "num_frames")}
-            ts = [timestep_transform(t, host_args, num_timesteps=self.num_timesteps) for t in ts]
-        return ts
+            grid = [int(round(v)) for v in grid]
+        steps = [torch.full((batch,), float(v), dtype=torch.float32) for v in grid]
+        if not self.use_timestep_transform:
+            return steps
+        geom = {k: model_args[k].detach().to("cpu").float() for k in ("height", "width", "num_frames")}
+        return [timestep_transform(v, geom, num_timesteps=full) for v in steps]
 
     @torch.no_grad()
     def sample(self, model, z, model_args, y_null, device=None, mask=None, guidance_scale=None, progress=True,
