@@ -67,3 +67,25 @@ def test_vae_grid_arithmetic():
     assert d.rows == 384 and d.guard == 0
     with pytest.raises(AssertionError):
         VaeGrid(1, 1, 4, 4, sample_rows=8)
+
+
+def test_cogvideox_vae_oracle_matches_live_reference_class():
+    """oracle/cogvideox_vae_oracle.py against the reference's AutoencoderKLCogVideoX run here (another seed, 7 latent frames =
+    frame batches 3 + 2 + 2, tiled 2 x 2) when /root/reference is present: bit-exact."""
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present on this box")
+    from oracle import cogvideox_vae_oracle as CV
+    from videosys_amd.vae_cogvideox import synth_state_dict
+
+    sd = synth_state_dict(5)
+    m = ref_loader.build_reference_cogvideox_vae(sd, sample_height=96, sample_width=160)
+    m.enable_tiling()
+    g = torch.Generator().manual_seed(6)
+    z = torch.randn(1, 16, 7, 8, 12, generator=g)
+    with torch.no_grad():
+        ref = m.decode(z).sample
+    out = CV.decode(sd, z, 96, 160, tiling=True)
+    assert out.shape == ref.shape == (1, 3, 25, 64, 96)
+    assert torch.equal(out, ref)

@@ -63,3 +63,24 @@ def test_vae_needs_gpu():
 
     with pytest.raises(RuntimeError):
         OpenSoraVAE({}, device="cpu")
+
+
+def test_vae_oracle_matches_live_reference_class():
+    """oracle/vae_oracle.py against the reference's VideoAutoencoderPipeline run here (another seed, another latent size, three
+    micro-batches incl. a 1-latent-frame tail) when /root/reference is present."""
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present on this box")
+    from oracle import vae_oracle as VO
+    from videosys_amd.vae_open_sora import synth_state_dict
+
+    sd = synth_state_dict(21)
+    model = ref_loader.build_reference_opensora_vae(sd)
+    g = torch.Generator().manual_seed(4)
+    z = torch.randn(1, 4, 11, 4, 6, generator=g)       # 5 + 5 + 1 latent frames -> 17 + 17 + 4 = 38 frames
+    with torch.no_grad():
+        ref = model.decode(z, num_frames=38)
+    out = VO.decode(sd, z, 38)
+    assert out.shape == ref.shape == (1, 3, 38, 32, 48)
+    assert (out - ref).abs().max().item() < 1e-4
