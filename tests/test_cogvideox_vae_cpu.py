@@ -89,3 +89,13 @@ def test_cogvideox_vae_oracle_matches_live_reference_class():
     out = CV.decode(sd, z, 96, 160, tiling=True)
     assert out.shape == ref.shape == (1, 3, 25, 64, 96)
     assert torch.equal(out, ref)
+
+
+def test_cogvideox_vae_needs_gpu():
+    from videosys_amd.vae_cogvideox import CogVideoXVAE
+    from videosys_amd.vae_open_sora import AutoencoderKLDecoder
+
+    with pytest.raises(RuntimeError):
+        CogVideoXVAE({}, device="cpu")
+    with pytest.raises(RuntimeError):
+        AutoencoderKLDecoder({}, device="cpu")
