@@ -737,6 +737,9 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = per_wave * wpb;
   const float scale = 0.11785113019775793f;
+  if (g_flash_variant == 7 && T <= 32)  // lab: MFMA formulation (attention_t_mfma.hip), not validated on hardware yet
+    return launch_attn_temporal_d72_mfma(qkv, row_stride, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps,
+                                         scale, stream);
   if (T <= 20 && g_flash_variant != 9) {
     hipLaunchKernelGGL(attn_temporal_d72_v2_kernel<20>, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
                        k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, scale);
