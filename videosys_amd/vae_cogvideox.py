@@ -106,6 +106,10 @@ class CogVideoXVAE:
         self.use_tiling = False
 
     # ------------------------------------------------------------------------------------------------ building blocks
+    def clear_cache(self):
+        """Drop the zero-bordered staging buffers (they are kept per geometry; call after changing resolution to free HBM)."""
+        self._padded.clear()
+
     def _padded_buf(self, g: VaeGrid, C: int):
         key = (g.n, g.T, g.H, g.W, g.tf, C)
         hit = self._padded.get(key)

@@ -168,6 +168,10 @@ class OpenSoraVAE:
         return [t, h, w]
 
     # ------------------------------------------------------------------------------------------------ building blocks
+    def clear_cache(self):
+        """Drop the zero-bordered staging buffers (they are kept per geometry; call after changing resolution to free HBM)."""
+        self._padded.clear()
+
     def _padded_buf(self, g: VaeGrid, C: int):
         """Zero-bordered conv-input buffer for grid g, allocated once per geometry (kernels only ever write its interior)."""
         key = (g.n, g.T, g.H, g.W, g.tf, C)
