@@ -383,9 +383,12 @@ class VaeGrid:
 
 
 def conv(a, grid: VaeGrid, w, bias, cin, kt, ks, out=None, res=None):
-    """Tap-shifted implicit-GEMM conv over the padded grid ``grid`` whose rows are the 2-D tensor ``a`` (a view that has
-    grid.guard rows of slack on both sides in its storage).  ks = spatial kernel (1 or 3), kt = temporal taps (needs
-    grid.tf == kt - 1).  Returns rows of grid.conv_out() [M, N]."""
+    """Tap-shifted implicit-GEMM conv over the padded grid ``grid`` whose rows are the 2-D tensor ``a``.  ks = spatial kernel
+    (1 or 3), kt = temporal taps (needs grid.tf == kt - 1).  Returns rows of grid.conv_out() [M, N].
+
+    ``a`` MUST be the row view returned by ``grid.alloc`` (or a buffer laid out the same way): a 3 x 3 kernel reads up to
+    grid.guard = W + 3 rows before the first and after the last row of the view, and the border pixels / front frames of the
+    grid must be zero — that is where the convolution's zero padding comes from."""
     _chk(a, w, bias, res, out)
     _bf16(a, w, bias, res, out)
     assert grid.tf == kt - 1 and (ks == 1 or grid.pad == 1) and a.shape[0] == grid.rows and a.stride(1) == 1
