@@ -51,7 +51,7 @@ def sincos_2d(embed_dim: int, gh: int, gw: int, base_size: int, interpolation_sc
 def timestep_embedding(t: Tensor, dim: int = 256) -> Tensor:
     """Timesteps(256, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]."""
     half = dim // 2
-    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     a = t[:, None].float() * freqs[None]
     return torch.cat([torch.cos(a), torch.sin(a)], dim=-1)
 
@@ -64,6 +64,10 @@ def attention(x: Tensor, ctx: Tensor, sd, prefix: str, heads: int, bias_mask: Op
     q = linear(x, sd, prefix + ".to_q").view(B, Lq, heads, D).transpose(1, 2)
     k = linear(ctx, sd, prefix + ".to_k").view(B, Lk, heads, D).transpose(1, 2)
     v = linear(ctx, sd, prefix + ".to_v").view(B, Lk, heads, D).transpose(1, 2)
+    if x.dtype != torch.float32:  # low-precision run: AttnProcessor2_0 calls F.scaled_dot_product_attention
+        am = None if bias_mask is None else bias_mask[:, None].to(q.dtype).expand(B, 1, Lq, Lk)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=am).transpose(1, 2).reshape(B, Lq, C)
+        return linear(o, sd, prefix + ".to_out.0")
     s = q @ k.transpose(-1, -2) / math.sqrt(D)
     if bias_mask is not None:
         s = s + bias_mask[:, None]
@@ -104,8 +108,13 @@ def temporal_block(x, sd, prefix, heads, timestep6, eps):
 
 class LatteOracle:
     def __init__(self, sd: Dict[str, Tensor], num_layers: int, num_heads: int, head_dim: int, patch_size: int = 2,
-                 sample_size: int = 64, out_channels: int = 8, video_length: int = 16, norm_eps: float = 1e-6):
-        self.sd = {k: v.float() for k, v in sd.items()}
+                 sample_size: int = 64, out_channels: int = 8, video_length: int = 16, norm_eps: float = 1e-6,
+                 device=None, dtype=torch.float32):
+        # device / dtype: the full-depth parity tests run this oracle on the GPU as the checker (fp32) and once more in the
+        # low-precision dtype the reference runs in (its distance from fp32 = the noise floor); see stdit3_oracle.py header
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.dtype = dtype
+        self.sd = {k: v.to(device=self.device, dtype=dtype) for k, v in sd.items()}
         self.L, self.H, self.D = num_layers, num_heads, head_dim
         self.C = num_heads * head_dim
         self.p = patch_size
@@ -115,31 +124,35 @@ class LatteOracle:
         self.eps = norm_eps
 
     def forward(self, hidden_states: Tensor, timestep: Tensor, encoder_hidden_states: Tensor,
-                encoder_attention_mask: Optional[Tensor] = None, enable_temporal_attentions: bool = True) -> Tensor:
+                encoder_attention_mask: Optional[Tensor] = None, enable_temporal_attentions: bool = True,
+                on_hidden=None) -> Tensor:
         sd, C, p = self.sd, self.C, self.p
+        dev, dt = self.device, self.dtype
+        hidden_states, timestep, encoder_hidden_states = hidden_states.to(dev), timestep.to(dev), encoder_hidden_states.to(dev)
         B, cin, Fr, Hh, Ww = hidden_states.shape
-        x = hidden_states.float().permute(0, 2, 1, 3, 4).reshape(B * Fr, cin, Hh, Ww)  # b c f h w -> (b f) c h w (:1219)
+        x = hidden_states.to(dt).permute(0, 2, 1, 3, 4).reshape(B * Fr, cin, Hh, Ww)  # b c f h w -> (b f) c h w (:1219)
         bias = None
         if encoder_attention_mask is not None:  # :1245-1248
-            bias = ((1 - encoder_attention_mask.float()) * -10000.0).unsqueeze(1)
+            bias = ((1 - encoder_attention_mask.to(dev).to(dt)) * -10000.0).unsqueeze(1)
             bias = bias.repeat_interleave(Fr, dim=0)
         # PatchEmbed (:1266): conv patchify + sincos table for this grid
         gh, gw = Hh // p, Ww // p
         S = gh * gw
         x = F.conv2d(x, sd["pos_embed.proj.weight"], sd["pos_embed.proj.bias"], stride=p).flatten(2).transpose(1, 2)
         interp = max(self.sample_size // 64, 1)
-        x = x + sincos_2d(C, gh, gw, self.sample_size // p, interp)[None]
+        x = x + sincos_2d(C, gh, gw, self.sample_size // p, interp)[None].to(device=dev, dtype=dt)
         # AdaLayerNormSingle (:846-878): embedded = MLP(sinusoid(t)); timestep6 = Linear(SiLU(embedded))
-        emb = linear(F.silu(linear(timestep_embedding(timestep.float()), sd, "adaln_single.emb.timestep_embedder.linear_1")),
+        emb = linear(F.silu(linear(timestep_embedding(timestep.float()).to(dt), sd, "adaln_single.emb.timestep_embedder.linear_1")),
                      sd, "adaln_single.emb.timestep_embedder.linear_2")
         t6 = linear(F.silu(emb), sd, "adaln_single.linear")
         # caption projection (:1284) then one copy per frame (:1297-1299)
-        y = linear(F.gelu(linear(encoder_hidden_states.float(), sd, "caption_projection.linear_1"), approximate="tanh"),
+        y = linear(F.gelu(linear(encoder_hidden_states.to(dt), sd, "caption_projection.linear_1"), approximate="tanh"),
                    sd, "caption_projection.linear_2")
         y_sp = y.repeat_interleave(Fr, dim=0)
         t_sp = t6.repeat_interleave(Fr, dim=0)  # (b f) d
         t_tp = t6.repeat_interleave(S, dim=0)  # (b p) d
-        tpe = torch.from_numpy(sincos_1d(C, np.arange(0, self.video_length)[:, None].astype(np.float64))).float()[None]
+        tpe = torch.from_numpy(sincos_1d(C, np.arange(0, self.video_length)[:, None].astype(np.float64))).float()[None].to(
+            device=dev, dtype=dt)
         for i in range(self.L):
             x = spatial_block(x, sd, f"transformer_blocks.{i}", self.H, t_sp, y_sp, bias, self.eps)
             if enable_temporal_attentions:
@@ -148,6 +161,8 @@ class LatteOracle:
                     x = x + tpe[:, :Fr]
                 x = temporal_block(x, sd, f"temporal_transformer_blocks.{i}", self.H, t_tp, self.eps)
                 x = x.view(B, S, Fr, C).permute(0, 2, 1, 3).reshape(B * Fr, S, C)
+            if on_hidden is not None:
+                on_hidden(i, x)   # [(b f), S, C] after block pair i
         # final (:1443-1449) + unpatchify (:1452-1460)
         e = emb.repeat_interleave(Fr, dim=0)
         shift, scale = (sd["scale_shift_table"][None] + e[:, None]).chunk(2, dim=1)
@@ -156,7 +171,7 @@ class LatteOracle:
         co = self.out_channels
         x = x.reshape(-1, gh, gw, p, p, co)
         x = torch.einsum("nhwpqc->nchpwq", x).reshape(-1, co, gh * p, gw * p)
-        return x.view(B, Fr, co, gh * p, gw * p).permute(0, 2, 1, 3, 4).contiguous()
+        return x.view(B, Fr, co, gh * p, gw * p).permute(0, 2, 1, 3, 4).contiguous().float()
 
     __call__ = forward
 

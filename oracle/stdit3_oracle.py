@@ -19,6 +19,15 @@ rotary-embedding-torch (unpinned in requirements.txt) and timm ``Mlp``.
 Everything operates on a flat ``state_dict`` with the HF checkpoint key names
 (``spatial_blocks.N.attn.qkv.weight`` ...), so the same weights drive the
 reference, this oracle and the HIP path.
+
+Device / dtype: the oracle is plain PyTorch, so the full-depth parity tests run it
+AS THE CHECKER on the GPU (``STDiT3Oracle(..., device="cuda", dtype=torch.float32)``) where
+a config-2 step takes seconds instead of an hour.  ``dtype=torch.bfloat16`` is the
+"reference's own bf16 run": the same graph executed with torch's bf16 kernels the way
+the reference runs it (``model.to(bf16)``: nn.LayerNorm / F.gelu / F.linear / SDPA, and
+``native_attention`` with an fp32 softmax for sequences < 30, attentions.py:58,95-100,111-120)
+— its distance from the fp32 run is the bf16 noise floor the HIP path is held against.
+The fp32 path is unchanged op for op (the goldens pin it bit-tight).
 """
 from __future__ import annotations
 
@@ -36,6 +45,8 @@ Tensor = torch.Tensor
 # --------------------------------------------------------------------------
 def layer_norm(x: Tensor, eps: float = 1e-6) -> Tensor:
     """nn.LayerNorm(C, eps=1e-6, elementwise_affine=False) — open_sora_transformer_3d.py:117,129,58."""
+    if x.dtype != torch.float32:  # low-precision run: the reference's module is nn.LayerNorm (fp32 statistics inside)
+        return F.layer_norm(x, (x.shape[-1],), None, None, eps)
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
     return (x - mu) * torch.rsqrt(var + eps)
@@ -56,12 +67,16 @@ def rms_norm(x: Tensor, weight: Tensor, eps: float = 1e-6) -> Tensor:
 
 def gelu_tanh(x: Tensor) -> Tensor:
     """nn.GELU(approximate='tanh') — modules/activations.py:3."""
+    if x.dtype != torch.float32:
+        return F.gelu(x, approximate="tanh")
     return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x**3)))
 
 
 def linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
     w = sd[prefix + ".weight"]
     b = sd.get(prefix + ".bias")
+    if x.dtype != torch.float32:  # nn.Linear: bias added to the fp32 accumulator, one rounding
+        return F.linear(x, w, b)
     y = x @ w.t()
     return y + b if b is not None else y
 
@@ -69,7 +84,7 @@ def linear(x: Tensor, sd: Dict[str, Tensor], prefix: str) -> Tensor:
 def rope_table(freqs: Tensor, seq_len: int, pos_dtype=torch.float32):
     """cos/sin table of rotary_embedding_torch.RotaryEmbedding.forward (third-party, restated):
     angle[p, 2i] = angle[p, 2i+1] = p * freqs[i]."""
-    seq = torch.arange(seq_len, dtype=pos_dtype)
+    seq = torch.arange(seq_len, dtype=pos_dtype, device=freqs.device)
     ang = torch.einsum("p,f->pf", seq.type(freqs.dtype), freqs)
     ang = ang.repeat_interleave(2, dim=-1)
     return ang.cos(), ang.sin()
@@ -85,11 +100,22 @@ def rope_rotate(t: Tensor, freqs: Tensor) -> Tensor:
     return ((t * cos) + (rot * sin)).type(t.dtype)
 
 
-def sdpa(q: Tensor, k: Tensor, v: Tensor, key_len: Optional[Sequence[int]] = None) -> Tensor:
+def sdpa(q: Tensor, k: Tensor, v: Tensor, key_len: Optional[Sequence[int]] = None, native: bool = False) -> Tensor:
     """softmax(q k^T / sqrt(d)) v in fp32 — what F.scaled_dot_product_attention (attentions.py:100,269)
     and native_attention (attentions.py:111-120) both compute; key_len[i] masks keys >= len for batch i
-    (torch_impl mask, attentions.py:264-266)."""
+    (torch_impl mask, attentions.py:264-266).  In a low-precision run the two reference paths are kept apart:
+    ``native`` = native_attention (q pre-scaled, logits in the activation dtype, fp32 softmax, cast back), else SDPA."""
     d = q.shape[-1]
+    if q.dtype != torch.float32:
+        if native:
+            attn = ((q * d**-0.5) @ k.transpose(-2, -1)).to(torch.float32).softmax(dim=-1).to(q.dtype)
+            return attn @ v
+        attn_mask = None
+        if key_len is not None and any(m < k.shape[-2] for m in key_len):
+            attn_mask = torch.zeros(q.shape[0], 1, q.shape[-2], k.shape[-2], dtype=torch.bool, device=q.device)
+            for i, m in enumerate(key_len):
+                attn_mask[i, :, :, :m] = True
+        return F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask)
     s = (q @ k.transpose(-2, -1)) * (d**-0.5)
     if key_len is not None:
         L = k.shape[-2]
@@ -116,7 +142,7 @@ def self_attention(x: Tensor, sd, prefix: str, num_heads: int, rope_freqs: Optio
         if rope_freqs is not None:  # attentions.py:76-78 (after the norm)
             q = rope_rotate(q, rope_freqs)
             k = rope_rotate(k, rope_freqs)
-        o = sdpa(q, k, v)
+        o = sdpa(q, k, v, native=Np < 30)  # attentions.py:58 "use_flash_attn = N >= 30"
     o = o.transpose(1, 2).reshape(Bp, Np, C)
     return linear(o, sd, prefix + ".proj")
 
@@ -222,13 +248,14 @@ def dsp_all_to_all(shards: List[Tensor], scatter_dim: int, gather_dim: int, scat
 def timestep_embedding(t: Tensor, dim: int = 256, max_period: int = 10000) -> Tensor:
     """TimestepEmbedder.timestep_embedding — modules/embeddings.py:123-141."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t[:, None].float() * freqs[None]
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
 def embed_mlp(t_freq: Tensor, sd, prefix: str) -> Tensor:
     """Linear -> SiLU -> Linear (TimestepEmbedder/SizeEmbedder.mlp) — embeddings.py:114-118,143-146."""
+    t_freq = t_freq.to(sd[prefix + ".mlp.0.weight"].dtype)  # "if t_freq.dtype != dtype: t_freq = t_freq.to(dtype)"
     return linear(F.silu(linear(t_freq, sd, prefix + ".mlp.0")), sd, prefix + ".mlp.2")
 
 
@@ -346,8 +373,12 @@ class STDiT3Oracle:
     """STDiT3.forward — open_sora_transformer_3d.py:539-632, sp=cp=1, fp32, x_mask=None."""
 
     def __init__(self, sd: Dict[str, Tensor], depth: int, hidden_size: int, num_heads: int,
-                 patch_size=(1, 2, 2), in_channels: int = 4, input_sq_size: int = 512, pred_sigma: bool = True):
-        self.sd = {k: v.to(torch.float32) for k, v in sd.items()}
+                 patch_size=(1, 2, 2), in_channels: int = 4, input_sq_size: int = 512, pred_sigma: bool = True,
+                 device=None, dtype=torch.float32):
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.dtype = dtype
+        # rope.freqs stays fp32 in every run (the HIP model also keeps the checkpoint dtype for it)
+        self.sd = {k: v.to(device=self.device, dtype=torch.float32 if k == "rope.freqs" else dtype) for k, v in sd.items()}
         self.depth, self.C, self.H = depth, hidden_size, num_heads
         self.patch = tuple(patch_size)
         self.in_channels = in_channels
@@ -373,7 +404,10 @@ class STDiT3Oracle:
         S = H * W
         base_size = round(S**0.5)
         scale = ((float(height[0]) * float(width[0])) ** 0.5) / self.input_sq_size
-        pos = pos_embed_2d(self.C, H, W, scale, base_size)
+        dev, dt = self.device, self.dtype
+        x, timestep, y, fps = x.to(dev), timestep.to(dev), y.to(dev), fps.to(dev)
+        mask = None if mask is None else mask.to(dev)
+        pos = pos_embed_2d(self.C, H, W, scale, base_size).to(device=dev, dtype=dt)
         B = x.shape[0]
         t = embed_mlp(timestep_embedding(timestep.float()), sd, "t_embedder")
         f = fps.unsqueeze(1) if fps.ndim == 1 else fps
@@ -382,8 +416,8 @@ class STDiT3Oracle:
         fe = embed_mlp(timestep_embedding(f.reshape(-1).float()), sd, "fps_embedder").view(B, -1)
         t = t + fe
         t_mlp = linear(F.silu(t), sd, "t_block.1")
-        yy, y_lens = encode_text(y.float(), mask, sd)
-        xe = patch_embed(x.float(), sd, p).view(B, T, S, self.C) + pos
+        yy, y_lens = encode_text(y.to(dt), mask, sd)
+        xe = patch_embed(x.to(dt), sd, p).view(B, T, S, self.C) + pos
         return xe.reshape(B, T * S, self.C), t, t_mlp, yy, y_lens, (T, H, W, Tx, Hx, Wx)
 
     def forward(self, x, timestep, y, mask=None, fps=None, height=None, width=None, valid_depth=None,
@@ -399,11 +433,13 @@ class STDiT3Oracle:
                              self.pab, self._state(("s", d)), ts_int)
             x = stdit3_block(x, yy, t_mlp, y_lens, T, S, self.sd, f"temporal_blocks.{d}", self.H, True, rope_freqs,
                              self.pab, self._state(("t", d)), ts_int)
-            if return_hidden:
+            if callable(return_hidden):   # full-depth parity tests: per-block-pair error growth without keeping 28 copies
+                return_hidden(d, x)
+            elif return_hidden:
                 hidden.append(x.clone())
         out = final_layer(x, t, self.sd)
         out = unpatchify(out, T, H, W, Tx, Hx, Wx, self.patch, self.out_channels).to(torch.float32)
-        return (out, hidden) if return_hidden else out
+        return (out, hidden) if (return_hidden and not callable(return_hidden)) else out
 
     __call__ = forward
 
@@ -451,7 +487,7 @@ def rflow_sample(model, z, y, y_null, mask, fps, height, width, num_frames, num_
         tt = torch.cat([t, t], 0).to(model_dtype)  # STDiT3.forward casts timestep to model dtype (:562)
         out = model(z_in, tt, yy, mask=mask, fps=torch.cat([fps, fps]), height=torch.cat([height, height]),
                     width=torch.cat([width, width]))
-        pred = out.chunk(2, dim=1)[0]
+        pred = out.to(z.device).chunk(2, dim=1)[0]  # the model may run on another device (GPU-as-checker)
         pred_cond, pred_uncond = pred.chunk(2, dim=0)
         v_pred = pred_uncond + cfg_scale * (pred_cond - pred_uncond)
         dt = timesteps[i] - timesteps[i + 1] if i < len(timesteps) - 1 else timesteps[i]

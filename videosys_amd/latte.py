@@ -250,6 +250,8 @@ class LatteT2V:
                 if d == 0 and Fa > 1:
                     ops.add_bcast_rows(x, tpe, S, Fr)  # hidden + temp_pos_embed (:1410-1411)
                 x = self._temporal_block(2 * d + 1, x, mod[2 * d + 1], B, Fr, S, timestep_int, ats, Fa)
+            if getattr(self, "_hidden_tap", None) is not None:   # test hook: error growth per block pair
+                self._hidden_tap(d, x)
         out = ops.final_layer(x, w["scale_shift_table"], emb, w["proj_out.weight"], w["proj_out.bias"], B, Fr, gh, gw, Hh, Ww,
                               (1, p, p), self.out_channels)
         if sp is not None:  # gather_from_second_dim (:1477-1482): frames of all ranks, time padding dropped

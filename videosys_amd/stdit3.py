@@ -138,6 +138,7 @@ class STDiT3:
         self._text_cache = None
         self._fps_cache = {}
         self._ws = {}
+        self._hidden_tap = None   # test hook: callable(pair_index, x_rows) after every (spatial, temporal) block pair
         # attribute paths the reference's callers read (scheduling_rflow_open_sora.py:221, pipeline_open_sora.py:295)
         self.x_embedder = SimpleNamespace(proj=SimpleNamespace(weight=torch.empty(0, dtype=dtype)))
         self.y_embedder = SimpleNamespace(y_embedding=None)
@@ -350,6 +351,8 @@ class STDiT3:
         for d in range(valid_depth):
             for i in (2 * d, 2 * d + 1):
                 xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, timestep_int, all_timesteps)
+            if self._hidden_tap is not None:
+                self._hidden_tap(d, xcur)
 
         if sp is not None:
             xg = sp.gather(xcur.view(B, T, S, C), S_full)
