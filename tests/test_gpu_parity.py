@@ -47,7 +47,7 @@ def ops():
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("variant", [0, 8, 20])
+@pytest.mark.parametrize("variant", [0, 8, 20, 60, 70])
 @pytest.mark.parametrize("M,N,K", [(300, 192, 64), (1000, 576, 576), (257, 384, 128), (2048, 1152, 1152)])
 def test_gemm_bias(ops, M, N, K, variant):
     from videosys_amd import _lib
@@ -71,7 +71,7 @@ def _gemm_bias(ops, M, N, K):
     check(out, O.gelu_tanh(ref), what="gemm+gelu")
 
 
-@pytest.mark.parametrize("variant", [3, 6, 8, 20, 28, 30, 40, 103])
+@pytest.mark.parametrize("variant", [3, 6, 8, 20, 28, 30, 40, 60, 70, 103])
 def test_gemm_pipeline_variants(ops, variant):
     """Every main-loop schedule of the GEMM (LDS-DMA burst / interleaved, 2-stage / 3+2-slot, 8-wave / 4-wave geometry)
     must give the same result;
@@ -113,7 +113,7 @@ def test_gemm_is_transpose_exact(ops):
     assert torch.equal(out, x[:, perm])
 
 
-@pytest.mark.parametrize("variant", [0, 8, 20, 103])
+@pytest.mark.parametrize("variant", [0, 8, 20, 60, 70, 103])
 def test_gemm_gate_residual_aux(ops, variant):
     """variant 0 = the shape dispatch (small problems take the 128-row geometry); 8 / 20 / 103 force each kernel family
     through the gate + residual + aux epilogue."""
@@ -122,12 +122,16 @@ def test_gemm_gate_residual_aux(ops, variant):
     _lib.load().vsys_tune_gemm_variant(variant)
     try:
         _gate_residual_aux(ops)
+        # sample length a multiple of 64 rows (as on the denoise path): the ping-pong kernel (60 / 70) reads the gate vector
+        # through the scalar cache here; with rps = 400 above it hands the call to the 8-wave kernel
+        _gate_residual_aux(ops, M=1100, rps=448)
+        _gate_residual_aux(ops, M=2048, rps=1024, N=1152)
     finally:
         _lib.load().vsys_tune_gemm_variant(0)
 
 
-def _gate_residual_aux(ops):
-    M, N, K, rps = 1100, 576, 1152, 400  # 3 samples, tiles straddle sample boundaries
+def _gate_residual_aux(ops, M=1100, N=576, K=1152, rps=400):
+    # default: 3 samples, tiles straddle sample boundaries
     g = torch.Generator().manual_seed(11)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)

@@ -75,7 +75,7 @@ def main():
                 ms = timeit(fn, args.reps)
                 tf = 2.0 * N * n * k / (ms * 1e-3) / 1e12
                 res.setdefault(f"gemm_{name}_pipe{variant}", []).append((ms, tf))
-                if rd == 0 and (variant % 100 < 10 or variant in (20, 28, 30, 40)):  # schedules must not change results: same k order, same MFMA
+                if rd == 0 and (variant % 100 < 10 or variant in (20, 28, 30, 40, 60, 70)):  # schedules must not change results: same k order, same MFMA
                     got = out.clone()
                     lib.vsys_tune_gemm_variant(0)
                     fn()
@@ -114,8 +114,11 @@ def main():
     freqs = 1.0 / (10000 ** (torch.arange(0, 72, 2).float() / 72))
     ang = torch.einsum("p,f->pf", torch.arange(19).float(), freqs).repeat_interleave(2, -1)
     cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
-    ms = timeit(lambda: ops.attn_temporal(qkv, C, qw, qw, cos, sin, ao, 2, 19, 1024, H), args.reps)
-    res["attn_temporal"] = [(ms, (269.0 + 89.7) / ms)]  # GB/s
+    for fv in sorted(set([0] + [int(v) for v in args.flash_variants.split(',')])):
+        lib.vsys_tune_flash_variant(fv)
+        ms = timeit(lambda: ops.attn_temporal(qkv, C, qw, qw, cos, sin, ao, 2, 19, 1024, H), args.reps)
+        res["attn_temporal" + (f"_v{fv}" if fv else "")] = [(ms, (269.0 + 89.7) / ms)]  # GB/s
+    lib.vsys_tune_flash_variant(0)
     ms = timeit(lambda: ops.adaln_modulate(x, mod[0, :C], mod[0, C:2 * C], N // 2, 6 * C, out=ao), args.reps)
     res["adaln_modulate"] = [(ms, 179.3 / ms)]  # GB/s
     ms = timeit(lambda: ops.add_rows(ao, x), args.reps)

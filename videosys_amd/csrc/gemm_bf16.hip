@@ -674,6 +674,11 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     case 48: return launch_gemm_t<48, 256>(p, epi, stream);
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
+    case 60: case 70:  // ping-pong wave groups (gemm4_bf16.hip): 60 = one tile per workgroup, 70 = persistent (one workgroup per CU)
+      if (!gemm4_supports(p, epi)) return launch_gemm_t<8, 256>(p, epi, stream);
+      return launch_gemm4(p, epi, g_gemm_variant == 70, stream);
+    case 61: case 62: case 63: case 64: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 60, 0, stream) : VSYS_ERR_ARG;
+    case 71: case 72: case 73: case 74: case 78: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 70, 1, stream) : VSYS_ERR_ARG;
     case 40: return launch_gemm3(p, epi, stream);  // 5-slot ring, fragments always one k-step ahead (gemm3_bf16.hip)
     case 31: return (epi == EPI_BIAS && p.N % 384 == 0) ? launch_gemm2_stamp(p, stream) : VSYS_ERR_ARG;  // lab: cycle stamps
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile

@@ -71,7 +71,11 @@ int launch_t5_attention(const bf16_t* qkv, int64_t row_stride, int inner, const 
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream);
-int launch_gemm3(const GemmParams& p, int epi, hipStream_t stream);  // continuous k-step pipeline (gemm3_bf16.hip)
+int launch_gemm3(const GemmParams& p, int epi, hipStream_t stream);
+// ping-pong wave groups (gemm4_bf16.hip); persistent = 1: one workgroup per CU walks the tiles
+int launch_gemm4(const GemmParams& p, int epi, int persistent, hipStream_t stream);
+bool gemm4_supports(const GemmParams& p, int epi);
+int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t stream);
 int launch_gemm2_stamp(const GemmParams& p, hipStream_t stream);  // lab: per-stage cycle stamps into p.aux (int64)
 void set_gemm_variant(int v);
 void set_flash_variant(int v);
