@@ -265,3 +265,91 @@ def test_timestep_transform_bitwise_equals_reference_function():
         for k in range(30):
             t = torch.tensor([(1 - k / 30) * 1000.0])
             assert torch.equal(timestep_transform(t, kw, num_timesteps=1000), ref.timestep_transform(t, kw, num_timesteps=1000))
+
+
+def test_timestep_transform_bf16_geometry_equals_reference_function():
+    """The reference hands height / width / num_frames to timestep_transform as tensors of the MODEL dtype
+    (data_process.py:798-805: bf16, so 854 arrives as 856 and the ratio is computed in bf16 before the fp32 timestep promotes
+    it).  The pipeline builds them the same way (open_sora_geometry.prepare_multi_resolution_info): bitwise equal schedules."""
+    import importlib.util
+    import itertools
+
+    ref_path = "/root/reference/videosys/schedulers/scheduling_rflow_open_sora.py"
+    if not os.path.exists(ref_path):
+        pytest.skip("reference tree not present on this box")
+    spec = importlib.util.spec_from_file_location("ref_rflow_bf16", ref_path)
+    ref = importlib.util.module_from_spec(spec)
+    try:
+        spec.loader.exec_module(ref)
+    except Exception as e:
+        pytest.skip(f"reference scheduler not importable here: {e}")
+    from videosys_amd import open_sora_geometry as G
+    from videosys_amd.rflow import RFLOW, timestep_transform
+
+    for (H, W), F in itertools.product([(480, 854), (720, 1280), (512, 512), (240, 426), (1080, 1920)], [1, 51, 64, 102, 408]):
+        kw = G.prepare_multi_resolution_info(1, (H, W), F, 24, dtype=torch.bfloat16)
+        assert kw["width"].dtype == torch.bfloat16 and float(kw["width"][0]) == float(torch.tensor(float(W)).to(torch.bfloat16))
+        for k in range(30):
+            t = torch.tensor([(1 - k / 30) * 1000.0])
+            assert torch.equal(timestep_transform(t, kw, num_timesteps=1000), ref.timestep_transform(t, kw, num_timesteps=1000))
+        # and through the sampler's own schedule builder
+        ts = RFLOW(num_sampling_steps=30, use_timestep_transform=True).prepare_timesteps(1, kw)
+        want = [ref.timestep_transform(torch.tensor([(1 - k / 30) * 1000.0]), kw, num_timesteps=1000) for k in range(30)]
+        assert all(torch.equal(a, b) for a, b in zip(ts, want))
+
+
+def test_open_sora_geometry_vocabulary_matches_reference_tables():
+    """Every (resolution, aspect_ratio) pair of generate()'s vocabulary returns exactly the reference's size — or fails the same
+    assert — and the duration names map to the same frame counts (golden minted from data_process.py by
+    oracle/make_golden_geometry.py; re-derived live from the reference file when it is present)."""
+    from videosys_amd import open_sora_geometry as G
+
+    with open(os.path.join(GOLDEN, "opensora_image_sizes.json")) as f:
+        gold = json.load(f)
+    assert len(gold["image_sizes"]) == 13 * 17
+    tables = [gold]
+    if os.path.exists("/root/reference/videosys/pipelines/open_sora/data_process.py"):
+        from oracle.make_golden_geometry import reference_tables
+
+        lit, res_tab = reference_tables()
+        live = {f"{res}|{ar}": (list(lit[tab][key]) if key in lit[tab] else None)
+                for res, tab in res_tab.items() for ar, key in lit["ASPECT_RATIO_MAP"].items()}
+        assert live == gold["image_sizes"], "golden out of date with the reference file"
+        tables.append(dict(image_sizes=live, ratio_keys=lit["ASPECT_RATIO_MAP"], num_frames=lit["NUM_FRAMES_MAP"]))
+    for tab in tables:
+        for pair, want in tab["image_sizes"].items():
+            res, ar = pair.split("|")
+            if want is None:
+                with pytest.raises(AssertionError):
+                    G.get_image_size(res, ar)
+            else:
+                assert list(G.get_image_size(res, ar)) == want, pair
+        for ar, key in tab["ratio_keys"].items():
+            assert G.ratio_key(ar) == key
+        for name, n in tab["num_frames"].items():
+            assert G.get_num_frames(name) == n
+    assert G.get_num_frames(64) == 64 and G.get_num_frames("17") == 17
+    with pytest.raises(AssertionError):
+        G.get_image_size("512", "1:1")   # BASELINE's 512x512 cannot be named through the reference's own tables
+    with pytest.raises(KeyError):
+        G.get_image_size("480p", "7:5")
+
+
+def test_open_sora_prompt_preparation():
+    """prepare_prompt = extract_json_from_prompts + split_prompt / extract_prompts_loop + append_score_to_prompts +
+    text_preprocessing of the reference (pipeline_open_sora.py:548-615,705-792) for the text-to-video case."""
+    from videosys_amd.pipeline_open_sora import OpenSoraPipeline as P
+
+    assert P.prepare_prompt("  A Sunset over the SEA ") == "a sunset over the sea  aesthetic score: 6.5."   # tag appended, THEN stripped
+    assert P.prepare_prompt("A cat") == "a cat aesthetic score: 6.5."
+    assert P.prepare_prompt("A cat", aes=None) == "a cat"
+    assert P.prepare_prompt("A cat", aes=7, flow=3.25, camera_motion="pan right") == \
+        "a cat aesthetic score: 7.0. motion score: 3.2. camera motion: pan right."
+    assert P.prepare_prompt("a dog aesthetic score: 5.0.") == "a dog aesthetic score: 5.0."
+    assert P.prepare_prompt("|0| a beautiful day |2| a rainy day", aes=None, loop_i=0) == "a beautiful day"
+    assert P.prepare_prompt("|0| a beautiful day |2| a rainy day", aes=None, loop_i=2) == "a rainy day"
+    assert P.prepare_prompt('A cat{"reference_path": "", "mask_strategy": ""}', aes=None) == "a cat"
+    with pytest.raises(NotImplementedError):
+        P.prepare_prompt('A cat{"reference_path": "x.png"}')
+    with pytest.raises(AssertionError):
+        P.prepare_prompt('A cat{"foo": 1}')

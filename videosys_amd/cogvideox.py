@@ -171,11 +171,17 @@ class CogVideoXTransformer3DModel:
         if image_rotary_emb is None:
             return None, None
         cos, sin = image_rotary_emb
-        key = (cos.data_ptr(), tuple(cos.shape), cos._version)
-        if self._rope_cache is None or self._rope_cache[0] != key:
-            self._rope_cache = (key, cos.to(device=self.device, dtype=torch.float32).contiguous(),
-                                sin.to(device=self.device, dtype=torch.float32).contiguous())
-        return self._rope_cache[1], self._rope_cache[2]
+        # identity + version of the table tensors (strong references held): two resolutions can share a shape and, once the first
+        # table is freed, an address
+        c = self._rope_cache
+        if c is None or c[0] is not cos or c[1] is not sin or c[2] != (cos._version, sin._version):
+            c = (cos, sin, (cos._version, sin._version), cos.to(device=self.device, dtype=torch.float32).contiguous(),
+                 sin.to(device=self.device, dtype=torch.float32).contiguous())
+            self._rope_cache = c
+        return c[3], c[4]
+
+    def reset_text_cache(self):
+        self._rope_cache = None
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

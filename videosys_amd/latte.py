@@ -160,9 +160,11 @@ class LatteT2V:
         return ops.linear_small(x, w, b, out=kw.get("out"))
 
     def _encode_text(self, y, mask, frames):
-        key = (y.data_ptr(), tuple(y.shape), y._version, None if mask is None else (mask.data_ptr(), mask._version))
-        if self._text_cache is not None and self._text_cache["key"] == key:
-            return self._text_cache
+        # identity + version of the prompt tensors (strong references held): a recycled storage address is not the same prompt
+        c = self._text_cache
+        if (c is not None and c["y"] is y and c["y_version"] == y._version and c["mask"] is mask
+                and (mask is None or c["mask_version"] == mask._version)):
+            return c
         B, Lk, Cc = y.shape
         C, H = self.C, self.H
         if mask is None:
@@ -184,8 +186,12 @@ class LatteT2V:
         for d in range(self.L):
             self._gemm(ye, f"transformer_blocks.{d}.attn2.kv", out=kv)
             ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kps[d], vts[d], B, H, Lk)
-        self._text_cache = dict(key=key, lens=lens, kp=kps, vt=vts, Lk=Lk)
+        self._text_cache = dict(y=y, y_version=y._version, mask=mask, mask_version=None if mask is None else mask._version,
+                                lens=lens, kp=kps, vt=vts, Lk=Lk)
         return self._text_cache
+
+    def reset_text_cache(self):
+        self._text_cache = None
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()

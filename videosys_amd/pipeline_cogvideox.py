@@ -220,15 +220,19 @@ class CogVideoXPipeline:
             negative_prompt_embeds = self.text_encoder(negative_prompt or "")
         if guidance_scale <= 1.0:
             raise NotImplementedError("the MI355X path runs the classifier-free-guidance batch (guidance_scale > 1)")
+        from .utils import set_seed
+
+        seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
         pab.update_steps(num_inference_steps)
         self.transformer.reset_pab_state()
+        self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
         B = prompt_embeds.shape[0]
         emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
         self.scheduler.set_timesteps(num_inference_steps)
         c = self.transformer.config
         lat_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
         if latents is None:
-            g = torch.Generator(device="cpu").manual_seed(seed if seed >= 0 else 0)
+            g = torch.Generator(device="cpu").manual_seed(seed)
             latents = torch.randn(B, lat_frames, c.in_channels, height // self.vae_scale_factor_spatial,
                                   width // self.vae_scale_factor_spatial, generator=g, dtype=torch.float32)
         z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()

@@ -174,8 +174,12 @@ class LattePipeline:
             negative_prompt_embeds, negative_mask = self.text_encoder(negative_prompt)
         if guidance_scale <= 1.0:
             raise NotImplementedError("the MI355X path runs the classifier-free-guidance batch (guidance_scale > 1)")
+        from .utils import set_seed
+
+        seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
         pab.update_steps(num_inference_steps)
         self.transformer.reset_pab_state()
+        self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
         B = prompt_embeds.shape[0]
         emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
         mask = None if prompt_mask is None else torch.cat([negative_mask, prompt_mask], dim=0)
@@ -183,7 +187,7 @@ class LattePipeline:
         ts = self.scheduler.timesteps
         cin = self.transformer.in_channels
         if latents is None:
-            g = torch.Generator(device="cpu").manual_seed(seed if seed >= 0 else 0)
+            g = torch.Generator(device="cpu").manual_seed(seed)
             latents = torch.randn(B, cin, video_length, height // 8, width // 8, generator=g, dtype=torch.float32)
         z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
         all_ts = torch.tensor(ts)

@@ -2,10 +2,11 @@
 (OpenSoraPABConfig :32-69, OpenSoraConfig :72-163, OpenSoraPipeline :166-659) for the denoising hot path.
 
 ``OpenSoraConfig`` / ``OpenSoraPABConfig`` take the same kwargs with the same defaults, expose ``pipeline_cls`` and
-``num_gpus`` and drop into ``VideoSysEngine(config)`` unchanged.  This round builds the path from text embeddings +
-noise to denoised latents; the T5 text encoder and the VAE decoder are the "next" rows
-(§8f) and are pluggable callables here: ``generate`` accepts ``prompt_embeds``/``prompt_mask`` and returns latents
-when no VAE is attached, and raises a clear error if a raw prompt string arrives without a text encoder.
+``num_gpus`` and drop into ``VideoSysEngine(config)`` unchanged; ``generate`` keeps the reference's call shape
+(``resolution`` / ``aspect_ratio`` / ``num_frames="2s"`` through open_sora_geometry.py).  The T5 text encoder and the VAE
+decoder load from local checkpoint directories (no hub access here); ``generate`` also accepts ``prompt_embeds`` /
+``prompt_mask`` and returns latents when no VAE is attached, and raises a clear error if a raw prompt string arrives
+without a text encoder.
 No pretrained weights exist offline: ``transformer="synthetic:<seed>"`` (default when the HF name cannot be resolved
 locally) builds seeded random weights of the real STDiT3-XL/2 geometry.
 """
@@ -202,45 +203,87 @@ class OpenSoraPipeline:
         """pipeline_open_sora.py:294-296."""
         return self.transformer.y_embedder.y_embedding[None].repeat(n, 1, 1)[:, None]
 
+    @staticmethod
+    def text_preprocessing(text: str) -> str:
+        """pipeline_open_sora.py:417-424 without ``clean_caption`` (ftfy / bs4 are not in this image): lower-case + strip."""
+        return text.lower().strip()
+
+    @classmethod
+    def prepare_prompt(cls, prompt: str, aes: Optional[float] = 6.5, flow: Optional[float] = None, camera_motion=None,
+                       loop_i: int = 0) -> str:
+        """What generate() feeds the tokenizer for loop ``loop_i`` (pipeline_open_sora.py:548-615, 705-792): an optional JSON
+        tail (``{"reference_path": ..., "mask_strategy": ...}`` — conditioning, outside the MI355X hot path) is split off, a
+        ``|0| text |k| text`` schedule is resolved to the segment that covers the loop, the score tags the Open-Sora 1.2
+        checkpoints were trained with are appended, and the text is lower-cased."""
+        import json
+
+        text, brace, tail = prompt.partition("{")
+        if brace:
+            extra = json.loads(brace + tail)
+            unknown = set(extra) - {"reference_path", "mask_strategy"}
+            assert not unknown, f"Invalid key: {sorted(unknown)[0]}"
+            if any(extra.values()):
+                raise NotImplementedError("reference / mask-strategy conditioning is outside the MI355X hot path")
+        if text.startswith("|0|"):
+            fields = text.split("|")[1:]            # start, text, start, text, ...
+            starts = [int(v) for v in fields[0::2]]
+            texts = [v.strip() for v in fields[1::2]]
+            text = texts[max(i for i, s0 in enumerate(starts) if s0 <= loop_i)]
+        for tag, val, fmt in (("aesthetic score:", aes, "{:.1f}"), ("motion score:", flow, "{:.1f}"), ("camera motion:", camera_motion, "{}")):
+            if val is not None and tag not in text:
+                text = f"{text} {tag} {fmt.format(val)}."
+        return cls.text_preprocessing(text)
+
     @torch.no_grad()
-    def generate(self, prompt=None, resolution="480p", aspect_ratio="9:16", num_frames="2s", loop=1, seed: int = -1,
-                 verbose: bool = False, *, height: Optional[int] = None, width: Optional[int] = None,
+    def generate(self, prompt=None, resolution="480p", aspect_ratio="9:16", num_frames="2s", loop: int = 1,
+                 llm_refine: bool = False, negative_prompt: str = "", seed: int = -1, ms: Optional[str] = "",
+                 refs: Optional[str] = "", aes: Optional[float] = 6.5, flow: Optional[float] = None, camera_motion=None,
+                 condition_frame_length: int = 5, align: int = 5, condition_frame_edit: float = 0.0, return_dict: bool = True,
+                 verbose: bool = True, *, height: Optional[int] = None, width: Optional[int] = None,
                  prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
                  fps: float = 24.0, output_type: str = "auto"):
-        """pipeline_open_sora.py:426-656 for plain text-to-video.  ``height``/``width``/integer ``num_frames`` give the
-        geometry directly (the reference's "512"/"1:1" table lookup asserts, SURVEY.md §7, so 512x512 cannot be named
-        through it)."""
+        """pipeline_open_sora.py:426-656 for plain text-to-video, with the reference's positional / keyword call shape:
+        ``engine.generate(prompt, resolution="480p", aspect_ratio="9:16", num_frames="2s")`` (examples/open_sora/sample.py).
+
+        Geometry comes from the reference's vocabulary (open_sora_geometry.get_image_size / get_num_frames); keyword-only
+        ``height=`` / ``width=`` override it — an extension, needed because the reference's own tables cannot name 512x512
+        (("512", "1:1") fails its assert).  ``prompt_embeds`` / ``prompt_mask`` bypass the text encoder.  Image / video
+        conditioning (``refs``, ``ms``, ``loop`` > 1) is outside the MI355X hot path and raises."""
+        from . import open_sora_geometry as G
         from .utils import set_seed
 
+        if loop != 1 or ms or refs:
+            raise NotImplementedError("reference / mask-strategy conditioning and multi-loop generation are outside the MI355X hot path")
+        image_size = (int(height), int(width)) if height is not None and width is not None else G.get_image_size(resolution, aspect_ratio)
+        num_frames = G.get_num_frames(num_frames)
+        seed = set_seed(seed)   # -1 draws a fresh seed on rank 0 and broadcasts it (core/pipeline/pipeline.py _set_seed)
         if prompt_embeds is None:
             if self.text_encoder is None:
-                raise RuntimeError("no text encoder attached: pass prompt_embeds=[B,1,L,4096] (+ prompt_mask) — the T5 "
-                                   "encoder is a 'next' row (SURVEY.md §8f) and has no weights offline")
-            prompt_embeds, prompt_mask = self.text_encoder(prompt)
-        if height is None or width is None or not isinstance(num_frames, int):
-            raise ValueError("give the geometry as height=, width=, num_frames=<int>")
-        if seed >= 0:
-            set_seed(seed)
+                raise RuntimeError("no text encoder attached: pass prompt_embeds=[B,1,L,4096] (+ prompt_mask), or give "
+                                   "OpenSoraConfig(text_encoder=<local T5 checkpoint directory>)")
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            prompts = [self.prepare_prompt(q, aes=aes, flow=flow, camera_motion=camera_motion) for q in prompts]
+            prompt_embeds, prompt_mask = self.text_encoder(prompts[0] if len(prompts) == 1 else prompts)
         pab.update_steps(self._config.num_sampling_steps)
         self.transformer.reset_pab_state()
+        self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
         B = prompt_embeds.shape[0]
-        T, Hl, Wl = get_latent_size(num_frames, height, width)
+        T, Hl, Wl = get_latent_size(num_frames, *image_size)
         g = torch.Generator(device="cpu")
-        g.manual_seed(seed if seed >= 0 else 0)
+        g.manual_seed(seed)
         z = torch.randn(B, self.transformer.in_channels, T, Hl, Wl, generator=g, dtype=torch.float32)
         z = z.to(torch.bfloat16).float()  # the reference draws z in bf16 (pipeline_open_sora.py:622-624)
-        margs = dict(
-            y=prompt_embeds, mask=prompt_mask,
-            height=torch.tensor([float(height)] * B), width=torch.tensor([float(width)] * B),
-            num_frames=torch.tensor([float(num_frames)] * B), fps=torch.tensor([float(fps)] * B),
-        )
+        # the conditioning scalars are tensors of the MODEL dtype, as in the reference (data_process.py:798-805): 854 is 856 there
+        margs = dict(y=prompt_embeds, mask=prompt_mask)
+        margs.update(G.prepare_multi_resolution_info(B, image_size, num_frames, fps, dtype=self.transformer.dtype))
         y_null = self.null(B)
         samples = self.scheduler.sample(self.transformer, z, margs, y_null, device=self._device, progress=verbose)
         if self.vae_decoder is None or output_type == "latent":
-            return VideoSysPipelineOutput(video=samples)
+            out = VideoSysPipelineOutput(video=samples)
+            return out if return_dict else (samples,)
         video = self.vae_decoder(samples.to(torch.bfloat16), num_frames=num_frames)
         video = (video.clamp(-1, 1) * 0.5 + 0.5).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
-        return VideoSysPipelineOutput(video=video)
+        return VideoSysPipelineOutput(video=video) if return_dict else (video,)
 
     def save_video(self, video, output_path):
         from .utils import save_video

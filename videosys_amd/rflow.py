@@ -40,7 +40,9 @@ class RFLOW:
         steps = [torch.full((batch,), float(v), dtype=torch.float32) for v in grid]
         if not self.use_timestep_transform:
             return steps
-        geom = {k: model_args[k].detach().to("cpu").float() for k in ("height", "width", "num_frames")}
+        # the geometry tensors keep the dtype they arrive in (bf16 from the pipeline, as in the reference): the ratio is then
+        # computed in that dtype and promoted by the fp32 timestep exactly as scheduling_rflow_open_sora.py:47-70 does
+        geom = {k: model_args[k].detach().to("cpu") for k in ("height", "width", "num_frames")}
         return [timestep_transform(v, geom, num_timesteps=full) for v in steps]
 
     @torch.no_grad()
@@ -66,6 +68,8 @@ class RFLOW:
             tt = torch.cat([t, t], 0)
             out = model(z_in, tt, **fwd_args)
             dt = timesteps[i] - timesteps[i + 1] if i < len(timesteps) - 1 else timesteps[i]
+            if not bool((dt == dt[0]).all()):   # the reference applies dt per sample (:250); one geometry per call here
+                raise NotImplementedError("per-sample step sizes (mixed geometries in one batch) are not supported")
             dt = float(dt[0]) / self.num_timesteps
             ops.cfg_euler_step(z, out, guidance_scale, dt)
         return z

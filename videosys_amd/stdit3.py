@@ -254,10 +254,14 @@ class STDiT3:
 
     def _encode_text(self, y, mask):
         """encode_text (open_sora_transformer_3d.py:526-537) + every block's kv_linear and attention layout, cached
-        while the same (y, mask) tensors are presented (they are constant over the steps of one generate())."""
-        key = (y.data_ptr(), tuple(y.shape), y._version, None if mask is None else (mask.data_ptr(), mask._version))
-        if self._text_cache is not None and self._text_cache["key"] == key:
-            return self._text_cache
+        while the SAME (y, mask) tensor objects are presented unmodified (they are constant over the steps of one generate()).
+        The cache keeps strong references and compares identity + ``_version``: a storage address alone may recur for a
+        different prompt once the caching allocator recycles the block; ``reset_text_cache()`` (called by the pipeline at the
+        start of every generate()) drops it explicitly."""
+        c = self._text_cache
+        if (c is not None and c["y"] is y and c["y_version"] == y._version and c["mask"] is mask
+                and (mask is None or c["mask_version"] == mask._version)):
+            return c
         w = self.w
         B, _, L, Cc = y.shape
         C, H = self.hidden_size, self.num_heads
@@ -290,8 +294,13 @@ class STDiT3:
             else:
                 ops.linear_small(yp, w[p + ".weight"], w[p + ".bias"], out=kv)
             ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kps[i], vts[i], B, H, Lk)
-        self._text_cache = dict(key=key, y_lens=y_lens, kp=kps, vt=vts, Lk=Lk)
+        self._text_cache = dict(y=y, y_version=y._version, mask=mask, mask_version=None if mask is None else mask._version,
+                                y_lens=y_lens, kp=kps, vt=vts, Lk=Lk)
         return self._text_cache
+
+    def reset_text_cache(self):
+        """Forget the per-prompt text projections (and their references to the prompt tensors)."""
+        self._text_cache = None
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
