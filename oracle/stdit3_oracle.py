@@ -175,18 +175,43 @@ class PABSchedule:
     """Restates PABManager.if_broadcast_{spatial,temporal,cross} (pab_mgr.py:54-91):
     flag = enabled and count % range != 0 and lo < t < hi ; count = (count+1) % steps."""
 
-    def __init__(self, steps, spatial=None, temporal=None, cross=None):
+    def __init__(self, steps, spatial=None, temporal=None, cross=None, mlp_spatial=None, mlp_temporal=None):
         # each of spatial/temporal/cross: None (disabled) or (threshold_lo, threshold_hi, range)
+        # mlp_spatial / mlp_temporal: None (MLP broadcast off) or {timestep: {"block": [...], "skip_count": n}}
         self.steps = steps
         self.cfg = {"spatial": spatial, "temporal": temporal, "cross": cross}
+        self.mlp = {False: mlp_spatial, True: mlp_temporal}
+        self.mlp_store = {False: {}, True: {}}
 
     def enabled(self):
         return any(v is not None for v in self.cfg.values())
+
+    def mlp_enabled(self):
+        return self.mlp[False] is not None or self.mlp[True] is not None
 
     def decide(self, kind: str, timestep: int, count: int):
         c = self.cfg[kind]
         flag = bool(c is not None and timestep is not None and (count % c[2] != 0) and (c[0] < timestep < c[1]))
         return flag, (count + 1) % self.steps
+
+    def decide_mlp(self, timestep: int, block_idx: int, all_timesteps, temporal: bool):
+        """PABManager.if_skip_mlp + _is_t_in_skip_config (pab_mgr.py:93-141), counter dropped (nothing reads it):
+        returns (reuse stored output?, store this output?, key timestep of the window)."""
+        rule = self.mlp[temporal] or {}
+        window = None
+        for first in rule:                      # first configured window (dict order) that contains the timestep
+            if first not in all_timesteps:
+                continue
+            at = all_timesteps.index(first)
+            n = int(rule[first]["skip_count"])
+            if timestep in all_timesteps[at:at + 1 + n]:
+                window = (all_timesteps[at], all_timesteps[at + n])
+                break
+        if timestep in rule and block_idx in rule[timestep]["block"]:
+            return False, True, window
+        if window is not None and block_idx in rule[window[0]]["block"]:
+            return True, False, window
+        return False, False, window
 
 
 class _BlockState:
@@ -310,9 +335,10 @@ def encode_text(y: Tensor, mask: Optional[Tensor], sd):
 def stdit3_block(
     x, y, t_mlp, y_lens, T, S, sd, prefix, num_heads, temporal, rope_freqs,
     pab: Optional[PABSchedule] = None, state: Optional[_BlockState] = None, timestep_int: Optional[int] = None,
-    sp_shards: int = 1,
+    sp_shards: int = 1, block_idx: int = 0, all_timesteps=None,
 ):
-    """STDiT3Block.forward — open_sora_transformer_3d.py:162-286 (x_mask=None path; attention-only PAB)."""
+    """STDiT3Block.forward — open_sora_transformer_3d.py:162-286 (x_mask=None path), incl. the MLP broadcast (:232-280) when the
+    schedule carries MLP rules and ``all_timesteps`` is handed down (which the reference's STDiT3.forward forgets to do)."""
     B, N, C = x.shape
     mods = (sd[prefix + ".scale_shift_table"][None] + t_mlp.reshape(B, 6, -1)).chunk(6, dim=1)
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mods
@@ -348,9 +374,21 @@ def stdit3_block(
             state.last_cross = x_cross
         x = x + x_cross
 
-    x_m = t2i_modulate(layer_norm(x), shift_mlp, scale_mlp)
-    x_m = mlp(x_m, sd, prefix + ".mlp")
-    return x + gate_mlp * x_m
+    reuse = store = False
+    window = None
+    if pab is not None and pab.enabled() and pab.mlp_enabled():
+        reuse, store, window = pab.decide_mlp(timestep_int, block_idx, all_timesteps, temporal)
+    if reuse:   # get_mlp_output (pab_mgr.py:148-174): the entry is dropped at the window's last timestep
+        bank = pab.mlp_store[temporal]
+        x_m_s = bank[(window[0], block_idx)]
+        if timestep_int == window[1]:
+            del bank[(window[0], block_idx)]
+    else:
+        x_m = t2i_modulate(layer_norm(x), shift_mlp, scale_mlp)
+        x_m_s = gate_mlp * mlp(x_m, sd, prefix + ".mlp")
+        if store:
+            pab.mlp_store[temporal][(timestep_int, block_idx)] = x_m_s
+    return x + x_m_s
 
 
 def final_layer(x, t, sd):
@@ -421,7 +459,7 @@ class STDiT3Oracle:
         return xe.reshape(B, T * S, self.C), t, t_mlp, yy, y_lens, (T, H, W, Tx, Hx, Wx)
 
     def forward(self, x, timestep, y, mask=None, fps=None, height=None, width=None, valid_depth=None,
-                return_hidden=False):
+                return_hidden=False, all_timesteps=None):
         x, t, t_mlp, yy, y_lens, (T, H, W, Tx, Hx, Wx) = self.embed(x, timestep, y, mask, fps, height, width)
         S = H * W
         rope_freqs = self.sd["rope.freqs"]
@@ -430,9 +468,9 @@ class STDiT3Oracle:
         hidden = []
         for d in range(depth):
             x = stdit3_block(x, yy, t_mlp, y_lens, T, S, self.sd, f"spatial_blocks.{d}", self.H, False, None,
-                             self.pab, self._state(("s", d)), ts_int)
+                             self.pab, self._state(("s", d)), ts_int, block_idx=d, all_timesteps=all_timesteps)
             x = stdit3_block(x, yy, t_mlp, y_lens, T, S, self.sd, f"temporal_blocks.{d}", self.H, True, rope_freqs,
-                             self.pab, self._state(("t", d)), ts_int)
+                             self.pab, self._state(("t", d)), ts_int, block_idx=d, all_timesteps=all_timesteps)
             if callable(return_hidden):   # full-depth parity tests: per-block-pair error growth without keeping 28 copies
                 return_hidden(d, x)
             elif return_hidden:
@@ -485,8 +523,9 @@ def rflow_sample(model, z, y, y_null, mask, fps, height, width, num_frames, num_
     for i, t in enumerate(timesteps):
         z_in = torch.cat([z, z], 0)
         tt = torch.cat([t, t], 0).to(model_dtype)  # STDiT3.forward casts timestep to model dtype (:562)
+        extra = {"all_timesteps": all_timesteps} if getattr(getattr(model, "pab", None), "mlp_enabled", lambda: False)() else {}
         out = model(z_in, tt, yy, mask=mask, fps=torch.cat([fps, fps]), height=torch.cat([height, height]),
-                    width=torch.cat([width, width]))
+                    width=torch.cat([width, width]), **extra)
         pred = out.to(z.device).chunk(2, dim=1)[0]  # the model may run on another device (GPU-as-checker)
         pred_cond, pred_uncond = pred.chunk(2, dim=0)
         v_pred = pred_uncond + cfg_scale * (pred_cond - pred_uncond)

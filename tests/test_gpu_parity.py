@@ -453,6 +453,37 @@ def test_stdit3_pab_golden():
         pab.set_pab_manager(None)
 
 
+def test_stdit3_pab_mlp_broadcast_golden():
+    """Full PAB incl. the MLP broadcast (pab_mgr.py:93-174, open_sora_transformer_3d.py:232-280) against the reference model run
+    with ``all_timesteps`` handed to its blocks (oracle/make_golden_pab_mlp.py): windows opening at 900 / 640 (spatial) and 800
+    (temporal), replayed blocks, entries dropped at the window's end."""
+    from videosys_amd import pab
+
+    fx = load_golden("stdit3_pab_mlp_small.pt")
+    m = _small_model(fx)
+    p = fx["pab"]
+    cfg = pab.PABConfig(spatial_broadcast=True, spatial_threshold=list(p["spatial"][:2]), spatial_range=p["spatial"][2],
+                        temporal_broadcast=True, temporal_threshold=list(p["temporal"][:2]), temporal_range=p["temporal"][2],
+                        cross_broadcast=True, cross_threshold=list(p["cross"][:2]), cross_range=p["cross"][2],
+                        mlp_broadcast=True, mlp_spatial_broadcast_config=fx["mlp_spatial"],
+                        mlp_temporal_broadcast_config=fx["mlp_temporal"])
+    pab.set_pab_manager(cfg)
+    pab.update_steps(fx["steps"])
+    try:
+        i = fx["inputs"]
+        with pytest.raises(ValueError):   # the schedule is required (the reference dies with TypeError here)
+            m(i["x"], torch.tensor([900.0, 900.0]), i["y"], mask=i["mask"], fps=i["fps"], height=i["height"], width=i["width"])
+        m.reset_pab_state()
+        for t, ref in zip(fx["timesteps"], fx["outs"]):
+            tt = torch.tensor([float(t), float(t)])
+            out = m(i["x"], tt, i["y"], mask=i["mask"], fps=i["fps"], height=i["height"], width=i["width"],
+                    all_timesteps=fx["timesteps"])
+            _model_check(out, ref, f"PAB + MLP broadcast step t={t}")
+        assert (len(cfg.mlp_spatial_outputs), len(cfg.mlp_temporal_outputs)) == tuple(fx["stored_left"])
+    finally:
+        pab.set_pab_manager(None)
+
+
 def test_rflow_golden():
     from videosys_amd.rflow import RFLOW
 

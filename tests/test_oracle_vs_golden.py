@@ -91,6 +91,33 @@ def test_stdit3_pab_small():
         close(out, ref, 3e-4, 3e-4)
 
 
+def test_stdit3_pab_mlp_small():
+    """MLP broadcast (pab_mgr.py:93-174): oracle restatement vs the reference model with ``all_timesteps`` handed to its blocks
+    (oracle/make_golden_pab_mlp.py), and the fixture really exercises it: without the MLP rules the replayed steps differ."""
+    fx = load_golden("stdit3_pab_mlp_small.pt")
+    model, _ = _small_model(fx)
+    p = fx["pab"]
+    i = fx["inputs"]
+
+    def run(mlp):
+        kw = dict(mlp_spatial=fx["mlp_spatial"], mlp_temporal=fx["mlp_temporal"]) if mlp else {}
+        model.set_pab(O.PABSchedule(fx["steps"], p["spatial"], p["temporal"], p["cross"], **kw))
+        outs = []
+        for t in fx["timesteps"]:
+            tt = torch.tensor([float(t), float(t)])
+            outs.append(model.forward(i["x"], tt, i["y"], mask=i["mask"], fps=i["fps"], height=i["height"], width=i["width"],
+                                      all_timesteps=fx["timesteps"]))
+        return outs
+
+    outs = run(True)
+    for out, ref in zip(outs, fx["outs"]):
+        close(out, ref, 3e-4, 3e-4)
+    assert model.pab.mlp_store == {False: {}, True: {}} and tuple(fx["stored_left"]) == (0, 0)
+    plain = run(False)
+    changed = [float((a - b).abs().max()) > 1e-2 for a, b in zip(outs, plain)]
+    assert changed == [False, False, True, True, True, True, False], changed   # replays: spatial 900->(800, 704), 640->400; temporal 800->(704, 640)
+
+
 def test_rflow_small():
     fx = load_golden("rflow_small.pt")
     model, _ = _small_model(fx)

@@ -25,8 +25,9 @@ from .stdit3 import STDiT3, STDiT3Config, synth_state_dict
 
 
 class OpenSoraPABConfig(PABConfig):
-    """pipeline_open_sora.py:32-69 — identical defaults (note: mlp_broadcast=True is the reference default and raises
-    in the reference too; use mlp_broadcast=False for attention-only PAB, BASELINE config 3)."""
+    """pipeline_open_sora.py:32-69 — identical defaults, incl. mlp_broadcast=True with the three default windows (in the
+    reference that default raises TypeError because STDiT3.forward drops ``all_timesteps``; here the schedule
+    is handed down and the MLP broadcast runs).  mlp_broadcast=False = attention-only PAB, BASELINE config 3."""
 
     def __init__(
         self,

@@ -14,7 +14,8 @@ Differences from the reference that do not change results (SURVEY.md §7 "hard p
   * the 2*depth x 6 modulation vectors of a step come from one kernel (open_sora_transformer_3d.py:177-179);
   * no torch.utils.checkpoint wrapper around blocks (core/dcp/recompute.py:141-153 is pure overhead under no_grad);
   * PAB decisions use the host-side integer timestep (no ``int(timestep[0])`` device sync per block);
-  * ``all_timesteps`` IS forwarded to the blocks (the reference forgets to: SURVEY.md §0.9);
+  * ``all_timesteps`` IS forwarded to the blocks (the reference forgets to: SURVEY.md §0.9), so ``mlp_broadcast=True`` — the
+    default of OpenSoraPABConfig — works here instead of raising TypeError;
   * x_mask (image/video conditioning masks) is not supported on this path and raises NotImplementedError.
 """
 from __future__ import annotations
@@ -461,16 +462,28 @@ class STDiT3:
             ops.gemm(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], epilogue=ops.EPI_GATE_RES,
                      res=x, aux=aux, out=x)
 
-        # ---------------- MLP
+        # ---------------- MLP (+ PAB MLP broadcast, open_sora_transformer_3d.py:232-280 / pab_mgr.py:93-174: inside a configured
+        # window the block replays gate_mlp * mlp(...) of the window's first timestep).  ``all_timesteps`` reaches the blocks
+        # here; the reference's STDiT3.forward forgets to pass it on and raises TypeError with mlp_broadcast=True.
+        broadcast_mlp, broadcast_next, skip_range = False, False, None
         if use_pab and pab.PAB_MANAGER.config.mlp_broadcast:
-            raise NotImplementedError("PAB mlp_broadcast: the reference path raises TypeError here (SURVEY.md §0.9); "
-                                      "attention-only PAB (mlp_broadcast=False) is what BASELINE config 3 names")
+            if all_timesteps is None:
+                raise ValueError("PAB mlp_broadcast needs the sampler's schedule: call the model with all_timesteps=[...]")
+            ats = [int(v) for v in all_timesteps]
+            broadcast_mlp, st.mlp_count, broadcast_next, skip_range = pab.if_broadcast_mlp(timestep_int, st.mlp_count, st.block_idx,
+                                                                                           ats, is_temporal=temporal)
+        if broadcast_mlp:
+            ops.add_rows(x, pab.get_mlp_output(skip_range, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal))
+            return x
         xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, T * S, C6, out=self._buf("xm", (N, C)))
         hdim = w[p + ".mlp.fc1.weight"].shape[0]
         hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
                         out=self._buf("mlp_h", (N, hdim)))
+        aux = torch.empty_like(x) if broadcast_next else None   # the post-gate output, written by the fc2 epilogue
         ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
-                 gate_stride=C6, rows_per_sample=T * S, res=x, out=x)
+                 gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
+        if broadcast_next:
+            pab.save_mlp_output(timestep=timestep_int, block_idx=st.block_idx, ff_output=aux, is_temporal=temporal)
         return x
 
     def _spatial_attn_overlapped(self, p, xm, B, T, S, S_full):
