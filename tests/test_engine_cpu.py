@@ -1,0 +1,48 @@
+"""CPU (-m "not gpu"): VideoSysEngine process model over a 2-rank gloo group with a stand-in pipeline — results, error propagation
+from the driver and from a worker without leaving stale results behind, sentinel-based detection of a dead worker, constructor
+failures (reference behaviour: core/engine/engine.py:23-128, mp_utils.py:82-254)."""
+import time
+
+import pytest
+
+from engine_fakes import FakeConfig
+
+
+def _engine(**kw):
+    from videosys_amd.engine import VideoSysEngine
+
+    return VideoSysEngine(FakeConfig(**kw), backend="gloo")
+
+
+def test_engine_two_ranks_results_and_error_isolation():
+    eng = _engine(num_gpus=2)
+    try:
+        assert eng.generate(10) == 21.0              # (10 + 0) + (10 + 1) over the group: both ranks ran the call
+        with pytest.raises(RuntimeError, match="worker rank 1 failed: KeyError"):
+            eng.generate(1, mode="raise", who=1)
+        assert eng.generate(2) == 5.0                # nothing of the failed call is taken for this one's result
+        with pytest.raises(KeyError):
+            eng.generate(1, mode="raise", who=0)     # driver-side failure: the worker's result of that call is still collected
+        assert eng.generate(3) == 7.0
+        assert eng.save_video(None, "x.mp4") == "x.mp4"
+    finally:
+        eng.shutdown()
+
+
+def test_engine_dead_worker_fails_the_call_promptly():
+    eng = _engine(num_gpus=2)
+    try:
+        t0 = time.time()
+        with pytest.raises(ChildProcessError, match="worker died"):
+            eng.generate(1, mode="die", who=1)
+        assert time.time() - t0 < 20, "a dead worker must be noticed through its process sentinel, not by a timeout"
+        with pytest.raises(ChildProcessError):       # and the engine stays failed instead of hanging
+            eng.generate(1)
+    finally:
+        eng.shutdown()
+
+
+def test_engine_reports_worker_constructor_failure():
+    with pytest.raises((RuntimeError, ChildProcessError)) as ei:
+        _engine(num_gpus=2, fail_init_rank=1)
+    assert "constructor refused on rank 1" in str(ei.value) or "worker died" in str(ei.value)

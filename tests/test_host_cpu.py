@@ -353,3 +353,19 @@ def test_open_sora_prompt_preparation():
         P.prepare_prompt('A cat{"reference_path": "x.png"}')
     with pytest.raises(AssertionError):
         P.prepare_prompt('A cat{"foo": 1}')
+
+
+def test_videosys_alias_package_exports_reference_names():
+    """``from videosys import ...`` (the import line of every reference example) resolves to this build; run in a subprocess because
+    oracle/ref_loader.py parks the REFERENCE tree under the same module name for the oracle tests."""
+    import subprocess
+    import sys
+
+    code = ("import videosys, videosys_amd\n"
+            "from videosys import (initialize, VideoSysEngine, OpenSoraConfig, OpenSoraPABConfig, OpenSoraPipeline, LatteConfig,\n"
+            "                      LattePABConfig, LattePipeline, CogVideoXConfig, CogVideoXPABConfig, CogVideoXPipeline)\n"
+            "assert VideoSysEngine is videosys_amd.VideoSysEngine and OpenSoraConfig().pipeline_cls is OpenSoraPipeline\n"
+            "try:\n    from videosys import VchitectConfig\n    raise SystemExit(3)\nexcept ImportError as e:\n    assert 'outside' in str(e)\n"
+            "print('ok')")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-800:]

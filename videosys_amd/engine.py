@@ -2,9 +2,15 @@
 
 Same surface (``VideoSysEngine(config)``, ``generate``, ``save_video``, ``shutdown``) and the same process model:
 rank 0 runs in the caller's process, ranks 1..N-1 are *spawned* worker processes (one per GPU) that build the same
-pipeline and execute the same method with the same pickled arguments (engine.py:23-95, mp_utils.py:181-254); a
-worker that dies fails all pending calls (WorkerMonitor, mp_utils.py:111-151).  Rendezvous is tcp://127.0.0.1:<free
-port> (engine.py:38) and the collective backend is RCCL ("nccl" on ROCm).
+pipeline and execute the same method with the same pickled arguments (engine.py:23-95, mp_utils.py:181-254).
+Rendezvous is tcp://127.0.0.1:<free port> (engine.py:38) and the collective backend is RCCL ("nccl" on ROCm).
+
+Failure handling follows mp_utils.py:82-151.  Every call is one *future* per worker, keyed (task id, rank); a collector thread
+(``ResultHandler``) resolves them from the shared result queue, and a monitor thread (``WorkerMonitor``) sleeps in
+``multiprocessing.connection.wait`` on the workers' process SENTINELS — it wakes the instant any worker exits, kills the
+rest and fails every pending future with ``ChildProcessError("worker died")``, so a caller never hangs in a collective
+whose peer is gone.  ``_run_workers`` always collects the futures of ITS task id (also when the driver's own call raised or a
+worker reported an error), so nothing of one call can be mistaken for the result of the next.
 """
 from __future__ import annotations
 
@@ -13,10 +19,15 @@ import os
 import socket
 import threading
 import traceback
-from typing import Any
+from concurrent.futures import Future
+from multiprocessing.connection import wait as wait_sentinels
+from typing import Any, Dict, List, Tuple
 
 import torch
 import torch.distributed as dist
+
+_TERMINATE = "TERMINATE"   # queue sentinel (mp_utils.py:17)
+JOIN_TIMEOUT_S = 2
 
 
 def get_open_port() -> int:
@@ -26,25 +37,103 @@ def get_open_port() -> int:
 
 
 def _worker_main(rank, world_size, init_method, config, task_q, result_q, backend):
+    """Worker process event loop (mp_utils.py:181-216): build the pipeline, then serve (task id, method, args, kwargs) tuples."""
     try:
-        from . import dsp
+        try:
+            from . import dsp
 
-        dsp.initialize(rank=rank, world_size=world_size, init_method=init_method, backend=backend)
-        pipeline = config.pipeline_cls(config)
-        result_q.put((rank, "ready", None))
-        while True:
-            item = task_q.get()
-            if item is None:
-                break
+            dsp.initialize(rank=rank, world_size=world_size, init_method=init_method, backend=backend)
+            pipeline = config.pipeline_cls(config)
+        except BaseException as e:   # construction failed: say why before exiting (the monitor reports the exit itself)
+            result_q.put((rank, 0, ("err", f"{type(e).__name__}: {e}\n{traceback.format_exc()}")))
+            raise
+        result_q.put((rank, 0, ("ok", None)))
+        for item in iter(task_q.get, _TERMINATE):
             tid, method, args, kwargs = item
             try:
                 out = getattr(pipeline, method)(*args, **kwargs)
-                result_q.put((rank, tid, ("ok", None if rank != 0 else out)))
-            except BaseException as e:  # pickled back and re-raised in the caller (mp_utils.py:206-213)
+                result_q.put((rank, tid, ("ok", out if rank == 0 else None)))
+            except BaseException as e:  # reported to the caller, which re-raises (mp_utils.py:206-213)
                 result_q.put((rank, tid, ("err", f"{type(e).__name__}: {e}\n{traceback.format_exc()}")))
+    except KeyboardInterrupt:
+        pass
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
+
+
+class ResultHandler(threading.Thread):
+    """Resolves the per-(task, rank) futures from the result queue (mp_utils.py:82-108)."""
+
+    def __init__(self, result_q):
+        super().__init__(daemon=True)
+        self.result_q = result_q
+        self.tasks: Dict[Tuple[int, int], Future] = {}
+        self._lock = threading.Lock()
+        self._dead = False
+
+    def expect(self, tid: int, rank: int) -> Future:
+        fut: Future = Future()
+        with self._lock:
+            if self._dead:
+                fut.set_exception(ChildProcessError("worker died"))
+            else:
+                self.tasks[(tid, rank)] = fut
+        return fut
+
+    def run(self):
+        for rank, tid, (status, payload) in iter(self.result_q.get, _TERMINATE):
+            with self._lock:
+                fut = self.tasks.pop((tid, rank), None)
+            if fut is None:
+                continue   # nobody waits for it (a call that was abandoned): drop, never hand it to a later call
+            if status == "ok":
+                fut.set_result(payload)
+            else:
+                fut.set_exception(RuntimeError(f"worker rank {rank} failed: {payload}"))
+        with self._lock:   # make sure every waiter gets an exception
+            self._dead = True
+            pending, self.tasks = self.tasks, {}
+        for fut in pending.values():
+            fut.set_exception(ChildProcessError("worker died"))
+
+    def close(self):
+        self.result_q.put(_TERMINATE)
+
+
+class WorkerMonitor(threading.Thread):
+    """Blocks on the workers' process sentinels; the first exit takes everything down (mp_utils.py:111-151)."""
+
+    def __init__(self, workers: List[mp.Process], handler: ResultHandler):
+        super().__init__(daemon=True)
+        self.workers, self.handler = workers, handler
+        self._close = False
+        self.dead_exit_codes: Dict[str, int] = {}
+
+    def run(self):
+        dead = wait_sentinels([p.sentinel for p in self.workers])   # returns as soon as ANY worker process has exited
+        if not self._close:
+            self._close = True
+            for p in self.workers:
+                if p.sentinel in dead:
+                    p.join(JOIN_TIMEOUT_S)
+                if p.exitcode is not None and p.exitcode != 0:
+                    self.dead_exit_codes[p.name] = p.exitcode
+            for p in self.workers:
+                if p.is_alive():
+                    p.kill()
+            self.handler.close()   # after the workers are gone: fails whatever is still pending
+        for p in self.workers:
+            p.join(JOIN_TIMEOUT_S)
+
+    def close(self):
+        if self._close:
+            return
+        self._close = True
+        for p in self.workers:
+            if p.is_alive():
+                p.terminate()
+        self.handler.close()
 
 
 class VideoSysEngine:
@@ -62,50 +151,56 @@ class VideoSysEngine:
             assert world_size <= torch.cuda.device_count(), "num_gpus exceeds visible devices (engine.py:35)"
         init_method = f"tcp://127.0.0.1:{get_open_port()}"
         self.workers, self._task_qs = [], []
-        self._result_q = None
+        self._handler = self._monitor = None
+        ready: List[Future] = []
         if world_size > 1:
             ctx = mp.get_context("spawn")
-            self._result_q = ctx.Queue()
+            result_q = ctx.Queue()
+            self._handler = ResultHandler(result_q)
             for rank in range(1, world_size):
                 q = ctx.Queue()
-                p = ctx.Process(target=_worker_main, daemon=True,
-                                args=(rank, world_size, init_method, self.config, q, self._result_q, backend))
+                p = ctx.Process(target=_worker_main, daemon=True, name=f"VideoSysWorkerProcess-{rank}",
+                                args=(rank, world_size, init_method, self.config, q, result_q, backend))
+                ready.append(self._handler.expect(0, rank))
                 p.start()
                 self.workers.append(p)
                 self._task_qs.append(q)
+            self._handler.start()
+            self._monitor = WorkerMonitor(self.workers, self._handler)
+            self._monitor.start()
         from . import dsp
 
-        if world_size > 1 or not dist.is_initialized():
-            dsp.initialize(rank=0, world_size=world_size, init_method=init_method, backend=backend)
-        self.driver_worker = pipeline_cls(self.config)
-        for _ in self.workers:
-            rank, tag, _ = self._get_result()
-            assert tag == "ready"
-
-    def _get_result(self):
-        while True:
-            try:
-                return self._result_q.get(timeout=1.0)
-            except Exception:
-                dead = [p for p in self.workers if not p.is_alive()]
-                if dead:
-                    self._kill_all()
-                    raise ChildProcessError("worker died")
-
-    def _kill_all(self):
-        for p in self.workers:
-            if p.is_alive():
-                p.kill()
+        try:
+            if world_size > 1 or not dist.is_initialized():
+                dsp.initialize(rank=0, world_size=world_size, init_method=init_method, backend=backend)
+            self.driver_worker = pipeline_cls(self.config)
+            for fut in ready:
+                fut.result()   # raises the worker's construction error, or "worker died"
+        except BaseException:
+            self.shutdown()
+            raise
 
     def _run_workers(self, method: str, *args, **kwargs) -> Any:
+        if self._handler is not None and self._handler._dead:
+            raise ChildProcessError("worker died")   # fail fast: the driver must not enter a collective whose peers are gone
         self._tid += 1
+        tid = self._tid
+        futures = [self._handler.expect(tid, rank) for rank in range(1, len(self.workers) + 1)] if self._handler else []
         for q in self._task_qs:
-            q.put((self._tid, method, args, kwargs))
-        driver_out = getattr(self.driver_worker, method)(*args, **kwargs)
-        for _ in self.workers:
-            rank, tid, (status, payload) = self._get_result()
-            if status == "err":
-                raise RuntimeError(f"worker rank {rank} failed: {payload}")
+            q.put((tid, method, args, kwargs))
+        failure = None
+        driver_out = None
+        try:
+            driver_out = getattr(self.driver_worker, method)(*args, **kwargs)
+        except BaseException as e:
+            failure = e
+        for fut in futures:   # always collect what belongs to THIS call before returning or raising
+            try:
+                fut.result()
+            except BaseException as e:
+                failure = failure or e
+        if failure is not None:
+            raise failure
         return [driver_out]
 
     def generate(self, *args, **kwargs):
@@ -119,10 +214,17 @@ class VideoSysEngine:
             return
         self._closed = True
         for q in self._task_qs:
-            q.put(None)
+            try:
+                q.put(_TERMINATE)
+            except Exception:
+                pass
         for p in self.workers:
             p.join(timeout=10)
-        self._kill_all()
+        if self._monitor is not None:
+            self._monitor.close()
+        for p in self.workers:
+            if p.is_alive():
+                p.kill()
         if dist.is_initialized():
             dist.destroy_process_group()
 

@@ -411,7 +411,7 @@ def gemm128(a, w, bias=None, res=None, out=None, out_f32=None, out_scale=1.0, ba
     _chk(a, w, bias, res, out, out_f32)
     _bf16(a, w, bias, res, out)
     M = a.shape[0] if M is None else M
-    N, K = w.shape[0] if batch == 1 else w.shape[-2], a.shape[-1]
+    N, K = w.shape[-2], a.shape[-1]   # (a batched w is [batch, N, K]; also when the batch happens to be 1)
     if out is None and out_f32 is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     o = out if out is not None else out_f32

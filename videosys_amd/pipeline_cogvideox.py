@@ -17,6 +17,7 @@ from typing import Callable, List, Optional
 import numpy as np
 import torch
 
+from .utils import StagedOffloadMixin
 from . import ops, pab
 from .cogvideox import CogVideoXTransformer3DModel, synth_state_dict
 from .pab import PABConfig
@@ -131,7 +132,7 @@ def get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size, t
     return freqs.cos().contiguous(), freqs.sin().contiguous()
 
 
-class CogVideoXPipeline:
+class CogVideoXPipeline(StagedOffloadMixin):
     vae_scale_factor_spatial = 8
     vae_scale_factor_temporal = 4
 
@@ -165,6 +166,9 @@ class CogVideoXPipeline:
         self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
         self._set_parallel()
+        # cpu_offload: each stage's weights live in pinned host memory and are resident only while the stage runs
+        self._init_stages(config.cpu_offload, self._device, text_encoder=getattr(self.text_encoder, "encoder", None),
+                          transformer=self.transformer, vae=self.vae_decoder)
 
     def _load_vae(self, config, base):
         """pipeline_cogvideox.py:146-147,170-172: AutoencoderKLCogVideoX from ``<model_path>/vae`` (local safetensors) or
@@ -216,6 +220,7 @@ class CogVideoXPipeline:
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, 226, 4096]")
+            self._enter_stage("text_encoder")
             prompt_embeds = self.text_encoder(prompt)
             negative_prompt_embeds = self.text_encoder(negative_prompt or "")
         if guidance_scale <= 1.0:
@@ -223,6 +228,7 @@ class CogVideoXPipeline:
         from .utils import set_seed
 
         seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
+        self._enter_stage("transformer")
         pab.update_steps(num_inference_steps)
         self.transformer.reset_pab_state()
         self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
@@ -248,8 +254,11 @@ class CogVideoXPipeline:
             ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, c_z, c_v, cond_first=False)
             z.copy_(z.to(torch.bfloat16).float())  # latents = latents.to(prompt_embeds.dtype) (:723)
         if self.vae_decoder is None or output_type in ("latent", "latents"):
+            self._enter_stage(None)
             return VideoSysPipelineOutput(video=z)
+        self._enter_stage("vae")
         frames = self.vae_decoder(z.to(torch.bfloat16))   # decode_latents (:359-364) -> [B, 3, T, H, W]
+        self._enter_stage(None)
         if not torch.is_tensor(frames) or frames.dtype == torch.uint8:
             return VideoSysPipelineOutput(video=frames)
         # VideoProcessor.postprocess_video (diffusers, third-party) denormalises to [0, 1]; here: uint8 [B, T, H, W, C] on the CPU

@@ -15,6 +15,7 @@ from typing import Callable, List, Optional
 
 import torch
 
+from .utils import StagedOffloadMixin
 from . import ops, pab
 from .latte import LatteT2V, synth_state_dict
 from .pab import PABConfig
@@ -93,7 +94,7 @@ class DDIMScheduler:
         return math.sqrt(a_prev / a_t), math.sqrt(1 - a_prev) - math.sqrt(a_prev * (1 - a_t) / a_t)
 
 
-class LattePipeline:
+class LattePipeline(StagedOffloadMixin):
     def __init__(self, config: LatteConfig, device=None, text_encoder: Optional[Callable] = None,
                  vae_decoder: Optional[Callable] = None):
         self._config = config
@@ -123,6 +124,9 @@ class LattePipeline:
         self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
         self._set_parallel()
+        # cpu_offload: each stage's weights live in pinned host memory and are resident only while the stage runs
+        self._init_stages(config.cpu_offload, self._device, text_encoder=getattr(self.text_encoder, "encoder", None),
+                          transformer=self.transformer, vae=self.vae_decoder)
 
     def _load_vae(self, config):
         """pipeline_latte.py:211-217.  Built here: the plain ``AutoencoderKL`` branch (``enable_vae_temporal_decoder=False``) from a
@@ -170,6 +174,7 @@ class LattePipeline:
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, L, 4096]")
+            self._enter_stage("text_encoder")
             prompt_embeds, prompt_mask = self.text_encoder(prompt)
             negative_prompt_embeds, negative_mask = self.text_encoder(negative_prompt)
         if guidance_scale <= 1.0:
@@ -177,6 +182,7 @@ class LattePipeline:
         from .utils import set_seed
 
         seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
+        self._enter_stage("transformer")
         pab.update_steps(num_inference_steps)
         self.transformer.reset_pab_state()
         self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
@@ -199,8 +205,12 @@ class LattePipeline:
             c_z, c_eps = self.scheduler.coeffs(t)
             ops.cfg_linear_step(z, out, guidance_scale, c_z, c_eps, cond_first=False)
         if self.vae_decoder is None or output_type in ("latent", "latents"):
+            self._enter_stage(None)
             return VideoSysPipelineOutput(video=z)
-        return VideoSysPipelineOutput(video=self.vae_decoder(z))
+        self._enter_stage("vae")
+        video = self.vae_decoder(z)
+        self._enter_stage(None)
+        return VideoSysPipelineOutput(video=video)
 
     def save_video(self, video, output_path):
         from .utils import save_video

@@ -22,6 +22,7 @@ from . import pab
 from .pab import PABConfig
 from .rflow import RFLOW
 from .stdit3 import STDiT3, STDiT3Config, synth_state_dict
+from .utils import StagedOffloadMixin
 
 
 class OpenSoraPABConfig(PABConfig):
@@ -117,7 +118,7 @@ def get_latent_size(num_frames: int, height: int, width: int):
     return (t, height // 8, width // 8)
 
 
-class OpenSoraPipeline:
+class OpenSoraPipeline(StagedOffloadMixin):
     """The per-rank pipeline object the engine instantiates (engine.py:68-72) and whose ``generate`` it calls."""
 
     def __init__(self, config: OpenSoraConfig, device=None, text_encoder: Optional[Callable] = None,
@@ -152,6 +153,15 @@ class OpenSoraPipeline:
         else:
             pab.set_pab_manager(None)
         self._set_parallel()
+        # cpu_offload (pipeline_open_sora.py:241-244): every stage parks its weights in pinned host memory and holds HBM only
+        # while it runs — text encoder -> transformer -> VAE decoder, one at a time
+        self._init_stages(config.cpu_offload, self._device, text_encoder=getattr(self.text_encoder, "encoder", None),
+                          transformer=self.transformer, vae=self.vae_decoder)
+
+    def _after_onload(self, name):
+        if name == "transformer":   # attribute paths the sampler reads alias entries of the weight table
+            self.transformer.x_embedder.proj.weight = self.transformer.w["x_embedder.proj.weight"]
+            self.transformer.y_embedder.y_embedding = self.transformer.w["y_embedder.y_embedding"]
 
     def _load_text_encoder(self, name):
         """pipeline_open_sora.py:211-214: T5EncoderModel + AutoTokenizer from ``config.text_encoder`` — here a LOCAL directory
@@ -160,6 +170,16 @@ class OpenSoraPipeline:
         import glob
         import json
 
+        if isinstance(name, str) and name.startswith("synthetic:"):
+            # offline stand-in: random T5 v1.1 weights of the geometry the transformer's caption projection expects (XXL for the
+            # real 4096-wide model) + a byte tokenizer — lets generate(prompt) run end to end without any checkpoint
+            from .t5 import ByteTokenizer, T5Encoder, T5TextEncoder
+
+            d = self.transformer.config.caption_channels
+            geo = dict(d_model=4096, d_ff=10240, num_layers=24, num_heads=64) if d == 4096 else \
+                dict(d_model=d, d_ff=2 * d, num_layers=2, num_heads=max(d // 64, 2))
+            enc = T5Encoder(device=self._device, **geo).init_random_(int(name.split(":", 1)[1]))
+            return T5TextEncoder(enc, ByteTokenizer(enc.config.vocab_size), max_length=self.transformer.config.model_max_length)
         if not (isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "config.json"))):
             return None
         from safetensors.torch import load_file
@@ -264,7 +284,9 @@ class OpenSoraPipeline:
                                    "OpenSoraConfig(text_encoder=<local T5 checkpoint directory>)")
             prompts = [prompt] if isinstance(prompt, str) else list(prompt)
             prompts = [self.prepare_prompt(q, aes=aes, flow=flow, camera_motion=camera_motion) for q in prompts]
+            self._enter_stage("text_encoder")
             prompt_embeds, prompt_mask = self.text_encoder(prompts[0] if len(prompts) == 1 else prompts)
+        self._enter_stage("transformer")
         pab.update_steps(self._config.num_sampling_steps)
         self.transformer.reset_pab_state()
         self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
@@ -280,9 +302,12 @@ class OpenSoraPipeline:
         y_null = self.null(B)
         samples = self.scheduler.sample(self.transformer, z, margs, y_null, device=self._device, progress=verbose)
         if self.vae_decoder is None or output_type == "latent":
+            self._enter_stage(None)
             out = VideoSysPipelineOutput(video=samples)
             return out if return_dict else (samples,)
+        self._enter_stage("vae")
         video = self.vae_decoder(samples.to(torch.bfloat16), num_frames=num_frames)
+        self._enter_stage(None)
         video = (video.clamp(-1, 1) * 0.5 + 0.5).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
         return VideoSysPipelineOutput(video=video) if return_dict else (video,)
 

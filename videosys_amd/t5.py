@@ -157,6 +157,27 @@ class T5TextEncoder:
         return emb[:, None], tok["attention_mask"]
 
 
+class ByteTokenizer:
+    """Offline stand-in for the HF tokenizer of ``text_encoder="synthetic:<seed>"`` pipelines (the sentencepiece model of
+    DeepFloyd/t5-v1_1-xxl cannot be fetched here): UTF-8 bytes + 3 as token ids, id 1 (``</s>``) appended, id 0 padding — the
+    call signature and the returned ``input_ids`` / ``attention_mask`` tensors of ``tokenizer(..., return_tensors="pt")``."""
+
+    def __init__(self, vocab_size: int = 32128):
+        self.vocab_size = vocab_size
+
+    def __call__(self, prompts, max_length=300, padding="max_length", truncation=True, return_attention_mask=True,
+                 add_special_tokens=True, return_tensors="pt"):
+        if isinstance(prompts, str):
+            prompts = [prompts]
+        ids = torch.zeros(len(prompts), max_length, dtype=torch.int64)
+        mask = torch.zeros(len(prompts), max_length, dtype=torch.int64)
+        for b, text in enumerate(prompts):
+            toks = [(v + 3) % self.vocab_size for v in text.encode("utf-8")][: max_length - 1] + [1]
+            ids[b, : len(toks)] = torch.tensor(toks)
+            mask[b, : len(toks)] = 1
+        return {"input_ids": ids, "attention_mask": mask}
+
+
 def synth_state_dict(d_model=4096, d_ff=10240, num_layers=24, num_heads=64, vocab_size=32128, num_buckets=32, seed: int = 5):
     """Seeded random weights with the HF T5EncoderModel key names (bf16-representable fp32)."""
     g = torch.Generator().manual_seed(seed)

@@ -35,3 +35,117 @@ def save_video(video, output_path, fps=24):
 
     os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)
     np.save(os.path.splitext(output_path)[0] + ".npy", video.cpu().numpy())
+
+
+class HostOffload:
+    """``cpu_offload=True`` (pipeline_open_sora.py:241-244 ``enable_model_cpu_offload``; diffusers hooks in the reference): one
+    stage of a pipeline — text encoder, transformer or VAE decoder — keeps its weights in PINNED host memory and holds HBM only
+    while it runs.  The kernels here take raw device pointers, so nothing can page in lazily: ``to_device()`` brings every weight
+    tensor of the object graph back before the stage is entered and ``to_host()`` releases the HBM afterwards.
+
+    Works on any of this package's weight holders: it walks attributes, dicts, lists, tuples and SimpleNamespaces, moves every CUDA
+    tensor it finds and preserves aliasing (one tensor object referenced from two places stays one tensor)."""
+
+    def __init__(self, obj, device=None, skip=("_ws", "_text_cache", "_rope_cache", "_pos_cache", "_fps_cache", "_bias_cache", "_padded")):
+        self.obj = obj
+        self.skip = set(skip)
+        self.device = torch.device(device) if device is not None else getattr(obj, "device", torch.device("cuda"))
+        self.on_device = True
+        self._parked = set()   # ids of the pinned host copies made by to_host(): only these travel back (tensors the holder
+                               # keeps on the host on purpose — rope.freqs, bias tables — stay where they are)
+
+    def _walk(self, o, move, memo, depth=0):
+        if torch.is_tensor(o):
+            key = id(o)
+            if key not in memo:
+                memo[key] = move(o)
+            return memo[key]
+        if depth > 8:
+            return o
+        if isinstance(o, dict):
+            for k in list(o):
+                if k not in self.skip:
+                    o[k] = self._walk(o[k], move, memo, depth + 1)
+            return o
+        if isinstance(o, list):
+            for i in range(len(o)):
+                o[i] = self._walk(o[i], move, memo, depth + 1)
+            return o
+        if isinstance(o, tuple):
+            return tuple(self._walk(v, move, memo, depth + 1) for v in o)
+        mod = type(o).__module__ or ""
+        if mod.startswith("videosys_amd") or mod == "types":   # this package's holders and SimpleNamespace
+            d = getattr(o, "__dict__", None)
+            if d is not None:
+                for k in list(d):
+                    if k not in self.skip and k != "device":
+                        d[k] = self._walk(d[k], move, memo, depth + 1)
+        return o
+
+    def drop_workspaces(self):
+        for name in self.skip:
+            v = getattr(self.obj, name, None)
+            if isinstance(v, dict):
+                v.clear()
+            elif v is not None and name in ("_text_cache", "_rope_cache") and not isinstance(v, dict):
+                setattr(self.obj, name, None)
+
+    def to_host(self):
+        if not self.on_device:
+            return self
+        pin = torch.cuda.is_available()
+
+        parked = self._parked = set()
+        keep = self._keep = []   # the ids stay valid while the copies are referenced here
+
+        def move(t):
+            if not t.is_cuda:
+                return t
+            h = torch.empty(t.shape, dtype=t.dtype, device="cpu", pin_memory=pin)
+            h.copy_(t)
+            parked.add(id(h))
+            keep.append(h)
+            return h
+
+        self.drop_workspaces()
+        self._walk(self.obj, move, {})
+        self.on_device = False
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        return self
+
+    def to_device(self):
+        if self.on_device:
+            return self
+        parked = self._parked
+        self._walk(self.obj, lambda t: t.to(self.device, non_blocking=True) if id(t) in parked else t, {})
+        self._parked, self._keep = set(), []
+        self.on_device = True
+        return self
+
+
+class StagedOffloadMixin:
+    """Pipeline side of ``cpu_offload``: ``_init_stages`` parks the named weight holders on the host when the config asks for it,
+    ``_enter_stage(name)`` makes exactly that stage resident (``None``: none).  A no-op without cpu_offload."""
+
+    _stages = None
+
+    def _init_stages(self, enabled: bool, device, **holders):
+        self._stages = {}
+        if enabled:
+            for name, obj in holders.items():
+                if obj is not None and hasattr(obj, "__dict__"):
+                    self._stages[name] = HostOffload(obj, device=device).to_host()
+
+    def _enter_stage(self, name):
+        if not self._stages:
+            return
+        for other, off in self._stages.items():
+            if other != name:
+                off.to_host()
+        if name in self._stages:
+            self._stages[name].to_device()
+            self._after_onload(name)
+
+    def _after_onload(self, name):   # hook: refresh attribute aliases of weight-table entries
+        pass
