@@ -44,16 +44,17 @@ const char* vsys_strerror(int code);
 /* number of HIP devices visible to the library (fails loudly instead of falling back when 0) */
 int vsys_device_count(void);
 
-/* Tuning knobs (A/B measurement only; every non-lab variant gives identical results).
- * gemm: 0 = shipped default (schedule 8: three A slots + two W slots, counted waits), 3 = two-stage LDS-DMA burst,
- *       6 = two-stage with fragment double-buffering, 103 = 128-row tiles / two workgroups per CU; ids >= 10 with a
- *       non-zero tens digit are lab ablations (skip epilogue / stores) whose OUTPUT IS NOT VALID.
- * flash: 0 = shipped default (two workgroups per CU); 3 = three workgroups per CU; 1 = lab ablation (K/V tiles not
- *        fetched), output not valid; 2 = lab phase timers (vsys_lab_flash_debug_buffer). */
+/* Kernel selection for A/B measurement.  EVERY id this library accepts selects a kernel with VALID output — the GEMM ids differ
+ * in schedule / geometry only and are bit-identical to each other; an id the build does not contain returns VSYS_ERR_ARG and
+ * leaves the selection unchanged.  (Ablation and cycle-stamp variants whose output is NOT valid exist only in -DVSYS_LAB builds
+ * together with include/videosys_amd_lab.h; the shipped library has no such path.)
+ * gemm:  0 = shape dispatch (default); 8 = schedule 8 for every shape (three A slots + two W slots, counted waits); 3 / 6 =
+ *        two-stage LDS-DMA schedules; 9 = schedule 8, plain row-major tile order; 20 = 4-wave workgroups, two per CU; 28 =
+ *        schedule 8 + producer waves; 30 = 256 x 384 tile; 60 / 70 = ping-pong wave groups, one tile per workgroup / persistent;
+ *        103 = 128-row tiles.
+ * flash: 0 = default (two workgroups per CU); 3 = three workgroups per CU; 9 = online-softmax temporal kernel for every T. */
 int vsys_tune_gemm_variant(int variant);
 int vsys_tune_flash_variant(int variant);
-/* lab: device buffer of 5 uint64 phase-cycle accumulators filled by flash variant 2 (NULL = off) */
-int vsys_lab_flash_debug_buffer(void* dev_u64x5);
 
 /* nn.Linear on token rows with fused epilogue (bf16 in/out, fp32 MFMA accumulate).
  * Replaces: attentions.py:59 (qkv), :107 (proj) + open_sora_transformer_3d.py:219,228 (gate, residual);

@@ -45,15 +45,22 @@ def _stdit3_worker(rank, world, port, outdir, T, HW):
         model = STDiT3(STDiT3Config(**cfg), device="cuda:0")
         model.load_state_dict(sd)
         ref = model(x, t, y, **kw).float().cpu()
-        model.enable_parallel(1, world, False)
+        model.enable_parallel(1, world, False, overlap=False)   # batched path (no side streams)
+        assert not model._overlap
         out = model(x, t, y, **kw).float().cpu()
         out2 = model(x, t, y, **kw).float().cpu()
-        # opt-in comm/compute overlap: the two CFG samples on two side streams, collectives issued A1, B1, A2, B2
-        model.enable_parallel(1, world, False, overlap=True)
-        assert model._overlap and model._side is not None
+        # the default: comm/compute overlap — the two CFG samples on two side streams, collectives issued A1, B1, A2, B2
+        model.enable_parallel(1, world, False)
+        assert model._overlap and model._side is not None and model._switch_order(2, T, (HW // 2) ** 2) == "activations"
         out3 = model(x, t, y, **kw).float().cpu()
         out4 = model(x, t, y, **kw).float().cpu()
         torch.cuda.synchronize()
+        # the other order of the exchange: qkv GEMM at rest on the un-padded shard, the 3C-wide q|k|v travels
+        model._switch = "qkv"
+        out6 = model(x, t, y, **kw).float().cpu()
+        model._switch = "auto"
+        torch.cuda.synchronize()
+        assert torch.equal(out6, ref), "qkv-first exchange"
         # enable_cp: the CFG pair split over the two ranks (cp = 2, sp = 1), outputs gathered along the batch
         model.enable_parallel(1, world, True)
         assert model.parallel_manager.cp_size == 2 and model.parallel_manager.sp_size == 1 and model._sp is None
@@ -219,6 +226,10 @@ def test_bench_two_ranks_dry_run():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
     assert j["roofline"]["frac"] > 0
+    d = j["dsp"]   # per-rank collective time and the overlap report the first multi-GPU run is meant to deliver
+    assert len(d["comm_ms_per_step_per_rank_serialized"]) == 2 and d["collectives_per_step"] >= 2 * 2 + 1   # 2 spatial blocks x 2 exchanges + the final gather
+    assert d["overlap_default"] is True and d["switch_order"] == "activations" and 0.0 <= d["overlap_fraction"] <= 1.0
+    assert d["step_ms_overlap_off"] > 0 and d["step_ms_overlap_on"] > 0
 
 
 def test_batched_copy_executor_matches_plan_semantics():

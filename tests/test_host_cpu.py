@@ -188,6 +188,36 @@ def test_dsp_two_ranks_gloo(T, S):
         assert status == "ok", f"rank {rank}: {status}"
 
 
+@pytest.mark.parametrize("T,S", [(19, 16), (38, 24)])
+def test_dsp_eight_ranks_gloo(T, S):
+    """The BASELINE degree (P = 8) with the frame counts of configs 2 and 4: T = 19 -> 3 padded frames per rank, ranks 6 / 7
+    hold 1 / 0 valid frames; T = 38 -> 5 per rank, rank 7 holds 3.  Same checks as the 2-rank test, 8 real processes."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dsp_worker, args=(r, 8, port, 2, T, S, 8, ret)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [ret.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in res:
+        assert status == "ok", f"rank {rank}: {status}"
+
+
+def test_dsp_switch_cost_model():
+    """dsp.choose_spatial_switch: what travels through the exchange of a spatial block.  At every BASELINE geometry the padded
+    qkv GEMM costs less than tripling the message, so the reference's order stays; a frame count that pads badly on a slow GEMM
+    flips it."""
+    from videosys_amd import dsp
+
+    for B, T, S, P in ((2, 19, 1024, 8), (2, 19, 1024, 4), (2, 38, 3600, 8)):
+        m = dsp.choose_spatial_switch(B, T, S, 1152, P)
+        assert m["order"] == "activations" and m["padded_frames_per_rank"] == -(-T // P)
+    m = dsp.choose_spatial_switch(2, 9, 1024, 1152, 8, gemm_tflops=50.0, a2a_gbytes_s=900.0)
+    assert m["order"] == "qkv" and m["gemm_extra_us"] > m["comm_extra_us"]
+
+
 # ------------------------------------------------------------------------------------------------ Ulysses over gloo
 def _ulysses_worker(rank, world, port, B, Lt, Lv, C, ret):
     try:

@@ -35,6 +35,8 @@ def main():
     from videosys_amd import _lib, ops
 
     lib = _lib.load()
+    if not hasattr(lib, "vsys_lab_flash_debug_buffer"):
+        sys.exit("this probe uses ablation / stamp variants: build the lab flavour first (VSYS_LAB=1 python -c 'import __graft_entry__ as g; g.build()') and run with VSYS_LAB=1")
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
     M = 38912

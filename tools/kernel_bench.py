@@ -63,7 +63,7 @@ def main():
     resid = rnd(N, C)
     for rd in range(args.rounds):
         for variant in [int(v) for v in args.variants.split(',')]:
-            lib.vsys_tune_gemm_variant(variant)
+            assert lib.vsys_tune_gemm_variant(variant) == 0, f"GEMM variant {variant} is not in this build"
             for name, n, k, epi in shapes:
                 w, b, out = bufs[name]
                 a = h if k == 4 * C else x

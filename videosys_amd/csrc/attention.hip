@@ -687,7 +687,19 @@ __global__ __launch_bounds__(256) void attn_temporal_d72_v2_kernel(const bf16_t*
 
 static int g_flash_variant = 0;
 static unsigned long long* g_flash_dbg = nullptr;
-void set_flash_variant(int v) { g_flash_variant = v; }
+// 0 = shipped default, 3 = three workgroups per CU, 9 = force the online-softmax temporal kernel: all valid.  1 (K/V tiles not
+// fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
+int set_flash_variant(int v) {
+  switch (v) {
+    case 0: case 3: case 9: break;
+#ifdef VSYS_LAB
+    case 1: case 2: break;
+#endif
+    default: return VSYS_ERR_ARG;
+  }
+  g_flash_variant = v;
+  return 0;
+}
 void set_flash_debug_buffer(void* p) { g_flash_dbg = reinterpret_cast<unsigned long long*>(p); }
 void* get_lab_debug_buffer() { return g_flash_dbg; }
 
@@ -716,9 +728,12 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   dim3 grid((unsigned)nblk);
   const size_t lds = 2 * KV_STAGE;
   p.dbg = g_flash_dbg;
+#ifdef VSYS_LAB
   if (g_flash_variant == 1) hipLaunchKernelGGL((flash_attn_d72_kernel<1, 2>), grid, dim3(256), lds, stream, p);
   else if (g_flash_variant == 2) hipLaunchKernelGGL((flash_attn_d72_kernel<2, 2>), grid, dim3(256), lds, stream, p);
-  else if (g_flash_variant == 3) hipLaunchKernelGGL((flash_attn_d72_kernel<0, 3>), grid, dim3(256), lds, stream, p);
+  else
+#endif
+  if (g_flash_variant == 3) hipLaunchKernelGGL((flash_attn_d72_kernel<0, 3>), grid, dim3(256), lds, stream, p);
   else hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2>), grid, dim3(256), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
@@ -737,9 +752,6 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = per_wave * wpb;
   const float scale = 0.11785113019775793f;
-  if (g_flash_variant == 7 && T <= 32)  // lab: MFMA formulation (attention_t_mfma.hip), not validated on hardware yet
-    return launch_attn_temporal_d72_mfma(qkv, row_stride, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps,
-                                         scale, stream);
   if (T <= 20 && g_flash_variant != 9) {
     hipLaunchKernelGGL(attn_temporal_d72_v2_kernel<20>, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
                        k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, scale);

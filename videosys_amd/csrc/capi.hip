@@ -31,20 +31,16 @@ int vsys_device_count(void) {
   return n;
 }
 
-int vsys_tune_gemm_variant(int variant) {
-  set_gemm_variant(variant);
-  return 0;
-}
+int vsys_tune_gemm_variant(int variant) { return set_gemm_variant(variant); }
 
-int vsys_tune_flash_variant(int variant) {
-  set_flash_variant(variant);
-  return 0;
-}
+int vsys_tune_flash_variant(int variant) { return set_flash_variant(variant); }
 
+#ifdef VSYS_LAB   // include/videosys_amd_lab.h
 int vsys_lab_flash_debug_buffer(void* dev_u64x5) {
   set_flash_debug_buffer(dev_u64x5);
   return 0;
 }
+#endif
 
 int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
                    int64_t M, int64_t N, int64_t K, int epilogue, const void* gate, int64_t gate_sample_stride,

@@ -399,6 +399,7 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
+#ifdef VSYS_LAB
 int launch_gemm2_stamp(const GemmParams& p_, hipStream_t stream) {
   using G = G2<4>;
   GemmParams p = p_;
@@ -409,6 +410,8 @@ int launch_gemm2_stamp(const GemmParams& p_, hipStream_t stream) {
   hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, 4, 1>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
+
+#endif  // VSYS_LAB
 
 // wide = 0: 256 x 192 tile, two workgroups per CU (variant 20); wide = 1: 256 x 384 tile, one 8-wave workgroup per CU (variant 30)
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream) {

@@ -566,6 +566,7 @@ static int g4_grid(const GemmParams& p, int persistent) {
   return ntiles < ncu ? ntiles : ncu;
 }
 
+#ifdef VSYS_LAB
 // lab: ablations / stamps of the ping-pong loop (EPI_BIAS only): abl = 1 no in-loop DMA, 2 no in-loop reads, 3 both, 4 stamps
 int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t stream) {
   if (p.N % BN != 0 || p.K % BK != 0 || p.K < 2 * BK) return VSYS_ERR_SHAPE;
@@ -587,6 +588,8 @@ int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t s
 #undef G4_LAB
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
+
+#endif  // VSYS_LAB
 
 // true when launch_gemm4 can take the problem (otherwise the caller stays on gemm_bf16.hip): at least two K-tiles, and a gate vector
 // that is uniform over each wave's 64 rows (see g4_epilogue)

@@ -635,7 +635,19 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 // Variant id understood by set_gemm_variant / vsys_tune_gemm_variant:  PIPE (+ 100 for the 128-row, two-workgroups-per-CU
 // geometry).  0 = the shipped default.
 static int g_gemm_variant = 0;
-void set_gemm_variant(int v) { g_gemm_variant = v > 0 ? v : 0; }  // 0 = shape dispatch (default)
+// 0 = shape dispatch (default).  The shipped library only accepts ids whose kernels produce VALID output (they differ in
+// schedule / geometry only and are bit-identical); ablation and stamp variants exist in -DVSYS_LAB builds (VSYS_LAB=1 build()).
+int set_gemm_variant(int v) {
+  switch (v) {
+    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 60: case 70: case 103: break;
+#ifdef VSYS_LAB
+    case 18: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: break;
+#endif
+    default: return VSYS_ERR_ARG;
+  }
+  g_gemm_variant = v;
+  return 0;
+}
 
 template <int PIPE, int BM_, int RASTER = 1, int PROD = 0>
 static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
@@ -670,17 +682,19 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 384 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
   switch (g_gemm_variant == 50 ? 0 : g_gemm_variant) {
     case 6: return launch_gemm_t<6, 256>(p, epi, stream);
+#ifdef VSYS_LAB
     case 18: return launch_gemm_t<18, 256>(p, epi, stream);
     case 48: return launch_gemm_t<48, 256>(p, epi, stream);
+    case 40: return launch_gemm3(p, epi, stream);  // 5-slot ring, fragments always one k-step ahead (gemm3_bf16.hip)
+    case 31: return (epi == EPI_BIAS && p.N % 384 == 0) ? launch_gemm2_stamp(p, stream) : VSYS_ERR_ARG;  // lab: cycle stamps
+    case 61: case 62: case 63: case 64: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 60, 0, stream) : VSYS_ERR_ARG;
+    case 71: case 72: case 73: case 74: case 78: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 70, 1, stream) : VSYS_ERR_ARG;
+#endif
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
     case 60: case 70:  // ping-pong wave groups (gemm4_bf16.hip): 60 = one tile per workgroup, 70 = persistent (one workgroup per CU)
       if (!gemm4_supports(p, epi)) return launch_gemm_t<8, 256>(p, epi, stream);
       return launch_gemm4(p, epi, g_gemm_variant == 70, stream);
-    case 61: case 62: case 63: case 64: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 60, 0, stream) : VSYS_ERR_ARG;
-    case 71: case 72: case 73: case 74: case 78: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 70, 1, stream) : VSYS_ERR_ARG;
-    case 40: return launch_gemm3(p, epi, stream);  // 5-slot ring, fragments always one k-step ahead (gemm3_bf16.hip)
-    case 31: return (epi == EPI_BIAS && p.N % 384 == 0) ? launch_gemm2_stamp(p, stream) : VSYS_ERR_ARG;  // lab: cycle stamps
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
     case 28: return launch_gemm_t<8, 256, 1, 1>(p, epi, stream);  // schedule 8 + four producer waves (store-only epilogues)

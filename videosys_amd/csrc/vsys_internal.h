@@ -77,8 +77,8 @@ int launch_gemm4(const GemmParams& p, int epi, int persistent, hipStream_t strea
 bool gemm4_supports(const GemmParams& p, int epi);
 int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t stream);
 int launch_gemm2_stamp(const GemmParams& p, hipStream_t stream);  // lab: per-stage cycle stamps into p.aux (int64)
-void set_gemm_variant(int v);
-void set_flash_variant(int v);
+int set_gemm_variant(int v);   // VSYS_ERR_ARG for ids this build does not contain
+int set_flash_variant(int v);
 void set_flash_debug_buffer(void* p);
 void* get_lab_debug_buffer();
 int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,
@@ -129,10 +129,6 @@ int launch_gate_add_rows(bf16_t* x, const bf16_t* y, const bf16_t* gate, int64_t
 int launch_unpatchify_cvx(const bf16_t* x, int64_t ldx, float* out, int B, int F, int Hp, int Wp, int Cout, int p,
                           hipStream_t stream);
 int launch_im2col_patch(const float* z, int Bz, bf16_t* out, int B, int F, int Cin, int H, int W, int p, hipStream_t stream);
-// lab (flash variant 7): the same contract on the matrix pipe, T <= 32 (attention_t_mfma.hip)
-int launch_attn_temporal_d72_mfma(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
-                                  const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T, int S,
-                                  int heads, float eps, float scale, hipStream_t stream);
 int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
                              const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T,
                              int S, int heads, float eps, hipStream_t stream);

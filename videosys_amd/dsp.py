@@ -147,6 +147,73 @@ def plan_gather(B, T, Sl, S, C, P):
     return ops, (B, T, S, C)
 
 
+def choose_spatial_switch(B: int, T: int, S: int, C: int, P: int, gemm_tflops: float = 750.0, a2a_gbytes_s: float = 300.0,
+                          overlapped: bool = True) -> dict:
+    """Cost model for the layout switch around the spatial attention of one block on one rank (bf16, critical-path rank).
+
+    ``"activations"`` (the reference's order, open_sora_transformer_3d.py:208-216): the C-wide modulated activations travel,
+    the qkv GEMM runs on the T-shard — whose frame count is PADDED to ceil(T/P) per rank, so the busiest rank multiplies
+    B*ceil(T/P)*S rows instead of B*T*S/P.  ``"qkv"``: the qkv GEMM runs at rest on the un-padded S-shard and the 3C-wide q|k|v
+    travels (3x the message of the first exchange; the way back is the same).  Returns the estimated extra time of each order
+    over the ideal and the cheaper one; constants are the measured per-rank GEMM rate at M = 4864 and a conservative share of
+    7 x 153 GB/s of xGMI; with the two CFG samples overlapped only the un-hidden half of the extra traffic is charged."""
+    Tp = -(-T // P)
+    Sl = -(-S // P)
+    rows_padded, rows_rest = B * Tp * S, B * T * Sl
+    gemm_extra_s = 2.0 * max(rows_padded - rows_rest, 0) * C * (3 * C) / (gemm_tflops * 1e12)
+    msg_bytes = (P - 1) / P * B * Tp * P * Sl * C * 2          # what leaves a rank in the first exchange (C wide)
+    comm_extra_s = 2.0 * msg_bytes / (a2a_gbytes_s * 1e9) * (0.5 if overlapped else 1.0)
+    best = "qkv" if comm_extra_s < gemm_extra_s else "activations"
+    return dict(order=best, padded_frames_per_rank=Tp, gemm_extra_us=gemm_extra_s * 1e6, comm_extra_us=comm_extra_s * 1e6,
+                first_message_mb=msg_bytes / 1e6)
+
+
+class CommTimer:
+    """HIP-event brackets around the collectives of one rank (bench.py --gpus N reports them per rank): ``with timer.comm():``
+    around a collective records its device time; ``report()`` sums them after a synchronize."""
+
+    def __init__(self):
+        self.events = []
+        self.enabled = False
+
+    def comm(self):
+        return _CommSpan(self) if self.enabled and torch.cuda.is_available() else _NullSpan()
+
+    def reset(self):
+        self.events = []
+
+    def report(self) -> dict:
+        ms = [s.elapsed_time(e) for s, e in self.events]
+        return dict(collectives=len(ms), comm_ms=sum(ms))
+
+
+class _NullSpan:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+class _CommSpan:
+    def __init__(self, timer):
+        self.timer = timer
+
+    def __enter__(self):
+        self.s = torch.cuda.Event(enable_timing=True)
+        self.e = torch.cuda.Event(enable_timing=True)
+        self.s.record()   # on the stream the collective is enqueued on (torch's current stream)
+        return self
+
+    def __exit__(self, *a):
+        self.e.record()
+        self.timer.events.append((self.s, self.e))
+        return False
+
+
+COMM_TIMER = CommTimer()
+
+
 def hip_copy_executor(src: torch.Tensor, dst: torch.Tensor, ops: List[CopyOp]):
     """The product executor: ONE vsys_copy_4d_batch launch for the whole plan (device tensors only)."""
     from . import ops as vops
@@ -185,7 +252,8 @@ class SequenceParallel:
     def gather(self, x, S):
         B, T, Sl, C = x.shape
         recv = self._buf("gather_recv", (self.P, B, T, Sl, C), x)
-        dist.all_gather_into_tensor(recv.view(self.P * B, T, Sl, C), x.contiguous(), group=self.group)
+        with COMM_TIMER.comm():
+            dist.all_gather_into_tensor(recv.view(self.P * B, T, Sl, C), x.contiguous(), group=self.group)
         ops, shape = plan_gather(B, T, Sl, S, C, self.P)
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, ops)
@@ -199,7 +267,8 @@ class SequenceParallel:
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
-        dist.all_to_all_single(recv, send, group=self.group)
+        with COMM_TIMER.comm():
+            dist.all_to_all_single(recv, send, group=self.group)
         if out is None:
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, unpack)
@@ -212,7 +281,8 @@ class SequenceParallel:
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
-        dist.all_to_all_single(recv, send, group=self.group)
+        with COMM_TIMER.comm():
+            dist.all_to_all_single(recv, send, group=self.group)
         if out is None:
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, unpack)

@@ -208,11 +208,13 @@ class STDiT3:
             self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
         else:
             self._sp = None
-        # comm/compute overlap of the two CFG samples around the spatial attention (opt-in: VSYS_DSP_OVERLAP=1 or overlap=True;
-        # validated bit-exact with two ranks on one GPU, not yet timed on a multi-GPU node)
+        # comm/compute overlap of the two CFG samples around the spatial attention: ON by default whenever the sequence is sharded
+        # (bit-exact against the batched path with two ranks on one GPU, tests/test_gpu_sp.py); VSYS_DSP_OVERLAP=0 or
+        # overlap=False turns it off.  VSYS_DSP_SWITCH = activations | qkv | auto picks what travels (dsp.choose_spatial_switch).
         if overlap is None:
-            overlap = os.environ.get("VSYS_DSP_OVERLAP", "0") == "1"
+            overlap = os.environ.get("VSYS_DSP_OVERLAP", "1") != "0"
         self._overlap = bool(overlap) and self._sp is not None
+        self._switch = os.environ.get("VSYS_DSP_SWITCH", "auto")
         self._side = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)] if self._overlap else None
 
     # ------------------------------------------------------------------ helpers
@@ -414,8 +416,22 @@ class STDiT3:
                 cos, sin = self._rope(T)
                 ops.attn_temporal(qkv, C, w[p + ".attn.q_norm.weight"], w[p + ".attn.k_norm.weight"], cos, sin, ao, B, T, S, H)
             else:
-                if sp is not None and T > 1 and B == 2 and getattr(self, "_overlap", False):
+                if sp is not None and T > 1 and B == 2 and getattr(self, "_overlap", False) and self._switch_order(B, T, S_full) != "qkv":
                     ao = self._spatial_attn_overlapped(p, xm, B, T, S, S_full)
+                    xa = None
+                elif sp is not None and T > 1 and self._switch_order(B, T, S_full) == "qkv":
+                    # qkv GEMM at rest on the un-padded S-shard; the 3C-wide q|k|v travels (dsp.choose_spatial_switch)
+                    qkv_l = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv_rest", (N, 3 * C)))
+                    qkv4 = sp.to_temporal_shard(qkv_l.view(B, T, S, 3 * C), S_full, tag="_qkv",
+                                                out=self._buf("qkv", (B, -(-T // sp.P), S_full, 3 * C)))
+                    Tp = qkv4.shape[1]
+                    nf, Na = B * Tp, B * Tp * S_full
+                    qkv = qkv4.view(Na, 3 * C)
+                    kp, vt = self._kv_spatial(nf, S_full)
+                    ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, nf, H, S_full)
+                    ao = self._buf("attn_out", (Na, C))
+                    ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, nf, H, S_full, S_full)
+                    ao = sp.to_spatial_shard(ao.view(B, Tp, S_full, C), T, S, out=self._buf("attn_back", (B, T, S, C))).view(N, C)
                     xa = None
                 elif sp is not None and T > 1:
                     xt = sp.to_temporal_shard(xm.view(B, T, S, C), S_full)  # [B, Tp, S_full, C]
@@ -517,6 +533,15 @@ class STDiT3:
                 sp.to_spatial_shard(ao.view(1, Tp, S_full, C), T, S, out=back[i:i + 1], tag=f"_{i}")
                 main.wait_event(self._side[i].record_event())
         return back.view(B * T * S, C)
+
+    def _switch_order(self, B, T, S_full):
+        """What travels through the DSP exchange of a spatial block: "activations" (reference order) or "qkv"."""
+        if self._switch in ("activations", "qkv"):
+            return self._switch
+        key = ("switch", B, T, S_full)
+        if key not in self._ws:
+            self._ws[key] = dsp.choose_spatial_switch(B, T, S_full, self.hidden_size, self._sp.P, overlapped=self._overlap)["order"]
+        return self._ws[key]
 
     def _kv_spatial(self, batch, kv_len):
         key = ("kv_spatial", batch, kv_len)
