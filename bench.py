@@ -375,8 +375,8 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=45.0):
         torch.set_num_threads(n)
         run(probe, 1)                  # warm-up at this pool size
         sweep[n] = run(probe, 1)
-        if time.perf_counter() - t_start > budget_s * 0.3:
-            break
+        if sweep[n] > 1.5 * min(sweep.values()) or time.perf_counter() - t_start > budget_s * 0.3:
+            break   # past the knee (on this class of host the pool gets slower beyond ~physical/4) or out of sweep time
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
     per_frame = sweep[best] / 2

@@ -52,7 +52,8 @@ int vsys_device_count(void);
  *        two-stage LDS-DMA schedules; 9 = schedule 8, plain row-major tile order; 20 = 4-wave workgroups, two per CU; 28 =
  *        schedule 8 + producer waves; 30 = 256 x 384 tile; 60 / 70 = ping-pong wave groups, one tile per workgroup / persistent;
  *        103 = 128-row tiles.
- * flash: 0 = default (two workgroups per CU); 3 = three workgroups per CU; 9 = online-softmax temporal kernel for every T. */
+ * flash: 0 = default (two workgroups per CU; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
+ *        4 = VALU temporal kernel (v2) for T <= 40; 9 = online-softmax temporal kernel for every T. */
 int vsys_tune_gemm_variant(int variant);
 int vsys_tune_flash_variant(int variant);
 

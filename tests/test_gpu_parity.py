@@ -312,6 +312,48 @@ def test_attn_temporal_golden(ops, golden_ops, name):
     check(out, ref, what=f"{name} vs reference (pre-proj)")
 
 
+@pytest.mark.parametrize("B,T,S,H,norm,rope", [(2, 19, 64, 16, True, True), (1, 5, 33, 3, True, False), (1, 32, 16, 4, False, True),
+                                                 (1, 1, 8, 2, True, True), (1, 16, 40, 16, False, False), (2, 38, 16, 5, True, True)])
+def test_attn_temporal_kernels_agree_with_oracle(ops, B, T, S, H, norm, rope):
+    """The three temporal kernels — matrix-pipe (default, T <= 32; attention_t3.hip), VALU two-pass (flash variant 4, T <= 40) and
+    online-softmax (variant 9) — against the fp32 oracle and each other: with / without qk-norm and RoPE (Latte runs without
+    either), head counts that leave waves idle, T = 1 (output = v) and T = 38 (falls through to the VALU kernel)."""
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    C = H * 72
+    g = torch.Generator().manual_seed(33 + T)
+    qkv = torch.randn(B * T * S, 3 * C, generator=g).to(torch.bfloat16)
+    qw = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16) if norm else None
+    kw_ = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16) if norm else None
+    freqs = 1.0 / (10000 ** (torch.arange(0, 72, 2).float() / 72))
+    cos = sin = None
+    if rope:
+        cos, sin = (t.float().contiguous().to(dev()) for t in O.rope_table(freqs, T))
+    # oracle: q, k, v [B*S, H, T, 72] from the (b, t, s)-ordered rows
+    x = qkv.float().view(B, T, S, 3, H, 72).permute(3, 0, 2, 4, 1, 5).reshape(3, B * S, H, T, 72)
+    q, k, v = x[0].to(torch.bfloat16), x[1].to(torch.bfloat16), x[2]
+    if norm:
+        q, k = O.rms_norm(q, qw.float()), O.rms_norm(k, kw_.float())
+    q, k = q.float(), k.float()
+    if rope:
+        q, k = O.rope_rotate(q, freqs), O.rope_rotate(k, freqs)
+    ref = (O.sdpa(q, k, v) if T > 1 else v).view(B, S, H, T, 72).permute(0, 3, 1, 2, 4).reshape(B * T * S, C)
+    outs = {}
+    for fv in (0, 4, 9):
+        assert lib.vsys_tune_flash_variant(fv) == 0
+        try:
+            out = torch.full((B * T * S, C), 7.0, dtype=torch.bfloat16, device=dev())
+            ops.attn_temporal(bf(qkv), C, None if qw is None else qw.to(dev()), None if kw_ is None else kw_.to(dev()), cos, sin,
+                              out, B, T, S, H)
+            outs[fv] = out.float().cpu()
+        finally:
+            lib.vsys_tune_flash_variant(0)
+        check(outs[fv], ref, what=f"temporal kernel variant {fv} vs oracle")
+    scale = ref.abs().max().item()
+    assert (outs[0] - outs[4]).abs().max().item() <= 2.0 ** -6 * scale
+
+
 def test_attn_config2_sizes_vs_torch(ops):
     """Config-2 geometry for one CFG sample slice: spatial (frames x 1024 tokens, 16 heads) vs torch fp32 SDPA on the
     GPU for sampled (frame, head) pairs, plus the softmax-of-constant-V property on everything."""

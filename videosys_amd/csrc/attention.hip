@@ -687,11 +687,11 @@ __global__ __launch_bounds__(256) void attn_temporal_d72_v2_kernel(const bf16_t*
 
 static int g_flash_variant = 0;
 static unsigned long long* g_flash_dbg = nullptr;
-// 0 = shipped default, 3 = three workgroups per CU, 9 = force the online-softmax temporal kernel: all valid.  1 (K/V tiles not
+// 0 = shipped default, 3 = three workgroups per CU, 4 / 9 = force the VALU (v2) / online-softmax temporal kernels: all valid.  1 (K/V tiles not
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 9: break;
+    case 0: case 3: case 4: case 9: break;
 #ifdef VSYS_LAB
     case 1: case 2: break;
 #endif
@@ -752,6 +752,9 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = per_wave * wpb;
   const float scale = 0.11785113019775793f;
+  if (T <= 32 && g_flash_variant != 9 && g_flash_variant != 4)   // the MFMA formulation (attention_t3.hip); 4 = force the v2 kernel
+    return launch_attn_temporal_d72_v3(qkv, row_stride, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps,
+                                       scale, stream);
   if (T <= 20 && g_flash_variant != 9) {
     hipLaunchKernelGGL(attn_temporal_d72_v2_kernel<20>, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
                        k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, scale);

@@ -1,0 +1,247 @@
+// attn_temporal_d72_v3: temporal self-attention (sequence = the T <= 32 frames of one pixel token, head dim 72) on the matrix
+// pipe, operands loaded from HBM straight into MFMA fragment layout.
+//
+// Replaces (/root/reference/videosys): models/modules/attentions.py:55-120 for the temporal blocks — the two `(B S) T C` rearranges
+// (open_sora_transformer_3d.py:204,206), LlamaRMSNorm on q and k (modules/normalization.py:19-33), RotaryEmbedding on q and k
+// (rotary_embedding_torch, attentions.py:76-78) and native_attention (:111-120: q * scale in the activation dtype, fp32 softmax,
+// probabilities cast back to the activation dtype before P V).  Same contract as attn_temporal_d72 (attention.hip); Latte calls it
+// without norm / RoPE.
+//
+// Why: attn_temporal_d72_v2 parks K / V in LDS as fp32 and every lane re-reads all of it (228 KiB of LDS reads and ~2600 VALU
+// instructions per (b, s, h) problem): it runs at 2.0-2.3 TB/s of algorithmic traffic, LDS- and VALU-bound
+// (profiles/r01_run4_pmc_hot_kernels.txt).  Here a problem is two tiny matrix products:
+//   S^T = K Q^T   5 x v_mfma_f32_32x32x16_bf16 (d = 72 -> 80; A = K rows, B = Q rows: a lane's 16-byte loads ARE the fragments)
+//   O^T = V^T P^T 6 x v_mfma_f32_32x32x16_bf16 (3 blocks of 32 output dims x 2 chunks of 16 keys)
+// The key order of the A operand of the first product is permuted (row m of the MFMA holds key 8*((m>>2)&1) + r + 8*(r>=8),
+// r = (m&3) + 4*(m>>3)) so that the 16 accumulators of a lane are keys 8hi..8hi+7 and 16+8hi..16+8hi+7: packed to bf16 they are
+// exactly the B fragments of the second product — the probabilities never cross lanes.  V is the one operand whose natural layout
+// (dims contiguous) is not a fragment layout: each lane writes its row transposed into a 7.5 KiB wave-private LDS image [d][key]
+// (80-byte pitch: conflict-free ds_read_b128) and reads the V^T fragments back.  RoPE angles come from a compact [T][36] table in
+// LDS (the reference's table repeats every value twice), norm weights likewise: ~30 KiB of LDS reads per problem instead of 228.
+//
+// One workgroup = 4 waves = one pixel token (b, s); wave w walks heads w, w+4, ...: the 16 heads of a token read the same 6.9 KB
+// qkv rows, so the rows stay in L1 / L2 between waves.  HBM-bound: 10.9 KB per problem in and out.
+#include "common.h"
+#include "vsys_internal.h"
+
+namespace vsys {
+namespace {
+
+constexpr int HD = 72;
+constexpr int VT_PITCH = 80;               // bytes per output-dim row of the V^T image: 32 keys x 2 B + 16 (5 r + chunk mod 16 distinct)
+constexpr int VT_BYTES = 96 * VT_PITCH;    // 7680
+constexpr int TAB_ROW = 36;                // floats per position in the compact cos / sin tables
+constexpr int TAB_BYTES = 32 * TAB_ROW * 4;  // 4608
+constexpr int W_BYTES = 160;               // one norm-weight vector (72 bf16, padded)
+constexpr int LDS_HEAD = 2 * TAB_BYTES + 2 * W_BYTES;  // 9536
+constexpr float NEG_BIG = -1e30f;
+
+typedef __attribute__((ext_vector_type(2))) float t3_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 t3_bf16x2;
+// two fp32 -> one dword of two bf16 (round to nearest even): ONE v_cvt_pk_bf16_f32
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(t3_f32x2{lo, hi}, t3_bf16x2));
+}
+
+__global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
+    const bf16_t* __restrict__ qkv, int64_t row_stride, int C, const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, bf16_t* __restrict__ out, int64_t out_stride, int B, int T,
+    int S, int heads, float eps, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  float* cosc = reinterpret_cast<float*>(smem);
+  float* sinc = reinterpret_cast<float*>(smem + TAB_BYTES);
+  bf16_t* qw = reinterpret_cast<bf16_t*>(smem + 2 * TAB_BYTES);
+  bf16_t* kw = reinterpret_cast<bf16_t*>(smem + 2 * TAB_BYTES + W_BYTES);
+  char* vt = smem + LDS_HEAD + wave * VT_BYTES;
+  const bool has_norm = q_norm_w != nullptr, has_rope = rope_cos != nullptr;
+
+  // ---- per-workgroup tables (compact RoPE angles, norm weights) and the zeroed V^T image (key columns >= T stay zero for good:
+  // they meet probability 0 in the second product and must be finite)
+  if (has_rope) {
+    for (int i = tid; i < T * TAB_ROW; i += 256) {
+      const int t = i / TAB_ROW, j = i - t * TAB_ROW;
+      cosc[i] = rope_cos[t * HD + 2 * j];
+      sinc[i] = rope_sin[t * HD + 2 * j];
+    }
+  }
+  if (has_norm && tid < HD) {
+    qw[tid] = q_norm_w[tid];
+    kw[tid] = k_norm_w[tid];
+  }
+  for (int i = lane * 16; i < VT_BYTES; i += 64 * 16) *reinterpret_cast<uint4*>(vt + i) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const int64_t bs = blockIdx.x;
+  const int s = (int)(bs % S), b = (int)(bs / S);
+  // A-operand row m = l31 of the first product holds this key (see header); query / value rows are natural
+  const int r_of_m = (l31 & 3) + 4 * (l31 >> 3);
+  const int krow = 8 * ((l31 >> 2) & 1) + r_of_m + (r_of_m >= 8 ? 8 : 0);
+  const bool q_ok = l31 < T, k_ok = krow < T;
+  const int qrow_c = q_ok ? l31 : T - 1, krow_c = k_ok ? krow : T - 1;
+  const bf16_t* qbase = qkv + (((int64_t)b * T + qrow_c) * S + s) * row_stride + 8 * hi;          // q and v of row l31
+  const bf16_t* kbase = qkv + (((int64_t)b * T + krow_c) * S + s) * row_stride + C + 8 * hi;      // k of row key(l31)
+  bf16_t* obase = out + (((int64_t)b * T + qrow_c) * S + s) * out_stride + 8 * hi;
+
+  // norm + RoPE (+ q scale) of one row's pieces held by this lane, on PACKED bf16 pairs: every rounding point of the reference
+  // (x * rstd -> bf16, * weight -> bf16, rotation -> bf16, q * scale -> bf16) is one v_cvt_pk_bf16_f32 on a pair, and the last
+  // one IS the fragment dword.  raw[c] = 8 values at dims 16c + 8hi .. +7 (piece 4 of the hi half is padding).
+  auto make_frags = [&](const uint4 (&raw)[5], bf16x8 (&frag)[5], const bf16_t* w, int pos, bool zero_row, bool scaled) {
+    float rstd = 1.f;
+    if (has_norm) {
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += bflo(u[e]) * bflo(u[e]) + bfhi(u[e]) * bfhi(u[e]);
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      rstd = rsqrtf(ss / (float)HD + eps);
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+      if (c < 4 || hi == 0) {
+        if (has_norm) {
+          const uint4 wv = *reinterpret_cast<const uint4*>(w + 16 * c + 8 * hi);
+          const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t n1 = pk_bf16(bflo(u[e]) * rstd, bfhi(u[e]) * rstd);           // .to(input_dtype) (normalization.py:32)
+            u[e] = pk_bf16(bflo(n1) * bflo(wu[e]), bfhi(n1) * bfhi(wu[e]));              // weight * (...)   (:33)
+          }
+        }
+        if (has_rope) {
+          const float4 cs = *reinterpret_cast<const float4*>(cosc + pos * TAB_ROW + 8 * c + 4 * hi);
+          const float4 sn = *reinterpret_cast<const float4*>(sinc + pos * TAB_ROW + 8 * c + 4 * hi);
+          const float cv[4] = {cs.x, cs.y, cs.z, cs.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = bflo(u[e]), x1 = bfhi(u[e]);
+            u[e] = pk_bf16(x0 * cv[e] - x1 * sv[e], x1 * cv[e] + x0 * sv[e]);
+          }
+        }
+        if (scaled) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = pk_bf16(bflo(u[e]) * scale, bfhi(u[e]) * scale);   // q = q * self.scale (attentions.py:113)
+        }
+      }
+      if (zero_row) u[0] = u[1] = u[2] = u[3] = 0u;
+      frag[c] = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
+    }
+  };
+
+  for (int h = wave; h < heads; h += 4) {
+    // ---- one round trip: the 4 / 5 sixteen-byte pieces of this lane's q, k and v rows
+    uint4 rq[5], rk[5], rv[5];
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      rq[c] = rk[c] = rv[c] = make_uint4(0, 0, 0, 0);
+      if (c < 4 || hi == 0) {
+        rk[c] = *reinterpret_cast<const uint4*>(kbase + h * HD + 16 * c);
+        rv[c] = *reinterpret_cast<const uint4*>(qbase + 2 * C + h * HD + 16 * c);
+        rq[c] = *reinterpret_cast<const uint4*>(qbase + h * HD + 16 * c);
+      }
+    }
+    // ---- V: transposed into the wave's LDS image (lanes of real frames only)
+    if (q_ok) {
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        if (c < 4 || hi == 0) {
+          const uint32_t u[4] = {rv[c].x, rv[c].y, rv[c].z, rv[c].w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const bf16_t val = (bf16_t)((e & 1) ? (u[e >> 1] >> 16) : (u[e >> 1] & 0xffffu));
+            *reinterpret_cast<bf16_t*>(vt + (16 * c + 8 * hi + e) * VT_PITCH + l31 * 2) = val;
+          }
+        }
+      }
+    }
+    // ---- K, then Q: norm, RoPE, (q: scale) -> fragments
+    bf16x8 kf[5], qf[5];
+    make_frags(rk, kf, kw, krow_c, !k_ok, false);
+    make_frags(rq, qf, qw, qrow_c, false, true);
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[c], sacc, 0, 0, 0);
+    // ---- softmax over the keys of this lane's query (16 here, 16 in lane ^ 32); accumulator r <-> key 8hi + r + 8 (r >= 8)
+    float m = NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 8 * hi + r + (r >= 8 ? 8 : 0);
+      if (key >= T) sacc[r] = NEG_BIG;
+      m = fmaxf(m, sacc[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float p[16], l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f((sacc[r] - m) * 1.4426950408889634f);
+      l += p[r];
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    bf16x8 p0, p1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      p0[e] = (__bf16)(p[e] * inv);        // attn.to(dtype) before attn @ v (:117)
+      p1[e] = (__bf16)(p[8 + e] * inv);
+    }
+    // ---- O^T = V^T P^T
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    f32x16 oacc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bf16x8 v0 = *reinterpret_cast<const bf16x8*>(vt + (d * 32 + l31) * VT_PITCH + hi * 16);
+      const bf16x8 v1 = *reinterpret_cast<const bf16x8*>(vt + (d * 32 + l31) * VT_PITCH + 32 + hi * 16);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+      oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p0, oacc[d], 0, 0, 0);
+      oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p1, oacc[d], 0, 0, 0);
+    }
+    // the image is rewritten by the next head: its reads above must have been issued (in-order LDS) — and the compiler must not
+    // move the next iteration's writes up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // ---- store: accumulator 4g + r' of block d <-> dim 32d + 8g + 4hi + r'; swap pairs of groups -> 16 contiguous bytes per lane
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      uint2 o[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        o[g].x = pack2bf(oacc[d][4 * g], oacc[d][4 * g + 1]);
+        o[g].y = pack2bf(oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        auto sx = __builtin_amdgcn_permlane32_swap(o[2 * k].x, o[2 * k + 1].x, false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(o[2 * k].y, o[2 * k + 1].y, false, false);
+        const int dim0 = 32 * d + 16 * k;   // + 8 hi inside obase
+        if (q_ok && dim0 + 8 * hi + 8 <= HD)
+          *reinterpret_cast<uint4*>(obase + h * HD + dim0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
+                                const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T, int S,
+                                int heads, float eps, float scale, hipStream_t stream) {
+  if (T > 32 || T < 1) return VSYS_ERR_SHAPE;
+  const int64_t grid = (int64_t)B * S;
+  if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
+  const int lds = LDS_HEAD + 4 * VT_BYTES;   // 40256
+  hipLaunchKernelGGL(attn_temporal_d72_v3_kernel, dim3((unsigned)grid), dim3(256), lds, stream, qkv, row_stride, C, q_norm_w, k_norm_w,
+                     rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+}  // namespace vsys
