@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-t5", action="store_true", help="skip the (untimed-region) T5 encode measurement")
     ap.add_argument("--text-len", type=int, default=300)
     ap.add_argument("--gemm-variant", type=int, default=0, help="lab: vsys_tune_gemm_variant id (0 = shipped shape dispatch)")
+    ap.add_argument("--flash-variant", type=int, default=0, help="lab: vsys_tune_flash_variant id (0 = shipped)")
     return ap.parse_args()
 
 
@@ -83,7 +84,9 @@ def main():
     from videosys_amd import _lib, ops, pab
 
     if args.gemm_variant:
-        _lib.load().vsys_tune_gemm_variant(args.gemm_variant)
+        assert _lib.load().vsys_tune_gemm_variant(args.gemm_variant) == 0
+    if args.flash_variant:
+        assert _lib.load().vsys_tune_flash_variant(args.flash_variant) == 0
     from videosys_amd.pipeline_open_sora import OpenSoraPABConfig, get_latent_size
     from videosys_amd.rflow import RFLOW
     from videosys_amd.stdit3 import STDiT3, STDiT3Config, synth_state_dict

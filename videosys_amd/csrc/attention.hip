@@ -157,6 +157,40 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
   const int b = bh / p.heads, h = bh - b * p.heads;
   const int q0 = qb * 128 + wave * 32;
 
+  // ---- K/V staging by LDS-DMA: 9 K pieces (1 KiB each, the tile is contiguous) + 10 Vt pieces (8 rows x 128 B each,
+  // rows 0..79; rows 80..95 of the LDS image are zeroed once and never overwritten); wave w issues pieces w, w+4, ...
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const bf16_t* kbase = p.kp + (int64_t)bh * p.kv_pad * HD;         // tile t: + t*64*72 (contiguous 9216 bytes)
+  const bf16_t* vbase = p.vt + (int64_t)bh * HD_ROWS * p.kv_pad;    // row d: + d*kv_pad, tile t: + t*64
+  const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.kv_pad * HD * 2, 0x00020000);
+  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, HD_ROWS * p.kv_pad * 2, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int k_voff = lane * 16;
+  // Vt piece j: lane -> row 8j + (lane>>3), physical slot lane&7 holds logical slot (lane&7) ^ ((row>>1)&7);
+  // (row>>1)&7 = ((j&1)<<2) | (lane>>4), so odd pieces differ from even ones by XOR 64 in the byte offset
+  const int v_voff = (lane >> 3) * p.kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
+  auto stage = [&](int t, int buf) {
+    char* base = smem + buf * KV_STAGE;
+#pragma unroll
+    for (int idx = 0; idx < 5; ++idx) {
+      const int piece = wave_u + 4 * idx;
+      if (piece < 9) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
+      } else if (piece < 19) {
+        const int j = piece - 9;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((j & 1) << 6),
+                                                 j * 8 * p.kv_pad * 2 + t * 128, 0, 0);
+      }
+    }
+  };
+  // the first K/V tile is requested BEFORE the Q rows: both round trips are in flight together (with 300 text keys a workgroup
+  // lives for five tiles only, so a serialized prologue is a tenth of it)
+  stage(0, 0);
+  {  // rows 80..95 of both Vt images (MFMA padding the DMA never writes): 2 x 2 KiB of zeros
+    char* z = smem + (tid >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (tid & 127) * 16;
+    *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
+  }
+
   // ---- Q fragment (B operand): lane holds Q[q0 + l31][16c + 8hi .. +8], c = 0..4 (d >= 72 -> 0)
   bf16x8 qf[5];
   {
@@ -197,32 +231,6 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
       for (int e = 0; e < 8; ++e) qf[c][e] = (__bf16)x[c][e];
   }
 
-  // ---- K/V staging by LDS-DMA: 9 K pieces (1 KiB each, the tile is contiguous) + 10 Vt pieces (8 rows x 128 B each,
-  // rows 0..79; rows 80..95 of the LDS image are zeroed once and never overwritten); wave w issues pieces w, w+4, ...
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const bf16_t* kbase = p.kp + (int64_t)bh * p.kv_pad * HD;         // tile t: + t*64*72 (contiguous 9216 bytes)
-  const bf16_t* vbase = p.vt + (int64_t)bh * HD_ROWS * p.kv_pad;    // row d: + d*kv_pad, tile t: + t*64
-  const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.kv_pad * HD * 2, 0x00020000);
-  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, HD_ROWS * p.kv_pad * 2, 0x00020000);
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  const int k_voff = lane * 16;
-  // Vt piece j: lane -> row 8j + (lane>>3), physical slot lane&7 holds logical slot (lane&7) ^ ((row>>1)&7);
-  // (row>>1)&7 = ((j&1)<<2) | (lane>>4), so odd pieces differ from even ones by XOR 64 in the byte offset
-  const int v_voff = (lane >> 3) * p.kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
-  auto stage = [&](int t, int buf) {
-    char* base = smem + buf * KV_STAGE;
-#pragma unroll
-    for (int idx = 0; idx < 5; ++idx) {
-      const int piece = wave_u + 4 * idx;
-      if (piece < 9) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
-      } else if (piece < 19) {
-        const int j = piece - 9;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((j & 1) << 6),
-                                                 j * 8 * p.kv_pad * 2 + t * 128, 0, 0);
-      }
-    }
-  };
   // Vt fragment read offsets: row dt*32 + l31, logical slot kt*4 + 2hi + cc  ->  + dt*4096, ^ ((kt*4 + cc) << 4)
   const int v_roff = K_TILE_BYTES + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4);
 
@@ -242,11 +250,6 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
   for (int r = 0; r < 16; ++r) minit[r] = 0.f;
 
   const int ntiles = (p.kv_len + 63) / 64;  // tiles made only of keys >= kv_len are never touched (kv_pad is the stride)
-  stage(0, 0);
-  {  // rows 80..95 of both Vt images (MFMA padding the DMA never writes): 2 x 2 KiB of zeros
-    char* z = smem + (tid >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (tid & 127) * 16;
-    *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -379,20 +382,27 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi
   const float inv = 1.0f / o[2][4];  // d = 72 (hi = 0) / 76 (hi = 1): the ones rows of Vt, i.e. sum_k P[k][q]
   const int qs = q0 + l31;
-  if (qs < p.q_len) {
-    bf16_t* orow = p.out + ((int64_t)b * p.q_len + qs) * p.out_stride + h * HD;
+  // Stores widened to 16 bytes (cdna_hip_programming.md T21): group pair (g, g+1) of a 32-dim block is exchanged between the
+  // half-waves with v_permlane32_swap, after which lanes 0-31 hold dims 32dt + 16k .. +7 and lanes 32-63 dims +8 .. +15 of their
+  // row: 5 dwordx4 stores per lane instead of 9 dwordx2 (the tail is store-issue bound, not bandwidth bound).
+  {
+    bf16_t* orow = p.out + ((int64_t)b * p.q_len + (qs < p.q_len ? qs : p.q_len - 1)) * p.out_stride + h * HD + 8 * hi;
 #pragma unroll
-    for (int dt = 0; dt < 3; ++dt)
+    for (int dt = 0; dt < 3; ++dt) {
+      uint2 w[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int d = dt * 32 + 8 * g + 4 * hi;
-        if (d < HD) {
-          uint2 w;
-          w.x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-          w.y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-          *reinterpret_cast<uint2*>(orow + d) = w;
-        }
+        w[g].x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[g].y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
       }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const auto sx = __builtin_amdgcn_permlane32_swap(w[2 * k].x, w[2 * k + 1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(w[2 * k].y, w[2 * k + 1].y, false, false);
+        const int d0 = dt * 32 + 16 * k;   // + 8 hi (in orow)
+        if (qs < p.q_len && d0 + 8 * hi + 8 <= HD) *reinterpret_cast<uint4*>(orow + d0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
+    }
   }
 #endif
 }
