@@ -129,14 +129,26 @@ class LattePipeline(StagedOffloadMixin):
                           transformer=self.transformer, vae=self.vae_decoder)
 
     def _load_vae(self, config):
-        """pipeline_latte.py:211-217.  Built here: the plain ``AutoencoderKL`` branch (``enable_vae_temporal_decoder=False``) from a
-        local ``<model_path>/vae/diffusion_pytorch_model.safetensors`` or ``"synthetic:<seed>"``; the SVD temporal decoder
-        (AutoencoderKLTemporalDecoder, the reference default) is not built: pass ``vae_decoder=`` or read latents."""
+        """pipeline_latte.py:211-217: ``enable_vae_temporal_decoder=True`` (the reference default) -> the SVD
+        ``AutoencoderKLTemporalDecoder`` from ``<model_path>/vae_temporal_decoder``, else the plain ``AutoencoderKL`` from
+        ``<model_path>/vae`` — local ``diffusion_pytorch_model.safetensors`` files, or ``"synthetic:<seed>"`` weights (no hub
+        access here).  Returns None (latents out) when neither is available."""
+        name = config.model_path
+        if not isinstance(name, str):
+            return None
+        if config.enable_vae_temporal_decoder:
+            from .vae_svd_temporal import AutoencoderKLTemporalDecoder, synth_state_dict as svd_synth
+
+            if name.startswith("synthetic:"):
+                return AutoencoderKLTemporalDecoder(svd_synth(int(name.split(":", 1)[1])), device=self._device)
+            st = os.path.join(name, "vae_temporal_decoder", "diffusion_pytorch_model.safetensors")
+            if os.path.exists(st):
+                from safetensors.torch import load_file
+
+                return AutoencoderKLTemporalDecoder(load_file(st), device=self._device)
+            return None
         from .vae_open_sora import AutoencoderKLDecoder, synth_state_dict as vae_synth
 
-        name = config.model_path
-        if config.enable_vae_temporal_decoder or not isinstance(name, str):
-            return None
         if name.startswith("synthetic:"):
             pre = "spatial_vae.module."
             sd = {k[len(pre):]: v for k, v in vae_synth(int(name.split(":", 1)[1])).items() if k.startswith(pre)}
