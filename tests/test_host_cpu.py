@@ -399,3 +399,16 @@ def test_videosys_alias_package_exports_reference_names():
             "print('ok')")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-800:]
+
+
+def test_torch_custom_ops_are_registered():
+    """``torch.ops.videosys_amd.*`` (north_star: "through PyTorch-ROCm custom ops"): every op of videosys_amd/torch_ops.py is
+    registered with an out-variant schema that names the tensors it mutates; on CPU tensors it raises (no fallback)."""
+    import videosys_amd.torch_ops as T
+    from videosys_amd._lib import VsysError
+
+    for name in T.OPS:
+        schema = str(getattr(torch.ops.videosys_amd, name).default._schema)
+        assert schema.startswith(f"videosys_amd::{name}(") and "!)" in schema and schema.endswith("-> ()"), schema
+    with pytest.raises(VsysError):
+        torch.ops.videosys_amd.add_rows(torch.zeros(2, 8, dtype=torch.bfloat16), torch.zeros(2, 8, dtype=torch.bfloat16))
