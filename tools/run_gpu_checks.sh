@@ -10,7 +10,7 @@ for a in "$@"; do case $a in
   benchpab) timeout 900 python bench.py --steps 30 --warmup 30 --pab > gpurun_out/bench_pab.log 2>&1; tail -2 gpurun_out/bench_pab.log;;
   prof) (cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof.log 2>&1);;
 esac; done
-# PMC passes (own runs, --kernel-trace only): usage  bash run_gpu_checks.sh pmc
+# PMC passes (own runs, --kernel-trace only): usage  bash tools/run_gpu_checks.sh pmc
 if [ "$1" = "pmc" ]; then
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 -L > $R/gpurun_out/counters_list.txt 2>&1
