@@ -154,6 +154,57 @@ def _gate_residual_aux(ops, M=1100, N=576, K=1152, rps=400):
     check(out2, res.float() + x.float() @ w.float().t() + b.float(), what="residual only")
 
 
+@pytest.mark.parametrize("M,N,K", [(38912, 1152, 1152), (38912, 1152, 4608), (13000, 1152, 512), (38912, 3456, 1152)])
+def test_gemm_streamk_tail(ops, M, N, K):
+    """Variant 80 (persistent ping-pong GEMM + stream-K split of the partial last round of tiles).  Tiles of the full rounds are
+    bit-identical to schedule 8; a split tile adds its fp32 partial sums in a different order, so those may differ by the bf16
+    rounding of a 1e-7-relative fp32 difference: at most one bf16 ulp, on a small fraction of the elements.  Deterministic.
+    All three epilogues; M = 13000 has a ragged last row tile (306 tiles: one full round + 50 split tiles, K loop of 8)."""
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev())
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev())
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(dev())
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev())
+    rps = 19456 if M == 38912 else 6528
+    mod = torch.randn(-(-M // rps), 6 * N, generator=g).to(torch.bfloat16).to(dev())
+
+    def run():
+        o1 = ops.gemm(x, w, b)
+        o2 = ops.gemm(x, w, b, epilogue=ops.EPI_BIAS_GELU)
+        xr = res.clone()
+        aux = torch.empty_like(res)
+        o3 = ops.gemm(x, w, b, epilogue=ops.EPI_GATE_RES, gate=mod[0, 2 * N:3 * N], gate_stride=6 * N, rows_per_sample=rps, res=xr,
+                      aux=aux, out=xr)
+        torch.cuda.synchronize()
+        return o1, o2, o3, aux
+
+    try:
+        assert lib.vsys_tune_gemm_variant(8) == 0
+        base = run()
+        assert lib.vsys_tune_gemm_variant(80) == 0
+        sk = run()
+        sk2 = run()
+    finally:
+        lib.vsys_tune_gemm_variant(0)
+    for name, a, c, c2 in zip(("bias", "gelu", "gate+res", "aux"), base, sk, sk2):
+        assert torch.equal(c, c2), f"{name}: stream-K result not deterministic"
+        af, cf = a.float(), c.float()
+        d = (af - cf).abs()
+        ulp = torch.maximum(af.abs(), cf.abs()) * 2.0 ** -7 + 4e-6
+        if name == "gate+res":   # res + bf16(gate * (...)): the ulp that may flip is the one of the gated term
+            ulp = ulp + base[3].float().abs() * 2.0 ** -7
+        assert bool((d <= ulp).all()), f"{name}: differs from schedule 8 by more than one bf16 ulp (max {float((d / ulp).max()):.2f})"
+        frac = float((d > 0).float().mean())
+        assert frac < 0.02, f"{name}: {frac:.4f} of the elements differ (split tiles are < 16 % of the output)"
+    # and against fp32 on sampled rows (independent of the other kernel)
+    rows = torch.randint(0, M, (64,), generator=g).to(dev())
+    ref = x[rows].float() @ w.float().t() + b.float()
+    check(sk[0][rows], ref.cpu(), what=f"stream-K gemm {M}x{N}x{K}")
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from videosys_amd._lib import VsysError
 

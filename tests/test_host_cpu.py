@@ -412,3 +412,79 @@ def test_torch_custom_ops_are_registered():
         assert schema.startswith(f"videosys_amd::{name}(") and "!)" in schema and schema.endswith("-> ()"), schema
     with pytest.raises(VsysError):
         torch.ops.videosys_amd.add_rows(torch.zeros(2, 8, dtype=torch.bfloat16), torch.zeros(2, 8, dtype=torch.bfloat16))
+
+
+# ---- stream-K segment plan of GEMM variant 80 (host-only entry point: no GPU needed)
+def _streamk_plan(ntiles, nt, grid):
+    import ctypes
+
+    import numpy as np
+
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    cap = grid * 8
+    segs = np.zeros((cap, 4), dtype=np.int32)
+    nseg = ctypes.c_int(0)
+    n = lib.vsys_gemm_streamk_plan(ntiles, nt, grid, segs.ctypes.data_as(ctypes.c_void_p), cap, ctypes.byref(nseg))
+    assert n >= 0, n
+    return (segs[:n].reshape(grid, nseg.value, 4) if n else None), nseg.value
+
+
+@pytest.mark.parametrize("ntiles,nt,grid", [
+    (912, 18, 256),    # config 2: proj / cross-attention GEMMs (38 912 rows x 1152 columns, K = 1152): 3.56 rounds
+    (912, 72, 256),    # fc2 (K = 4608)
+    (2736, 18, 256),   # qkv: 10.69 rounds
+    (3648, 18, 256),   # fc1: 14.25 rounds
+    (300, 8, 256), (511, 4, 256), (257, 18, 256), (700, 33, 128),
+])
+def test_streamk_plan_covers_partial_round_exactly_once(ntiles, nt, grid):
+    segs, nseg_max = _streamk_plan(ntiles, nt, grid)
+    rem = ntiles % grid
+    first = ntiles - rem
+    if segs is None:
+        # only legal when a cut would leave a piece shorter than two K-tiles (tiny rounds): every shape of the denoise path splits
+        assert (ntiles, nt) not in [(912, 18), (912, 72), (2736, 18), (3648, 18)]
+        return
+    cover = {t: [0] * nt for t in range(first, ntiles)}
+    dump_of = {}
+    for b in range(grid):
+        rows = segs[b]
+        live = [r for r in rows if r[0] >= 0]
+        assert len(live) < nseg_max and rows[len(live)][0] == -1                      # terminated list
+        assert all(r[0] < 0 for r in rows[len(live):])
+        kinds = [int(r[2]) & 0xff for r in live]
+        assert kinds == sorted(kinds, key=lambda k: {1: 0, 0: 1, 2: 2}[k])            # DUMP first, FINAL last
+        assert kinds.count(1) <= 1 and kinds.count(2) <= 1                            # one workspace slot per workgroup
+        for r in live:
+            lin, kb, ke, kind, nsrc = int(r[0]), int(r[1]) & 0xffff, int(r[1]) >> 16, int(r[2]) & 0xff, int(r[2]) >> 8
+            assert first <= lin < ntiles and lin % 8 == b % 8                         # the tile stays on the workgroup's XCD
+            assert 0 <= kb < ke <= nt and ke - kb >= 2                                # the K loop needs two K-tiles
+            for k in range(kb, ke):
+                cover[lin][k] += 1
+            if kind == 0:
+                assert kb == 0 and ke == nt and nsrc == 0
+            elif kind == 1:
+                assert ke < nt and nsrc == 0
+                dump_of[b] = (lin, kb, ke)
+            else:
+                assert kind == 2 and kb > 0 and ke == nt and nsrc >= 1 and b - 8 * nsrc >= 0
+    assert all(c == 1 for t in cover.values() for c in t)                            # every K-tile of every tile exactly once
+    # a FINAL reads the slots of b - 8, ..., b - 8 nsrc: exactly the other ranges of its tile, contiguous in K, lower-numbered
+    for b in range(grid):
+        for r in segs[b]:
+            if r[0] >= 0 and (int(r[2]) & 0xff) == 2:
+                lin, kb, nsrc = int(r[0]), int(r[1]) & 0xffff, int(r[2]) >> 8
+                pieces = sorted(dump_of[b - 8 * k] for k in range(1, nsrc + 1))
+                assert all(p[0] == lin for p in pieces)
+                assert pieces[0][1] == 0 and pieces[-1][2] == kb
+                assert all(pieces[i][2] == pieces[i + 1][1] for i in range(len(pieces) - 1))
+    # balance: the longest workgroup list is within two K-tiles of the ideal share
+    work = [sum((int(r[1]) >> 16) - (int(r[1]) & 0xffff) for r in segs[b] if r[0] >= 0) for b in range(grid)]
+    assert max(work) <= -(-rem * nt // grid) + 2
+
+
+def test_streamk_plan_not_split_when_no_partial_round():
+    assert _streamk_plan(512, 18, 256)[0] is None      # whole rounds only
+    assert _streamk_plan(200, 18, 256)[0] is None      # fewer tiles than workgroups
+    assert _streamk_plan(912, 3, 256)[0] is None       # K loop too short to cut

@@ -19,6 +19,7 @@ SIGNATURES = {
     "vsys_device_count": [],
     "vsys_tune_gemm_variant": [_int],
     "vsys_tune_flash_variant": [_int],
+    "vsys_gemm_streamk_plan": [_int, _int, _int, _ptr, _int, _ptr],
     "vsys_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _ptr, _i64,
                        _ptr, _i64, _ptr],
     "vsys_linear_small": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],

@@ -35,6 +35,19 @@ int vsys_tune_gemm_variant(int variant) { return set_gemm_variant(variant); }
 
 int vsys_tune_flash_variant(int variant) { return set_flash_variant(variant); }
 
+int vsys_gemm_streamk_plan(int ntiles, int nt, int grid, int32_t* segs, int cap_rows, int* nseg_max) {
+  if (ntiles <= 0 || nt <= 0 || grid <= 0 || segs == nullptr || nseg_max == nullptr) return VSYS_ERR_ARG;
+  std::vector<int4> v;
+  int m = 0;
+  if (!sk_plan(ntiles, nt, grid, v, m)) return 0;
+  if ((int)v.size() > cap_rows) return VSYS_ERR_ARG;
+  for (size_t i = 0; i < v.size(); ++i) {
+    segs[4 * i] = v[i].x; segs[4 * i + 1] = v[i].y; segs[4 * i + 2] = v[i].z; segs[4 * i + 3] = v[i].w;
+  }
+  *nseg_max = m;
+  return (int)v.size();
+}
+
 #ifdef VSYS_LAB   // include/videosys_amd_lab.h
 int vsys_lab_flash_debug_buffer(void* dev_u64x5) {
   set_flash_debug_buffer(dev_u64x5);

@@ -36,6 +36,12 @@
 #include "common.h"
 #include "vsys_internal.h"
 
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 namespace vsys {
 namespace {
 
@@ -68,14 +74,16 @@ typedef const __attribute__((address_space(4))) uint32_t* sptr_t;
 // K loop of the NEXT tile stores two of them per K-tile from its LOAD segments.  Every workgroup finishes its tiles at the same
 // moment, so an in-place store phase is a chip-wide 25 MB burst that runs at the HBM write rate (~7 k cycles per tile with the
 // matrix pipe idle, measured); spread over six K-tiles the same bytes overlap the MFMAs and never queue.
-template <int EPI, int ABL>
+// Row blocks [I0, I1) of the wave tile only: the stream-K body runs the two halves one after the other (half the residual and
+// output registers live at a time — it has no deferred stores to hide behind and no registers to spare).
+template <int EPI, int ABL, int I0 = 0, int I1 = 2>
 __device__ __forceinline__ void g4_epilogue(const GemmParams& p, f32x16 (&acc)[2][3], int row0, int col0, int wm, int wn, int l31,
                                             int hi, uint4 (&ob)[12], bf16_t* (&orow)[2]) {
   const int ncol0 = col0 + wn * 96;   // wave-uniform
   int grow_[2];
   bool ok_[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = I0; i < I1; ++i) {
     const int gr = row0 + wm * 64 + i * 32 + l31;
     ok_[i] = gr < p.M;
     grow_[i] = ok_[i] ? gr : p.M - 1;
@@ -84,7 +92,7 @@ __device__ __forceinline__ void g4_epilogue(const GemmParams& p, f32x16 (&acc)[2
   if (EPI == EPI_GATE_RES) {
     if (p.res != nullptr) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = I0; i < I1; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -106,7 +114,7 @@ __device__ __forceinline__ void g4_epilogue(const GemmParams& p, f32x16 (&acc)[2
     sg = (sptr_t)(p.gate + (int64_t)s_first * p.gate_stride + (seg_first ? p.gate_alt : 0) + ncol0);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = I0; i < I1; ++i) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       // the 16 dwords (32 columns) of this block, pinned to SGPRs: without the pin hipcc folds the half-wave select into the
@@ -183,7 +191,7 @@ __device__ __forceinline__ void g4_store_piece(const uint4& v, bf16_t* row, int 
 // pieces 2 t_ and 2 t_ + 1 of the pending tile, from LOAD(2 t_) of the running one
 #define G4_FLUSH_STEP(t_)                                             \
   do {                                                                \
-    if (pend) {                                                       \
+    if (!SK && pend) {                                                \
       if ((t_) == 0) { G4_STORE(0); G4_STORE(1); }                    \
       else if ((t_) == 1) { G4_STORE(2); G4_STORE(3); }               \
       else if ((t_) == 2) { G4_STORE(4); G4_STORE(5); }               \
@@ -195,7 +203,7 @@ __device__ __forceinline__ void g4_store_piece(const uint4& v, bf16_t* row, int 
 // whatever is still pending from piece first_ on (tiles with fewer than six K-tiles; the last tile of a workgroup)
 #define G4_FLUSH_REST(first_)                                         \
   do {                                                                \
-    if (pend) {                                                       \
+    if (!SK && pend) {                                                \
       if ((first_) <= 0) G4_STORE(0);                                 \
       if ((first_) <= 1) G4_STORE(1);                                 \
       if ((first_) <= 2) G4_STORE(2);                                 \
@@ -212,6 +220,94 @@ __device__ __forceinline__ void g4_store_piece(const uint4& v, bf16_t* row, int 
     }                                                                 \
   } while (0)
 
+// ---- stream-K tail (SK = true).  A persistent grid of G workgroups leaves ceil(tiles / G) - tiles / G of the last round idle
+// (N = 1152 at 38 912 rows: 912 tiles on 256 CUs = 3.56 rounds, 11 % lost).  The launcher therefore runs the tiles of the FULL
+// rounds with the persistent body (SkArgs::tile_limit) in workgroups [0, G) and the remaining tiles with the SK = true body in
+// workgroups [G, 2 G) of the same grid (gemm4_sk_kernel), in which every workgroup gets a SEGMENT list (sk_plan below): the
+// K-tiles of the remaining tiles cut into G equal ranges.  (One body for both parts was built first: with the deferred-store
+// registers live across the hand-off code it needs more than 256 VGPRs and hipcc spills inside the K loop; the SK body stores
+// its tiles in place instead.)
+// A range that does not end with its tile is a DUMP segment: the fp32 accumulators go to the workgroup's slot of a workspace in
+// the accumulator layout (the consumer is the same wave / lane of another workgroup, so no layout change) and a per-wave flag is
+// released at agent scope.  The range that ends a tile is its FINAL segment: it waits for the flags of the
+// workgroups that hold the earlier K ranges of that tile, adds their partial sums in a fixed order and runs the normal epilogue.
+// A workgroup runs its DUMP segment FIRST and its FINAL segment LAST, and a FINAL only depends on DUMPs of lower-numbered
+// workgroups of its own XCD (b - 8, b - 16, ...): nothing a running workgroup waits for can be undispatched, and the partial sums were
+// written long before they are read (no spinning in practice).  Results differ from the unsplit kernels by fp32 summation order only (deterministic).
+struct SkArgs {
+  const int4* segs;   // [grid][nseg_max]: x = linear tile id (-1 ends the list), y = kb | ke << 16 (K-tile range), z = kind | nsrc << 8
+  float* ws;          // [grid][8 waves][24][64 lanes] float4
+  int* flags;         // [grid][8 waves]: epoch of the launch whose partial sums the slot holds
+  int nseg_max, epoch;
+  int tile_limit;     // SK = false: tiles [0, tile_limit) only (0 = all); the rest belongs to the SK role
+  int abl;            // lab builds: 1 = no DUMP stores (flag only), 2 = no FINAL poll / gather, 4 = SK role does nothing (wrong results)
+};
+constexpr int SK_FULL = 0, SK_DUMP = 1, SK_FINAL = 2;
+#ifdef VSYS_LAB
+#define SK_LAB_ON(bit_) (!(sk.abl & (bit_)))
+#else
+#define SK_LAB_ON(bit_) true
+#endif
+
+// Hand-off (cdna_hip_programming.md §6 Guideline 16, recipe R1): the partial sums leave as 16-byte WRITE-THROUGH (sc1) buffer
+// stores, every storing wave drains its own stores and publishes its own flag (a wave's slot is read by the same wave index of
+// the consumer, so no workgroup barrier is needed — the barrier sequence of the K loop stays untouched); the consumer polls that
+// one word relaxed and reads the slot with sc1 loads (L1-bypassing; valid because the producer stored sc1).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// row i of this workgroup's segment list through the scalar cache (the list is constant for the launch; a plain load of memory the
+// kernel cannot prove read-only becomes a VECTOR load and drags tile coordinates and loop bounds into VGPRs)
+__device__ __forceinline__ int4 sk_seg(const SkArgs& sk, int bid, int i) {
+  const sptr_t q = (sptr_t)(sk.segs + bid * sk.nseg_max + i);
+  uint32_t x = q[0], y = q[1], z = q[2];
+  asm volatile("" : "+s"(x), "+s"(y), "+s"(z));
+  return make_int4((int)x, (int)y, (int)z, 0);
+}
+constexpr int SK_SC1 = 16;
+constexpr int SK_WAVE_BYTES = 24 * 64 * 16;   // one wave's accumulators: 24 x 16 bytes per lane
+
+__device__ __forceinline__ void g4_sk_dump(const SkArgs& sk, f32x16 (&acc)[2][3], int bid, int wave_u, int lane) {
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(sk.ws) + (int64_t)(bid * 8 + wave_u) * SK_WAVE_BYTES),
+                                                    0, SK_WAVE_BYTES, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        u32x4 v;
+        v.x = __float_as_uint(acc[i][j][4 * g]); v.y = __float_as_uint(acc[i][j][4 * g + 1]);
+        v.z = __float_as_uint(acc[i][j][4 * g + 2]); v.w = __float_as_uint(acc[i][j][4 * g + 3]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, ((i * 3 + j) * 4 + g) * 1024, SK_SC1);
+      }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lane == 0) __hip_atomic_store(sk.flags + bid * 8 + wave_u, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void g4_sk_gather(const SkArgs& sk, f32x16 (&acc)[2][3], int bid, int wave_u, int lane, int nsrc) {
+  for (int s = 1; s <= nsrc; ++s) {
+    const int src = bid - 8 * s;
+    const int* f = sk.flags + src * 8 + wave_u;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) __builtin_amdgcn_s_sleep(8);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(sk.ws) + (int64_t)(src * 8 + wave_u) * SK_WAVE_BYTES), 0,
+                                                      SK_WAVE_BYTES, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        u32x4 v[4];   // one accumulator block (16 registers) in flight at a time: more makes hipcc spill inside the K loop
+#pragma unroll
+        for (int g = 0; g < 4; ++g) v[g] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, ((i * 3 + j) * 4 + g) * 1024, SK_SC1);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          acc[i][j][4 * g] += __uint_as_float(v[g].x); acc[i][j][4 * g + 1] += __uint_as_float(v[g].y);
+          acc[i][j][4 * g + 2] += __uint_as_float(v[g].z); acc[i][j][4 * g + 3] += __uint_as_float(v[g].w);
+        }
+        G4_SB();
+      }
+  }
+}
+
 // PERSISTENT form: the grid is min(#tiles, #CUs) workgroups; workgroup b computes tiles b, b + grid, b + 2 grid, ... and the
 // K-tile stream (and with it the LDS-DMA ring, its slot counters and the counted waits) simply runs on across tile borders:
 // during the last two K-tiles of a tile the pieces issued are the first K-tiles of the NEXT tile, so no tile but the first pays
@@ -222,10 +318,10 @@ __device__ __forceinline__ void g4_store_piece(const uint4& v, bf16_t* row, int 
 // ABL (lab builds only, bit mask): 1 = no LDS-DMA inside the K loop (the ring keeps the prologue's bytes: wrong results, same
 // instruction stream otherwise), 2 = no fragment reads inside the K loop, 4 = s_memtime stamps per segment, summed per wave into
 // the lab debug buffer as int64[blocks][8 waves][8] = {load, barrier after load, mfma, barrier after mfma, loop, epilogue, start, nt}.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* stamps) {
+// bid / nblk: this workgroup's index and the workgroup count of ITS role (gemm4_sk_kernel runs two roles in one grid)
+template <int EPI, int ABL, bool SK>
+__device__ __forceinline__ void gemm4_body(const GemmParams& p, long long* stamps, const SkArgs& sk, char* smem, const int bid, const int nblk) {
 #if __HIP_DEVICE_COMPILE__
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int grp = wave_u >> 2;           // 0: rows 0..127 (leads), 1: rows 128..255 (one interval behind)
@@ -325,30 +421,32 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
   f32x16 acc[2][3];
   // fragment registers: W of the whole K-tile (4 k-steps x 3 column blocks), A of one half K-tile (2 k-steps x 2 row blocks)
   bf16x8 w00, w01, w02, w10, w11, w12, w20, w21, w22, w30, w31, w32, a00, a01, a10, a11;
+  // The slot base (a multiple of 8 KiB) is added BEFORE the k-step XOR (bits 5, 6: same address either way): the XOR then depends
+  // on the ring slot and cannot be hoisted out of the K loop into nine more loop-invariant address registers.
 #define G4_READ_W(sw_)                                                          \
   do {                                                                          \
-    const char* wb_ = smem + (sw_) * B_BYTES;                                   \
-    w00 = *reinterpret_cast<const bf16x8*>(wb_ + wo[0]);                        \
-    w01 = *reinterpret_cast<const bf16x8*>(wb_ + wo[1]);                        \
-    w02 = *reinterpret_cast<const bf16x8*>(wb_ + wo[2]);                        \
-    w10 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[0] ^ 32));                 \
-    w11 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[1] ^ 32));                 \
-    w12 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[2] ^ 32));                 \
-    w20 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[0] ^ 64));                 \
-    w21 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[1] ^ 64));                 \
-    w22 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[2] ^ 64));                 \
-    w30 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[0] ^ 96));                 \
-    w31 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[1] ^ 96));                 \
-    w32 = *reinterpret_cast<const bf16x8*>(wb_ + (wo[2] ^ 96));                 \
+    const int w0_ = wo[0] + (sw_) * B_BYTES, w1_ = wo[1] + (sw_) * B_BYTES, w2_ = wo[2] + (sw_) * B_BYTES; \
+    w00 = *reinterpret_cast<const bf16x8*>(smem + w0_);                         \
+    w01 = *reinterpret_cast<const bf16x8*>(smem + w1_);                         \
+    w02 = *reinterpret_cast<const bf16x8*>(smem + w2_);                         \
+    w10 = *reinterpret_cast<const bf16x8*>(smem + (w0_ ^ 32));                  \
+    w11 = *reinterpret_cast<const bf16x8*>(smem + (w1_ ^ 32));                  \
+    w12 = *reinterpret_cast<const bf16x8*>(smem + (w2_ ^ 32));                  \
+    w20 = *reinterpret_cast<const bf16x8*>(smem + (w0_ ^ 64));                  \
+    w21 = *reinterpret_cast<const bf16x8*>(smem + (w1_ ^ 64));                  \
+    w22 = *reinterpret_cast<const bf16x8*>(smem + (w2_ ^ 64));                  \
+    w30 = *reinterpret_cast<const bf16x8*>(smem + (w0_ ^ 96));                  \
+    w31 = *reinterpret_cast<const bf16x8*>(smem + (w1_ ^ 96));                  \
+    w32 = *reinterpret_cast<const bf16x8*>(smem + (w2_ ^ 96));                  \
   } while (0)
   // A fragments of k-steps ks0_, ks0_+1 of the tile in slot sa_
 #define G4_READ_A(sa_, ks0_)                                                    \
   do {                                                                          \
-    const char* ab_ = smem + (sa_) * A_BYTES;                                   \
-    a00 = *reinterpret_cast<const bf16x8*>(ab_ + (xo[0] ^ ((ks0_) << 5)));      \
-    a01 = *reinterpret_cast<const bf16x8*>(ab_ + (xo[1] ^ ((ks0_) << 5)));      \
-    a10 = *reinterpret_cast<const bf16x8*>(ab_ + (xo[0] ^ (((ks0_) + 1) << 5))); \
-    a11 = *reinterpret_cast<const bf16x8*>(ab_ + (xo[1] ^ (((ks0_) + 1) << 5))); \
+    const int x0_ = xo[0] + (sa_) * A_BYTES, x1_ = xo[1] + (sa_) * A_BYTES;     \
+    a00 = *reinterpret_cast<const bf16x8*>(smem + (x0_ ^ ((ks0_) << 5)));       \
+    a01 = *reinterpret_cast<const bf16x8*>(smem + (x1_ ^ ((ks0_) << 5)));       \
+    a10 = *reinterpret_cast<const bf16x8*>(smem + (x0_ ^ (((ks0_) + 1) << 5))); \
+    a11 = *reinterpret_cast<const bf16x8*>(smem + (x1_ ^ (((ks0_) + 1) << 5))); \
   } while (0)
   // one k-step: 6 MFMAs in the k order of gemm_bf16.hip (each accumulator sees ks = 0, 1, 2, 3 of every K-tile in order)
 #define G4_KSTEP(W0_, W1_, W2_, X0_, X1_)                                                       \
@@ -377,7 +475,8 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
     G4_SB();                                                        \
   } while (0)
 
-  const int nt = p.K / BK;   // >= 2 (launch check)
+  int nt = p.K / BK;   // K-tiles of the current segment: >= 2 (launch check / sk_plan)
+  int kb_c = 0, kb_n = 0, kind_c = SK_FULL, nsrc_c = 0, seg_i = 0;   // SK: first K-tile of the current / next segment, ...
   constexpr bool DMA_ON = !(ABL & 1), READ_ON = !(ABL & 2), STAMP = (ABL & 4) != 0;
   unsigned long long st_l = 0, st_b1 = 0, st_m = 0, st_b2 = 0, st_e = 0, st_t0 = 0, st_begin = 0;
 #define G4_STAMP(acc_)                                                        \
@@ -392,7 +491,12 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
   } while (0)
 
   // ---- first tile + prologue: its K-tile 0 complete before the first barrier, K-tile 1 on its way
-  int lin = blockIdx.x, row0, col0;
+  int lin = bid, row0, col0;
+  if constexpr (SK) {
+    const int4 s0 = sk_seg(sk, bid, 0);
+    if (s0.x < 0 || !SK_LAB_ON(4)) return;   // no segment for this workgroup (uniform: before the first barrier)
+    lin = s0.x; kb_c = s0.y & 0xffff; nt = (s0.y >> 16) - kb_c; kind_c = s0.z & 0xff; nsrc_c = s0.z >> 8;
+  }
   decode(lin, row0, col0);
   auto ra_c = mk_a(row0), ra_n = ra_c;
   auto rb_c = mk_b(col0), rb_n = rb_c;
@@ -400,11 +504,11 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
   a_offsets(row0, a_off_c);
 #pragma unroll
   for (int i = 0; i < NA; ++i) a_off_n[i] = a_off_c[i];
-  G4_DMA_A(ra_c, a_off_c, 0, 0);
-  G4_DMA_W(rb_c, 0, 0);
-  G4_DMA_A(ra_c, a_off_c, 1, 1);
+  G4_DMA_A(ra_c, a_off_c, kb_c, 0);
+  G4_DMA_W(rb_c, kb_c, 0);
+  G4_DMA_A(ra_c, a_off_c, kb_c + 1, 1);
   if (grp == 1) {
-    G4_DMA_W(rb_c, 1, 1);
+    G4_DMA_W(rb_c, kb_c + 1, 1);
     asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   } else {
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -417,13 +521,13 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
   // K-tile tt_ of the stream seen from the current tile: tt_ < nt is this tile's, otherwise the next tile's tt_ - nt
 #define G4_ISSUE_A(tt_, slot_)                                              \
   do {                                                                      \
-    if ((tt_) < nt) G4_DMA_A(ra_c, a_off_c, (tt_), (slot_));                \
-    else G4_DMA_A(ra_n, a_off_n, (tt_) - nt, (slot_));                      \
+    if ((tt_) < nt) G4_DMA_A(ra_c, a_off_c, kb_c + (tt_), (slot_));         \
+    else G4_DMA_A(ra_n, a_off_n, kb_n + (tt_) - nt, (slot_));               \
   } while (0)
 #define G4_ISSUE_W(tt_, slot_)                                              \
   do {                                                                      \
-    if ((tt_) < nt) G4_DMA_W(rb_c, (tt_), (slot_));                         \
-    else G4_DMA_W(rb_n, (tt_) - nt, (slot_));                               \
+    if ((tt_) < nt) G4_DMA_W(rb_c, kb_c + (tt_), (slot_));                  \
+    else G4_DMA_W(rb_n, kb_n + (tt_) - nt, (slot_));                        \
   } while (0)
 
   int sa = 0, sw = 0;   // ring slots of the current K-tile (carried across tiles)
@@ -431,8 +535,13 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
   bf16_t* orow[2] = {nullptr, nullptr};
   bool pend = false;
   for (;;) {
-    const int nlin = lin + (int)gridDim.x;
-    const bool has_next = nlin < ntiles;
+    int nlin = lin + nblk, nt_n = nt, kind_n = SK_FULL, nsrc_n = 0;
+    bool has_next = nlin < (sk.tile_limit > 0 ? sk.tile_limit : ntiles);
+    if constexpr (SK) {
+      const int4 sn = sk_seg(sk, bid, seg_i + 1);   // every list ends with a lin = -1 row
+      nlin = sn.x; has_next = nlin >= 0;
+      kb_n = sn.y & 0xffff; nt_n = (sn.y >> 16) - kb_n; kind_n = sn.z & 0xff; nsrc_n = sn.z >> 8;
+    }
     int nrow0 = row0, ncol0 = col0;
     if (has_next) {
       decode(nlin, nrow0, ncol0);
@@ -479,8 +588,24 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
         sw ^= 1;
       }
       G4_FLUSH_REST(2 * nt);   // only when nt < 6
-      g4_epilogue<EPI, ABL>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);   // same interval as LOAD(0) of the next tile
-      pend = true;
+      if (SK && kind_c == SK_DUMP) {
+        if (SK_LAB_ON(1)) g4_sk_dump(sk, acc, bid, wave_u, lane);
+        else if (lane == 0) __hip_atomic_store(sk.flags + bid * 8 + wave_u, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // lab: flag only
+      } else {
+        if (SK && kind_c == SK_FINAL && SK_LAB_ON(2)) g4_sk_gather(sk, acc, bid, wave_u, lane, nsrc_c);
+        if constexpr (SK) {   // no deferred stores in the SK body (registers): two halves, stored in place
+          uint4 ob[12];   // (shadows the deferred-store registers of the persistent body: nothing of this tile outlives the block)
+          bf16_t* orow[2] = {nullptr, nullptr};
+          g4_epilogue<EPI, ABL, 0, 1>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);
+          G4_STORE(0); G4_STORE(1); G4_STORE(2); G4_STORE(3); G4_STORE(4); G4_STORE(5);
+          G4_SB();
+          g4_epilogue<EPI, ABL, 1, 2>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);
+          G4_STORE(6); G4_STORE(7); G4_STORE(8); G4_STORE(9); G4_STORE(10); G4_STORE(11);
+        } else {
+          g4_epilogue<EPI, ABL>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);   // same interval as LOAD(0) of the next tile
+          pend = true;
+        }
+      }
       G4_STAMP(st_e);
     } else {
       for (int t = 0; t < nt; ++t) {
@@ -520,8 +645,24 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
         sw ^= 1;
       }
       G4_FLUSH_REST(2 * nt);   // only when nt < 6
-      g4_epilogue<EPI, ABL>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);   // right behind the last MFMA segment, in front of its barrier
-      pend = true;
+      if (SK && kind_c == SK_DUMP) {
+        if (SK_LAB_ON(1)) g4_sk_dump(sk, acc, bid, wave_u, lane);
+        else if (lane == 0) __hip_atomic_store(sk.flags + bid * 8 + wave_u, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // lab: flag only
+      } else {
+        if (SK && kind_c == SK_FINAL && SK_LAB_ON(2)) g4_sk_gather(sk, acc, bid, wave_u, lane, nsrc_c);
+        if constexpr (SK) {
+          uint4 ob[12];   // (shadows the deferred-store registers of the persistent body: nothing of this tile outlives the block)
+          bf16_t* orow[2] = {nullptr, nullptr};
+          g4_epilogue<EPI, ABL, 0, 1>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);
+          G4_STORE(0); G4_STORE(1); G4_STORE(2); G4_STORE(3); G4_STORE(4); G4_STORE(5);
+          G4_SB();
+          g4_epilogue<EPI, ABL, 1, 2>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);
+          G4_STORE(6); G4_STORE(7); G4_STORE(8); G4_STORE(9); G4_STORE(10); G4_STORE(11);
+        } else {
+          g4_epilogue<EPI, ABL>(p, acc, row0, col0, wm, wn, l31, hi, ob, orow);   // right behind the last MFMA segment, in front of its barrier
+          pend = true;
+        }
+      }
       G4_STAMP(st_e);
       if (has_next) {
         G4_BAR();
@@ -530,6 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
     }
     if (!has_next) break;   // (the pieces of the last tile are stored below)
     lin = nlin;
+    if constexpr (SK) { kb_c = kb_n; nt = nt_n; kind_c = kind_n; nsrc_c = nsrc_n; ++seg_i; }
     row0 = nrow0;
     col0 = ncol0;
     ra_c = ra_n;
@@ -541,12 +683,29 @@ __global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* 
   if constexpr (STAMP) {
     if (lane == 0 && stamps != nullptr) {
       const unsigned long long end = __builtin_amdgcn_s_memtime();
-      long long* d = stamps + ((long long)blockIdx.x * 8 + wave_u) * 8;
+      long long* d = stamps + ((long long)bid * 8 + wave_u) * 8;
       d[0] = (long long)st_l; d[1] = (long long)st_b1; d[2] = (long long)st_m; d[3] = (long long)st_b2;
       d[4] = (long long)(end - st_begin); d[5] = (long long)st_e; d[6] = (long long)st_begin; d[7] = nt;
     }
   }
 #endif
+}
+
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm4_kernel(GemmParams p, long long* stamps, SkArgs sk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  gemm4_body<EPI, ABL, false>(p, stamps, sk, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two roles in ONE grid of 2 G workgroups (no kernel boundary, no second launch): workgroups [0, G) walk the tiles of the full
+// rounds (tile_limit), workgroups [G, 2 G) are dispatched as the first ones retire and run the segment lists of the partial round.
+// Workgroup G + b lands on XCD b % 8 like workgroup b (G is a multiple of 8).
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm4_sk_kernel(GemmParams p, SkArgs sk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int G = (int)gridDim.x >> 1;
+  if ((int)blockIdx.x < G) gemm4_body<EPI, 0, false>(p, nullptr, sk, smem, (int)blockIdx.x, G);
+  else gemm4_body<EPI, 0, true>(p, nullptr, sk, smem, (int)blockIdx.x - G, G);
 }
 
 }  // namespace
@@ -566,6 +725,111 @@ static int g4_grid(const GemmParams& p, int persistent) {
   return ntiles < ncu ? ntiles : ncu;
 }
 
+// ---- stream-K plan (host).  Segment lists per workgroup for the tiles [ntiles - ntiles % grid, ntiles) of (ntiles, nt, grid);
+// see the kernel comment.  Returns false when the shape gains nothing (no partial round) or cannot be cut into pieces of >= 2
+// K-tiles with at most one DUMP per workgroup.
+bool sk_plan(int ntiles, int nt, int grid, std::vector<int4>& segs, int& nseg_max) {
+  const int R = ntiles / grid, rem = ntiles % grid;
+  if (R < 1 || rem == 0 || nt < 4 || grid % 8 != 0 || nt >= 0x7fff) return false;
+  const int G = grid / 8;
+  std::vector<std::vector<int4>> dumps(grid), fulls(grid), finals(grid);   // the tiles of the partial round only
+  for (int x = 0; x < 8; ++x) {
+    int cx = 0;
+    while (R * grid + x + 8 * cx < ntiles) ++cx;   // tiles of the partial round whose linear id is on XCD x
+    if (cx == 0) continue;
+    const long long units = (long long)cx * nt;
+    std::vector<int> earlier(cx, 0);
+    auto cut = [&](int j) {
+      long long c = (long long)j * units / G;
+      const int m = (int)(c % nt);
+      if (m == 1) c -= 1; else if (m == nt - 1) c += 1;   // no 1-K-tile pieces at a tile border
+      return c;
+    };
+    for (int j = 0; j < G; ++j) {
+      const int b = x + 8 * j;
+      long long u = cut(j);
+      const long long u1 = cut(j + 1);
+      while (u < u1) {
+        const int i = (int)(u / nt), kb = (int)(u % nt);
+        const int ke = (int)std::min<long long>(nt, kb + (u1 - u));
+        if (ke - kb < 2) return false;
+        const int lin = R * grid + x + 8 * i;
+        if (kb == 0 && ke == nt) fulls[b].push_back(make_int4(lin, nt << 16, SK_FULL, 0));
+        else if (ke < nt) {
+          dumps[b].push_back(make_int4(lin, kb | (ke << 16), SK_DUMP, 0));
+          ++earlier[i];
+        } else {
+          if (earlier[i] < 1 || 8 * earlier[i] > b) return false;
+          finals[b].push_back(make_int4(lin, kb | (ke << 16), SK_FINAL | (earlier[i] << 8), 0));
+        }
+        u += ke - kb;
+      }
+      if (dumps[b].size() > 1 || finals[b].size() > 1) return false;   // one workspace slot per workgroup
+    }
+  }
+  // a FINAL of workgroup b reads the slots of b - 8, ..., b - 8 nsrc: they must be exactly the DUMPs of the same tile
+  for (int b = 0; b < grid; ++b)
+    for (const int4& f : finals[b])
+      for (int k = 1; k <= (f.z >> 8); ++k) {
+        const int src = b - 8 * k;
+        if (src < 0 || dumps[src].size() != 1 || dumps[src][0].x != f.x) return false;
+      }
+  size_t mx = 0;
+  for (int b = 0; b < grid; ++b) mx = std::max(mx, dumps[b].size() + fulls[b].size() + finals[b].size());
+  nseg_max = (int)mx + 1;
+  segs.assign((size_t)grid * nseg_max, make_int4(-1, 0, 0, 0));
+  for (int b = 0; b < grid; ++b) {
+    size_t o = (size_t)b * nseg_max;
+    for (const int4& v : dumps[b]) segs[o++] = v;
+    for (const int4& v : fulls[b]) segs[o++] = v;
+    for (const int4& v : finals[b]) segs[o++] = v;
+  }
+  return true;
+}
+
+namespace {
+struct SkPlanDev { int4* d_segs = nullptr; int nseg_max = 0; bool ok = false; };
+struct SkWorkspace { float* ws = nullptr; int* flags = nullptr; int epoch = 0; int grid = 0; };
+std::mutex g_sk_mutex;
+std::map<std::tuple<int, int, int>, SkPlanDev> g_sk_plans;      // (ntiles, nt, grid)
+std::map<hipStream_t, SkWorkspace> g_sk_ws;                      // launches on one stream are serialised: one workspace per stream
+}  // namespace
+
+// fills sk for a launch on `stream`; false: run the plain persistent kernel
+static bool sk_prepare(const GemmParams& p, int grid, hipStream_t stream, SkArgs& sk) {
+  const int ntiles = ((p.M + BM - 1) / BM) * (p.N / BN), nt = p.K / BK;
+  std::lock_guard<std::mutex> lock(g_sk_mutex);
+  SkPlanDev& pl = g_sk_plans[std::make_tuple(ntiles, nt, grid)];
+  if (pl.d_segs == nullptr && !pl.ok && pl.nseg_max == 0) {
+    pl.nseg_max = -1;   // built (possibly without success)
+    std::vector<int4> segs;
+    int nseg_max = 0;
+    if (sk_plan(ntiles, nt, grid, segs, nseg_max)) {
+      if (hipMalloc(&pl.d_segs, segs.size() * sizeof(int4)) == hipSuccess &&
+          hipMemcpy(pl.d_segs, segs.data(), segs.size() * sizeof(int4), hipMemcpyHostToDevice) == hipSuccess) {
+        pl.nseg_max = nseg_max;
+        pl.ok = true;
+      }
+    }
+  }
+  if (!pl.ok) return false;
+  SkWorkspace& w = g_sk_ws[stream];
+  if (w.ws == nullptr || w.grid < grid) {
+    if (w.ws != nullptr) { (void)hipFree(w.ws); (void)hipFree(w.flags); w.ws = nullptr; }
+    const size_t wb = (size_t)grid * 8 * 24 * 64 * sizeof(float4), fb = (size_t)grid * 8 * sizeof(int);
+    if (hipMalloc(&w.ws, wb) != hipSuccess) { w.ws = nullptr; return false; }
+    if (hipMalloc(&w.flags, fb) != hipSuccess || hipMemset(w.flags, 0, fb) != hipSuccess) { (void)hipFree(w.ws); w.ws = nullptr; return false; }
+    w.grid = grid;
+    w.epoch = 0;
+  }
+  sk.segs = pl.d_segs;
+  sk.nseg_max = pl.nseg_max;
+  sk.ws = w.ws;
+  sk.flags = w.flags;
+  sk.epoch = ++w.epoch;
+  return true;
+}
+
 #ifdef VSYS_LAB
 // lab: ablations / stamps of the ping-pong loop (EPI_BIAS only): abl = 1 no in-loop DMA, 2 no in-loop reads, 3 both, 4 stamps
 int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t stream) {
@@ -575,7 +839,7 @@ int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t s
 #define G4_LAB(A_)                                                                                                       \
   case A_:                                                                                                               \
     (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI_BIAS, A_>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); \
-    hipLaunchKernelGGL((gemm4_kernel<EPI_BIAS, A_>), dim3(grid), dim3(512), LDS_BYTES, stream, p, st);                   \
+    hipLaunchKernelGGL((gemm4_kernel<EPI_BIAS, A_>), dim3(grid), dim3(512), LDS_BYTES, stream, p, st, SkArgs{});         \
     break
   switch (abl) {
     G4_LAB(1);
@@ -603,20 +867,40 @@ bool gemm4_supports(const GemmParams& p, int epi) {
   return true;
 }
 
+// persistent: 0 = one tile per workgroup, 1 = one workgroup per CU walks the tiles, 2 = 1 + stream-K split of the partial last round
 int launch_gemm4(const GemmParams& p, int epi, int persistent, hipStream_t stream) {
   if (!gemm4_supports(p, epi)) return VSYS_ERR_SHAPE;
+  int sk_abl = 0;
+  if (persistent > 2) { sk_abl = persistent - 2; persistent = 2; }   // lab: 3 .. 9 = stream-K with ablation bits persistent - 2
   const int grid = g4_grid(p, persistent);
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm4_kernel<EPI_GATE_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm4_sk_kernel<EPI_BIAS>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm4_sk_kernel<EPI_BIAS_GELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm4_sk_kernel<EPI_GATE_RES>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     attr_set = true;
   }
+  SkArgs sk{};
+  if (persistent == 2 && sk_prepare(p, grid, stream, sk)) {
+    // one grid, two roles: workgroups [0, grid) = full rounds on tiles [0, R grid), workgroups [grid, 2 grid) = the segment lists
+    const int ntiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+    sk.tile_limit = ntiles - ntiles % grid;
+    sk.abl = sk_abl;
+    switch (epi) {
+      case EPI_BIAS: hipLaunchKernelGGL((gemm4_sk_kernel<EPI_BIAS>), dim3(2 * grid), dim3(512), LDS_BYTES, stream, p, sk); break;
+      case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm4_sk_kernel<EPI_BIAS_GELU>), dim3(2 * grid), dim3(512), LDS_BYTES, stream, p, sk); break;
+      case EPI_GATE_RES: hipLaunchKernelGGL((gemm4_sk_kernel<EPI_GATE_RES>), dim3(2 * grid), dim3(512), LDS_BYTES, stream, p, sk); break;
+      default: return VSYS_ERR_ARG;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm4_kernel<EPI_BIAS>), dim3(grid), dim3(512), LDS_BYTES, stream, p, (long long*)nullptr); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm4_kernel<EPI_BIAS_GELU>), dim3(grid), dim3(512), LDS_BYTES, stream, p, (long long*)nullptr); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm4_kernel<EPI_GATE_RES>), dim3(grid), dim3(512), LDS_BYTES, stream, p, (long long*)nullptr); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm4_kernel<EPI_BIAS>), dim3(grid), dim3(512), LDS_BYTES, stream, p, (long long*)nullptr, sk); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm4_kernel<EPI_BIAS_GELU>), dim3(grid), dim3(512), LDS_BYTES, stream, p, (long long*)nullptr, sk); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm4_kernel<EPI_GATE_RES>), dim3(grid), dim3(512), LDS_BYTES, stream, p, (long long*)nullptr, sk); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;

@@ -639,9 +639,9 @@ static int g_gemm_variant = 0;
 // schedule / geometry only and are bit-identical); ablation and stamp variants exist in -DVSYS_LAB builds (VSYS_LAB=1 build()).
 int set_gemm_variant(int v) {
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 60: case 70: case 103: break;
+    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 60: case 70: case 80: case 103: break;
 #ifdef VSYS_LAB
-    case 18: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: break;
+    case 18: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
 #endif
     default: return VSYS_ERR_ARG;
   }
@@ -689,12 +689,15 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     case 31: return (epi == EPI_BIAS && p.N % 384 == 0) ? launch_gemm2_stamp(p, stream) : VSYS_ERR_ARG;  // lab: cycle stamps
     case 61: case 62: case 63: case 64: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 60, 0, stream) : VSYS_ERR_ARG;
     case 71: case 72: case 73: case 74: case 78: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 70, 1, stream) : VSYS_ERR_ARG;
+    case 81: case 82: case 83: case 84:   // stream-K ablations (wrong results): 81 no DUMP, 82 no gather, 83 neither, 84 no SK role at all
+      return gemm4_supports(p, epi) ? launch_gemm4(p, epi, 2 + g_gemm_variant - 80, stream) : VSYS_ERR_ARG;
 #endif
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
-    case 60: case 70:  // ping-pong wave groups (gemm4_bf16.hip): 60 = one tile per workgroup, 70 = persistent (one workgroup per CU)
+    case 60: case 70: case 80:  // ping-pong wave groups (gemm4_bf16.hip): 60 = one tile per workgroup, 70 = persistent (one
+      // workgroup per CU), 80 = persistent + stream-K split of the partial last round (fp32 summation order differs: not bit-identical)
       if (!gemm4_supports(p, epi)) return launch_gemm_t<8, 256>(p, epi, stream);
-      return launch_gemm4(p, epi, g_gemm_variant == 70, stream);
+      return launch_gemm4(p, epi, (g_gemm_variant - 60) / 10, stream);
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
     case 28: return launch_gemm_t<8, 256, 1, 1>(p, epi, stream);  // schedule 8 + four producer waves (store-only epilogues)

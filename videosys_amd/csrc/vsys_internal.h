@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <vector>
+
 #include "../../include/videosys_amd.h"
 
 namespace vsys {
@@ -72,9 +74,10 @@ int launch_t5_attention(const bf16_t* qkv, int64_t row_stride, int inner, const 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream);
 int launch_gemm3(const GemmParams& p, int epi, hipStream_t stream);
-// ping-pong wave groups (gemm4_bf16.hip); persistent = 1: one workgroup per CU walks the tiles
+// ping-pong wave groups (gemm4_bf16.hip); persistent = 1: one workgroup per CU walks the tiles, 2: + stream-K tail
 int launch_gemm4(const GemmParams& p, int epi, int persistent, hipStream_t stream);
 bool gemm4_supports(const GemmParams& p, int epi);
+bool sk_plan(int ntiles, int nt, int grid, std::vector<int4>& segs, int& nseg_max);  // stream-K segment lists (host)
 int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t stream);
 int launch_gemm2_stamp(const GemmParams& p, hipStream_t stream);  // lab: per-stage cycle stamps into p.aux (int64)
 int set_gemm_variant(int v);   // VSYS_ERR_ARG for ids this build does not contain
