@@ -405,6 +405,48 @@ def test_attn_temporal_kernels_agree_with_oracle(ops, B, T, S, H, norm, rope):
     assert (outs[0] - outs[4]).abs().max().item() <= 2.0 ** -6 * scale
 
 
+@pytest.mark.parametrize("q_len,kv_len,heads,batch,norm", [
+    (1024, 1024, 4, 3, True),    # spatial shape: 16 KV tiles, 4 query blocks of 256
+    (700, 300, 2, 2, False),     # cross shape: ragged last tile (300 = 4 x 64 + 44), ragged query block
+    (100, 64, 2, 1, True),       # one tile, fewer rows than one wave group
+    (256, 129, 1, 2, True),      # 3 tiles, the last with one key
+    (333, 448, 3, 1, False),     # 7 tiles: ring of five stages wraps
+    (257, 192, 2, 2, True),      # 3 tiles = exactly the prologue depth; second query block has one row
+])
+def test_flash_pingpong_matches_default_and_torch(ops, q_len, kv_len, heads, batch, norm):
+    """flash variant 5 (8-wave workgroups, matrix / VALU phases alternating between the two waves of a SIMD, five-stage K/V ring)
+    does the arithmetic of the default kernel in the same order per query row: results must be BIT-identical to it, for every
+    prologue / wrap / ragged-tail case of the ring; and both against torch fp32 SDPA."""
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    C = heads * 72
+    g = torch.Generator().manual_seed(q_len + kv_len)
+    q = torch.randn(batch * q_len, C, generator=g).to(torch.bfloat16).to(dev())
+    k = torch.randn(batch * kv_len, C, generator=g).to(torch.bfloat16).to(dev())
+    v = torch.randn(batch * kv_len, C, generator=g).to(torch.bfloat16).to(dev())
+    qw = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16).to(dev()) if norm else None
+    kw_ = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16).to(dev()) if norm else None
+    try:
+        assert lib.vsys_tune_flash_variant(0) == 0
+        base = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        assert lib.vsys_tune_flash_variant(5) == 0
+        pp = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        torch.cuda.synchronize()
+    finally:
+        lib.vsys_tune_flash_variant(0)
+    for bi in range(batch):
+        for h in range(heads):
+            qq = q[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72]
+            kk = k[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72]
+            vv = v[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72].float()
+            if norm:
+                qq, kk = O.rms_norm(qq, qw.float()), O.rms_norm(kk, kw_.float())
+            ref = O.sdpa(qq.float()[None], kk.float()[None], vv[None])[0]
+            check(pp[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, what=f"ping-pong flash b{bi} h{h}")
+    assert torch.equal(pp, base), f"ping-pong flash differs from the default kernel: max {float((pp.float() - base.float()).abs().max()):.3e}"
+
+
 def test_attn_config2_sizes_vs_torch(ops):
     """Config-2 geometry for one CFG sample slice: spatial (frames x 1024 tokens, 16 heads) vs torch fp32 SDPA on the
     GPU for sampled (frame, head) pairs, plus the softmax-of-constant-V property on everything."""

@@ -143,6 +143,8 @@ struct FlashParams {
 // slower: the peeled last tile spills and three workgroups per CU buy nothing — 0.31 vs 0.28 ms at config 2).
 // ABL (lab builds): 1 = K/V tiles after the first are not fetched (compute, LDS and barriers only); 2 = s_memtime stamps
 // at the phase boundaries of every tile, summed per wave into p.dbg[0..4] (QK issue | max chain | exp + PV | vmcnt | barrier).
+// (An 8-wave form of this kernel — 256 rows share a K/V tile and its 19 LDS-DMA pieces, one workgroup per CU — measured 0.256 vs
+// 0.247 ms at the config-2 spatial shape: the per-tile barrier then couples both waves of every SIMD.  Not kept.)
 template <int ABL, int WPS>
 __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p) {
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
@@ -400,6 +402,330 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
         const auto sx = __builtin_amdgcn_permlane32_swap(w[2 * k].x, w[2 * k + 1].x, false, false);
         const auto sy = __builtin_amdgcn_permlane32_swap(w[2 * k].y, w[2 * k + 1].y, false, false);
         const int d0 = dt * 32 + 16 * k;   // + 8 hi (in orow)
+        if (qs < p.q_len && d0 + 8 * hi + 8 <= HD) *reinterpret_cast<uint4*>(orow + d0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
+    }
+  }
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// flash_attn_d72_pp: the same contraction, fragment layouts, K/V images and softmax arithmetic as flash_attn_d72_kernel, with
+// the work of a KV tile re-cut into a MATRIX phase and a VALU phase that the two waves of every SIMD run in opposite order.
+//
+// In flash_attn_d72_kernel a wave runs QK^T -> max -> exp -> PV as one dependent chain and relies on the other workgroup of
+// the CU to fill the matrix pipe meanwhile; the two drift freely and the pipe is busy 41 % of the time (PMC).
+// Here one workgroup = 8 waves = 256 query rows: G0 = waves 0-3 (rows 0..127), G1 = waves 4-7 (rows 128..255), a SIMD hosts one
+// wave of each.  A wave software-pipelines its chain into
+//     M(k): O += Vt(k-1) P(k-1)^T  (12 MFMAs)  and  S(k) = K(k) Q^T - m  (10 MFMAs)      -- matrix pipe + LDS reads only
+//     V(k): mask / max / rescale / P(k) = exp2(S(k))                                      -- VALU only, no LDS
+// and the barrier sequence makes the groups alternate: while G0 is in M(k), G1 is in V(k-1); while G0 is in V(k), G1 is in M(k).
+// The matrix pipe of a SIMD therefore always has exactly one wave feeding it and the exp / max work of the other wave runs
+// beside it.  K/V tiles are shared by 256 rows (half the L2 -> LDS bytes per row) in a ring of FIVE 22.5 KiB stages: tile k + 3
+// is requested during M(k) into the stage tile k - 2 left (last read by both groups' M(k - 1)), every wave issuing pieces w,
+// w + 8, w + 16 of the 19, and the counted wait in front of each barrier admits only the tiles beyond k + 1 as pending.
+//
+// MEASURED (tools/flash_pp_probe.py, profiles/r02_flash_pingpong_*.json): bit-identical to flash_attn_d72_kernel, but SLOWER —
+// 0.38-0.41 vs 0.25 ms (spatial), 0.150 vs 0.100 ms (cross).  Cycle stamps per KV tile: a matrix phase takes 2000-2500 cycles
+// for 704 cycles of MFMA — 450 of them are the wave's two or three LDS-DMA issues, 400 (older wave group) to 1000 (younger)
+// are lost to the partner's VALU phase (MFMA issue arbitrates with the partner's VALU stream by age), the rest is read latency
+// at the head of the phase — and the VALU phase takes 1150-1450.  The free-running default overlaps the same work statistically
+// and wins.  Selectable as flash variant 5 (valid, tested); never dispatched.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int PP_NBUF = 5;
+constexpr int PP_LEAD = 3;   // tile k + PP_LEAD is staged during M(k)
+
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void flash_attn_d72_pp_kernel(FlashParams p) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int grp = wave_u >> 2;
+  const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = tile_id / p.nqb;
+  const int qb = tile_id - bh * p.nqb;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = qb * 256 + wave_u * 32;
+
+  const bf16_t* kbase = p.kp + (int64_t)bh * p.kv_pad * HD;
+  const bf16_t* vbase = p.vt + (int64_t)bh * HD_ROWS * p.kv_pad;
+  const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.kv_pad * HD * 2, 0x00020000);
+  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, HD_ROWS * p.kv_pad * 2, 0x00020000);
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int k_voff = lane * 16;
+  const int v_voff = (lane >> 3) * p.kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
+  // this wave's pieces of tile t (19 per tile: 9 K + 10 Vt, see flash_attn_d72_kernel) into ring stage buf
+  auto stage = [&](int t, int buf) {
+    char* base = smem + buf * KV_STAGE;
+#pragma unroll
+    for (int idx = 0; idx < 3; ++idx) {
+      const int piece = wave_u + 8 * idx;
+      if (piece < 9) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
+      } else if (piece < 19) {
+        const int j = piece - 9;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((j & 1) << 6),
+                                                 j * 8 * p.kv_pad * 2 + t * 128, 0, 0);
+      }
+    }
+  };
+  const int ntiles = (p.kv_len + 63) / 64;
+#pragma unroll
+  for (int t = 0; t < PP_LEAD; ++t)
+    if (t < ntiles) stage(t, t);
+  // rows 80..95 of the Vt image of every stage (MFMA padding the DMA never writes): 5 x 2 KiB of zeros
+  for (int q = tid; q < PP_NBUF * 128; q += 512)
+    *reinterpret_cast<uint4*>(smem + (q >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (q & 127) * 16) = make_uint4(0, 0, 0, 0);
+
+  // ---- Q fragment (as flash_attn_d72_kernel)
+  bf16x8 qf[5];
+  {
+    int qs = q0 + l31;
+    qs = qs < p.q_len ? qs : p.q_len - 1;
+    const bf16_t* qrow = p.q + ((int64_t)b * p.q_len + qs) * p.q_stride + h * HD;
+    float x[5][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int d0 = 16 * c + 8 * hi;
+      if (d0 < HD) {
+        unpack8(*reinterpret_cast<const uint4*>(qrow + d0), x[c]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[c][e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
+    }
+    if (p.q_norm_w != nullptr) {
+      ss += __shfl_xor(ss, 32, 64);
+      const float rstd = rsqrtf(ss / (float)HD + p.eps);
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int d0 = 16 * c + 8 * hi;
+        if (d0 < HD) {
+          float w[8];
+          unpack8(*reinterpret_cast<const uint4*>(p.q_norm_w + d0), w);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[c][e] = bf2f(f2bf(x[c][e] * rstd)) * w[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) qf[c][e] = (__bf16)x[c][e];
+  }
+
+  const int v_roff = K_TILE_BYTES + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4);
+  const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+  const int k_roff = krow * KROW + 16 * hi;
+
+  f32x16 o[3];
+#pragma unroll
+  for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  f32x16 minit;   // negated running max, splatted: C operand of the first QK^T MFMA of each 32-key block
+#pragma unroll
+  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
+  f32x16 s[2];
+  bf16x8 pf0[2], pf1[2];
+  const float defer_thr = 8.0f;
+  // pieces this wave has in flight per staged tile (pieces w, w + 8, w + 16 < 19)
+  const int np = wave_u < 3 ? 3 : 2;
+
+#define PP_SB() __builtin_amdgcn_sched_barrier(0)
+#define PP_BAR()                      \
+  do {                                \
+    PP_SB();                          \
+    __builtin_amdgcn_s_barrier();     \
+    PP_SB();                          \
+  } while (0)
+  // in front of a barrier that ends M(k) or V(k): this wave's pieces of every tile <= k + 1 have landed; the tiles beyond
+  // (k + 2 .. min(k + PP_LEAD, ntiles - 1), staged last) may stay in flight
+  auto wait_tiles = [&](int k) {
+    int pend = ntiles - 2 - k;
+    pend = pend < 0 ? 0 : (pend > PP_LEAD - 1 ? PP_LEAD - 1 : pend);
+    if (pend == 2) {
+      if (np == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else if (pend == 1) {
+      if (np == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+
+  // ---- M(k): PV(k - 1) then QK^T(k); stages tile k + PP_LEAD at its end (the DMA issue time then falls into the barrier wait).
+  // Fragment reads are issued in three groups (Vt keys 0..31 and 32..63 up front, K behind the first six PV MFMAs, into the
+  // registers the first Vt group leaves): with all 88 fragment registers live at once hipcc splits the live range of the three O
+  // accumulators and copies all 48 registers in the middle of the phase, with the matrix pipe drained.
+  auto mphase = [&](int k, int bk, int bv) {   // bk / bv: ring stages of tiles k / k - 1
+    const char* skv = smem + bv * KV_STAGE;
+    const char* skk = smem + bk * KV_STAGE;
+    bf16x8 vf0[2][3], vf1[2][3], kf0[5], kf1[5];
+    if (k >= 1) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) vf0[cc][dt] = *reinterpret_cast<const bf16x8*>(skv + dt * 32 * VROW + (v_roff ^ ((0 * 4 + cc) << 4)));
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) vf1[cc][dt] = *reinterpret_cast<const bf16x8*>(skv + dt * 32 * VROW + (v_roff ^ ((1 * 4 + cc) << 4)));
+      PP_SB();
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[cc][dt], pf0[cc], o[dt], 0, 0, 0);
+      PP_SB();
+    }
+    if (k < ntiles) {
+#pragma unroll
+      for (int cc = 0; cc < 5; ++cc) {
+        kf0[cc] = *reinterpret_cast<const bf16x8*>(skk + k_roff + 32 * cc);
+        kf1[cc] = *reinterpret_cast<const bf16x8*>(skk + 32 * KROW + k_roff + 32 * cc);
+      }
+      PP_SB();
+    }
+    if (k >= 1) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[cc][dt], pf1[cc], o[dt], 0, 0, 0);
+      PP_SB();
+    }
+    if (k < ntiles) {
+      // D != C on purpose (the builtin ties them and hipcc would first copy the 16 minit registers into s)
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[0]) : "v"(kf0[0]), "v"(qf[0]), "v"(minit));
+#pragma unroll
+      for (int cc = 1; cc < 5; ++cc) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[cc], qf[cc], s[0], 0, 0, 0);
+      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[1]) : "v"(kf1[0]), "v"(qf[0]), "v"(minit));
+#pragma unroll
+      for (int cc = 1; cc < 5; ++cc) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[cc], qf[cc], s[1], 0, 0, 0);
+    }
+    PP_SB();
+    if (!(ABL & 4) && k + PP_LEAD < ntiles) {
+      int bn = bk + PP_LEAD;
+      bn = bn >= PP_NBUF ? bn - PP_NBUF : bn;
+      stage(k + PP_LEAD, bn);
+    }
+  };
+
+  // ---- V(k): online softmax of tile k (lane: query l31; keys 64k + 32kt + 16hi + r), exactly the arithmetic of
+  // flash_attn_d72_kernel: deferred running max, only the last tile of a ragged kv_len masks
+  auto vphase = [&](int k, const bool masked) {
+    if (masked) {
+      const int lim = p.kv_len - (k * 64 + 16 * hi);
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (kt * 32 + r >= lim) s[kt][r] = NEG_BIG;
+    }
+    // four independent chains (the partner wave of the SIMD is in its matrix phase: nothing else covers VALU latency here)
+    float m4[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[0][c], s[1][c]);
+#pragma unroll
+    for (int r = 4; r < 16; r += 4)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) m4[c] = fmaxf(m4[c], fmaxf(s[0][r + c], s[1][r + c]));
+    float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    if (k == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0) {
+      asm volatile("; rescale path (rare): kept out of line" ::: "memory");
+      const float delta = k == 0 ? mx : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) minit[r] -= delta;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pf0[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pf1[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[1][r]);
+  };
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();   // tiles 0 .. PP_LEAD - 1 and the zero rows are in LDS
+
+  // Barrier sequence: G0 runs M(0) B V(0) B M(1) B ... V(n-1) B M(n) B, G1 the same stream one interval later (B first, no B
+  // at its end): 2n + 1 barriers each.
+  const bool ragged = (p.kv_len & 63) != 0;
+  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;   // lab (ABL == 2): cycles in M | barrier after M | V | barrier after V
+#define PP_STAMP(i_)                                                 \
+  do {                                                               \
+    if (ABL & 2) {                                                   \
+      PP_SB();                                                       \
+      const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+      tacc[i_] += now_ - tprev;                                      \
+      tprev = now_;                                                  \
+      PP_SB();                                                       \
+    }                                                                \
+  } while (0)
+  if (grp == 1) PP_BAR();
+  if (ABL & 2) tprev = __builtin_amdgcn_s_memtime();
+  int bk = 0;   // ring stage of tile k
+  for (int k = 0; k < ntiles; ++k) {
+    const int bv = bk == 0 ? PP_NBUF - 1 : bk - 1;
+    mphase(k, bk, bv);
+    wait_tiles(k);
+    PP_STAMP(0);
+    PP_BAR();
+    PP_STAMP(1);
+    if (!(ABL & 8)) {
+      if (ragged && k == ntiles - 1) vphase(k, true);
+      else vphase(k, false);
+    }
+    wait_tiles(k);
+    PP_STAMP(2);
+    PP_BAR();
+    PP_STAMP(3);
+    bk = bk == PP_NBUF - 1 ? 0 : bk + 1;
+  }
+  mphase(ntiles, bk, bk == 0 ? PP_NBUF - 1 : bk - 1);   // PV of the last tile only
+  if (grp == 0) PP_BAR();
+  if ((ABL & 2) && lane == 0 && p.dbg != nullptr) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(p.dbg + i + 4 * grp, tacc[i]);   // dbg[0..3] = G0, dbg[4..7] = G1
+  }
+#undef PP_STAMP
+#undef PP_SB
+#undef PP_BAR
+
+  // ---- epilogue (as flash_attn_d72_kernel)
+  const float inv = 1.0f / o[2][4];
+  const int qs = q0 + l31;
+  {
+    bf16_t* orow = p.out + ((int64_t)b * p.q_len + (qs < p.q_len ? qs : p.q_len - 1)) * p.out_stride + h * HD + 8 * hi;
+#pragma unroll
+    for (int dt = 0; dt < 3; ++dt) {
+      uint2 w[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        w[g].x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+        w[g].y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const auto sx = __builtin_amdgcn_permlane32_swap(w[2 * k].x, w[2 * k + 1].x, false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(w[2 * k].y, w[2 * k + 1].y, false, false);
+        const int d0 = dt * 32 + 16 * k;
         if (qs < p.q_len && d0 + 8 * hi + 8 <= HD) *reinterpret_cast<uint4*>(orow + d0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
       }
     }
@@ -701,9 +1027,9 @@ static unsigned long long* g_flash_dbg = nullptr;
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 9: break;
+    case 0: case 3: case 4: case 5: case 9: break;
 #ifdef VSYS_LAB
-    case 1: case 2: break;
+    case 1: case 2: case 6: case 61: case 62: break;
 #endif
     default: return VSYS_ERR_ARG;
   }
@@ -738,6 +1064,33 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   dim3 grid((unsigned)nblk);
   const size_t lds = 2 * KV_STAGE;
   p.dbg = g_flash_dbg;
+#ifdef VSYS_LAB
+  if (g_flash_variant == 6 || g_flash_variant == 61 || g_flash_variant == 62) {   // lab: ping-pong kernel with phase stamps into
+    p.nqb = (q_len + 255) / 256;                                                   // the debug buffer (8 x u64); 61 = no DMA in the
+    const dim3 gr((unsigned)((int64_t)p.nqb * batch * heads));                     // loop, 62 = no VALU phase work (output NOT valid)
+#define PP_LAB(A_)                                                                                                                \
+    do {                                                                                                                          \
+      (void)hipFuncSetAttribute((const void*)flash_attn_d72_pp_kernel<A_>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_NBUF * KV_STAGE); \
+      hipLaunchKernelGGL((flash_attn_d72_pp_kernel<A_>), gr, dim3(512), PP_NBUF * KV_STAGE, stream, p);                           \
+    } while (0)
+    if (g_flash_variant == 6) PP_LAB(2);
+    else if (g_flash_variant == 61) PP_LAB(6);
+    else PP_LAB(10);
+#undef PP_LAB
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
+#endif
+  if (g_flash_variant == 5) {   // ping-pong wave groups: 256 query rows per workgroup, five-stage K/V ring
+    p.nqb = (q_len + 255) / 256;
+    const int64_t nb = (int64_t)p.nqb * batch * heads;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)flash_attn_d72_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_NBUF * KV_STAGE);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((flash_attn_d72_pp_kernel<0>), dim3((unsigned)nb), dim3(512), PP_NBUF * KV_STAGE, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
 #ifdef VSYS_LAB
   if (g_flash_variant == 1) hipLaunchKernelGGL((flash_attn_d72_kernel<1, 2>), grid, dim3(256), lds, stream, p);
   else if (g_flash_variant == 2) hipLaunchKernelGGL((flash_attn_d72_kernel<2, 2>), grid, dim3(256), lds, stream, p);
