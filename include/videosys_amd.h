@@ -53,9 +53,11 @@ int vsys_device_count(void);
  *        schedule 8 + producer waves; 30 = 256 x 384 tile; 60 / 70 = ping-pong wave groups, one tile per workgroup / persistent;
  *        103 = 128-row tiles.  80 = 70 + stream-K split of the partial last round of tiles: valid output, deterministic, but NOT
  *        bit-identical to the others (fp32 partial sums of a split tile are added in a different order).
- * flash: 0 = default (two workgroups per CU; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
+ * flash: 0 = default (two workgroups per CU; resident K/V for few keys; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
  *        4 = VALU temporal kernel (v2) for T <= 40; 5 = ping-pong wave groups (8-wave workgroups, matrix / VALU phases alternate
- *        between the two waves of a SIMD; bit-identical, measured slower); 9 = online-softmax temporal kernel for every T. */
+ *        between the two waves of a SIMD; bit-identical, measured slower); 8 / 10 = the resident-K/V kernel (all KV tiles of a
+ *        (batch, head) staged once per workgroup; default for <= 320 keys and many query rows) whenever the keys fit / never;
+ *        9 = online-softmax temporal kernel for every T. */
 int vsys_tune_gemm_variant(int variant);
 int vsys_tune_flash_variant(int variant);
 

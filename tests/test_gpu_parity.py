@@ -412,11 +412,14 @@ def test_attn_temporal_kernels_agree_with_oracle(ops, B, T, S, H, norm, rope):
     (256, 129, 1, 2, True),      # 3 tiles, the last with one key
     (333, 448, 3, 1, False),     # 7 tiles: ring of five stages wraps
     (257, 192, 2, 2, True),      # 3 tiles = exactly the prologue depth; second query block has one row
+    (2000, 300, 16, 2, False),   # resident kernel: chunks = 8 workgroups per (batch, head) walk 8 query blocks unevenly, ragged tail
+    (1500, 320, 40, 7, True),    # more (batch, head) pairs than CUs: one chunk each, 6 query blocks, five full tiles
 ])
 def test_flash_pingpong_matches_default_and_torch(ops, q_len, kv_len, heads, batch, norm):
     """flash variant 5 (8-wave workgroups, matrix / VALU phases alternating between the two waves of a SIMD, five-stage K/V ring)
-    does the arithmetic of the default kernel in the same order per query row: results must be BIT-identical to it, for every
-    prologue / wrap / ragged-tail case of the ring; and both against torch fp32 SDPA."""
+    and variant 8 (resident K/V: every KV tile staged once per workgroup, query blocks walked without DMA or barriers) do the
+    arithmetic of the streaming kernel in the same order per query row: results must be BIT-identical to it, for every prologue /
+    wrap / ragged-tail / chunking case; and against torch fp32 SDPA."""
     from videosys_amd import _lib
 
     lib = _lib.load()
@@ -428,13 +431,16 @@ def test_flash_pingpong_matches_default_and_torch(ops, q_len, kv_len, heads, bat
     qw = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16).to(dev()) if norm else None
     kw_ = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16).to(dev()) if norm else None
     try:
-        assert lib.vsys_tune_flash_variant(0) == 0
+        assert lib.vsys_tune_flash_variant(10) == 0          # the streaming kernel (two-stage ring, one barrier per tile)
         base = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
         assert lib.vsys_tune_flash_variant(5) == 0
         pp = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        assert lib.vsys_tune_flash_variant(8) == 0           # resident K/V (kv_len <= 320; otherwise the streaming kernel again)
+        res = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
         torch.cuda.synchronize()
     finally:
         lib.vsys_tune_flash_variant(0)
+    assert torch.equal(res, base), f"resident-K/V flash differs from the streaming kernel: max {float((res.float() - base.float()).abs().max()):.3e}"
     for bi in range(batch):
         for h in range(heads):
             qq = q[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72]
@@ -443,7 +449,8 @@ def test_flash_pingpong_matches_default_and_torch(ops, q_len, kv_len, heads, bat
             if norm:
                 qq, kk = O.rms_norm(qq, qw.float()), O.rms_norm(kk, kw_.float())
             ref = O.sdpa(qq.float()[None], kk.float()[None], vv[None])[0]
-            check(pp[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, what=f"ping-pong flash b{bi} h{h}")
+            # P and the output are bf16: 2^-6 of max|ref| over up to 280 (batch, head) slices (the three kernels agree bit for bit)
+            check(pp[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"flash b{bi} h{h}")
     assert torch.equal(pp, base), f"ping-pong flash differs from the default kernel: max {float((pp.float() - base.float()).abs().max()):.3e}"
 
 

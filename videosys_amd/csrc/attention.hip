@@ -135,6 +135,7 @@ struct FlashParams {
   const bf16_t* vt;                        // [batch][H][96][kv_pad]
   bf16_t* out; int64_t out_stride;         // out(b, s, h) at out + (b*q_len + s)*out_stride + h*72
   int heads, q_len, kv_len, kv_pad, nqb;
+  int chunks;                              // RES kernel: workgroups per (batch, head), each walks nqb / chunks query blocks
   float eps;
   unsigned long long* dbg;                 // lab variant 2 only: 5 phase-cycle accumulators
 };
@@ -145,8 +146,13 @@ struct FlashParams {
 // at the phase boundaries of every tile, summed per wave into p.dbg[0..4] (QK issue | max chain | exp + PV | vmcnt | barrier).
 // (An 8-wave form of this kernel — 256 rows share a K/V tile and its 19 LDS-DMA pieces, one workgroup per CU — measured 0.256 vs
 // 0.247 ms at the config-2 spatial shape: the per-tile barrier then couples both waves of every SIMD.  Not kept.)
-template <int ABL, int WPS>
-__global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p) {
+// RES ("resident K/V", few keys — the cross attention against <= 320 text tokens): one workgroup = 8 waves = 256 query rows per
+// step stages ALL KV tiles of its (batch, head) into LDS once (<= 5 stages = 112.5 KiB) and then walks nqb / chunks query blocks
+// with no LDS-DMA, no vmcnt wait and no barrier in the loop: a wave's 5 pieces per tile cost it ~180 cycles each at issue
+// (DESIGN.md §3.2), which for 5-tile problems is most of the per-tile overhead.  Same tile() code, same arithmetic, same bits.
+constexpr int RES_MAX_TILES = 5;
+template <int ABL, int WPS, bool RES = false>
+__global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72_kernel(FlashParams p) {
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -154,10 +160,11 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
   // 1-D grid with the XCD remap: the q-blocks of one (batch, head) share K/V, so they must be CONSECUTIVE on one XCD to
   // hit its L2 (a 2-D grid with gridDim.x == 8 puts each of them on a different XCD: 5.7x over-fetch measured).
   const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = tile_id / p.nqb;
-  const int qb = tile_id - bh * p.nqb;
+  const int bh = RES ? tile_id / p.chunks : tile_id / p.nqb;
+  const int qb = RES ? tile_id - bh * p.chunks : tile_id - bh * p.nqb;   // RES: the chunk of query blocks this workgroup walks
   const int b = bh / p.heads, h = bh - b * p.heads;
-  const int q0 = qb * 128 + wave * 32;
+  constexpr int NW = RES ? 8 : 4;
+  int q0 = qb * 128 + wave * 32;   // (RES: set per query block below)
 
   // ---- K/V staging by LDS-DMA: 9 K pieces (1 KiB each, the tile is contiguous) + 10 Vt pieces (8 rows x 128 B each,
   // rows 0..79; rows 80..95 of the LDS image are zeroed once and never overwritten); wave w issues pieces w, w+4, ...
@@ -174,8 +181,8 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
   auto stage = [&](int t, int buf) {
     char* base = smem + buf * KV_STAGE;
 #pragma unroll
-    for (int idx = 0; idx < 5; ++idx) {
-      const int piece = wave_u + 4 * idx;
+    for (int idx = 0; idx < (RES ? 3 : 5); ++idx) {
+      const int piece = wave_u + NW * idx;
       if (piece < 9) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
       } else if (piece < 19) {
@@ -187,15 +194,21 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
   };
   // the first K/V tile is requested BEFORE the Q rows: both round trips are in flight together (with 300 text keys a workgroup
   // lives for five tiles only, so a serialized prologue is a tenth of it)
-  stage(0, 0);
-  {  // rows 80..95 of both Vt images (MFMA padding the DMA never writes): 2 x 2 KiB of zeros
+  const int ntiles = (p.kv_len + 63) / 64;  // tiles made only of keys >= kv_len are never touched (kv_pad is the stride)
+  if constexpr (RES) {
+    for (int t = 0; t < ntiles; ++t) stage(t, t);   // every tile of this (batch, head), once
+    for (int q = tid; q < ntiles * 128; q += 512)
+      *reinterpret_cast<uint4*>(smem + (q >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (q & 127) * 16) = make_uint4(0, 0, 0, 0);
+  } else {
+    stage(0, 0);
+    // rows 80..95 of both Vt images (MFMA padding the DMA never writes): 2 x 2 KiB of zeros
     char* z = smem + (tid >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (tid & 127) * 16;
     *reinterpret_cast<uint4*>(z) = make_uint4(0, 0, 0, 0);
   }
 
   // ---- Q fragment (B operand): lane holds Q[q0 + l31][16c + 8hi .. +8], c = 0..4 (d >= 72 -> 0)
   bf16x8 qf[5];
-  {
+  auto load_q = [&]() {
     int qs = q0 + l31;
     qs = qs < p.q_len ? qs : p.q_len - 1;
     const bf16_t* qrow = p.q + ((int64_t)b * p.q_len + qs) * p.q_stride + h * HD;
@@ -231,7 +244,8 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
     for (int c = 0; c < 5; ++c)
 #pragma unroll
       for (int e = 0; e < 8; ++e) qf[c][e] = (__bf16)x[c][e];
-  }
+  };
+  if constexpr (!RES) load_q();
 
   // Vt fragment read offsets: row dt*32 + l31, logical slot kt*4 + 2hi + cc  ->  + dt*4096, ^ ((kt*4 + cc) << 4)
   const int v_roff = K_TILE_BYTES + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4);
@@ -240,18 +254,19 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
   const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
 
   f32x16 o[3];
+  f32x16 minit;
+  auto reset_acc = [&]() {
 #pragma unroll
-  for (int dt = 0; dt < 3; ++dt)
+    for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+      for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) minit[r] = 0.f;
+  };
+  reset_acc();
   // Running max m (exp2 domain: K carries scale*log2e) is kept NEGATED and splatted over 16 registers: it is the C input
   // of the first QK^T MFMA of every 32-key tile, so the accumulators come out as s - m, ready for v_exp, with no
   // per-tile zero-init and no per-element subtract.  The row sum l lives in o[2][4] (Vt rows 72/76 are ones).
-  f32x16 minit;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
-
-  const int ntiles = (p.kv_len + 63) / 64;  // tiles made only of keys >= kv_len are never touched (kv_pad is the stride)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -361,33 +376,13 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
     FLASH_STAMP(2);
   };
 
-  if (ABL == 2) tprev = __builtin_amdgcn_s_memtime();
-  for (int t = 0; t < ntiles - 1; ++t) {  // last tile peeled: no conditional staging inside the loop
-    const int cur = t & 1;
-    if (ABL != 1) stage(t + 1, cur ^ 1);  // every wave finished reading buffer cur^1 before the barrier of tile t-1
-    __builtin_amdgcn_sched_barrier(0);
-    tile(t, cur, false);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
-    FLASH_STAMP(3);
-    __syncthreads();                                   // ... and so have everybody else's
-    FLASH_STAMP(4);
-  }
-  if (p.kv_len & 63) tile(ntiles - 1, (ntiles - 1) & 1, true);
-  else tile(ntiles - 1, (ntiles - 1) & 1, false);
-
-  if (ABL == 2 && lane == 0 && p.dbg != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) atomicAdd(p.dbg + i, tacc[i]);
-  }
-#undef FLASH_STAMP
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi
-  const float inv = 1.0f / o[2][4];  // d = 72 (hi = 0) / 76 (hi = 1): the ones rows of Vt, i.e. sum_k P[k][q]
-  const int qs = q0 + l31;
   // Stores widened to 16 bytes (cdna_hip_programming.md T21): group pair (g, g+1) of a 32-dim block is exchanged between the
   // half-waves with v_permlane32_swap, after which lanes 0-31 hold dims 32dt + 16k .. +7 and lanes 32-63 dims +8 .. +15 of their
   // row: 5 dwordx4 stores per lane instead of 9 dwordx2 (the tail is store-issue bound, not bandwidth bound).
-  {
+  auto store_o = [&]() {
+    const float inv = 1.0f / o[2][4];  // d = 72 (hi = 0) / 76 (hi = 1): the ones rows of Vt, i.e. sum_k P[k][q]
+    const int qs = q0 + l31;
     bf16_t* orow = p.out + ((int64_t)b * p.q_len + (qs < p.q_len ? qs : p.q_len - 1)) * p.out_stride + h * HD + 8 * hi;
 #pragma unroll
     for (int dt = 0; dt < 3; ++dt) {
@@ -405,7 +400,45 @@ __global__ __launch_bounds__(256, WPS) void flash_attn_d72_kernel(FlashParams p)
         if (qs < p.q_len && d0 + 8 * hi + 8 <= HD) *reinterpret_cast<uint4*>(orow + d0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
       }
     }
+  };
+
+  if constexpr (RES) {
+    // every KV tile is resident: walk this workgroup's query blocks (256 rows each) with nothing but tile() in the loop
+    const int nqb = (p.q_len + 255) >> 8;
+    const int qb0 = (int)((int64_t)qb * nqb / p.chunks), qb1 = (int)((int64_t)(qb + 1) * nqb / p.chunks);
+    const bool ragged = (p.kv_len & 63) != 0;
+    for (int blk = qb0; blk < qb1; ++blk) {
+      q0 = blk * 256 + wave * 32;
+      if (blk != qb0) reset_acc();
+      load_q();
+      for (int t = 0; t < ntiles - 1; ++t) tile(t, t, false);
+      if (ragged) tile(ntiles - 1, ntiles - 1, true);
+      else tile(ntiles - 1, ntiles - 1, false);
+      store_o();
+    }
+  } else {
+    if (ABL == 2) tprev = __builtin_amdgcn_s_memtime();
+    for (int t = 0; t < ntiles - 1; ++t) {  // last tile peeled: no conditional staging inside the loop
+      const int cur = t & 1;
+      if (ABL != 1) stage(t + 1, cur ^ 1);  // every wave finished reading buffer cur^1 before the barrier of tile t-1
+      __builtin_amdgcn_sched_barrier(0);
+      tile(t, cur, false);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
+      FLASH_STAMP(3);
+      __syncthreads();                                   // ... and so have everybody else's
+      FLASH_STAMP(4);
+    }
+    if (p.kv_len & 63) tile(ntiles - 1, (ntiles - 1) & 1, true);
+    else tile(ntiles - 1, (ntiles - 1) & 1, false);
+
+    if (ABL == 2 && lane == 0 && p.dbg != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 5; ++i) atomicAdd(p.dbg + i, tacc[i]);
+    }
+    store_o();
   }
+#undef FLASH_STAMP
 #endif
 }
 
@@ -1023,11 +1056,12 @@ __global__ __launch_bounds__(256) void attn_temporal_d72_v2_kernel(const bf16_t*
 
 static int g_flash_variant = 0;
 static unsigned long long* g_flash_dbg = nullptr;
-// 0 = shipped default, 3 = three workgroups per CU, 4 / 9 = force the VALU (v2) / online-softmax temporal kernels: all valid.  1 (K/V tiles not
+// 0 = shipped default (resident-K/V kernel for <= 320 keys and many query rows), 3 = three workgroups per CU, 4 / 9 = force the VALU (v2) /
+// online-softmax temporal kernels, 5 = ping-pong wave groups, 8 = resident-K/V kernel whenever the keys fit, 10 = never: all valid.  1 (K/V tiles not
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 5: case 9: break;
+    case 0: case 3: case 4: case 5: case 8: case 9: case 10: break;
 #ifdef VSYS_LAB
     case 1: case 2: case 6: case 61: case 62: break;
 #endif
@@ -1059,6 +1093,7 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
   p.nqb = (q_len + 127) / 128;
+  p.chunks = 1;
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
   if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
   dim3 grid((unsigned)nblk);
@@ -1080,6 +1115,31 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
     return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
   }
 #endif
+  // few keys (cross attention: <= 320 text tokens) and enough query rows to give every CU one workgroup: resident-K/V kernel
+  if ((g_flash_variant == 0 || g_flash_variant == 8) && (kv_len + 63) / 64 <= RES_MAX_TILES) {
+    static int ncu = 0;
+    if (ncu == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+      if (ncu <= 0) ncu = 256;
+    }
+    const int nqb = (q_len + 255) / 256;
+    int chunks = ncu / (batch * heads);
+    chunks = chunks < 1 ? 1 : (chunks > nqb ? nqb : chunks);
+    // worth it when a workgroup walks several query blocks (the K/V load is paid once per workgroup); variant 8 forces it
+    if (g_flash_variant == 8 || nqb >= 2 * chunks) {
+      p.chunks = chunks;
+      p.nqb = nqb;
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)flash_attn_d72_kernel<0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_TILES * KV_STAGE);
+        attr_set = true;
+      }
+      hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE, stream, p);
+      return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+    }
+  }
   if (g_flash_variant == 5) {   // ping-pong wave groups: 256 query rows per workgroup, five-stage K/V ring
     p.nqb = (q_len + 255) / 256;
     const int64_t nb = (int64_t)p.nqb * batch * heads;
