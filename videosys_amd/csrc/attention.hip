@@ -23,6 +23,9 @@
 #include "common.h"
 #include "vsys_internal.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace vsys {
 namespace {
 
@@ -151,6 +154,7 @@ struct FlashParams {
 // with no LDS-DMA, no vmcnt wait and no barrier in the loop: a wave's 5 pieces per tile cost it ~180 cycles each at issue
 // (DESIGN.md §3.2), which for 5-tile problems is most of the per-tile overhead.  Same tile() code, same arithmetic, same bits.
 constexpr int RES_MAX_TILES = 5;
+constexpr int RES_Q_BYTES = 5 * 1024;   // per-wave Q image (32 rows x 144 B = 4.5 KiB, staged in 5 LDS-DMA pieces)
 template <int ABL, int WPS, bool RES = false>
 __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72_kernel(FlashParams p) {
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
@@ -208,21 +212,24 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
 
   // ---- Q fragment (B operand): lane holds Q[q0 + l31][16c + 8hi .. +8], c = 0..4 (d >= 72 -> 0)
   bf16x8 qf[5];
-  auto load_q = [&]() {
-    int qs = q0 + l31;
+  // split in two so that the resident-K/V loop can request the rows of query block i + 1 before the tiles of block i
+  uint4 qraw[5];
+  auto fetch_q = [&](int q0_) {
+    int qs = q0_ + l31;
     qs = qs < p.q_len ? qs : p.q_len - 1;
     const bf16_t* qrow = p.q + ((int64_t)b * p.q_len + qs) * p.q_stride + h * HD;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int d0 = 16 * c + 8 * hi;
+      qraw[c] = d0 < HD ? *reinterpret_cast<const uint4*>(qrow + d0) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto finish_q = [&]() {
     float x[5][8];
     float ss = 0.f;
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
-      const int d0 = 16 * c + 8 * hi;
-      if (d0 < HD) {
-        unpack8(*reinterpret_cast<const uint4*>(qrow + d0), x[c]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[c][e] = 0.f;
-      }
+      unpack8(qraw[c], x[c]);
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
     }
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
 #pragma unroll
       for (int e = 0; e < 8; ++e) qf[c][e] = (__bf16)x[c][e];
   };
-  if constexpr (!RES) load_q();
+  if constexpr (!RES) { fetch_q(q0); finish_q(); }
 
   // Vt fragment read offsets: row dt*32 + l31, logical slot kt*4 + 2hi + cc  ->  + dt*4096, ^ ((kt*4 + cc) << 4)
   const int v_roff = K_TILE_BYTES + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4);
@@ -407,13 +414,170 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
     const int nqb = (p.q_len + 255) >> 8;
     const int qb0 = (int)((int64_t)qb * nqb / p.chunks), qb1 = (int)((int64_t)(qb + 1) * nqb / p.chunks);
     const bool ragged = (p.kv_len & 63) != 0;
+    // The Q rows of query block i + 1 travel HBM -> LDS (wave-private 5 KiB image: 32 rows x 144 B, contiguous 16-byte units) by
+    // LDS-DMA under the tiles of block i: a register prefetch (20 VGPRs) makes hipcc spill inside tile(), and without a prefetch
+    // the global round trip (~2 us) is exposed once per five tiles.
+    char* qlds = smem + RES_MAX_TILES * KV_STAGE + wave_u * RES_Q_BYTES;
+    const auto rsrc_q = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + (int64_t)b * p.q_len * p.q_stride + h * HD), 0, 0x7fffffff, 0x00020000);
+    auto dma_q = [&](int q0_) {
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));   // opaque: the ten row / chunk terms below are recomputed per block, not kept in VGPRs across tile()
+#pragma unroll
+      for (int pc = 0; pc < 5; ++pc) {
+        const int u = pc * 64 + lane_o;          // 16-byte unit: row u / 9, chunk u % 9 (units >= 288 re-read row 31: never used)
+        int row = (u * 7282) >> 16;              // u / 9 for u < 320
+        const int ch = u - 9 * row;
+        row = row < 32 ? row : 31;
+        int r = q0_ + row;
+        r = r < p.q_len ? r : p.q_len - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_q, (lds_ptr_t)(qlds + pc * 1024), 16, (int)(r * (int)p.q_stride * 2 + ch * 16), 0, 0, 0);
+      }
+    };
+    dma_q(qb0 * 256 + wave * 32);
     for (int blk = qb0; blk < qb1; ++blk) {
       q0 = blk * 256 + wave * 32;
       if (blk != qb0) reset_acc();
-      load_q();
-      for (int t = 0; t < ntiles - 1; ++t) tile(t, t, false);
-      if (ragged) tile(ntiles - 1, ntiles - 1, true);
-      else tile(ntiles - 1, ntiles - 1, false);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q image has landed (nobody else touches it)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int d0 = 16 * c + 8 * hi;
+        qraw[c] = d0 < HD ? *reinterpret_cast<const uint4*>(qlds + l31 * KROW + (2 * c + hi) * 16) : make_uint4(0, 0, 0, 0);
+      }
+      finish_q();
+      __builtin_amdgcn_sched_barrier(0);
+      if (blk + 1 < qb1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads above are done before the image is overwritten
+        dma_q(q0 + 256);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ABL == 3) {   // lab: the unpipelined tile() sequence (A/B of the software pipeline below; same bits)
+        for (int t = 0; t < ntiles - 1; ++t) tile(t, t, false);
+        if (ragged) tile(ntiles - 1, ntiles - 1, true);
+        else tile(ntiles - 1, ntiles - 1, false);
+      } else {
+        // Software pipeline over the KV tiles (nothing in this loop waits for memory or for another wave, so the only thing
+        // between the matrix pipe and its work is the order of this wave's own instruction stream):
+        //   (a)  S(t+1) = K(t+1) Q^T - m   [10 MFMAs]   beside   P(t) = exp2(S(t)), keys 0..31     [16 exp]
+        //   (b)  O += Vt(t) P(t)^T         [12 MFMAs]   beside   exp2 of keys 32..63, then mask / max of S(t+1)
+        //   rare: rescale O, m, S(t+1) when the max of tile t+1 overshoots (same rule and arithmetic as tile())
+        // Same operations on the same values in the same per-accumulator order as tile(): bit-identical results.
+        f32x16 sa[2], sb[2];
+        bf16x8 pa0[2], pa1[2];
+        auto qk = [&](int t, f32x16 (&d)[2]) {
+          const char* sk = smem + t * KV_STAGE;
+          bf16x8 kf0[5], kf1[5];
+#pragma unroll
+          for (int cc = 0; cc < 5; ++cc) {
+            kf0[cc] = *reinterpret_cast<const bf16x8*>(sk + krow * KROW + 16 * hi + 32 * cc);
+            kf1[cc] = *reinterpret_cast<const bf16x8*>(sk + (32 + krow) * KROW + 16 * hi + 32 * cc);
+          }
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d[0]) : "v"(kf0[0]), "v"(qf[0]), "v"(minit));
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d[1]) : "v"(kf1[0]), "v"(qf[0]), "v"(minit));
+#pragma unroll
+          for (int cc = 1; cc < 5; ++cc) {
+            d[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[cc], qf[cc], d[0], 0, 0, 0);
+            d[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[cc], qf[cc], d[1], 0, 0, 0);
+          }
+        };
+        // mask (last ragged tile) and tile max: VALU only, scheduled beside the PV MFMAs of the previous tile
+        auto tile_max = [&](int t, f32x16 (&d)[2], const bool masked) -> float {
+          if (masked) {   // (wave-uniform, last tile of a ragged kv_len only)
+            const int lim = p.kv_len - (t * 64 + 16 * hi);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r)
+                if (kt * 32 + r >= lim) d[kt][r] = NEG_BIG;
+          }
+          float mx = d[0][0];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, d[kt][r]);
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+          return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        };
+        // deferred rescale of everything that is relative to the running max (rare after the first tile)
+        auto rescale = [&](int t, f32x16 (&d)[2], float mx) {
+          if (t == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0) {
+            asm volatile("; rescale path (rare): kept out of line" ::: "memory");
+            const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) minit[r] -= delta;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) d[kt][r] -= delta;
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+              for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          }
+        };
+#define RES_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)
+        // one pipeline step on S(t) in sc (already max-processed); S(t+1) is produced into sn
+        // (has_next is a compile-time tag: as a run-time condition it splits (a) and (b) into several basic blocks and nothing can
+        // be scheduled across them)
+        auto step = [&](auto has_next_tag, int t, f32x16 (&sc)[2], f32x16 (&sn)[2], const bool next_masked) {
+          const char* sk = smem + t * KV_STAGE;
+          constexpr bool has_next = decltype(has_next_tag)::value;
+          // (a)
+          if constexpr (has_next) qk(t + 1, sn);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pa0[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(sc[0][r]);
+          bf16x8 vf0[2][3], vf1[2][3];
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) {
+              vf0[cc][dt] = *reinterpret_cast<const bf16x8*>(sk + dt * 32 * VROW + (v_roff ^ ((0 * 4 + cc) << 4)));
+              vf1[cc][dt] = *reinterpret_cast<const bf16x8*>(sk + dt * 32 * VROW + (v_roff ^ ((1 * 4 + cc) << 4)));
+            }
+          // emitted order of (a): the 20 K fragment reads, then every QK^T MFMA followed by two exps, a convert and a Vt read —
+          // left alone hipcc issues the ten MFMAs back to back and the exps behind them, i.e. nothing overlaps (in-order issue)
+          if constexpr (has_next) {
+            RES_SGB(0x100, 20);
+#pragma unroll
+            for (int i = 0; i < 10; ++i) { RES_SGB(0x008, 1); RES_SGB(0x400, 2); RES_SGB(0x002, 1); RES_SGB(0x100, 1); }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          // (b)
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[cc][dt], pa0[cc], o[dt], 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 16; ++r) pa1[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(sc[1][r]);
+#pragma unroll
+          for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+            for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[cc][dt], pa1[cc], o[dt], 0, 0, 0);
+          float mxn = 0.f;
+          if constexpr (has_next) mxn = tile_max(t + 1, sn, next_masked);
+          // first six PV MFMAs: the 16 exps + 8 converts of keys 32..63 beside them; last six: the max chain of S(t+1)
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { RES_SGB(0x008, 1); RES_SGB(0x400, 3); RES_SGB(0x002, 2); }
+#pragma unroll
+          for (int i = 0; i < 6; ++i) { RES_SGB(0x008, 1); RES_SGB(0x002, 5); }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (has_next) rescale(t + 1, sn, mxn);
+        };
+        qk(0, sa);
+        rescale(0, sa, (ragged && ntiles == 1) ? tile_max(0, sa, true) : tile_max(0, sa, false));
+        int t = 0;
+        for (; t + 2 < ntiles; t += 2) {   // two steps per trip: the S buffers swap roles without register copies
+          step(std::true_type{}, t, sa, sb, false);
+          step(std::true_type{}, t + 1, sb, sa, ragged && t + 2 == ntiles - 1);
+        }
+        if (t + 1 < ntiles) {   // two tiles left
+          step(std::true_type{}, t, sa, sb, ragged);
+          step(std::false_type{}, t + 1, sb, sa, false);
+        } else {
+          step(std::false_type{}, t, sa, sb, false);
+        }
+#undef RES_SGB
+      }
       store_o();
     }
   } else {
@@ -1128,15 +1292,16 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
     int chunks = ncu / (batch * heads);
     chunks = chunks < 1 ? 1 : (chunks > nqb ? nqb : chunks);
     // worth it when a workgroup walks several query blocks (the K/V load is paid once per workgroup); variant 8 forces it
-    if (g_flash_variant == 8 || nqb >= 2 * chunks) {
+    const bool fits = (int64_t)q_len * q_stride * 2 < 0x7fffffff;   // 32-bit row offsets in the Q staging
+    if (fits && (g_flash_variant == 8 || nqb >= 2 * chunks)) {
       p.chunks = chunks;
       p.nqb = nqb;
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)flash_attn_d72_kernel<0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_TILES * KV_STAGE);
+        (void)hipFuncSetAttribute((const void*)flash_attn_d72_kernel<0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES);
         attr_set = true;
       }
-      hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE, stream, p);
+      hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES, stream, p);
       return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
     }
   }
@@ -1156,7 +1321,11 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   else if (g_flash_variant == 2) hipLaunchKernelGGL((flash_attn_d72_kernel<2, 2>), grid, dim3(256), lds, stream, p);
   else
 #endif
-  if (g_flash_variant == 3) hipLaunchKernelGGL((flash_attn_d72_kernel<0, 3>), grid, dim3(256), lds, stream, p);
+  // three workgroups per CU pay for long, unmasked key sequences (spatial attention: 0.241 vs 0.251 ms); with a masked last tile
+  // the 168-register variant spills in the peeled tile (cross shape 0.156 vs 0.099 ms)
+  static const bool wps3_ok = [] { const char* e = getenv("VSYS_FLASH_WPS3"); return !(e && e[0] == '0'); }();
+  if (g_flash_variant == 3 || (g_flash_variant == 0 && wps3_ok && kv_len >= 512 && (kv_len & 63) == 0))
+    hipLaunchKernelGGL((flash_attn_d72_kernel<0, 3>), grid, dim3(256), lds, stream, p);
   else hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2>), grid, dim3(256), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
