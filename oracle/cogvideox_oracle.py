@@ -107,8 +107,13 @@ class CogVideoXOracle:
                  out_channels: int = 16, max_text_seq_length: int = 226, sample_width: int = 90, sample_height: int = 60,
                  sample_frames: int = 49, temporal_compression_ratio: int = 4, spatial_interpolation_scale: float = 1.875,
                  temporal_interpolation_scale: float = 1.0, use_rotary_positional_embeddings: bool = False,
-                 norm_eps: float = 1e-5):
-        self.sd = {k: v.float() for k, v in sd.items()}
+                 norm_eps: float = 1e-5, device=None, dtype: torch.dtype = torch.float32):
+        """device / dtype: the checker may run on the GPU; dtype = bfloat16 executes the same module graph with torch's bf16
+        kernels, i.e. the way the reference itself runs the model (its distance from the fp32 run is the reference's own noise
+        floor — tests/fulldepth_util.py)."""
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        self.dtype = dtype
+        self.sd = {k: v.to(device=self.device, dtype=dtype) for k, v in sd.items()}
         self.L, self.H, self.D, self.C = num_layers, num_heads, head_dim, num_heads * head_dim
         self.p, self.co = patch_size, out_channels
         self.max_text = max_text_seq_length
@@ -116,7 +121,7 @@ class CogVideoXOracle:
         self.eps = norm_eps
         pf = (sample_frames - 1) // temporal_compression_ratio + 1
         self.pos3d = sincos_3d(self.C, sample_width // patch_size, sample_height // patch_size, pf,
-                               spatial_interpolation_scale, temporal_interpolation_scale)
+                               spatial_interpolation_scale, temporal_interpolation_scale).to(device=self.device, dtype=dtype)
 
     def attn(self, x: Tensor, prefix: str, text_len: int, rope) -> Tensor:
         """CogVideoXAttnProcessor2_0 on the joint sequence x [B, Lt + Lv, C]."""
@@ -130,17 +135,28 @@ class CogVideoXOracle:
             n = cos.shape[0]
             q = torch.cat([q[:, :, :text_len], apply_rope(q[:, :, text_len:text_len + n], cos, sin), q[:, :, text_len + n:]], 2)
             k = torch.cat([k[:, :, :text_len], apply_rope(k[:, :, text_len:text_len + n], cos, sin), k[:, :, text_len + n:]], 2)
-        o = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v
+        if L > 4096 or self.dtype != torch.float32:
+            # long sequences (config 5: 17 776 rows) / low precision: F.scaled_dot_product_attention, which is what the reference's
+            # CogVideoXAttnProcessor2_0 calls (same softmax(q k^T / sqrt(D)) v; no [B, H, L, L] score tensor)
+            o = torch.cat([F.scaled_dot_product_attention(q[:, h0:h0 + 4], k[:, h0:h0 + 4], v[:, h0:h0 + 4]) for h0 in range(0, H, 4)], 1)
+        else:
+            o = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v
         return linear(o.transpose(1, 2).reshape(B, L, C), sd, prefix + ".to_out.0")
 
-    def forward(self, hidden_states: Tensor, encoder_hidden_states: Tensor, timestep: Tensor, image_rotary_emb=None) -> Tensor:
+    def forward(self, hidden_states: Tensor, encoder_hidden_states: Tensor, timestep: Tensor, image_rotary_emb=None,
+                on_hidden=None) -> Tensor:
+        """on_hidden(i, x): called with the joint hidden state after block i (full-depth parity tables)."""
         sd, C, p = self.sd, self.C, self.p
+        dd = dict(device=self.device, dtype=self.dtype)
+        hidden_states, encoder_hidden_states = hidden_states.to(**dd), encoder_hidden_states.to(**dd)
+        if image_rotary_emb is not None:
+            image_rotary_emb = tuple(t.to(**dd) for t in image_rotary_emb)
         B, Fr, cin, Hh, Ww = hidden_states.shape
-        emb = linear(F.silu(linear(timestep_embedding(timestep.float(), C), sd, "time_embedding.linear_1")), sd,
+        emb = linear(F.silu(linear(timestep_embedding(timestep.float(), C).to(**dd), sd, "time_embedding.linear_1")), sd,
                      "time_embedding.linear_2")
-        txt = linear(encoder_hidden_states.float(), sd, "patch_embed.text_proj")
+        txt = linear(encoder_hidden_states, sd, "patch_embed.text_proj")
         Lt = txt.shape[1]
-        img = F.conv2d(hidden_states.float().reshape(-1, cin, Hh, Ww), sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"],
+        img = F.conv2d(hidden_states.reshape(-1, cin, Hh, Ww), sd["patch_embed.proj.weight"], sd["patch_embed.proj.bias"],
                        stride=p)
         img = img.view(B, Fr, C, -1).transpose(2, 3).flatten(1, 2)
         Lv = img.shape[1]
@@ -160,6 +176,8 @@ class CogVideoXOracle:
             h = torch.cat([n[:, :Lt] * (1 + esc)[:, None] + esh[:, None], n[:, Lt:] * (1 + sc)[:, None] + sh[:, None]], 1)
             f = linear(F.gelu(linear(h, sd, pre + ".ff.net.0.proj"), approximate="tanh"), sd, pre + ".ff.net.2")
             x = torch.cat([x[:, :Lt] + eg[:, None] * f[:, :Lt], x[:, Lt:] + g[:, None] * f[:, Lt:]], 1)
+            if on_hidden is not None:
+                on_hidden(i, x)
         # norm_final: on the video rows (2B) or on the joint sequence then sliced (5B) — LayerNorm is row-wise: identical
         v = ln(x[:, Lt:], sd, "norm_final", self.eps)
         shift, scale = linear(silu_emb, sd, "norm_out.linear").chunk(2, dim=1)  # chunk_dim=1: (shift, scale)

@@ -170,3 +170,51 @@ def opensora_pab_schedule(hip, ref, floor, y_null, z, y, mask, geom, steps=30, c
         finally:
             m.set_pab(None)
     return dict(steps=steps, z_hip=stats(z_hip, res["ref"]), z_floor=stats(res["floor"], res["ref"]))
+
+
+# ------------------------------------------------------------------------------------------------ CogVideoX, config 5 geometry
+def cogvideox_models(model="5b", layers=None, seed=777, device="cuda:0"):
+    """CogVideoX-5B (48 heads x 64, 42 layers, 3-D RoPE) / -2B (30 heads, 30 layers, sincos table) geometry, seeded synthetic
+    weights (bf16-representable): product, fp32 oracle and the oracle's bf16 run, all on the GPU."""
+    from oracle import cogvideox_oracle as CO
+    from videosys_amd.cogvideox import CogVideoXTransformer3DModel
+
+    geo = dict(num_attention_heads=48, num_layers=42, use_rotary_positional_embeddings=True) if model == "5b" else \
+        dict(num_attention_heads=30, num_layers=30, use_rotary_positional_embeddings=False)
+    if layers:
+        geo["num_layers"] = layers
+    sd = CO.synth_state_dict(geo["num_layers"], geo["num_attention_heads"], seed=seed)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+    hip = CogVideoXTransformer3DModel(**geo, device=torch.device(device))
+    hip.load_state_dict(sd)
+    kw = dict(num_layers=geo["num_layers"], num_heads=geo["num_attention_heads"],
+              use_rotary_positional_embeddings=geo["use_rotary_positional_embeddings"], device=device)
+    ref = CO.CogVideoXOracle(sd, dtype=torch.float32, **kw)
+    floor = CO.CogVideoXOracle(sd, dtype=torch.bfloat16, **kw)
+    return hip, ref, floor, geo
+
+
+def cogvideox_one_step(hip, ref, floor, geo, frames=13, hh=60, ww=90, text_len=226, t_value=801, seed=0):
+    """One CFG-batched forward (BASELINE config 5: 720x480x49f -> latent [13, 16, 60, 90], 17 550 video + 226 text rows per
+    sample): output + per-block hidden-state error against the fp32 oracle, next to the oracle's own bf16 run."""
+    from oracle import cogvideox_oracle as CO
+
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(1, frames, 16, hh, ww, generator=g).to(torch.bfloat16).float().repeat(2, 1, 1, 1, 1)
+    y = (torch.randn(2, text_len, 4096, generator=g) * 0.1).to(torch.bfloat16).float()
+    t = torch.tensor([t_value, t_value])
+    rope = CO.prepare_rope(hh * 8, ww * 8, frames, 64) if geo["use_rotary_positional_embeddings"] else None
+    ref_h = []
+    out_ref = ref.forward(x, y, t, image_rotary_emb=rope, on_hidden=lambda i, h: ref_h.append(h.detach().clone()))
+    floor_stats = []
+    out_floor = floor.forward(x, y, t, image_rotary_emb=rope, on_hidden=lambda i, h: floor_stats.append(stats(h, ref_h[i])))
+    hip_stats = []
+    hip._hidden_tap = lambda i, h: hip_stats.append(stats(h, ref_h[i]))
+    try:
+        out_hip = hip(x, y, t, image_rotary_emb=rope, return_dict=False)[0]
+    finally:
+        hip._hidden_tap = None
+    torch.cuda.synchronize()
+    rows = [dict(block=i, hip_rel_rms=a["rel_rms"], floor_rel_rms=b["rel_rms"], hip_cos=a["cosine"], floor_cos=b["cosine"])
+            for i, (a, b) in enumerate(zip(hip_stats, floor_stats))]
+    return dict(out_hip=stats(out_hip, out_ref), out_floor=stats(out_floor, out_ref), per_block=rows)

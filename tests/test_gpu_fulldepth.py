@@ -70,3 +70,27 @@ def test_latte_config1_full_depth():
     for row in r["per_pair"]:
         assert row["hip_rel_rms"] <= 1.5 * row["floor_rel_rms"], f"hidden state after pair {row['pair']}: {row}"
     torch.cuda.empty_cache()
+
+
+def test_cogvideox_config5_full_depth():
+    """BASELINE config 5 geometry exactly: CogVideoX-5B, 42 blocks, 48 heads x 64, 3-D RoPE, latent [13, 16, 60, 90] = 17 550 video +
+    226 text rows per sample, CFG batch 2 (the d64 flash kernel on a 17 776-row joint sequence, LayerNormZero with two modulation
+    sets, the gated residual epilogues, the im2col patch GEMM): one full-depth step against the fp32 oracle on the GPU, next to the
+    oracle's own bf16 run."""
+    import gc
+
+    from videosys_amd import pab
+
+    pab.set_pab_manager(None)
+    hip, ref, floor, geo = U.cogvideox_models("5b")
+    r = U.cogvideox_one_step(hip, ref, floor, geo)
+    print("\n[fulldepth] cogvideox-5b config5 one step: " + json.dumps({k: v for k, v in r.items() if k != "per_block"}))
+    print("[fulldepth] cogvideox-5b per block (hip / floor rel-rms): " +
+          " ".join(f"{row['block']}:{row['hip_rel_rms']:.4f}/{row['floor_rel_rms']:.4f}" for row in r["per_block"][::6]))
+    why = U.verdict(r["out_hip"], r["out_floor"])
+    assert not why, f"CogVideoX-5B config 5 output: {why}"
+    for row in r["per_block"]:
+        assert row["hip_rel_rms"] <= 1.5 * row["floor_rel_rms"], f"hidden state after block {row['block']}: {row}"
+    del hip, ref, floor
+    gc.collect()
+    torch.cuda.empty_cache()

@@ -83,6 +83,7 @@ class CogVideoXTransformer3DModel:
         self.w: Dict[str, torch.Tensor] = {}
         self.parallel_manager = SimpleNamespace(sp_size=1, cp_size=1, dp_size=1, dp_rank=0, sp_group=None, cp_group=None)
         self._ws = {}
+        self._hidden_tap = None
         pf = (sample_frames - 1) // temporal_compression_ratio + 1
         self._pos3d = None
         if not use_rotary_positional_embeddings:
@@ -270,6 +271,8 @@ class CogVideoXTransformer3DModel:
                           out=self._buf("mlp_h", (B * Ll, w[pre + ".ff.net.0.proj.weight"].shape[0])))
             ops.gemm_gate2(hb, w[pre + ".ff.net.2.weight"], w[pre + ".ff.net.2.bias"], m2[0, 2 * C:3 * C], ms, Ll, Lt, 3 * C, res=x,
                            out=x)
+            if self._hidden_tap is not None:   # test hook (tests/fulldepth_util.py): joint hidden state after block i
+                self._hidden_tap(i, x.view(B, Ll, C))
         # 3. norm_final -> norm_out (AdaLayerNorm, chunk_dim=1: shift, scale) -> proj_out -> unpatchify, video rows only
         mo = mod[:, 2 * self.L * C6:]
         xv = self._buf("xm", (B * Lvl, C))
