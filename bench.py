@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--no-t5", action="store_true", help="skip the (untimed-region) T5 encode measurement")
     ap.add_argument("--text-len", type=int, default=300)
+    ap.add_argument("--geometry", default="512x512x64f", choices=["512x512x64f", "720p128f"],
+                    help="512x512x64f = BASELINE config 2 (the contract's workload); 720p128f = BASELINE configs[3] geometry "
+                         "(1280x720, 128 frames: 273 600 token rows), reported as its own workload, DiT step only")
     ap.add_argument("--gemm-variant", type=int, default=0, help="lab: vsys_tune_gemm_variant id (0 = shipped shape dispatch)")
     ap.add_argument("--flash-variant", type=int, default=0, help="lab: vsys_tune_flash_variant id (0 = shipped)")
     return ap.parse_args()
@@ -92,7 +95,10 @@ def main():
     from videosys_amd.stdit3 import STDiT3, STDiT3Config, synth_state_dict
 
     # ---- workload: BASELINE config 2 (config 3 with --pab)
-    frames, height, width = 64, 512, 512
+    frames, height, width = (64, 512, 512) if args.geometry == "512x512x64f" else (128, 720, 1280)
+    base_geo = args.geometry == "512x512x64f"
+    if not base_geo:
+        args.no_cpu_baseline = args.no_vae = args.no_t5 = True
     T, Hl, Wl = get_latent_size(frames, height, width)
     cfg = STDiT3Config(depth=args.depth)
     model = STDiT3(cfg, device=dev)
@@ -195,7 +201,7 @@ def main():
         roof = {
             "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> + vsys::gemm2_kernel<EPI> (256x192 tile, bf16 MFMA 32x32x16, shape-dispatched, all epilogues)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic if base_geo else None,
             "traffic_source": "profiles/r01_gemm_traffic.json (committed rocprofv3 PMC passes of the same kernels and shapes; NOT "
                               "re-measured by this run)",
             "annotations_not_measured_by_this_run": {
@@ -312,18 +318,20 @@ def main():
     if rank == 0:
         vpm = 60.0 / (STEPS_PER_VIDEO * step_s)
         line = {
-            "metric": "videos/min (Open-Sora 512x512x64f, 30 denoise steps, DiT denoising only) + sec/denoise-step",
+            "metric": (f"videos/min (Open-Sora {'512x512x64f' if base_geo else '1280x720x128f'}, 30 denoise steps, DiT denoising only) "
+                       "+ sec/denoise-step"),
             "value": round(vpm, 4), "unit": "videos/min", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(step_s * 1e3, 3), "sec_per_denoise_step": round(step_s, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {
-                "workload": ("open-sora-v1.2 STDiT3-XL/2 512x512x64f, latent [4,19,64,64], CFG batch 2 = 38912 token rows, "
+                "workload": ((f"open-sora-v1.2 STDiT3-XL/2 {'512x512x64f' if base_geo else '1280x720x128f (BASELINE configs[3] geometry)'}, "
+                              f"latent [4,{T},{Hl},{Wl}], CFG batch 2 = {2 * T * (Hl // 2) * (Wl // 2)} token rows, ") +
                              f"{L} text tokens, depth {args.depth}" + (", PAB attention-only (config 3)" if args.pab else "")),
                 "steps_per_video": STEPS_PER_VIDEO, "parallelism": f"dsp{world}",
                 "not_included": "value is DiT denoising only; vae_decode / t5_encode report the other two terms of the metric beside it",
-                "algorithmic_tflop_per_step": 89.4 if args.depth == 28 and L == 300 else None,
+                "algorithmic_tflop_per_step": 89.4 if args.depth == 28 and L == 300 and base_geo else None,
             },
-            "step_tflops": round(89.4 / step_s, 1) if args.depth == 28 and L == 300 and not args.pab else None,
+            "step_tflops": round(89.4 / step_s, 1) if args.depth == 28 and L == 300 and not args.pab and base_geo else None,
             "roofline": roof, "cpu_baseline": cpu, "vae_decode": vae, "t5_encode": t5, "dsp": dsp_info,
         }
         print(json.dumps(line), flush=True)

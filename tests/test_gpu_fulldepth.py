@@ -94,3 +94,41 @@ def test_cogvideox_config5_full_depth():
     del hip, ref, floor
     gc.collect()
     torch.cuda.empty_cache()
+
+
+def test_open_sora_720p_128f_geometry_two_block_pairs():
+    """BASELINE configs[3] geometry on ONE GPU (the 8-way DSP run shards exactly this): 720p x 128 frames -> latent [4, 38, 90, 160]
+    = 38 frames x 3600 tokens, CFG batch 2 = 273 600 token rows; spatial attention over 3600 keys (57 KV tiles, ragged last tile),
+    temporal attention over T = 38 (the register-resident VALU kernel: the MFMA kernel covers T <= 32), 300 text keys (resident-K/V
+    kernel, 1069 query blocks per sample).  Two block pairs of the XL/2 width against the fp32 oracle on the GPU, same tolerance."""
+    from oracle import stdit3_oracle as O
+    from videosys_amd.pipeline_open_sora import get_latent_size
+    from videosys_amd.stdit3 import STDiT3, STDiT3Config
+
+    T, Hl, Wl = get_latent_size(128, 720, 1280)
+    assert (T, Hl, Wl) == (38, 90, 160)
+    depth = 2
+    sd = U.bf16_round(O.synth_state_dict(depth, 1152, 16, seed=4321))
+    hip = STDiT3(STDiT3Config(depth=depth), device="cuda:0")
+    hip.load_state_dict(sd)
+    ref = O.STDiT3Oracle(sd, depth, 1152, 16, device="cuda:0", dtype=torch.float32)
+    floor = O.STDiT3Oracle(sd, depth, 1152, 16, device="cuda:0", dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 4, T, Hl, Wl, generator=g).to(torch.bfloat16).float()
+    y = (torch.randn(1, 1, 300, 4096, generator=g) * 0.1).to(torch.bfloat16).float()
+    mask = torch.zeros(1, 300, dtype=torch.long)
+    mask[:, :300] = 1
+    x = torch.cat([z, z], 0)
+    yy = torch.cat([y, sd["y_embedder.y_embedding"][None, None]], 0)
+    t = torch.tensor([600.0, 600.0]).to(torch.bfloat16).float()
+    kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([720.0, 720.0]), width=torch.tensor([1280.0, 1280.0]))
+    out_ref = ref.forward(x, t, yy, **kw)
+    out_floor = floor.forward(x, t, yy, **kw)
+    out_hip = hip(x, t, yy, **kw)
+    torch.cuda.synchronize()
+    r = dict(out_hip=U.stats(out_hip, out_ref), out_floor=U.stats(out_floor, out_ref))
+    print("\n[fulldepth] open-sora 720p x 128f, 2 block pairs: " + json.dumps(r))
+    why = U.verdict(r["out_hip"], r["out_floor"])
+    assert not why, f"720p x 128f geometry: {why}"
+    del hip, ref, floor
+    torch.cuda.empty_cache()
