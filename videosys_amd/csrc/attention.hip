@@ -182,18 +182,44 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
   // Vt piece j: lane -> row 8j + (lane>>3), physical slot lane&7 holds logical slot (lane&7) ^ ((row>>1)&7);
   // (row>>1)&7 = ((j&1)<<2) | (lane>>4), so odd pieces differ from even ones by XOR 64 in the byte offset
   const int v_voff = (lane >> 3) * p.kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
+  // Streaming kernel (4 waves, 5 slots each): slots 0, 1 = K pieces w, w + 4; slots 2, 3 = Vt pieces w, w + 4; slot 4 = K piece 8
+  // (wave 0), Vt piece 8 (wave 1), Vt piece 9 (waves 2 and 3: the same bytes twice).  The kind of a slot is then a COMPILE-TIME
+  // property except for slot 4, whose descriptor / offsets are selected once up here: with "pieces w, w + 4, ..." the kind of
+  // every slot depends on the wave and the tile loop carries 15 scalar branches per tile around its five loads.
+  const bool s4k = wave_u == 0;
+  const int s4j = wave_u == 1 ? 8 : 9;
+  const auto rsrc_4 = __builtin_amdgcn_make_buffer_rsrc((void*)(s4k ? kbase : vbase), 0, s4k ? p.kv_pad * HD * 2 : HD_ROWS * p.kv_pad * 2,
+                                                        0x00020000);
+  const int voff_4 = s4k ? k_voff : (v_voff ^ ((s4j & 1) << 6));
+  const int soff_4 = s4k ? 8 * 1024 : s4j * 8 * p.kv_pad * 2, step_4 = s4k ? K_TILE_BYTES : 128;
+  const int lds_4 = s4k ? 8 * 1024 : K_TILE_BYTES + s4j * 1024;
   auto stage = [&](int t, int buf) {
     char* base = smem + buf * KV_STAGE;
+    if constexpr (RES) {
 #pragma unroll
-    for (int idx = 0; idx < (RES ? 3 : 5); ++idx) {
-      const int piece = wave_u + NW * idx;
-      if (piece < 9) {
+      for (int idx = 0; idx < 3; ++idx) {
+        const int piece = wave_u + NW * idx;
+        if (piece < 9) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
+        } else if (piece < 19) {
+          const int j = piece - 9;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((j & 1) << 6),
+                                                   j * 8 * p.kv_pad * 2 + t * 128, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int piece = wave_u + 4 * i;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
-      } else if (piece < 19) {
-        const int j = piece - 9;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((j & 1) << 6),
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int j = wave_u + 4 * i;   // (j & 1) == (wave & 1)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((wave_u & 1) << 6),
                                                  j * 8 * p.kv_pad * 2 + t * 128, 0, 0);
       }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_4, (lds_ptr_t)(base + lds_4), 16, voff_4, soff_4 + t * step_4, 0, 0);
     }
   };
   // the first K/V tile is requested BEFORE the Q rows: both round trips are in flight together (with 300 text keys a workgroup
