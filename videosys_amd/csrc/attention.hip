@@ -143,8 +143,9 @@ struct FlashParams {
   unsigned long long* dbg;                 // lab variant 2 only: 5 phase-cycle accumulators
 };
 
-// WPS = waves per SIMD the register allocation targets: 2 (two workgroups per CU, no spills; shipped) or 3 (measured
-// slower: the peeled last tile spills and three workgroups per CU buy nothing — 0.31 vs 0.28 ms at config 2).
+// WPS = waves per SIMD the register allocation targets: 2 (two workgroups per CU, no spills) or 3 (168 registers: the peeled
+// MASKED last tile spills — cross shape 0.156 vs 0.099 ms — but unmasked long key sequences gain: spatial 0.241 vs 0.251 ms;
+// the launcher picks 3 for kv_len >= 512 that is a multiple of 64).
 // ABL (lab builds): 1 = K/V tiles after the first are not fetched (compute, LDS and barriers only); 2 = s_memtime stamps
 // at the phase boundaries of every tile, summed per wave into p.dbg[0..4] (QK issue | max chain | exp + PV | vmcnt | barrier).
 // (An 8-wave form of this kernel — 256 rows share a K/V tile and its 19 LDS-DMA pieces, one workgroup per CU — measured 0.256 vs
