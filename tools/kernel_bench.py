@@ -56,7 +56,7 @@ def main():
     h = rnd(N, 4 * C)
     mod = rnd(2, 6 * C, scale=0.3)
     shapes = [("qkv", 3 * C, C, ops.EPI_BIAS), ("proj", C, C, ops.EPI_GATE_RES), ("fc1", 4 * C, C, ops.EPI_BIAS_GELU),
-              ("fc2", C, 4 * C, ops.EPI_GATE_RES)]
+              ("fc2", C, 4 * C, ops.EPI_GATE_RES), ("crossq", C, C, ops.EPI_BIAS)]
     bufs = {}
     for name, n, k, epi in shapes:
         bufs[name] = (rnd(n, k, scale=1 / math.sqrt(k)), rnd(n, scale=0.1), torch.empty(N, n, dtype=torch.bfloat16, device=dev))
