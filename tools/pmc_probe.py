@@ -40,6 +40,11 @@ kp, vt = ops.alloc_kv_buffers(38, H, 1024, dev)
 for _ in range(3):
     ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kp, vt, 38, H, 1024)
     ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024)
+kv = rnd(600, 2 * C)   # cross attention: 300 text keys per sample (resident-K/V kernel)
+kpc, vtc = ops.alloc_kv_buffers(2, H, 300, dev)
+ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kpc, vtc, 2, H, 300)
+for _ in range(3):
+    ops.flash_attn(x, None, kpc, vtc, ao, 2, H, 19456, 300)
 freqs = 1.0 / (10000 ** (torch.arange(0, 72, 2).float() / 72))
 ang = torch.einsum("p,f->pf", torch.arange(19).float(), freqs).repeat_interleave(2, -1)
 cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
