@@ -795,7 +795,8 @@ std::map<std::tuple<int, int, int>, SkPlanDev> g_sk_plans;      // (ntiles, nt, 
 std::map<hipStream_t, SkWorkspace> g_sk_ws;                      // launches on one stream are serialised: one workspace per stream
 }  // namespace
 
-// fills sk for a launch on `stream`; false: run the plain persistent kernel
+// fills sk for a launch on `stream`; false: run the plain persistent kernel.  Plans and workspaces live on the device that is current
+// at first use: this library's process model is one process per GPU (engine.py / torchrun), as is the reference's.
 static bool sk_prepare(const GemmParams& p, int grid, hipStream_t stream, SkArgs& sk) {
   const int ntiles = ((p.M + BM - 1) / BM) * (p.N / BN), nt = p.K / BK;
   std::lock_guard<std::mutex> lock(g_sk_mutex);
