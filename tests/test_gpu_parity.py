@@ -269,6 +269,22 @@ def test_adaln_config2_property(ops):
     assert (out.var(-1, unbiased=False) - 1).abs().max().item() < 3e-2
 
 
+def test_adaln_width_1152_vs_torch(ops):
+    """C = 1152 takes the two-rows-per-wave kernel: an odd row count (the last wave has one row), two samples with different
+    modulation vectors, against LayerNorm + modulate in fp32."""
+    C, rps = 1152, 334
+    rows = 2 * rps - 1
+    g = torch.Generator().manual_seed(12)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.3).to(torch.bfloat16)
+    mod = (torch.randn(2, 6 * C, generator=g) * 0.3).to(torch.bfloat16)
+    out = ops.adaln_modulate(bf(x), bf(mod)[0, :C], bf(mod)[0, C:2 * C], rps, 6 * C)
+    xf = x.float()
+    ln = torch.nn.functional.layer_norm(xf, (C,), eps=1e-6)
+    sample = (torch.arange(rows) // rps)
+    ref = ln * (1 + mod[sample, C:2 * C].float()) + mod[sample, :C].float()
+    check(out, ref, what="adaln 1152")
+
+
 def test_mod_table_and_embeddings(ops, golden_ops):
     g = torch.Generator().manual_seed(4)
     table = torch.randn(6, 6 * 64, generator=g).to(torch.bfloat16)
