@@ -44,32 +44,22 @@ const char* vsys_strerror(int code);
 /* number of HIP devices visible to the library (fails loudly instead of falling back when 0) */
 int vsys_device_count(void);
 
-/* Kernel selection for A/B measurement.  EVERY id this library accepts selects a kernel with VALID output — the GEMM ids differ
+/* Kernel selection for A/B measurement and for the schedule-equivalence tests — NOT part of the per-call data path: the
+ * selection is one process-wide atomic word read once per launch (safe to set from any thread, but it applies to every thread's
+ * launches; the product never calls it).  EVERY id this library accepts selects a kernel with VALID output — the GEMM ids differ
  * in schedule / geometry only and are bit-identical to each other; an id the build does not contain returns VSYS_ERR_ARG and
- * leaves the selection unchanged.  (Ablation and cycle-stamp variants whose output is NOT valid exist only in -DVSYS_LAB builds
- * together with include/videosys_amd_lab.h; the shipped library has no such path.)
+ * leaves the selection unchanged.  (Ablation / cycle-stamp variants whose output is NOT valid, and the measured-but-not-shipped
+ * ping-pong / persistent / stream-K GEMMs 60 / 70 / 80, exist only in -DVSYS_LAB builds together with
+ * include/videosys_amd_lab.h; the shipped library contains no such code, and no launch path of it allocates or synchronises.)
  * gemm:  0 = shape dispatch (default); 8 = schedule 8 for every shape (three A slots + two W slots, counted waits); 3 / 6 =
  *        two-stage LDS-DMA schedules; 9 = schedule 8, plain row-major tile order; 20 = 4-wave workgroups, two per CU; 28 =
- *        schedule 8 + producer waves; 30 = 256 x 384 tile; 60 / 70 = ping-pong wave groups, one tile per workgroup / persistent;
- *        103 = 128-row tiles.  80 = 70 + stream-K split of the partial last round of tiles: valid output, deterministic, but NOT
- *        bit-identical to the others (fp32 partial sums of a split tile are added in a different order).
+ *        schedule 8 + producer waves; 30 = 256 x 384 tile; 103 = 128-row tiles.
  * flash: 0 = default (two workgroups per CU; resident K/V for few keys; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
- *        4 = VALU temporal kernel (v2) for T <= 40; 5 = ping-pong wave groups (8-wave workgroups, matrix / VALU phases alternate
- *        between the two waves of a SIMD; bit-identical, measured slower); 8 / 10 = the resident-K/V kernel (all KV tiles of a
+ *        4 = VALU temporal kernel (v2) for T <= 40; 8 / 10 = the resident-K/V kernel (all KV tiles of a
  *        (batch, head) staged once per workgroup; default for <= 320 keys and many query rows) whenever the keys fit / never;
  *        9 = online-softmax temporal kernel for every T. */
 int vsys_tune_gemm_variant(int variant);
 int vsys_tune_flash_variant(int variant);
-
-/* Host-only introspection of the stream-K segment plan of GEMM variant 80 for `ntiles` output tiles of `nt` K-tiles on a
- * persistent grid of `grid` workgroups (no GPU needed; tests/test_host_cpu.py checks coverage and dependency order with it).
- * The tiles [0, ntiles - ntiles % grid) run as whole tiles in the persistent kernel; the plan covers the remaining ones.
- * segs receives grid * (*nseg_max) rows of 4 ints, (*nseg_max) rows per workgroup: linear tile id (-1 ends the workgroup's list),
- * kb | ke << 16 (K-tile range), kind | nsrc << 8 (kind 0 = whole tile, 1 = partial sums dumped to the workgroup's workspace
- * slot, 2 = final range: adds the partial sums of workgroups b - 8 .. b - 8 nsrc, then the epilogue), 0.  Returns the number of
- * rows written, 0 when the shape is not split (no partial round, or a piece would be shorter than two K-tiles), VSYS_ERR_ARG when
- * cap_rows is too small. */
-int vsys_gemm_streamk_plan(int ntiles, int nt, int grid, int32_t* segs, int cap_rows, int* nseg_max);
 
 /* nn.Linear on token rows with fused epilogue (bf16 in/out, fp32 MFMA accumulate).
  * Replaces: attentions.py:59 (qkv), :107 (proj) + open_sora_transformer_3d.py:219,228 (gate, residual);

@@ -18,6 +18,13 @@ class FakePipeline:
             raise KeyError(f"bad prompt on rank {self.rank}")
         if mode == "die" and self.rank == who:
             os._exit(3)
+        if mode == "raise_peers_in_collective":
+            # rank `who` fails BEFORE the collective its peers enter: they block in all_reduce waiting for it
+            if self.rank == who:
+                raise KeyError(f"bad prompt on rank {self.rank}")
+            t = torch.tensor([float(x)])
+            dist.all_reduce(t)
+            return float(t)
         if mode in ("raise", "die"):
             return None   # the other ranks do not enter a collective their peer will never reach
         t = torch.tensor([float(x) + self.rank])

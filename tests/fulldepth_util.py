@@ -143,33 +143,42 @@ def verdict(hip: dict, floor: dict, factor=1.5) -> str:
 
 
 # ------------------------------------------------------------------------------------------------ config 3: PAB over the schedule
-def opensora_pab_schedule(hip, ref, floor, y_null, z, y, mask, geom, steps=30, cfg_scale=7.0):
-    """BASELINE config 3 (OpenSoraPABConfig defaults, attention-only: spatial [450,930]/2, temporal /4, cross /6) over the whole
-    30-step RFLOW schedule; ref / floor run the SAME broadcast schedule (oracle PABSchedule = pab_mgr.py:54-91 restated)."""
+def opensora_pab_schedule(hip, ref, floor, y_null, z, y, mask, geom, steps=30, cfg_scale=7.0, mlp_rule=None, oracle=True):
+    """BASELINE config 3 (OpenSoraPABConfig defaults: spatial [450,930]/2, temporal /4, cross /6; ``mlp_rule`` = None for the
+    attention-only form BASELINE names, or the {timestep: {"block", "skip_count"}} dict used for BOTH the spatial and the temporal
+    MLP broadcast, pipeline_open_sora.py:44-54) over the whole 30-step RFLOW schedule; ref / floor run the SAME broadcast
+    schedule (oracle PABSchedule = pab_mgr.py:54-141 restated).  ``oracle=False`` runs only the product (returns its latent)."""
     from oracle import stdit3_oracle as O
     from videosys_amd import pab
     from videosys_amd.rflow import RFLOW
 
     sched = RFLOW(num_sampling_steps=steps, cfg_scale=cfg_scale, use_timestep_transform=True)
     margs = dict(y=y, mask=mask, **geom)
+    kw = dict(mlp_broadcast=True, mlp_spatial_broadcast_config=mlp_rule, mlp_temporal_broadcast_config=mlp_rule) if mlp_rule else {}
     pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[450, 930], spatial_range=2,
                                       temporal_broadcast=True, temporal_threshold=[450, 930], temporal_range=4,
-                                      cross_broadcast=True, cross_threshold=[450, 930], cross_range=6))
+                                      cross_broadcast=True, cross_threshold=[450, 930], cross_range=6, **kw))
     pab.update_steps(steps)
     try:
         hip.reset_pab_state()
         z_hip = sched.sample(hip, z, margs, y_null).float().cpu()
+        left = (len(pab.PAB_MANAGER.config.mlp_spatial_outputs), len(pab.PAB_MANAGER.config.mlp_temporal_outputs))
     finally:
         pab.set_pab_manager(None)
+        hip.reset_pab_state()
+    if not oracle:
+        return dict(steps=steps, z=z_hip, mlp_left=left)
     res = {}
     for name, m in (("ref", ref), ("floor", floor)):
-        m.set_pab(O.PABSchedule(steps, spatial=(450, 930, 2), temporal=(450, 930, 4), cross=(450, 930, 6)))
+        m.set_pab(O.PABSchedule(steps, spatial=(450, 930, 2), temporal=(450, 930, 4), cross=(450, 930, 6),
+                                mlp_spatial=mlp_rule, mlp_temporal=mlp_rule))
         try:
             res[name] = O.rflow_sample(m, z, y, y_null, mask, geom["fps"], geom["height"], geom["width"], geom["num_frames"],
                                        num_sampling_steps=steps, cfg_scale=cfg_scale, model_dtype=torch.bfloat16)
         finally:
             m.set_pab(None)
-    return dict(steps=steps, z_hip=stats(z_hip, res["ref"]), z_floor=stats(res["floor"], res["ref"]))
+        torch.cuda.empty_cache()
+    return dict(steps=steps, z_hip=stats(z_hip, res["ref"]), z_floor=stats(res["floor"], res["ref"]), z=z_hip, mlp_left=left)
 
 
 # ------------------------------------------------------------------------------------------------ CogVideoX, config 5 geometry

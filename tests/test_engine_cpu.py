@@ -46,3 +46,23 @@ def test_engine_reports_worker_constructor_failure():
     with pytest.raises((RuntimeError, ChildProcessError)) as ei:
         _engine(num_gpus=2, fail_init_rank=1)
     assert "constructor refused on rank 1" in str(ei.value) or "worker died" in str(ei.value)
+
+
+def test_engine_driver_failure_with_peers_blocked_in_a_collective(monkeypatch):
+    """rank 0 raises before a collective the workers already entered.  The workers can never report, their
+    processes never exit, so neither the futures nor the monitor would ever fire: the engine must bound the wait, take the
+    workers down, re-raise the DRIVER's error and refuse further calls."""
+    import videosys_amd.engine as E
+
+    monkeypatch.setattr(E, "DRIVER_FAIL_GRACE_S", 3.0)
+    eng = _engine(num_gpus=2)
+    try:
+        t0 = time.time()
+        with pytest.raises(KeyError, match="bad prompt on rank 0"):
+            eng.generate(1, mode="raise_peers_in_collective", who=0)
+        assert time.time() - t0 < 30
+        assert all(not p.is_alive() for p in eng.workers)
+        with pytest.raises(RuntimeError, match="engine is dead"):
+            eng.generate(1)
+    finally:
+        eng.shutdown()

@@ -89,7 +89,7 @@ def test_ln_modulate_two_segments_and_plain():
 def test_gemm_gate2_and_gate_add_rows(variant):
     from videosys_amd import _lib
 
-    _lib.load().vsys_tune_gemm_variant(variant)
+    assert _lib.load().vsys_tune_gemm_variant(variant) == 0
     try:
         _gemm_gate2_and_gate_add_rows()
     finally:

@@ -47,12 +47,12 @@ def ops():
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
-@pytest.mark.parametrize("variant", [0, 8, 20, 60, 70])
+@pytest.mark.parametrize("variant", [0, 8, 20])
 @pytest.mark.parametrize("M,N,K", [(300, 192, 64), (1000, 576, 576), (257, 384, 128), (2048, 1152, 1152)])
 def test_gemm_bias(ops, M, N, K, variant):
     from videosys_amd import _lib
 
-    _lib.load().vsys_tune_gemm_variant(variant)
+    assert _lib.load().vsys_tune_gemm_variant(variant) == 0, f"variant {variant} rejected: the default would be tested instead"
     try:
         _gemm_bias(ops, M, N, K)
     finally:
@@ -71,7 +71,7 @@ def _gemm_bias(ops, M, N, K):
     check(out, O.gelu_tanh(ref), what="gemm+gelu")
 
 
-@pytest.mark.parametrize("variant", [3, 6, 8, 9, 20, 28, 30, 60, 70, 103])
+@pytest.mark.parametrize("variant", [3, 6, 8, 9, 20, 28, 30, 103])
 def test_gemm_pipeline_variants(ops, variant):
     """Every main-loop schedule of the GEMM (LDS-DMA burst / interleaved, 2-stage / 3+2-slot, 8-wave / 4-wave geometry)
     must give the same result;
@@ -81,7 +81,7 @@ def test_gemm_pipeline_variants(ops, variant):
     lib = _lib.load()
     g = torch.Generator().manual_seed(40 + variant)
     try:
-        lib.vsys_tune_gemm_variant(variant)
+        assert lib.vsys_tune_gemm_variant(variant) == 0, f"variant {variant} rejected: the default would be tested instead"
         for M, N, K in ((515, 192, 64), (300, 384, 128), (1000, 576, 1152), (777, 576, 192), (600, 1152, 320)):
             x = torch.randn(M, K, generator=g).to(torch.bfloat16)
             w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
@@ -113,18 +113,16 @@ def test_gemm_is_transpose_exact(ops):
     assert torch.equal(out, x[:, perm])
 
 
-@pytest.mark.parametrize("variant", [0, 8, 20, 60, 70, 103])
+@pytest.mark.parametrize("variant", [0, 8, 20, 103])
 def test_gemm_gate_residual_aux(ops, variant):
     """variant 0 = the shape dispatch (small problems take the 128-row geometry); 8 / 20 / 103 force each kernel family
     through the gate + residual + aux epilogue."""
     from videosys_amd import _lib
 
-    _lib.load().vsys_tune_gemm_variant(variant)
+    assert _lib.load().vsys_tune_gemm_variant(variant) == 0, f"variant {variant} rejected: the default would be tested instead"
     try:
         _gate_residual_aux(ops)
-        # sample length a multiple of 64 rows (as on the denoise path): the ping-pong kernel (60 / 70) reads the gate vector
-        # through the scalar cache here; with rps = 400 above it hands the call to the 8-wave kernel
-        _gate_residual_aux(ops, M=1100, rps=448)
+        _gate_residual_aux(ops, M=1100, rps=448)   # sample length a multiple of 64 rows, as on the denoise path
         _gate_residual_aux(ops, M=2048, rps=1024, N=1152)
     finally:
         _lib.load().vsys_tune_gemm_variant(0)
@@ -152,57 +150,6 @@ def _gate_residual_aux(ops, M=1100, N=576, K=1152, rps=400):
     xr2 = res.to(dev()).clone()
     out2 = ops.gemm(x.to(dev()), w.to(dev()), b.to(dev()), epilogue=ops.EPI_GATE_RES, res=xr2, out=xr2)
     check(out2, res.float() + x.float() @ w.float().t() + b.float(), what="residual only")
-
-
-@pytest.mark.parametrize("M,N,K", [(38912, 1152, 1152), (38912, 1152, 4608), (13000, 1152, 512), (38912, 3456, 1152)])
-def test_gemm_streamk_tail(ops, M, N, K):
-    """Variant 80 (persistent ping-pong GEMM + stream-K split of the partial last round of tiles).  Tiles of the full rounds are
-    bit-identical to schedule 8; a split tile adds its fp32 partial sums in a different order, so those may differ by the bf16
-    rounding of a 1e-7-relative fp32 difference: at most one bf16 ulp, on a small fraction of the elements.  Deterministic.
-    All three epilogues; M = 13000 has a ragged last row tile (306 tiles: one full round + 50 split tiles, K loop of 8)."""
-    from videosys_amd import _lib
-
-    lib = _lib.load()
-    g = torch.Generator().manual_seed(M + K)
-    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev())
-    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev())
-    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(dev())
-    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev())
-    rps = 19456 if M == 38912 else 6528
-    mod = torch.randn(-(-M // rps), 6 * N, generator=g).to(torch.bfloat16).to(dev())
-
-    def run():
-        o1 = ops.gemm(x, w, b)
-        o2 = ops.gemm(x, w, b, epilogue=ops.EPI_BIAS_GELU)
-        xr = res.clone()
-        aux = torch.empty_like(res)
-        o3 = ops.gemm(x, w, b, epilogue=ops.EPI_GATE_RES, gate=mod[0, 2 * N:3 * N], gate_stride=6 * N, rows_per_sample=rps, res=xr,
-                      aux=aux, out=xr)
-        torch.cuda.synchronize()
-        return o1, o2, o3, aux
-
-    try:
-        assert lib.vsys_tune_gemm_variant(8) == 0
-        base = run()
-        assert lib.vsys_tune_gemm_variant(80) == 0
-        sk = run()
-        sk2 = run()
-    finally:
-        lib.vsys_tune_gemm_variant(0)
-    for name, a, c, c2 in zip(("bias", "gelu", "gate+res", "aux"), base, sk, sk2):
-        assert torch.equal(c, c2), f"{name}: stream-K result not deterministic"
-        af, cf = a.float(), c.float()
-        d = (af - cf).abs()
-        ulp = torch.maximum(af.abs(), cf.abs()) * 2.0 ** -7 + 4e-6
-        if name == "gate+res":   # res + bf16(gate * (...)): the ulp that may flip is the one of the gated term
-            ulp = ulp + base[3].float().abs() * 2.0 ** -7
-        assert bool((d <= ulp).all()), f"{name}: differs from schedule 8 by more than one bf16 ulp (max {float((d / ulp).max()):.2f})"
-        frac = float((d > 0).float().mean())
-        assert frac < 0.02, f"{name}: {frac:.4f} of the elements differ (split tiles are < 16 % of the output)"
-    # and against fp32 on sampled rows (independent of the other kernel)
-    rows = torch.randint(0, M, (64,), generator=g).to(dev())
-    ref = x[rows].float() @ w.float().t() + b.float()
-    check(sk[0][rows], ref.cpu(), what=f"stream-K gemm {M}x{N}x{K}")
 
 
 def test_gemm_rejects_bad_shapes(ops):
@@ -431,11 +378,10 @@ def test_attn_temporal_kernels_agree_with_oracle(ops, B, T, S, H, norm, rope):
     (2000, 300, 16, 2, False),   # resident kernel: chunks = 8 workgroups per (batch, head) walk 8 query blocks unevenly, ragged tail
     (1500, 320, 40, 7, True),    # more (batch, head) pairs than CUs: one chunk each, 6 query blocks, five full tiles
 ])
-def test_flash_pingpong_matches_default_and_torch(ops, q_len, kv_len, heads, batch, norm):
-    """flash variant 5 (8-wave workgroups, matrix / VALU phases alternating between the two waves of a SIMD, five-stage K/V ring)
-    and variant 8 (resident K/V: every KV tile staged once per workgroup, query blocks walked without DMA or barriers) do the
-    arithmetic of the streaming kernel in the same order per query row: results must be BIT-identical to it, for every prologue /
-    wrap / ragged-tail / chunking case; and against torch fp32 SDPA."""
+def test_flash_resident_matches_streaming_and_torch(ops, q_len, kv_len, heads, batch, norm):
+    """flash variant 8 (resident K/V: every KV tile staged once per workgroup, query blocks walked without DMA or barriers) does the
+    arithmetic of the streaming kernel (variant 10) in the same order per query row: results must be BIT-identical to it, for every
+    prologue / ragged-tail / chunking case; and against torch fp32 SDPA."""
     from videosys_amd import _lib
 
     lib = _lib.load()
@@ -449,8 +395,6 @@ def test_flash_pingpong_matches_default_and_torch(ops, q_len, kv_len, heads, bat
     try:
         assert lib.vsys_tune_flash_variant(10) == 0          # the streaming kernel (two-stage ring, one barrier per tile)
         base = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
-        assert lib.vsys_tune_flash_variant(5) == 0
-        pp = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
         assert lib.vsys_tune_flash_variant(8) == 0           # resident K/V (kv_len <= 320; otherwise the streaming kernel again)
         res = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
         torch.cuda.synchronize()
@@ -465,9 +409,8 @@ def test_flash_pingpong_matches_default_and_torch(ops, q_len, kv_len, heads, bat
             if norm:
                 qq, kk = O.rms_norm(qq, qw.float()), O.rms_norm(kk, kw_.float())
             ref = O.sdpa(qq.float()[None], kk.float()[None], vv[None])[0]
-            # P and the output are bf16: 2^-6 of max|ref| over up to 280 (batch, head) slices (the three kernels agree bit for bit)
-            check(pp[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"flash b{bi} h{h}")
-    assert torch.equal(pp, base), f"ping-pong flash differs from the default kernel: max {float((pp.float() - base.float()).abs().max()):.3e}"
+            # P and the output are bf16: 2^-6 of max|ref| over up to 280 (batch, head) slices (the two kernels agree bit for bit)
+            check(res[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"flash b{bi} h{h}")
 
 
 def test_attn_config2_sizes_vs_torch(ops):

@@ -414,15 +414,58 @@ def test_torch_custom_ops_are_registered():
         torch.ops.videosys_amd.add_rows(torch.zeros(2, 8, dtype=torch.bfloat16), torch.zeros(2, 8, dtype=torch.bfloat16))
 
 
-# ---- stream-K segment plan of GEMM variant 80 (host-only entry point: no GPU needed)
+# ---- the LAB flavour of the library (-DVSYS_LAB: ablation / stamp variants, gemm3 / gemm4) must keep compiling (it
+# silently broke once), and its host-only stream-K planner (GEMM lab variant 80, include/videosys_amd_lab.h) is checked here
+@pytest.fixture(scope="module")
+def lab_lib(tmp_path_factory):
+    import ctypes
+    import shutil
+
+    import __graft_entry__ as G
+
+    if shutil.which(G._hipcc()) is None and not os.path.exists(G._hipcc()):
+        pytest.skip("no hipcc on this machine")
+    out = str(tmp_path_factory.mktemp("lab") / "libvideosys_amd_lab.so")
+    G.compile_library(out, lab=True)     # objects are cached under videosys_amd/csrc/build/lab
+    lib = ctypes.CDLL(out)
+    for name in ("vsys_lab_flash_debug_buffer", "vsys_gemm_streamk_plan", "vsys_gemm_bf16", "vsys_tune_gemm_variant"):
+        assert hasattr(lib, name), name
+    return lib
+
+
+def test_lab_build_compiles_and_accepts_lab_ids(lab_lib):
+    for v in (60, 70, 80, 31, 40, 61, 78, 84):
+        assert lab_lib.vsys_tune_gemm_variant(v) == 0, v
+    assert lab_lib.vsys_tune_gemm_variant(0) == 0
+    for v in (1, 2):
+        assert lab_lib.vsys_tune_flash_variant(v) == 0, v
+    assert lab_lib.vsys_tune_flash_variant(5) != 0       # the ping-pong flash kernel is gone from every flavour
+    assert lab_lib.vsys_tune_flash_variant(0) == 0
+
+
+def test_shipped_build_rejects_lab_ids():
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    if hasattr(lib, "vsys_lab_flash_debug_buffer"):
+        pytest.skip("the in-tree library is a lab build")
+    for v in (60, 70, 80, 31, 40, 61):
+        assert lib.vsys_tune_gemm_variant(v) != 0, f"lab GEMM id {v} accepted by the shipped library"
+    for v in (1, 2, 5, 6):
+        assert lib.vsys_tune_flash_variant(v) != 0, f"lab flash id {v} accepted by the shipped library"
+    assert not hasattr(lib, "vsys_gemm_streamk_plan")
+
+
+_LAB = {}
+
+
 def _streamk_plan(ntiles, nt, grid):
     import ctypes
 
     import numpy as np
 
-    from videosys_amd import _lib
-
-    lib = _lib.load()
+    lib = _LAB["lib"]
+    lib.vsys_gemm_streamk_plan.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     cap = grid * 8
     segs = np.zeros((cap, 4), dtype=np.int32)
     nseg = ctypes.c_int(0)
@@ -438,7 +481,8 @@ def _streamk_plan(ntiles, nt, grid):
     (3648, 18, 256),   # fc1: 14.25 rounds
     (300, 8, 256), (511, 4, 256), (257, 18, 256), (700, 33, 128),
 ])
-def test_streamk_plan_covers_partial_round_exactly_once(ntiles, nt, grid):
+def test_streamk_plan_covers_partial_round_exactly_once(lab_lib, ntiles, nt, grid):
+    _LAB["lib"] = lab_lib
     segs, nseg_max = _streamk_plan(ntiles, nt, grid)
     rem = ntiles % grid
     first = ntiles - rem
@@ -484,7 +528,8 @@ def test_streamk_plan_covers_partial_round_exactly_once(ntiles, nt, grid):
     assert max(work) <= -(-rem * nt // grid) + 2
 
 
-def test_streamk_plan_not_split_when_no_partial_round():
+def test_streamk_plan_not_split_when_no_partial_round(lab_lib):
+    _LAB["lib"] = lab_lib
     assert _streamk_plan(512, 18, 256)[0] is None      # whole rounds only
     assert _streamk_plan(200, 18, 256)[0] is None      # fewer tiles than workgroups
     assert _streamk_plan(912, 3, 256)[0] is None       # K loop too short to cut

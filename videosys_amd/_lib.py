@@ -19,7 +19,6 @@ SIGNATURES = {
     "vsys_device_count": [],
     "vsys_tune_gemm_variant": [_int],
     "vsys_tune_flash_variant": [_int],
-    "vsys_gemm_streamk_plan": [_int, _int, _int, _ptr, _int, _ptr],
     "vsys_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _ptr, _i64,
                        _ptr, _i64, _ptr],
     "vsys_linear_small": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],
@@ -85,6 +84,8 @@ def load() -> ctypes.CDLL:
     if hasattr(lib, "vsys_lab_flash_debug_buffer"):   # -DVSYS_LAB build (include/videosys_amd_lab.h)
         lib.vsys_lab_flash_debug_buffer.argtypes = [_ptr]
         lib.vsys_lab_flash_debug_buffer.restype = _int
+        lib.vsys_gemm_streamk_plan.argtypes = [_int, _int, _int, _ptr, _int, _ptr]
+        lib.vsys_gemm_streamk_plan.restype = _int
     lib.vsys_strerror.argtypes = [_int]
     lib.vsys_strerror.restype = ctypes.c_char_p
     _lib = lib

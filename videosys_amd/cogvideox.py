@@ -27,6 +27,7 @@ import numpy as np
 import torch
 
 from . import ops, pab
+from .utils import same_tensor
 
 
 def _sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
@@ -175,7 +176,7 @@ class CogVideoXTransformer3DModel:
         # identity + version of the table tensors (strong references held): two resolutions can share a shape and, once the first
         # table is freed, an address
         c = self._rope_cache
-        if c is None or c[0] is not cos or c[1] is not sin or c[2] != (cos._version, sin._version):
+        if c is None or not same_tensor(c[0], cos) or not same_tensor(c[1], sin) or c[2] != (cos._version, sin._version):
             c = (cos, sin, (cos._version, sin._version), cos.to(device=self.device, dtype=torch.float32).contiguous(),
                  sin.to(device=self.device, dtype=torch.float32).contiguous())
             self._rope_cache = c

@@ -634,331 +634,8 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// flash_attn_d72_pp: the same contraction, fragment layouts, K/V images and softmax arithmetic as flash_attn_d72_kernel, with
-// the work of a KV tile re-cut into a MATRIX phase and a VALU phase that the two waves of every SIMD run in opposite order.
-//
-// In flash_attn_d72_kernel a wave runs QK^T -> max -> exp -> PV as one dependent chain and relies on the other workgroup of
-// the CU to fill the matrix pipe meanwhile; the two drift freely and the pipe is busy 41 % of the time (PMC).
-// Here one workgroup = 8 waves = 256 query rows: G0 = waves 0-3 (rows 0..127), G1 = waves 4-7 (rows 128..255), a SIMD hosts one
-// wave of each.  A wave software-pipelines its chain into
-//     M(k): O += Vt(k-1) P(k-1)^T  (12 MFMAs)  and  S(k) = K(k) Q^T - m  (10 MFMAs)      -- matrix pipe + LDS reads only
-//     V(k): mask / max / rescale / P(k) = exp2(S(k))                                      -- VALU only, no LDS
-// and the barrier sequence makes the groups alternate: while G0 is in M(k), G1 is in V(k-1); while G0 is in V(k), G1 is in M(k).
-// The matrix pipe of a SIMD therefore always has exactly one wave feeding it and the exp / max work of the other wave runs
-// beside it.  K/V tiles are shared by 256 rows (half the L2 -> LDS bytes per row) in a ring of FIVE 22.5 KiB stages: tile k + 3
-// is requested during M(k) into the stage tile k - 2 left (last read by both groups' M(k - 1)), every wave issuing pieces w,
-// w + 8, w + 16 of the 19, and the counted wait in front of each barrier admits only the tiles beyond k + 1 as pending.
-//
-// MEASURED (tools/flash_pp_probe.py, profiles/r02_flash_pingpong_*.json): bit-identical to flash_attn_d72_kernel, but SLOWER —
-// 0.38-0.41 vs 0.25 ms (spatial), 0.150 vs 0.100 ms (cross).  Cycle stamps per KV tile: a matrix phase takes 2000-2500 cycles
-// for 704 cycles of MFMA — 450 of them are the wave's two or three LDS-DMA issues, 400 (older wave group) to 1000 (younger)
-// are lost to the partner's VALU phase (MFMA issue arbitrates with the partner's VALU stream by age), the rest is read latency
-// at the head of the phase — and the VALU phase takes 1150-1450.  The free-running default overlaps the same work statistically
-// and wins.  Selectable as flash variant 5 (valid, tested); never dispatched.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int PP_NBUF = 5;
-constexpr int PP_LEAD = 3;   // tile k + PP_LEAD is staged during M(k)
-
-template <int ABL>
-__global__ __launch_bounds__(512, 2) void flash_attn_d72_pp_kernel(FlashParams p) {
-#if __HIP_DEVICE_COMPILE__
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int l31 = lane & 31, hi = lane >> 5;
-  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int grp = wave_u >> 2;
-  const int tile_id = xcd_remap(blockIdx.x, gridDim.x);
-  const int bh = tile_id / p.nqb;
-  const int qb = tile_id - bh * p.nqb;
-  const int b = bh / p.heads, h = bh - b * p.heads;
-  const int q0 = qb * 256 + wave_u * 32;
-
-  const bf16_t* kbase = p.kp + (int64_t)bh * p.kv_pad * HD;
-  const bf16_t* vbase = p.vt + (int64_t)bh * HD_ROWS * p.kv_pad;
-  const auto rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, p.kv_pad * HD * 2, 0x00020000);
-  const auto rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, HD_ROWS * p.kv_pad * 2, 0x00020000);
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  const int k_voff = lane * 16;
-  const int v_voff = (lane >> 3) * p.kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
-  // this wave's pieces of tile t (19 per tile: 9 K + 10 Vt, see flash_attn_d72_kernel) into ring stage buf
-  auto stage = [&](int t, int buf) {
-    char* base = smem + buf * KV_STAGE;
-#pragma unroll
-    for (int idx = 0; idx < 3; ++idx) {
-      const int piece = wave_u + 8 * idx;
-      if (piece < 9) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (lds_ptr_t)(base + piece * 1024), 16, k_voff, t * K_TILE_BYTES + piece * 1024, 0, 0);
-      } else if (piece < 19) {
-        const int j = piece - 9;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (lds_ptr_t)(base + K_TILE_BYTES + j * 1024), 16, v_voff ^ ((j & 1) << 6),
-                                                 j * 8 * p.kv_pad * 2 + t * 128, 0, 0);
-      }
-    }
-  };
-  const int ntiles = (p.kv_len + 63) / 64;
-#pragma unroll
-  for (int t = 0; t < PP_LEAD; ++t)
-    if (t < ntiles) stage(t, t);
-  // rows 80..95 of the Vt image of every stage (MFMA padding the DMA never writes): 5 x 2 KiB of zeros
-  for (int q = tid; q < PP_NBUF * 128; q += 512)
-    *reinterpret_cast<uint4*>(smem + (q >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (q & 127) * 16) = make_uint4(0, 0, 0, 0);
-
-  // ---- Q fragment (as flash_attn_d72_kernel)
-  bf16x8 qf[5];
-  {
-    int qs = q0 + l31;
-    qs = qs < p.q_len ? qs : p.q_len - 1;
-    const bf16_t* qrow = p.q + ((int64_t)b * p.q_len + qs) * p.q_stride + h * HD;
-    float x[5][8];
-    float ss = 0.f;
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-      const int d0 = 16 * c + 8 * hi;
-      if (d0 < HD) {
-        unpack8(*reinterpret_cast<const uint4*>(qrow + d0), x[c]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[c][e] = 0.f;
-      }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
-    }
-    if (p.q_norm_w != nullptr) {
-      ss += __shfl_xor(ss, 32, 64);
-      const float rstd = rsqrtf(ss / (float)HD + p.eps);
-#pragma unroll
-      for (int c = 0; c < 5; ++c) {
-        const int d0 = 16 * c + 8 * hi;
-        if (d0 < HD) {
-          float w[8];
-          unpack8(*reinterpret_cast<const uint4*>(p.q_norm_w + d0), w);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) x[c][e] = bf2f(f2bf(x[c][e] * rstd)) * w[e];
-        }
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < 5; ++c)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) qf[c][e] = (__bf16)x[c][e];
-  }
-
-  const int v_roff = K_TILE_BYTES + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4);
-  const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
-  const int k_roff = krow * KROW + 16 * hi;
-
-  f32x16 o[3];
-#pragma unroll
-  for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  f32x16 minit;   // negated running max, splatted: C operand of the first QK^T MFMA of each 32-key block
-#pragma unroll
-  for (int r = 0; r < 16; ++r) minit[r] = 0.f;
-  f32x16 s[2];
-  bf16x8 pf0[2], pf1[2];
-  const float defer_thr = 8.0f;
-  // pieces this wave has in flight per staged tile (pieces w, w + 8, w + 16 < 19)
-  const int np = wave_u < 3 ? 3 : 2;
-
-#define PP_SB() __builtin_amdgcn_sched_barrier(0)
-#define PP_BAR()                      \
-  do {                                \
-    PP_SB();                          \
-    __builtin_amdgcn_s_barrier();     \
-    PP_SB();                          \
-  } while (0)
-  // in front of a barrier that ends M(k) or V(k): this wave's pieces of every tile <= k + 1 have landed; the tiles beyond
-  // (k + 2 .. min(k + PP_LEAD, ntiles - 1), staged last) may stay in flight
-  auto wait_tiles = [&](int k) {
-    int pend = ntiles - 2 - k;
-    pend = pend < 0 ? 0 : (pend > PP_LEAD - 1 ? PP_LEAD - 1 : pend);
-    if (pend == 2) {
-      if (np == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    } else if (pend == 1) {
-      if (np == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  };
-
-  // ---- M(k): PV(k - 1) then QK^T(k); stages tile k + PP_LEAD at its end (the DMA issue time then falls into the barrier wait).
-  // Fragment reads are issued in three groups (Vt keys 0..31 and 32..63 up front, K behind the first six PV MFMAs, into the
-  // registers the first Vt group leaves): with all 88 fragment registers live at once hipcc splits the live range of the three O
-  // accumulators and copies all 48 registers in the middle of the phase, with the matrix pipe drained.
-  auto mphase = [&](int k, int bk, int bv) {   // bk / bv: ring stages of tiles k / k - 1
-    const char* skv = smem + bv * KV_STAGE;
-    const char* skk = smem + bk * KV_STAGE;
-    bf16x8 vf0[2][3], vf1[2][3], kf0[5], kf1[5];
-    if (k >= 1) {
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt) vf0[cc][dt] = *reinterpret_cast<const bf16x8*>(skv + dt * 32 * VROW + (v_roff ^ ((0 * 4 + cc) << 4)));
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt) vf1[cc][dt] = *reinterpret_cast<const bf16x8*>(skv + dt * 32 * VROW + (v_roff ^ ((1 * 4 + cc) << 4)));
-      PP_SB();
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0[cc][dt], pf0[cc], o[dt], 0, 0, 0);
-      PP_SB();
-    }
-    if (k < ntiles) {
-#pragma unroll
-      for (int cc = 0; cc < 5; ++cc) {
-        kf0[cc] = *reinterpret_cast<const bf16x8*>(skk + k_roff + 32 * cc);
-        kf1[cc] = *reinterpret_cast<const bf16x8*>(skk + 32 * KROW + k_roff + 32 * cc);
-      }
-      PP_SB();
-    }
-    if (k >= 1) {
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc)
-#pragma unroll
-        for (int dt = 0; dt < 3; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1[cc][dt], pf1[cc], o[dt], 0, 0, 0);
-      PP_SB();
-    }
-    if (k < ntiles) {
-      // D != C on purpose (the builtin ties them and hipcc would first copy the 16 minit registers into s)
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[0]) : "v"(kf0[0]), "v"(qf[0]), "v"(minit));
-#pragma unroll
-      for (int cc = 1; cc < 5; ++cc) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[cc], qf[cc], s[0], 0, 0, 0);
-      asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[1]) : "v"(kf1[0]), "v"(qf[0]), "v"(minit));
-#pragma unroll
-      for (int cc = 1; cc < 5; ++cc) s[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1[cc], qf[cc], s[1], 0, 0, 0);
-    }
-    PP_SB();
-    if (!(ABL & 4) && k + PP_LEAD < ntiles) {
-      int bn = bk + PP_LEAD;
-      bn = bn >= PP_NBUF ? bn - PP_NBUF : bn;
-      stage(k + PP_LEAD, bn);
-    }
-  };
-
-  // ---- V(k): online softmax of tile k (lane: query l31; keys 64k + 32kt + 16hi + r), exactly the arithmetic of
-  // flash_attn_d72_kernel: deferred running max, only the last tile of a ragged kv_len masks
-  auto vphase = [&](int k, const bool masked) {
-    if (masked) {
-      const int lim = p.kv_len - (k * 64 + 16 * hi);
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (kt * 32 + r >= lim) s[kt][r] = NEG_BIG;
-    }
-    // four independent chains (the partner wave of the SIMD is in its matrix phase: nothing else covers VALU latency here)
-    float m4[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) m4[c] = fmaxf(s[0][c], s[1][c]);
-#pragma unroll
-    for (int r = 4; r < 16; r += 4)
-#pragma unroll
-      for (int c = 0; c < 4; ++c) m4[c] = fmaxf(m4[c], fmaxf(s[0][r + c], s[1][r + c]));
-    float mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
-    {
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    if (k == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0) {
-      asm volatile("; rescale path (rare): kept out of line" ::: "memory");
-      const float delta = k == 0 ? mx : fmaxf(mx, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) minit[r] -= delta;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
-#pragma unroll
-      for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pf0[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[0][r]);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) pf1[r >> 3][r & 7] = (__bf16)__builtin_amdgcn_exp2f(s[1][r]);
-  };
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();   // tiles 0 .. PP_LEAD - 1 and the zero rows are in LDS
-
-  // Barrier sequence: G0 runs M(0) B V(0) B M(1) B ... V(n-1) B M(n) B, G1 the same stream one interval later (B first, no B
-  // at its end): 2n + 1 barriers each.
-  const bool ragged = (p.kv_len & 63) != 0;
-  unsigned long long tacc[4] = {0, 0, 0, 0}, tprev = 0;   // lab (ABL == 2): cycles in M | barrier after M | V | barrier after V
-#define PP_STAMP(i_)                                                 \
-  do {                                                               \
-    if (ABL & 2) {                                                   \
-      PP_SB();                                                       \
-      const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
-      tacc[i_] += now_ - tprev;                                      \
-      tprev = now_;                                                  \
-      PP_SB();                                                       \
-    }                                                                \
-  } while (0)
-  if (grp == 1) PP_BAR();
-  if (ABL & 2) tprev = __builtin_amdgcn_s_memtime();
-  int bk = 0;   // ring stage of tile k
-  for (int k = 0; k < ntiles; ++k) {
-    const int bv = bk == 0 ? PP_NBUF - 1 : bk - 1;
-    mphase(k, bk, bv);
-    wait_tiles(k);
-    PP_STAMP(0);
-    PP_BAR();
-    PP_STAMP(1);
-    if (!(ABL & 8)) {
-      if (ragged && k == ntiles - 1) vphase(k, true);
-      else vphase(k, false);
-    }
-    wait_tiles(k);
-    PP_STAMP(2);
-    PP_BAR();
-    PP_STAMP(3);
-    bk = bk == PP_NBUF - 1 ? 0 : bk + 1;
-  }
-  mphase(ntiles, bk, bk == 0 ? PP_NBUF - 1 : bk - 1);   // PV of the last tile only
-  if (grp == 0) PP_BAR();
-  if ((ABL & 2) && lane == 0 && p.dbg != nullptr) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(p.dbg + i + 4 * grp, tacc[i]);   // dbg[0..3] = G0, dbg[4..7] = G1
-  }
-#undef PP_STAMP
-#undef PP_SB
-#undef PP_BAR
-
-  // ---- epilogue (as flash_attn_d72_kernel)
-  const float inv = 1.0f / o[2][4];
-  const int qs = q0 + l31;
-  {
-    bf16_t* orow = p.out + ((int64_t)b * p.q_len + (qs < p.q_len ? qs : p.q_len - 1)) * p.out_stride + h * HD + 8 * hi;
-#pragma unroll
-    for (int dt = 0; dt < 3; ++dt) {
-      uint2 w[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        w[g].x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
-        w[g].y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-      }
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const auto sx = __builtin_amdgcn_permlane32_swap(w[2 * k].x, w[2 * k + 1].x, false, false);
-        const auto sy = __builtin_amdgcn_permlane32_swap(w[2 * k].y, w[2 * k + 1].y, false, false);
-        const int d0 = dt * 32 + 16 * k;
-        if (qs < p.q_len && d0 + 8 * hi + 8 <= HD) *reinterpret_cast<uint4*>(orow + d0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
-      }
-    }
-  }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// attn_temporal_d72: sequence = the T frames of one pixel token; batch = B*S; heads H.  qkv rows are the
+// attn_temporal_d72 (the long-sequence kernel: dispatched for T > 40, where the scores no longer fit the register-resident
+// kernels below; also flash variant 9 as a cross-check): sequence = the T frames of one pixel token; batch = B*S; heads H.  qkv rows are the
 // (b, t, s)-ordered tokens: q(b,t,s,h) at qkv + ((b*T + t)*S + s)*row_stride + h*72 (k at +C, v at +2C), so the
 // "(B S) T C" view is just a stride of S rows.  One wave per (b, s, h); lane = (frame, third of the head dim).
 // K,V rows (RMS-norm + RoPE applied to K) are parked in wave-private LDS as fp32; queries stay in registers.
@@ -1245,20 +922,22 @@ __global__ __launch_bounds__(256) void attn_temporal_d72_v2_kernel(const bf16_t*
 
 }  // namespace
 
-static int g_flash_variant = 0;
+// A/B selector of the measurement tools and the kernel-equivalence tests (vsys_tune_flash_variant): process-wide, read once per
+// launch.  Every id the SHIPPED build accepts selects a valid kernel for the same contract.
+static std::atomic<int> g_flash_variant_a{0};
 static unsigned long long* g_flash_dbg = nullptr;
 // 0 = shipped default (resident-K/V kernel for <= 320 keys and many query rows), 3 = three workgroups per CU, 4 / 9 = force the VALU (v2) /
-// online-softmax temporal kernels, 5 = ping-pong wave groups, 8 = resident-K/V kernel whenever the keys fit, 10 = never: all valid.  1 (K/V tiles not
+// online-softmax temporal kernels, 8 = resident-K/V kernel whenever the keys fit, 10 = never: all valid.  1 (K/V tiles not
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 5: case 8: case 9: case 10: break;
+    case 0: case 3: case 4: case 8: case 9: case 10: break;
 #ifdef VSYS_LAB
-    case 1: case 2: case 6: case 61: case 62: break;
+    case 1: case 2: break;
 #endif
     default: return VSYS_ERR_ARG;
   }
-  g_flash_variant = v;
+  g_flash_variant_a.store(v, std::memory_order_relaxed);
   return 0;
 }
 void set_flash_debug_buffer(void* p) { g_flash_dbg = reinterpret_cast<unsigned long long*>(p); }
@@ -1290,31 +969,10 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   dim3 grid((unsigned)nblk);
   const size_t lds = 2 * KV_STAGE;
   p.dbg = g_flash_dbg;
-#ifdef VSYS_LAB
-  if (g_flash_variant == 6 || g_flash_variant == 61 || g_flash_variant == 62) {   // lab: ping-pong kernel with phase stamps into
-    p.nqb = (q_len + 255) / 256;                                                   // the debug buffer (8 x u64); 61 = no DMA in the
-    const dim3 gr((unsigned)((int64_t)p.nqb * batch * heads));                     // loop, 62 = no VALU phase work (output NOT valid)
-#define PP_LAB(A_)                                                                                                                \
-    do {                                                                                                                          \
-      (void)hipFuncSetAttribute((const void*)flash_attn_d72_pp_kernel<A_>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_NBUF * KV_STAGE); \
-      hipLaunchKernelGGL((flash_attn_d72_pp_kernel<A_>), gr, dim3(512), PP_NBUF * KV_STAGE, stream, p);                           \
-    } while (0)
-    if (g_flash_variant == 6) PP_LAB(2);
-    else if (g_flash_variant == 61) PP_LAB(6);
-    else PP_LAB(10);
-#undef PP_LAB
-    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
-  }
-#endif
+  const int g_flash_variant = g_flash_variant_a.load(std::memory_order_relaxed);
   // few keys (cross attention: <= 320 text tokens) and enough query rows to give every CU one workgroup: resident-K/V kernel
   if ((g_flash_variant == 0 || g_flash_variant == 8) && (kv_len + 63) / 64 <= RES_MAX_TILES) {
-    static int ncu = 0;
-    if (ncu == 0) {
-      int dev = 0;
-      hipDeviceProp_t prop;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-      if (ncu <= 0) ncu = 256;
-    }
+    const int ncu = cu_count_this_device();
     const int nqb = (q_len + 255) / 256;
     int chunks = ncu / (batch * heads);
     chunks = chunks < 1 ? 1 : (chunks > nqb ? nqb : chunks);
@@ -1323,34 +981,23 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
     if (fits && (g_flash_variant == 8 || nqb >= 2 * chunks)) {
       p.chunks = chunks;
       p.nqb = nqb;
-      static bool attr_set = false;
-      if (!attr_set) {
+      static std::atomic<unsigned long long> attr_seen{0};
+      if (first_use_on_this_device(attr_seen))
         (void)hipFuncSetAttribute((const void*)flash_attn_d72_kernel<0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES);
-        attr_set = true;
-      }
       hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES, stream, p);
       return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
     }
   }
-  if (g_flash_variant == 5) {   // ping-pong wave groups: 256 query rows per workgroup, five-stage K/V ring
-    p.nqb = (q_len + 255) / 256;
-    const int64_t nb = (int64_t)p.nqb * batch * heads;
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)flash_attn_d72_pp_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, PP_NBUF * KV_STAGE);
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((flash_attn_d72_pp_kernel<0>), dim3((unsigned)nb), dim3(512), PP_NBUF * KV_STAGE, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
-  }
-#ifdef VSYS_LAB
-  if (g_flash_variant == 1) hipLaunchKernelGGL((flash_attn_d72_kernel<1, 2>), grid, dim3(256), lds, stream, p);
-  else if (g_flash_variant == 2) hipLaunchKernelGGL((flash_attn_d72_kernel<2, 2>), grid, dim3(256), lds, stream, p);
-  else
-#endif
   // three workgroups per CU pay for long, unmasked key sequences (spatial attention: 0.241 vs 0.251 ms); with a masked last tile
   // the 168-register variant spills in the peeled tile (cross shape 0.156 vs 0.099 ms)
   static const bool wps3_ok = [] { const char* e = getenv("VSYS_FLASH_WPS3"); return !(e && e[0] == '0'); }();
+#ifdef VSYS_LAB
+  if (g_flash_variant == 1 || g_flash_variant == 2) {
+    if (g_flash_variant == 1) hipLaunchKernelGGL((flash_attn_d72_kernel<1, 2>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((flash_attn_d72_kernel<2, 2>), grid, dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
+#endif
   if (g_flash_variant == 3 || (g_flash_variant == 0 && wps3_ok && kv_len >= 512 && (kv_len & 63) == 0))
     hipLaunchKernelGGL((flash_attn_d72_kernel<0, 3>), grid, dim3(256), lds, stream, p);
   else hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2>), grid, dim3(256), lds, stream, p);
@@ -1371,6 +1018,7 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = per_wave * wpb;
   const float scale = 0.11785113019775793f;
+  const int g_flash_variant = g_flash_variant_a.load(std::memory_order_relaxed);
   if (T <= 32 && g_flash_variant != 9 && g_flash_variant != 4)   // the MFMA formulation (attention_t3.hip); 4 = force the v2 kernel
     return launch_attn_temporal_d72_v3(qkv, row_stride, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps,
                                        scale, stream);

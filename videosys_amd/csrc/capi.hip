@@ -35,6 +35,7 @@ int vsys_tune_gemm_variant(int variant) { return set_gemm_variant(variant); }
 
 int vsys_tune_flash_variant(int variant) { return set_flash_variant(variant); }
 
+#ifdef VSYS_LAB   // include/videosys_amd_lab.h
 int vsys_gemm_streamk_plan(int ntiles, int nt, int grid, int32_t* segs, int cap_rows, int* nseg_max) {
   if (ntiles <= 0 || nt <= 0 || grid <= 0 || segs == nullptr || nseg_max == nullptr) return VSYS_ERR_ARG;
   std::vector<int4> v;
@@ -48,7 +49,6 @@ int vsys_gemm_streamk_plan(int ntiles, int nt, int grid, int32_t* segs, int cap_
   return (int)v.size();
 }
 
-#ifdef VSYS_LAB   // include/videosys_amd_lab.h
 int vsys_lab_flash_debug_buffer(void* dev_u64x5) {
   set_flash_debug_buffer(dev_u64x5);
   return 0;

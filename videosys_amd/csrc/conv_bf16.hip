@@ -288,11 +288,10 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     return VSYS_ERR_SHAPE;  // tile-relative operand offsets are 32-bit (buffer addressing)
   const int64_t nbm = ((int64_t)p.M + BM - 1) / BM, nbn = p.N / BN;
   if (nbm * nbn > 0x7fffffff || p.batch > 65535) return VSYS_ERR_SHAPE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
+  if (first_use_on_this_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)conv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)conv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
   }
   const dim3 grid((unsigned)(nbm * nbn), (unsigned)p.batch);
   if (p.out32 != nullptr) hipLaunchKernelGGL(conv_kernel<1>, grid, dim3(256), LDS_BYTES, stream, p);

@@ -383,12 +383,11 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.N % G::BN != 0) return VSYS_ERR_SHAPE;
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / G::BN;
   const int grid = nbm * nbn;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
+  if (first_use_on_this_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    attr_set = true;
   }
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;

@@ -634,18 +634,20 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 
 // Variant id understood by set_gemm_variant / vsys_tune_gemm_variant:  PIPE (+ 100 for the 128-row, two-workgroups-per-CU
 // geometry).  0 = the shipped default.
-static int g_gemm_variant = 0;
+// (process-wide A/B selector of the measurement tools and the schedule-equivalence tests; read once per launch)
+static std::atomic<int> g_gemm_variant_a{0};
 // 0 = shape dispatch (default).  The shipped library only accepts ids whose kernels produce VALID output (they differ in
 // schedule / geometry only and are bit-identical); ablation and stamp variants exist in -DVSYS_LAB builds (VSYS_LAB=1 build()).
 int set_gemm_variant(int v) {
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 60: case 70: case 80: case 103: break;
+    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 103: break;
 #ifdef VSYS_LAB
+    case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
 #endif
     default: return VSYS_ERR_ARG;
   }
-  g_gemm_variant = v;
+  g_gemm_variant_a.store(v, std::memory_order_relaxed);
   return 0;
 }
 
@@ -656,12 +658,11 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
   const int grid = nbm * nbn;
   const size_t lds = (PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
+  if (first_use_on_this_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
   }
   constexpr int NTH = G::NT + PROD * 256;
   switch (epi) {
@@ -680,6 +681,7 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   if (epi == EPI_GATE_RES && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;
   // tile-relative operand offsets are 32-bit (buffer addressing)
   if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 384 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
+  const int g_gemm_variant = g_gemm_variant_a.load(std::memory_order_relaxed);
   switch (g_gemm_variant == 50 ? 0 : g_gemm_variant) {
     case 6: return launch_gemm_t<6, 256>(p, epi, stream);
 #ifdef VSYS_LAB
@@ -689,15 +691,15 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
     case 31: return (epi == EPI_BIAS && p.N % 384 == 0) ? launch_gemm2_stamp(p, stream) : VSYS_ERR_ARG;  // lab: cycle stamps
     case 61: case 62: case 63: case 64: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 60, 0, stream) : VSYS_ERR_ARG;
     case 71: case 72: case 73: case 74: case 78: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 70, 1, stream) : VSYS_ERR_ARG;
+    case 60: case 70: case 80:  // ping-pong wave groups (gemm4_bf16.hip): 60 = one tile per workgroup, 70 = persistent (one
+      // workgroup per CU), 80 = persistent + stream-K split of the partial last round (fp32 summation order differs: not bit-identical)
+      if (!gemm4_supports(p, epi)) return launch_gemm_t<8, 256>(p, epi, stream);
+      return launch_gemm4(p, epi, (g_gemm_variant - 60) / 10, stream);
     case 81: case 82: case 83: case 84:   // stream-K ablations (wrong results): 81 no DUMP, 82 no gather, 83 neither, 84 no SK role at all
       return gemm4_supports(p, epi) ? launch_gemm4(p, epi, 2 + g_gemm_variant - 80, stream) : VSYS_ERR_ARG;
 #endif
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
-    case 60: case 70: case 80:  // ping-pong wave groups (gemm4_bf16.hip): 60 = one tile per workgroup, 70 = persistent (one
-      // workgroup per CU), 80 = persistent + stream-K split of the partial last round (fp32 summation order differs: not bit-identical)
-      if (!gemm4_supports(p, epi)) return launch_gemm_t<8, 256>(p, epi, stream);
-      return launch_gemm4(p, epi, (g_gemm_variant - 60) / 10, stream);
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
     case 28: return launch_gemm_t<8, 256, 1, 1>(p, epi, stream);  // schedule 8 + four producer waves (store-only epilogues)

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <vector>
 
 #include "../../include/videosys_amd.h"
@@ -10,6 +11,29 @@
 namespace vsys {
 
 typedef uint16_t bf16_t;
+
+// One-time per-DEVICE work of a launcher (hipFuncSetAttribute for > 64 KiB of dynamic LDS is a per-device property of the
+// function): true exactly once per device per ``seen`` word, thread safe.  Not a stream operation, so it is legal while a
+// stream is being captured into a hipGraph.
+inline bool first_use_on_this_device(std::atomic<unsigned long long>& seen) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
+  const unsigned long long bit = 1ull << dev;
+  return (seen.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+}
+// multiprocessor count of the current device (cached per device)
+inline int cu_count_this_device() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return 256;
+  int n = cache[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    n = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    cache[dev].store(n, std::memory_order_relaxed);
+  }
+  return n;
+}
 
 enum { EPI_BIAS = VSYS_EPI_BIAS, EPI_BIAS_GELU = VSYS_EPI_BIAS_GELU, EPI_GATE_RES = VSYS_EPI_GATE_RES };
 enum { ACT_NONE = VSYS_ACT_NONE, ACT_SILU = VSYS_ACT_SILU, ACT_GELU_TANH = VSYS_ACT_GELU_TANH };

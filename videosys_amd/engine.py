@@ -28,6 +28,9 @@ import torch.distributed as dist
 
 _TERMINATE = "TERMINATE"   # queue sentinel (mp_utils.py:17)
 JOIN_TIMEOUT_S = 2
+# After the DRIVER's own call raised, its peers may sit in a collective rank 0 will never enter: they get this long to report
+# before the engine takes them down and re-raises the driver's error (VSYS_DRIVER_FAIL_GRACE_S overrides).
+DRIVER_FAIL_GRACE_S = float(os.environ.get("VSYS_DRIVER_FAIL_GRACE_S", "10"))
 
 
 def get_open_port() -> int:
@@ -141,6 +144,7 @@ class VideoSysEngine:
         self.config = config
         self._tid = 0
         self._closed = False
+        self._failed = None   # set when a driver-side failure forced the workers down: later calls fail fast
         self._init_worker(config.pipeline_cls, backend)
 
     def _init_worker(self, pipeline_cls, backend):
@@ -181,6 +185,8 @@ class VideoSysEngine:
             raise
 
     def _run_workers(self, method: str, *args, **kwargs) -> Any:
+        if self._failed is not None:
+            raise RuntimeError(f"engine is dead: an earlier call failed on the driver ({self._failed})")
         if self._handler is not None and self._handler._dead:
             raise ChildProcessError("worker died")   # fail fast: the driver must not enter a collective whose peers are gone
         self._tid += 1
@@ -194,6 +200,28 @@ class VideoSysEngine:
             driver_out = getattr(self.driver_worker, method)(*args, **kwargs)
         except BaseException as e:
             failure = e
+        if failure is not None and futures:
+            # The driver left the call early (OOM, bad input, ...): a worker that already entered a collective waits for a peer
+            # that will never arrive, never exits, and so never wakes the monitor.  Give the workers a bounded grace period to
+            # report (they may have failed the same way), then take them down, mark the engine dead and re-raise the DRIVER's
+            # error — the reference propagates it immediately (engine.py:85-95).
+            import time
+            from concurrent.futures import TimeoutError as FutTimeout
+
+            deadline = time.monotonic() + DRIVER_FAIL_GRACE_S
+            hung = False
+            for fut in futures:
+                try:
+                    fut.result(timeout=max(0.0, deadline - time.monotonic()))
+                except FutTimeout:
+                    hung = True
+                    break
+                except BaseException:
+                    pass
+            if hung:
+                self._failed = f"{type(failure).__name__}: {failure}"
+                self._teardown_workers()
+            raise failure
         for fut in futures:   # always collect what belongs to THIS call before returning or raising
             try:
                 fut.result()
@@ -202,6 +230,16 @@ class VideoSysEngine:
         if failure is not None:
             raise failure
         return [driver_out]
+
+    def _teardown_workers(self):
+        """Kill every worker now (no TERMINATE handshake: they may be blocked inside a collective)."""
+        if self._monitor is not None:
+            self._monitor.close()
+        for p in self.workers:
+            if p.is_alive():
+                p.kill()
+        for p in self.workers:
+            p.join(JOIN_TIMEOUT_S)
 
     def generate(self, *args, **kwargs):
         return self._run_workers("generate", *args, **kwargs)[0]

@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import dsp, ops, pab
+from .utils import same_tensor
 
 
 def _sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
@@ -162,7 +163,7 @@ class LatteT2V:
     def _encode_text(self, y, mask, frames):
         # identity + version of the prompt tensors (strong references held): a recycled storage address is not the same prompt
         c = self._text_cache
-        if (c is not None and c["y"] is y and c["y_version"] == y._version and c["mask"] is mask
+        if (c is not None and same_tensor(c["y"], y) and c["y_version"] == y._version and same_tensor(c["mask"], mask)
                 and (mask is None or c["mask_version"] == mask._version)):
             return c
         B, Lk, Cc = y.shape
@@ -324,13 +325,16 @@ class LatteT2V:
             broadcast_mlp, st.mlp_count, broadcast_next, rng = pab.if_broadcast_mlp(timestep_int, st.mlp_count, st.block_idx,
                                                                                     ats, is_temporal=temporal)
         if broadcast_mlp:
-            ops.add_rows(x, pab.get_mlp_output(rng, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal))
+            slab = pab.get_mlp_output(rng, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal)
+            ops.add_rows(x, slab)
+            if timestep_int == rng[-1]:   # window closed: hand the slab back (stream order keeps the add above ahead of a reuse)
+                self._ws.setdefault("mlp_slab_pool", []).append(slab)
             return
         shift, scale, gate = mod_i[0, 3 * C:4 * C], mod_i[0, 4 * C:5 * C], mod_i[0, 5 * C:6 * C]
         xm = ops.adaln_modulate(x, shift, scale, Fr * S, C6, eps=self.config.norm_eps, out=self._buf("xm", (N, C)))
         hb = ops.gemm(xm, w[p + ".ff.net.0.proj.weight"], w[p + ".ff.net.0.proj.bias"], epilogue=ops.EPI_BIAS_GELU,
                       out=self._buf("mlp_h", (N, 4 * C)))
-        aux = torch.empty_like(x) if broadcast_next else None
+        aux = self._mlp_slab(x) if broadcast_next else None
         ops.gemm(hb, w[p + ".ff.net.2.weight"], w[p + ".ff.net.2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate, gate_stride=C6,
                  rows_per_sample=Fr * S, res=x, aux=aux, out=x)
         if broadcast_next:
@@ -387,9 +391,22 @@ class LatteT2V:
         self._ff(i, x, mod_i, B, Fr, S, st, timestep_int, ats, temporal=True)
         return x
 
+    def _mlp_slab(self, like):
+        """A slab for a PAB MLP-broadcast window: taken from the pool of slabs that closed windows handed back (a window's stored
+        output lives until its last timestep, pab_mgr.py:148-174), so a generate() allocates at most as many 90 MB slabs as
+        windows are open at once instead of one per window opening."""
+        pool = self._ws.setdefault("mlp_slab_pool", [])
+        for k, b in enumerate(pool):
+            if b.shape == like.shape:
+                return pool.pop(k)
+        return torch.empty_like(like)
+
     def reset_pab_state(self):
         for st in self.states:
             st.attn_count = st.cross_count = st.mlp_count = 0
+        if pab.PAB_MANAGER is not None:
+            pab.PAB_MANAGER.config.mlp_spatial_outputs.clear()
+            pab.PAB_MANAGER.config.mlp_temporal_outputs.clear()
 
 
 def synth_state_dict(num_layers=28, num_heads=16, head_dim=72, caption_channels=4096, in_channels=4, out_channels=8,

@@ -28,6 +28,7 @@ from typing import Dict, Optional
 import torch
 
 from . import dsp, ops, pab
+from .utils import same_tensor
 
 
 class STDiT3Config:
@@ -262,7 +263,7 @@ class STDiT3:
         different prompt once the caching allocator recycles the block; ``reset_text_cache()`` (called by the pipeline at the
         start of every generate()) drops it explicitly."""
         c = self._text_cache
-        if (c is not None and c["y"] is y and c["y_version"] == y._version and c["mask"] is mask
+        if (c is not None and same_tensor(c["y"], y) and c["y_version"] == y._version and same_tensor(c["mask"], mask)
                 and (mask is None or c["mask_version"] == mask._version)):
             return c
         w = self.w
@@ -489,13 +490,16 @@ class STDiT3:
             broadcast_mlp, st.mlp_count, broadcast_next, skip_range = pab.if_broadcast_mlp(timestep_int, st.mlp_count, st.block_idx,
                                                                                            ats, is_temporal=temporal)
         if broadcast_mlp:
-            ops.add_rows(x, pab.get_mlp_output(skip_range, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal))
+            slab = pab.get_mlp_output(skip_range, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal)
+            ops.add_rows(x, slab)
+            if timestep_int == skip_range[-1]:   # the window closed (the store dropped the entry): the slab is free again,
+                self._ws.setdefault("mlp_slab_pool", []).append(slab)   # in stream order behind the add above
             return x
         xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, T * S, C6, out=self._buf("xm", (N, C)))
         hdim = w[p + ".mlp.fc1.weight"].shape[0]
         hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
                         out=self._buf("mlp_h", (N, hdim)))
-        aux = torch.empty_like(x) if broadcast_next else None   # the post-gate output, written by the fc2 epilogue
+        aux = self._mlp_slab(x) if broadcast_next else None   # the post-gate output, written by the fc2 epilogue
         ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
                  gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
         if broadcast_next:
@@ -549,9 +553,24 @@ class STDiT3:
             self._ws[key] = ops.alloc_kv_buffers(batch, self.num_heads, kv_len, self.device)
         return self._ws[key]
 
+    def _mlp_slab(self, like):
+        """A slab for a PAB MLP-broadcast window: taken from the pool of slabs that closed windows handed back (a window's stored
+        output lives until its last timestep, pab_mgr.py:148-174), so a generate() allocates at most as many 90 MB slabs as
+        windows are open at once instead of one per window opening."""
+        pool = self._ws.setdefault("mlp_slab_pool", [])
+        for k, b in enumerate(pool):
+            if b.shape == like.shape:
+                return pool.pop(k)
+        return torch.empty_like(like)
+
     def reset_pab_state(self):
+        """Counters to zero and every stored MLP output dropped (an aborted generate() must not pin its slabs, nor may the next
+        prompt replay them)."""
         for st in self.states:
             st.attn_count = st.cross_count = st.mlp_count = 0
+        if pab.PAB_MANAGER is not None:
+            pab.PAB_MANAGER.config.mlp_spatial_outputs.clear()
+            pab.PAB_MANAGER.config.mlp_temporal_outputs.clear()
 
 
 def synth_state_dict(config: STDiT3Config, seed: int = 1234) -> Dict[str, torch.Tensor]:

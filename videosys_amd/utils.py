@@ -25,6 +25,19 @@ def set_seed(seed, dp_rank=None):
     return seed
 
 
+def same_tensor(a, b) -> bool:
+    """True when ``b`` is ``a`` or a fresh VIEW OBJECT of exactly the same elements (same storage, offset, shape, strides) at the
+    same version counter — what a per-step ``y[rows]`` slice produces under CFG parallel.  Meant for caches that HOLD ``a``:
+    the strong reference keeps the storage alive, so its address cannot be recycled for another prompt meanwhile."""
+    if a is b:
+        return True
+    if a is None or b is None or not (torch.is_tensor(a) and torch.is_tensor(b)):
+        return False
+    return (a.dtype == b.dtype and a.device == b.device and a.shape == b.shape and a.stride() == b.stride()
+            and a.storage_offset() == b.storage_offset() and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr()
+            and a._version == b._version)
+
+
 def batch_func(func, *args):
     return tuple(func(a) if isinstance(a, torch.Tensor) and a.shape[0] > 0 else a for a in args)
 
