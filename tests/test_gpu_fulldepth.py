@@ -7,7 +7,9 @@ cosine >= 0.999 (or >= the floor's cosine - 5e-4 where the reference's own bf16 
 
   * config 2 exactly: STDiT3-XL/2 depth 28, latent [4,19,64,64] -> 38 912 token rows, 300 text tokens, weights seed 1234:
     one full step (with the per-block-pair error-growth table) and a 3-step RFLOW sample;
-  * config 3: attention-only PAB over the whole 30-step schedule at 17 frames (T = 5) of the same 512x512 geometry;
+  * config 2 over all 30 RFLOW steps;
+  * config 3: attention-only PAB over the whole 30-step schedule at 17 frames (T = 5), and EXACTLY (T = 19, L = 300) attention-only,
+    with the reference's default OpenSoraPABConfig() and with MLP-broadcast windows that open on this schedule;
   * config 1: Latte 256x256x16f, 28 + 28 blocks, one full-depth step.
 """
 import json
@@ -30,7 +32,7 @@ def opensora():
 
 
 def _report(name, r):
-    print(f"\n[fulldepth] {name}: " + json.dumps({k: v for k, v in r.items() if k != "per_pair"}))
+    print(f"\n[fulldepth] {name}: " + json.dumps({k: v for k, v in r.items() if k != "per_pair" and not torch.is_tensor(v)}))
 
 
 def test_config2_one_step_full_depth(opensora):
@@ -60,6 +62,47 @@ def test_config3_pab_thirty_steps_reduced_frames(opensora):
     _report("config3 PAB x30 (T=5)", r)
     why = U.verdict(r["z_hip"], r["z_floor"])
     assert not why, f"config 3 latents after the 30-step PAB schedule: {why}"
+
+
+def test_config2_rflow_all_thirty_steps(opensora):
+    """BASELINE configs[1] end to end: the whole 30-step RFLOW schedule (CFG 7, timestep transform on the bf16 geometry) at depth
+    28 / 38 912 rows / 300 text tokens — final latents of the product vs the fp32 oracle, next to the reference's own bf16 run."""
+    hip, ref, floor, y_null = opensora
+    z, y, mask, geom = U.opensora_inputs(T=19, HW=64, L=300)
+    r = U.opensora_rflow(hip, ref, floor, y_null, z, y, mask, geom, steps=30)
+    _report("config2 rflow x30", r)
+    why = U.verdict(r["z_hip"], r["z_floor"])
+    assert not why, f"config 2 latents after 30 RFLOW steps: {why}"
+
+
+# the 30-step schedule of configs[1]/[2] (tests/golden/pab_schedule_c2.json): ... 868 852 836 816 796 772 748 720 692 660 ...
+# The reference's DEFAULT MLP-broadcast keys (676 / 788 / 864, pipeline_open_sora.py:44-54) are not on this schedule, so its
+# default config opens no MLP window at 512x512x64f; MLP_HIT uses the same rule shape on timesteps that ARE on it.
+MLP_DEFAULT = {k: {"block": [0, 1, 2, 3, 4], "skip_count": 2} for k in (676, 788, 864)}
+MLP_HIT = {k: {"block": [0, 1, 2, 3, 4], "skip_count": 2} for k in (692, 796, 868)}
+
+
+def test_config3_pab_thirty_steps_exact_config(opensora):
+    """BASELINE configs[2] exactly: T = 19, 300 text tokens, depth 28, the 30-step schedule.
+    (a) attention-only PAB (what BASELINE names; SURVEY §0.9) vs the fp32 oracle running the same broadcast schedule;
+    (b) the reference's DEFAULT OpenSoraPABConfig() — mlp_broadcast=True with keys 676 / 788 / 864: no window opens on this
+        schedule, so the product must produce the SAME latents as (a) bit for bit, with nothing left in the MLP stores;
+    (c) the MLP broadcast with windows that do open (692 / 796 / 868, blocks 0-4, skip 2) vs the oracle (pab_mgr.py:93-174)."""
+    hip, ref, floor, y_null = opensora
+    z, y, mask, geom = U.opensora_inputs(T=19, HW=64, L=300)
+    a = U.opensora_pab_schedule(hip, ref, floor, y_null, z, y, mask, geom, steps=30)
+    _report("config3 PAB x30 attention-only (T=19, L=300)", {k: v for k, v in a.items() if k != "z"})
+    why = U.verdict(a["z_hip"], a["z_floor"])
+    assert not why, f"config 3 (attention-only PAB) latents after 30 steps: {why}"
+    b = U.opensora_pab_schedule(hip, ref, floor, y_null, z, y, mask, geom, steps=30, mlp_rule=MLP_DEFAULT, oracle=False)
+    assert torch.equal(b["z"], a["z"]), "default OpenSoraPABConfig(): keys off the schedule must change nothing"
+    assert b["mlp_left"] == (0, 0)
+    c = U.opensora_pab_schedule(hip, ref, floor, y_null, z, y, mask, geom, steps=30, mlp_rule=MLP_HIT)
+    _report("config3 PAB x30 + MLP broadcast windows 692/796/868", {k: v for k, v in c.items() if k != "z"})
+    assert not torch.equal(c["z"], a["z"]), "the MLP windows did not change anything: they never opened"
+    assert c["mlp_left"] == (0, 0), "stored MLP outputs must be dropped at the end of their windows"
+    why = U.verdict(c["z_hip"], c["z_floor"])
+    assert not why, f"config 3 (PAB + MLP broadcast) latents after 30 steps: {why}"
 
 
 def test_latte_config1_full_depth():

@@ -259,3 +259,81 @@ def test_batched_copy_executor_matches_plan_semantics():
     got = torch.zeros(sshape, dtype=torch.bfloat16, device="cuda:0")
     dsp.hip_copy_executor(src.to("cuda:0"), got, pk)
     assert torch.equal(got.cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------------ P = 8 on one GPU, in process
+def _rank_manager(group, P, r):
+    from types import SimpleNamespace
+
+    return SimpleNamespace(sp_size=P, cp_size=1, dp_size=1, dp_rank=0, sp_rank=r, cp_rank=0, sp_group=group, cp_group=None)
+
+
+@pytest.mark.parametrize("frames,hl,wl", [(128, 90, 160), (64, 64, 64)])
+def test_dsp_eight_ranks_in_process_equals_single_and_oracle(frames, hl, wl):
+    """BASELINE configs[3] (Open-Sora 720p x 128f, DSP degree 8) and configs[1] geometry sharded 8 ways, ALL EIGHT RANKS on the one
+    GPU of the box (tools/local_group.py: a rank = a thread, a collective = event-ordered device copies): per rank the real padded
+    T-shard shapes (T = 38 -> 40 frames: 5 per sample per rank, S = 3600 / 8 = 450 at rest; T = 19, S = 128), the HIP pack / unpack
+    launches, both side streams and the A1 B1 A2 B2 collective order.  Every layout — scatter "sample" (the reference's) and
+    "flat", exchange order "activations" and "qkv", overlap on and off — must reproduce the single-process output BIT FOR BIT on
+    every rank's gathered result; that output is then held against the fp32 oracle at the floor tolerance.  Two block pairs."""
+    import fulldepth_util as U
+    from oracle import stdit3_oracle as O
+    from tools.local_group import LocalWorld
+    from videosys_amd import pab
+    from videosys_amd.pipeline_open_sora import get_latent_size
+    from videosys_amd.stdit3 import STDiT3, STDiT3Config
+
+    pab.set_pab_manager(None)
+    P, depth = 8, 2
+    T, Hl, Wl = get_latent_size(frames, hl * 8, wl * 8)
+    assert (Hl, Wl) == (hl, wl)
+    sd = U.bf16_round(O.synth_state_dict(depth, 1152, 16, seed=4321))
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(1, 4, T, Hl, Wl, generator=g).to(torch.bfloat16).float()
+    y = (torch.randn(1, 1, 300, 4096, generator=g) * 0.1).to(torch.bfloat16).float()
+    mask = torch.ones(1, 300, dtype=torch.long)
+    x = torch.cat([z, z], 0)
+    yy = torch.cat([y, sd["y_embedder.y_embedding"][None, None]], 0)
+    t = torch.tensor([600.0, 600.0]).to(torch.bfloat16).float()
+    kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([hl * 8.0] * 2), width=torch.tensor([wl * 8.0] * 2))
+
+    single = STDiT3(STDiT3Config(depth=depth), device="cuda:0")
+    single.load_state_dict(sd)
+    out_single = single(x, t, yy, **kw)
+    torch.cuda.synchronize()
+
+    variants = [("flat", "activations", True), ("flat", "activations", False), ("sample", "activations", True),
+                ("sample", "activations", False), ("flat", "qkv", False), ("sample", "qkv", False)]
+    world = LocalWorld(P, timeout=300)
+
+    def rank_fn(r, group):
+        torch.cuda.set_device(0)
+        m = STDiT3(STDiT3Config(depth=depth), device="cuda:0")
+        m.load_state_dict(sd)
+        res = []
+        for scatter, order, overlap in variants:
+            m.enable_parallel(parallel_mgr=_rank_manager(group, P, r), overlap=overlap)
+            m._scatter, m._switch = scatter, order
+            assert m._overlap == overlap
+            out = m(x, t, yy, **kw)
+            torch.cuda.synchronize()
+            res.append(bool(torch.equal(out, out_single)))
+        S_full = (Hl // 2) * (Wl // 2)
+        nfr = {v: __import__("videosys_amd.dsp", fromlist=["x"]).frames_per_rank(2, T, P, v) for v in ("flat", "sample")}
+        return res, nfr, m._switch_order(1, 2 * T, S_full)
+
+    results = world.run(rank_fn)
+    for r, (res, nfr, _) in enumerate(results):
+        bad = [v for v, ok in zip(variants, res) if not ok]
+        assert not bad, f"rank {r}: sharded output differs from the single-process output for {bad}"
+    print(f"\n[dsp x8 in process] T={T} S={(Hl // 2) * (Wl // 2)}: frames on the busiest rank {results[0][1]}, auto order {results[0][2]}")
+
+    ref = O.STDiT3Oracle(sd, depth, 1152, 16, device="cuda:0", dtype=torch.float32)
+    floor = O.STDiT3Oracle(sd, depth, 1152, 16, device="cuda:0", dtype=torch.bfloat16)
+    out_ref = ref.forward(x, t, yy, **kw)
+    out_floor = floor.forward(x, t, yy, **kw)
+    r = dict(out_hip=U.stats(out_single, out_ref), out_floor=U.stats(out_floor, out_ref))
+    why = U.verdict(r["out_hip"], r["out_floor"])
+    assert not why, f"sharded geometry vs fp32 oracle: {why}"
+    del single, ref, floor
+    torch.cuda.empty_cache()

@@ -213,9 +213,69 @@ def test_dsp_switch_cost_model():
 
     for B, T, S, P in ((2, 19, 1024, 8), (2, 19, 1024, 4), (2, 38, 3600, 8)):
         m = dsp.choose_spatial_switch(B, T, S, 1152, P)
-        assert m["order"] == "activations" and m["padded_frames_per_rank"] == -(-T // P)
+        assert m["order"] == "activations" and m["padded_frames_per_rank"] == B * -(-T // P)
+        f = dsp.choose_spatial_switch(B, T, S, 1152, P, scatter="flat")
+        assert f["order"] == "activations" and f["padded_frames_per_rank"] == -(-B * T // P) <= m["padded_frames_per_rank"]
+    # config 2 at the BASELINE degree: 5 frames on the busiest rank instead of 6 (4.75 ideal)
+    assert (dsp.frames_per_rank(2, 19, 8, "sample"), dsp.frames_per_rank(2, 19, 8, "flat")) == (6, 5)
+    assert (dsp.frames_per_rank(2, 38, 8, "sample"), dsp.frames_per_rank(2, 38, 8, "flat")) == (10, 10)
     m = dsp.choose_spatial_switch(2, 9, 1024, 1152, 8, gemm_tflops=50.0, a2a_gbytes_s=900.0)
     assert m["order"] == "qkv" and m["gemm_extra_us"] > m["comm_extra_us"]
+
+
+@pytest.mark.parametrize("B,T,S,P", [(2, 19, 16, 8), (2, 38, 24, 8), (2, 5, 12, 4), (2, 1, 8, 4), (1, 7, 9, 2)])
+def test_dsp_flat_scatter_and_chunked_switch_in_process(B, T, S, P):
+    """The two layouts of the T-shard phase and the chunked (overlap) form of the switch, all P ranks as threads of this process
+    (tools/local_group.py implements the group protocol of dsp.py):
+      * "sample" (reference layout) equals the oracle's all_to_all_with_pad restatement;
+      * "flat" — the [B,T,Sl,C] shard viewed as [1,B*T,Sl,C] — hands rank r the frames r*Fp .. of the flattened (sample, frame)
+        axis, Fp = ceil(B*T/P) <= B*ceil(T/P), each frame whole and un-mixed;
+      * moving a rank's frame block in two chunks (the overlap path) fills exactly the same T-shard tensor, and the chunked way
+        back restores the S-shard bit for bit."""
+    from tools.local_group import LocalWorld
+    from videosys_amd import dsp
+
+    C = 8
+    g = torch.Generator().manual_seed(B * 100 + T)
+    x = torch.randn(B, T, S, C, generator=g).to(torch.bfloat16)
+    shards = O.dsp_split_sequence(x.float(), P, dim=2)
+    Sl = shards[0].shape[2]
+    t_ref = O.dsp_all_to_all(shards, 1, 2, O.dsp_pad(T, P), O.dsp_pad(S, P))
+    xf = x.reshape(1, B * T, S, C)
+    Fp = -(-B * T // P)
+
+    def rank_fn(r, group):
+        sp = dsp.SequenceParallel(group, copy_executor=torch_copy_executor)
+        assert (sp.P, sp.rank) == (P, r)
+        local = sp.split(x)
+        assert torch.equal(local.float(), shards[r])
+        # reference layout
+        tsh = sp.to_temporal_shard(local, S)
+        assert torch.equal(tsh.float(), t_ref[r]), "sample scatter vs oracle"
+        assert torch.equal(sp.to_spatial_shard(tsh, T, Sl), local)
+        # flat layout: whole frames of the flattened axis, zero frames past the end
+        lf = local.reshape(1, B * T, Sl, C)
+        tf = sp.to_temporal_shard(lf, S)
+        assert tf.shape == (1, Fp, S, C)
+        for j in range(Fp):
+            f = r * Fp + j
+            want = xf[0, f] if f < B * T else torch.zeros(S, C, dtype=x.dtype)
+            assert torch.equal(tf[0, j], want), f"flat scatter: rank {r} frame {j}"
+        assert torch.equal(sp.to_spatial_shard(tf, B * T, Sl).reshape(B, T, Sl, C), local)
+        # chunked switch (two chunks of the rank's block, private staging buffers)
+        if Fp >= 2:
+            h = -(-Fp // 2)
+            parts = [sp.to_temporal_shard(lf, S, tag=f"_{i}", chunk=ck) for i, ck in enumerate(((0, h), (h, Fp)))]
+            assert torch.equal(torch.cat(parts, 1), tf), "chunked to_temporal_shard"
+            back = torch.full((1, B * T, Sl, C), 7.0, dtype=x.dtype)
+            for i, ck in enumerate(((0, h), (h, Fp))):
+                sp.to_spatial_shard(parts[i], B * T, Sl, out=back, tag=f"_{i}", chunk=ck, Tp=Fp)
+            assert torch.equal(back, lf), "chunked to_spatial_shard"
+        full = sp.gather(local, S)
+        assert torch.equal(full, x)
+        return "ok"
+
+    assert LocalWorld(P, timeout=60).run(rank_fn) == ["ok"] * P
 
 
 # ------------------------------------------------------------------------------------------------ Ulysses over gloo

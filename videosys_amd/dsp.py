@@ -27,6 +27,33 @@ import torch.distributed as dist
 PAD_DICT = {}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# Group protocol.  ``group`` is a torch.distributed ProcessGroup (RCCL on a GPU node, gloo in the CPU tests) OR any object that
+# implements the collectives itself: ``size``, ``rank``, ``all_to_all_single(recv, send)``, ``all_gather_into_tensor(out, x)``
+# (stream-ordered on torch's current stream, like a ProcessGroupNCCL collective).  tools/local_group.py uses the second form to
+# run all P ranks of a DSP group inside one process on one GPU (tests) and to stub the wire for per-rank timing; it is also
+# where a peer-to-peer (IPC) exchange would plug in.
+# ---------------------------------------------------------------------------------------------------------
+def group_size(group) -> int:
+    return group.size if hasattr(group, "all_to_all_single") else dist.get_world_size(group)
+
+
+def group_rank(group) -> int:
+    return group.rank if hasattr(group, "all_to_all_single") else dist.get_rank(group)
+
+
+def all_to_all_single(recv, send, group):
+    if hasattr(group, "all_to_all_single"):
+        return group.all_to_all_single(recv, send)
+    return dist.all_to_all_single(recv, send, group=group)
+
+
+def all_gather_into_tensor(out, x, group):
+    if hasattr(group, "all_gather_into_tensor"):
+        return group.all_gather_into_tensor(out, x)
+    return dist.all_gather_into_tensor(out, x, group=group)
+
+
 def initialize(rank=0, world_size=1, init_method=None, backend: Optional[str] = None):
     """parallel_mgr.py:103-117.  backend defaults to "nccl" (RCCL) when a GPU is present, "gloo" otherwise."""
     if not dist.is_initialized():
@@ -103,37 +130,48 @@ def plan_split(B, T, S, C, P, rank):
     return [CopyOp(rank * Sl * C, 0, B, T, Sl, C, (T * S * C, S * C, C), (T * Sl * C, Sl * C, C), T, valid)], (B, T, Sl, C)
 
 
-def plan_switch_to_temporal_shard(B, T, Sl, S, C, P):
-    """[B,T,Sl,C] (S-shard) -> send [P][B,Tp,Sl,C]; after all_to_all_single recv [P][B,Tp,Sl,C] -> [B,Tp,S,C].
-    (all_to_all_with_pad with scatter_dim=1 (T, padded), gather_dim=2 (S, un-padded); open_sora_transformer_3d.py:299-303)"""
+def _chunk(Tp, chunk):
+    c0, c1 = (0, Tp) if chunk is None else chunk
+    assert 0 <= c0 < c1 <= Tp, (chunk, Tp)
+    return c0, c1 - c0
+
+
+def plan_switch_to_temporal_shard(B, T, Sl, S, C, P, chunk=None):
+    """[B,T,Sl,C] (S-shard) -> send [P][B,Tc,Sl,C]; after all_to_all_single recv [P][B,Tc,Sl,C] -> [B,Tc,S,C].
+    (all_to_all_with_pad with scatter_dim=1 (T, padded), gather_dim=2 (S, un-padded); open_sora_transformer_3d.py:299-303)
+    Rank r owns frames [r*Tp, (r+1)*Tp), Tp = ceil(T/P).  ``chunk = (c0, c1)`` moves only frames c0..c1-1 of every rank's block
+    (Tc = c1 - c0; default the whole block): two chunks on two streams overlap one's exchange with the other's attention."""
     Tp = (T + (P - T % P) % P) // P
+    c0, Tc = _chunk(Tp, chunk)
     run = Sl * C
-    pack = [CopyOp(r * Tp * run, r * B * Tp * run, B, Tp, 1, run, (T * run, run, run), (Tp * run, run, run),
-                   max(0, min(Tp, T - r * Tp)), 1) for r in range(P)]
+    pack = [CopyOp((r * Tp + c0) * run, r * B * Tc * run, B, Tc, 1, run, (T * run, run, run), (Tc * run, run, run),
+                   max(0, min(Tc, T - r * Tp - c0)), 1) for r in range(P)]
     unpack = []
     for src in range(P):
         valid = max(0, min(Sl, S - src * Sl))
         # narrowing side: copy only the valid columns (never zero-fill past the row end)
-        unpack.append(CopyOp(src * B * Tp * run, src * Sl * C, B, Tp, valid, C, (Tp * run, run, C), (Tp * S * C, S * C, C),
-                             Tp, valid))
+        unpack.append(CopyOp(src * B * Tc * run, src * Sl * C, B, Tc, valid, C, (Tc * run, run, C), (Tc * S * C, S * C, C),
+                             Tc, valid))
     unpack = [u for u in unpack if u.n2 > 0]
-    return pack, unpack, (P, B, Tp, Sl, C), (B, Tp, S, C)
+    return pack, unpack, (P, B, Tc, Sl, C), (B, Tc, S, C)
 
 
-def plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, P):
-    """[B,Tp,S,C] (T-shard) -> send [P][B,Tp,Sl,C]; recv -> [B,T,Sl,C] (scatter_dim=2 padded, gather_dim=1 narrowed)."""
+def plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, P, chunk=None):
+    """[B,Tc,S,C] (T-shard; frames c0..c1-1 of this rank's block of Tp) -> send [P][B,Tc,Sl,C]; recv -> the frames
+    src*Tp + c0 .. of [B,T,Sl,C] (scatter_dim=2 padded, gather_dim=1 narrowed)."""
+    c0, Tc = _chunk(Tp, chunk)
     run = Sl * C
     pack = []
     for r in range(P):
         valid = max(0, min(Sl, S - r * Sl))
-        pack.append(CopyOp(r * Sl * C, r * B * Tp * run, B, Tp, Sl, C, (Tp * S * C, S * C, C), (Tp * run, run, C), Tp, valid))
+        pack.append(CopyOp(r * Sl * C, r * B * Tc * run, B, Tc, Sl, C, (Tc * S * C, S * C, C), (Tc * run, run, C), Tc, valid))
     unpack = []
     for src in range(P):
-        valid = max(0, min(Tp, T - src * Tp))
+        valid = max(0, min(Tc, T - src * Tp - c0))
         if valid > 0:
-            unpack.append(CopyOp(src * B * Tp * run, src * Tp * run, B, valid, 1, run, (Tp * run, run, run),
+            unpack.append(CopyOp(src * B * Tc * run, (src * Tp + c0) * run, B, valid, 1, run, (Tc * run, run, run),
                                  (T * run, run, run), valid, 1))
-    return pack, unpack, (P, B, Tp, Sl, C), (B, T, Sl, C)
+    return pack, unpack, (P, B, Tc, Sl, C), (B, T, Sl, C)
 
 
 def plan_gather(B, T, Sl, S, C, P):
@@ -147,8 +185,16 @@ def plan_gather(B, T, Sl, S, C, P):
     return ops, (B, T, S, C)
 
 
+def frames_per_rank(B: int, T: int, P: int, scatter: str = "flat") -> int:
+    """Attention problems (frames) the busiest rank holds in the T-shard phase.  "sample" = the reference's layout: T is padded
+    and scattered per sample (comm.py:282-304 on the [B,T,S,C] view): B * ceil(T/P).  "flat" = the (sample, frame) axis is
+    scattered as ONE axis of B*T frames — spatial attention and the row-wise qkv GEMM do not care which sample a frame
+    belongs to: ceil(B*T/P) (config 2, P = 8: 5 instead of 6 frames against 4.75 ideal)."""
+    return -(-B * T // P) if scatter == "flat" else B * -(-T // P)
+
+
 def choose_spatial_switch(B: int, T: int, S: int, C: int, P: int, gemm_tflops: float = 750.0, a2a_gbytes_s: float = 300.0,
-                          overlapped: bool = True) -> dict:
+                          overlapped: bool = True, scatter: str = "sample") -> dict:
     """Cost model for the layout switch around the spatial attention of one block on one rank (bf16, critical-path rank).
 
     ``"activations"`` (the reference's order, open_sora_transformer_3d.py:208-216): the C-wide modulated activations travel,
@@ -159,12 +205,13 @@ def choose_spatial_switch(B: int, T: int, S: int, C: int, P: int, gemm_tflops: f
     7 x 153 GB/s of xGMI; with the two CFG samples overlapped only the un-hidden half of the extra traffic is charged."""
     Tp = -(-T // P)
     Sl = -(-S // P)
-    rows_padded, rows_rest = B * Tp * S, B * T * Sl
+    nfr = frames_per_rank(B, T, P, scatter)
+    rows_padded, rows_rest = nfr * S, B * T * Sl
     gemm_extra_s = 2.0 * max(rows_padded - rows_rest, 0) * C * (3 * C) / (gemm_tflops * 1e12)
-    msg_bytes = (P - 1) / P * B * Tp * P * Sl * C * 2          # what leaves a rank in the first exchange (C wide)
+    msg_bytes = (P - 1) / P * nfr * P * Sl * C * 2             # what leaves a rank in the first exchange (C wide)
     comm_extra_s = 2.0 * msg_bytes / (a2a_gbytes_s * 1e9) * (0.5 if overlapped else 1.0)
     best = "qkv" if comm_extra_s < gemm_extra_s else "activations"
-    return dict(order=best, padded_frames_per_rank=Tp, gemm_extra_us=gemm_extra_s * 1e6, comm_extra_us=comm_extra_s * 1e6,
+    return dict(order=best, padded_frames_per_rank=nfr, gemm_extra_us=gemm_extra_s * 1e6, comm_extra_us=comm_extra_s * 1e6,
                 first_message_mb=msg_bytes / 1e6)
 
 
@@ -229,8 +276,8 @@ class SequenceParallel:
 
     def __init__(self, group, copy_executor: Callable = hip_copy_executor):
         self.group = group
-        self.P = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.P = group_size(group)
+        self.rank = group_rank(group)
         self.exec = copy_executor
         self._bufs = {}
 
@@ -253,37 +300,40 @@ class SequenceParallel:
         B, T, Sl, C = x.shape
         recv = self._buf("gather_recv", (self.P, B, T, Sl, C), x)
         with COMM_TIMER.comm():
-            dist.all_gather_into_tensor(recv.view(self.P * B, T, Sl, C), x.contiguous(), group=self.group)
+            all_gather_into_tensor(recv.view(self.P * B, T, Sl, C), x.contiguous(), self.group)
         ops, shape = plan_gather(B, T, Sl, S, C, self.P)
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, ops)
         return out
 
-    def to_temporal_shard(self, x, S, out=None, tag=""):
-        """[B,T,Sl,C] -> [B,Tp,S,C]  (before spatial attention).  ``tag`` selects a private pair of staging buffers (two
-        switches in flight on different streams must not share them)."""
+    def to_temporal_shard(self, x, S, out=None, tag="", chunk=None):
+        """[B,T,Sl,C] -> [B,Tc,S,C]  (before spatial attention).  ``tag`` selects a private pair of staging buffers (two
+        switches in flight on different streams must not share them); ``chunk`` as in plan_switch_to_temporal_shard."""
         B, T, Sl, C = x.shape
-        pack, unpack, sshape, oshape = plan_switch_to_temporal_shard(B, T, Sl, S, C, self.P)
+        pack, unpack, sshape, oshape = plan_switch_to_temporal_shard(B, T, Sl, S, C, self.P, chunk)
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
         with COMM_TIMER.comm():
-            dist.all_to_all_single(recv, send, group=self.group)
+            all_to_all_single(recv, send, self.group)
         if out is None:
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, unpack)
         return out
 
-    def to_spatial_shard(self, x, T, Sl, out=None, tag=""):
-        """[B,Tp,S,C] -> [B,T,Sl,C]  (after spatial attention)."""
-        B, Tp, S, C = x.shape
-        pack, unpack, sshape, oshape = plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, self.P)
+    def to_spatial_shard(self, x, T, Sl, out=None, tag="", chunk=None, Tp=None):
+        """[B,Tc,S,C] -> frames of [B,T,Sl,C]  (after spatial attention).  With a ``chunk`` pass the rank's whole block size
+        ``Tp`` and a caller-owned ``out`` (the chunks of a block write disjoint frames of the same buffer)."""
+        B, Tc, S, C = x.shape
+        Tp = Tc if Tp is None else Tp
+        pack, unpack, sshape, oshape = plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, self.P, chunk)
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
         with COMM_TIMER.comm():
-            dist.all_to_all_single(recv, send, group=self.group)
+            all_to_all_single(recv, send, self.group)
         if out is None:
+            assert chunk is None, "a chunked switch writes part of the frames: the caller owns the output buffer"
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, unpack)
         return out
@@ -334,8 +384,8 @@ class UlyssesParallel:
 
     def __init__(self, group, copy_executor: Callable = hip_copy_executor):
         self.group = group
-        self.P = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.P = group_size(group)
+        self.rank = group_rank(group)
         self.exec = copy_executor
         self._bufs = {}
 
@@ -351,7 +401,7 @@ class UlyssesParallel:
         send = self._buf("u_send", sshape, qkv)
         recv = self._buf("u_recv", sshape, qkv)
         self.exec(qkv, send, pack)
-        dist.all_to_all_single(recv, send, group=self.group)
+        all_to_all_single(recv, send, self.group)
         if out is None:
             out = torch.empty(oshape, dtype=qkv.dtype, device=qkv.device)
         self.exec(qkv, out, unpack_local)
@@ -365,7 +415,7 @@ class UlyssesParallel:
         send = self._buf("g_send", sshape, ao)
         recv = self._buf("g_recv", sshape, ao)
         self.exec(ao, send, pack)
-        dist.all_to_all_single(recv, send, group=self.group)
+        all_to_all_single(recv, send, self.group)
         if out is None:
             out = torch.empty(oshape, dtype=ao.dtype, device=ao.device)
         self.exec(recv, out, unpack)

@@ -134,6 +134,7 @@ class STDiT3:
         self.rope_freqs: Optional[torch.Tensor] = None  # kept in the checkpoint dtype on the host
         self.parallel_manager = SimpleNamespace(sp_size=1, cp_size=1, dp_size=1, dp_rank=0, sp_group=None, cp_group=None)
         self._sp: Optional[dsp.SequenceParallel] = None
+        self._overlap, self._switch, self._scatter, self._side = False, "auto", "flat", None
         self.states = [_BlockState(i // 2, bool(i % 2)) for i in range(2 * self.depth)]
         self._pos_cache = {}
         self._rope_cache = {}
@@ -216,6 +217,11 @@ class STDiT3:
             overlap = os.environ.get("VSYS_DSP_OVERLAP", "1") != "0"
         self._overlap = bool(overlap) and self._sp is not None
         self._switch = os.environ.get("VSYS_DSP_SWITCH", "auto")
+        # which frames a rank attends over: "flat" = the (sample, frame) axis scattered as one (default), "sample" = per sample
+        # as the reference lays it out (comm.py:282-304); same result bit for bit, fewer padded frames on the busiest rank
+        self._scatter = os.environ.get("VSYS_DSP_SCATTER", "flat")
+        if self._scatter not in ("flat", "sample"):
+            raise ValueError("VSYS_DSP_SCATTER must be flat or sample")
         self._side = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)] if self._overlap else None
 
     # ------------------------------------------------------------------ helpers
@@ -416,48 +422,14 @@ class STDiT3:
                 ao = self._buf("attn_out", (N, C))
                 cos, sin = self._rope(T)
                 ops.attn_temporal(qkv, C, w[p + ".attn.q_norm.weight"], w[p + ".attn.k_norm.weight"], cos, sin, ao, B, T, S, H)
+            elif sp is None:
+                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (N, 3 * C)))
+                kp, vt = self._kv_spatial(B * T, S)
+                ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * T, H, S)
+                ao = self._buf("attn_out", (N, C))
+                ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * T, H, S, S)
             else:
-                if sp is not None and T > 1 and B == 2 and getattr(self, "_overlap", False) and self._switch_order(B, T, S_full) != "qkv":
-                    ao = self._spatial_attn_overlapped(p, xm, B, T, S, S_full)
-                    xa = None
-                elif sp is not None and T > 1 and self._switch_order(B, T, S_full) == "qkv":
-                    # qkv GEMM at rest on the un-padded S-shard; the 3C-wide q|k|v travels (dsp.choose_spatial_switch)
-                    qkv_l = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv_rest", (N, 3 * C)))
-                    qkv4 = sp.to_temporal_shard(qkv_l.view(B, T, S, 3 * C), S_full, tag="_qkv",
-                                                out=self._buf("qkv", (B, -(-T // sp.P), S_full, 3 * C)))
-                    Tp = qkv4.shape[1]
-                    nf, Na = B * Tp, B * Tp * S_full
-                    qkv = qkv4.view(Na, 3 * C)
-                    kp, vt = self._kv_spatial(nf, S_full)
-                    ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, nf, H, S_full)
-                    ao = self._buf("attn_out", (Na, C))
-                    ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, nf, H, S_full, S_full)
-                    ao = sp.to_spatial_shard(ao.view(B, Tp, S_full, C), T, S, out=self._buf("attn_back", (B, T, S, C))).view(N, C)
-                    xa = None
-                elif sp is not None and T > 1:
-                    xt = sp.to_temporal_shard(xm.view(B, T, S, C), S_full)  # [B, Tp, S_full, C]
-                    Tp = xt.shape[1]
-                    xa, Ta, Sa = xt.view(B * Tp * S_full, C), Tp, S_full
-                elif sp is not None:
-                    # image case (dynamic_switch is_image, :288-303): the batch is scattered instead of the single frame —
-                    # [B, 1, S/P, C] is the same memory as [1, B, S/P, C], so it is the same switch with "frames" = samples
-                    xt = sp.to_temporal_shard(xm.view(1, B, S, C), S_full)  # [1, ceil(B/P), S_full, C]
-                    xa, Ta, Sa = xt.view(-1, C), xt.shape[1], S_full
-                else:
-                    xa, Ta, Sa = xm, T, S
-                if xa is not None:
-                    image = sp is not None and T == 1
-                    nf = Ta if image else B * Ta          # attention problems (frames) on this rank
-                    Na = nf * Sa
-                    qkv = ops.gemm(xa, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (Na, 3 * C)))
-                    kp, vt = self._kv_spatial(nf, Sa)
-                    ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, nf, H, Sa)
-                    ao = self._buf("attn_out", (Na, C))
-                    ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, nf, H, Sa, Sa)
-                    if image:
-                        ao = sp.to_spatial_shard(ao.view(1, Ta, Sa, C), B, S, out=self._buf("attn_back", (1, B, S, C))).view(N, C)
-                    elif sp is not None:
-                        ao = sp.to_spatial_shard(ao.view(B, Ta, Sa, C), T, S, out=self._buf("attn_back", (B, T, S, C))).view(N, C)
+                ao = self._spatial_attn_sharded(p, xm, B, T, S, S_full)
             ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
                      gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
 
@@ -506,35 +478,78 @@ class STDiT3:
             pab.save_mlp_output(timestep=timestep_int, block_idx=st.block_idx, ff_output=aux, is_temporal=temporal)
         return x
 
-    def _spatial_attn_overlapped(self, p, xm, B, T, S, S_full):
-        """The DSP section of a spatial block (modulated activations -> all-to-all -> qkv -> attention -> all-to-all) with the
-        two CFG samples on two side streams.  The collectives are ISSUED in the order A1, B1, A2, B2 (RCCL runs the collectives of
-        a communicator in issue order), so sample B's first exchange travels while sample A computes and A's second exchange
-        travels while B computes.  Every op is per-sample independent, so the result equals the batched path bit for bit."""
+    def _spatial_attn_sharded(self, p, xm, B, T, S, S_full):
+        """The DSP section of a spatial block (dynamic_switch, open_sora_transformer_3d.py:208-216,288-315): modulated activations
+        [B,T,S/P,C] -> all-to-all -> T-shard [.., S, C] -> qkv GEMM -> spatial attention -> all-to-all -> [B,T,S/P,C].
+
+        Which frames a rank gets ("scatter"): "sample" is the reference's layout (T padded and scattered per sample); "flat"
+        (default) scatters the (sample, frame) axis as ONE axis of B*T frames — [B,T,S/P,C] is the same memory as
+        [1,B*T,S/P,C], spatial attention is per frame and the qkv GEMM per row, so the result is the same bit for bit while the
+        busiest rank holds ceil(B*T/P) instead of B*ceil(T/P) frames.  The reference's image case (T == 1: the batch is scattered,
+        :288-303) is the flat layout by definition.
+
+        What travels ("order"): the C-wide activations (reference order, qkv GEMM on the T-shard) or the 3C-wide q|k|v
+        (GEMM at rest on the un-padded shard), dsp.choose_spatial_switch.
+
+        Overlap: the block's frames are cut in two chunks that run on two side streams with the collectives ISSUED in the order
+        A1, B1, A2, B2 (a communicator executes collectives in issue order): B's first exchange travels while A computes, A's
+        second while B computes.  Every op is per frame / per row, so any cut gives the batched result bit for bit.  Chunks are
+        the two CFG samples ("sample") or the two halves of every rank's frame block ("flat")."""
         w, C, H, sp = self.w, self.hidden_size, self.num_heads, self._sp
+        flat = T == 1 or self._scatter == "flat"
+        Bv, Tv = (1, B * T) if flat else (B, T)
+        Tp = -(-Tv // sp.P)                        # frames of one sample view on this rank (padded)
+        order = self._switch_order(Bv, Tv, S_full)
+        wide = 3 * C if order == "qkv" else C
+        src = xm
+        if order == "qkv":   # qkv GEMM at rest on the un-padded S-shard; the 3C-wide q|k|v travels
+            src = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv_rest", (B * T * S, 3 * C)))
+        src4 = src.view(Bv, Tv, S, wide)
+        back = self._buf("attn_back", (Bv, Tv, S, C))
+
+        # the chunks: (view of the source, chunk of the frame block or None, Bc, frames per sample view)
+        if self._overlap and order != "qkv" and not flat and B == 2:
+            chunks = [(src4[i:i + 1], None, 1, Tp, back[i:i + 1]) for i in range(2)]
+        elif self._overlap and order != "qkv" and flat and Tp >= 2:
+            h = -(-Tp // 2)
+            chunks = [(src4, (0, h), Bv, h, back), (src4, (h, Tp), Bv, Tp - h, back)]
+        else:
+            chunks = [(src4, None, Bv, Tp, back)]
+
+        def attend(i, xt, Bc, Tc):
+            """qkv -> K/V layouts -> flash attention on Bc*Tc whole frames; xt: [Bc, Tc, S_full, wide]"""
+            nf = Bc * Tc
+            Na = nf * S_full
+            if order == "qkv":
+                qkv = xt.view(Na, 3 * C)
+            else:
+                qkv = ops.gemm(xt.view(Na, C), w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf(f"qkv_o{i}", (Na, 3 * C)))
+            key = ("kv_spatial_o", i, nf, S_full)
+            if key not in self._ws:
+                self._ws[key] = ops.alloc_kv_buffers(nf, H, S_full, self.device)
+            kp, vt = self._ws[key]
+            ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, nf, H, S_full)
+            ao = self._buf(f"attn_out_o{i}", (Na, C))
+            ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, nf, H, S_full, S_full)
+            return ao.view(Bc, Tc, S_full, C)
+
+        if len(chunks) == 1:
+            x4, ck, Bc, Tc, out = chunks[0]
+            xt = sp.to_temporal_shard(x4, S_full, out=self._buf("sp_xt0", (Bc, Tc, S_full, wide)))
+            sp.to_spatial_shard(attend(0, xt, Bc, Tc), Tv, S, out=out)
+            return back.view(B * T * S, C)
+
         main = torch.cuda.current_stream()
         ev_in = main.record_event()
-        xm4 = xm.view(B, T, S, C)
-        back = self._buf("attn_back", (B, T, S, C))
         xts = [None, None]
-        for i in range(2):   # phase 1: both first exchanges
+        for i, (x4, ck, Bc, Tc, out) in enumerate(chunks):   # phase 1: both first exchanges
             with torch.cuda.stream(self._side[i]):
                 self._side[i].wait_event(ev_in)
-                xts[i] = sp.to_temporal_shard(xm4[i:i + 1], S_full, tag=f"_{i}", out=self._buf(f"sp_xt{i}", (1, -(-T // sp.P), S_full, C)))
-        for i in range(2):   # phase 2: per-sample attention, then the exchange back
+                xts[i] = sp.to_temporal_shard(x4, S_full, tag=f"_{i}", chunk=ck, out=self._buf(f"sp_xt{i}", (Bc, Tc, S_full, wide)))
+        for i, (x4, ck, Bc, Tc, out) in enumerate(chunks):   # phase 2: per-chunk attention, then the exchange back
             with torch.cuda.stream(self._side[i]):
-                xt = xts[i]
-                Tp = xt.shape[1]
-                Na = Tp * S_full
-                qkv = ops.gemm(xt.view(Na, C), w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf(f"qkv_o{i}", (Na, 3 * C)))
-                key = ("kv_spatial_o", i, Tp, S_full)
-                if key not in self._ws:
-                    self._ws[key] = ops.alloc_kv_buffers(Tp, H, S_full, self.device)
-                kp, vt = self._ws[key]
-                ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, Tp, H, S_full)
-                ao = self._buf(f"attn_out_o{i}", (Na, C))
-                ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, Tp, H, S_full, S_full)
-                sp.to_spatial_shard(ao.view(1, Tp, S_full, C), T, S, out=back[i:i + 1], tag=f"_{i}")
+                ao = attend(i, xts[i], Bc, Tc)
+                sp.to_spatial_shard(ao, x4.shape[1], S, out=out, tag=f"_{i}", chunk=ck, Tp=Tp if ck is not None else None)
                 main.wait_event(self._side[i].record_event())
         return back.view(B * T * S, C)
 
@@ -544,7 +559,8 @@ class STDiT3:
             return self._switch
         key = ("switch", B, T, S_full)
         if key not in self._ws:
-            self._ws[key] = dsp.choose_spatial_switch(B, T, S_full, self.hidden_size, self._sp.P, overlapped=self._overlap)["order"]
+            self._ws[key] = dsp.choose_spatial_switch(B, T, S_full, self.hidden_size, self._sp.P, overlapped=self._overlap,
+                                                      scatter="sample")["order"]   # (called with the scattered view's B, T)
         return self._ws[key]
 
     def _kv_spatial(self, batch, kv_len):
