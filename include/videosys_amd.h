@@ -99,6 +99,20 @@ int vsys_final_layer(const void* x, const void* table, const void* tvec, const v
                      int64_t B, int64_t T, int64_t Hp, int64_t Wp, int64_t H, int64_t W, int64_t ph, int64_t pw,
                      int64_t Cout, int64_t C, float eps, void* stream);
 
+/* The same two layers on the S-shard of a sequence-parallel rank (DSP at rest: rank r holds tokens r*Sl .. r*Sl+Sl-1 of every
+ * (b, t), open_sora_transformer_3d.py:598-603,615-619): the patch embedding is computed for the local tokens only (tokens past
+ * Hp*Wp are the zero rows split_sequence pads with), the final layer runs on the local rows and leaves its ph*pw*Cout values per
+ * token in tokens_f32 [B, T, Sl, n_out]; after an all-gather of those (0.6 MB per rank at config 2 instead of the 11 MB of hidden
+ * state) vsys_unpatchify_tokens scatters [P, B, T, Sl, n_out] into out_f32 [B, Cout, T, H, W].  Same arithmetic per token as the
+ * whole-frame entry points. */
+int vsys_patch_embed_shard(const void* z_f32, int64_t Bz, const void* w, const void* bias, const void* pos, void* out, int64_t B,
+                           int64_t Cin, int64_t T, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t C, int64_t s0, int64_t Sl,
+                           void* stream);
+int vsys_final_layer_tokens(const void* x, const void* table, const void* tvec, const void* w, const void* bias, void* tokens_f32,
+                            int64_t B, int64_t T, int64_t Sl, int64_t n_out, int64_t C, float eps, void* stream);
+int vsys_unpatchify_tokens(const void* tokens_f32, void* out_f32, int64_t P, int64_t B, int64_t T, int64_t Sl, int64_t Hp,
+                           int64_t Wp, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Cout, void* stream);
+
 /* RFLOW CFG combine + Euler update (scheduling_rflow_open_sora.py:245-252): z fp32 [Bz, Cin, thw] +=
  * (uncond + g (cond - uncond)) * dt with cond = model_out[b, :Cin], uncond = model_out[b + Bz, :Cin]. */
 int vsys_cfg_euler_step(void* z_f32, const void* model_out_f32, int64_t Bz, int64_t Cin, int64_t Cout, int64_t thw,
@@ -273,6 +287,52 @@ int vsys_extract_planar(const void* x, const int64_t* grid, int64_t N, int64_t l
 /* row softmax over the first n of ld columns, fp32 [rows, ld] -> bf16 [rows, ld] with zeros in columns n..ld-1 (mid-block
  * attention of the 2-D decoder, keys padded to the 128-column tile; n % 4 == 0, ld % 4 == 0, ld <= 8192). */
 int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64_t ld, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------------------
+ * Launch programs.  A denoise step is ~450 launches of the entry points above with arguments that do not change from step to
+ * step (workspaces, weights and PAB slabs are resident; per-step values live in device buffers).  The host mirror records the
+ * sequence once per (geometry, PAB decision pattern, parallel layout) and replays it with ONE call: the loop below runs in C,
+ * so the per-launch host cost is hipLaunchKernel alone — what matters when P-way sequence parallelism shrinks a rank's device
+ * time per step P-fold while the launch count stays (the reference issues every op from Python every step,
+ * open_sora_transformer_3d.py:608-613).  A command = an entry point (VSYS_OP_*), its integer / pointer arguments in declaration
+ * order in a[], its float arguments in declaration order in f[], and the index of its stream in the table handed to
+ * vsys_program_run.  Commands run in order; the first failing command stops the run, its index goes to *failed_at and its error
+ * code is returned (nothing after it is enqueued).  No allocation, no synchronisation.  Host-side actions between launches
+ * (collectives, event record / wait across streams) stay with the caller, which replays the program in segments. */
+#define VSYS_OP_GEMM_BF16           1
+#define VSYS_OP_LINEAR_SMALL        2
+#define VSYS_OP_ADALN_MODULATE      3
+#define VSYS_OP_MOD_TABLE           4
+#define VSYS_OP_TIMESTEP_EMBEDDING  5
+#define VSYS_OP_PATCH_EMBED         6
+#define VSYS_OP_FINAL_LAYER         7
+#define VSYS_OP_CFG_EULER_STEP      8
+#define VSYS_OP_ADD_ROWS            9
+#define VSYS_OP_COPY_4D_BATCH      10   /* a[3] = HOST pointer to the descriptor array: must outlive the program */
+#define VSYS_OP_ATTN_PREP_KV       11
+#define VSYS_OP_FLASH_ATTN_D72     12
+#define VSYS_OP_ATTN_TEMPORAL_D72  13
+#define VSYS_OP_ADD_BCAST_ROWS     14
+#define VSYS_OP_GEMM_BF16_GATE2    15
+#define VSYS_OP_LN_MODULATE        16
+#define VSYS_OP_GATE_ADD_ROWS      17
+#define VSYS_OP_ATTN_PREP_KV64     18
+#define VSYS_OP_FLASH_ATTN_D64     19
+#define VSYS_OP_PATCH_EMBED_SHARD   20
+#define VSYS_OP_FINAL_LAYER_TOKENS  21
+#define VSYS_OP_UNPATCHIFY_TOKENS   22
+#define VSYS_OP_COUNT              23
+
+typedef struct vsys_cmd {
+  int32_t op;      /* VSYS_OP_* */
+  int32_t stream;  /* index into the streams[] table of vsys_program_run */
+  int64_t a[20];   /* integer and pointer arguments, declaration order, the trailing stream excluded */
+  float f[2];      /* float arguments, declaration order */
+} vsys_cmd;
+
+/* arity of an op (what the recorder must fill): 0, or VSYS_ERR_ARG for an unknown op */
+int vsys_program_op_info(int op, int* n_int, int* n_float);
+int vsys_program_run(const vsys_cmd* cmds, int64_t n, void* const* streams, int64_t n_streams, int64_t* failed_at);
 
 #ifdef __cplusplus
 }

@@ -270,6 +270,45 @@ def test_patch_embed_and_final(ops, golden_ops):
     check(out2, ref[:, :, :, :7, :5], what="final layer cropped")
 
 
+def test_patch_embed_and_final_on_sequence_shards(ops, golden_ops):
+    """The S-shard forms used by a sequence-parallel rank (vsys_patch_embed_shard, vsys_final_layer_tokens +
+    vsys_unpatchify_tokens) must reproduce the whole-frame entry points bit for bit: every rank's rows of the embedding (zero rows
+    past the frame's last token), and the pixels scattered from the gathered per-token outputs — for a shard size that does not
+    divide the token count (S = 20 over P = 3: 7 + 7 + 6, one padding row) and one that does."""
+    g = torch.Generator().manual_seed(6)
+    C, Cin = 576, 4
+    z = torch.randn(1, Cin, 3, 9, 7, generator=g).to(dev())     # Hp x Wp = 5 x 4 = 20 tokens per frame, odd H / W
+    w = bf((torch.randn(C, Cin, 1, 2, 2, generator=g) * 0.1).to(torch.bfloat16).reshape(C, -1))
+    b = bf((torch.randn(C, generator=g) * 0.02).to(torch.bfloat16))
+    pos = bf(O.pos_embed_2d(C, 5, 4, 0.25, 4)[0].to(torch.bfloat16))
+    full = ops.patch_embed(z, w, b, pos, 2, (1, 2, 2), C)          # [2, 3, 20, C]
+    for P in (3, 4):
+        Sl = -(-20 // P)
+        for r in range(P):
+            part = ops.patch_embed_shard(z, w, b, pos, 2, (1, 2, 2), C, r * Sl, Sl)
+            valid = max(0, min(Sl, 20 - r * Sl))
+            assert torch.equal(part[:, :, :valid], full[:, :, r * Sl:r * Sl + valid]), f"P={P} rank {r}"
+            assert not part[:, :, valid:].any(), "rows past the last token must be zero"
+
+    f = golden_ops["final"]
+    B, n, C = f["x"].shape
+    T, Hp, Wp = 3, 4, 4
+    x = bf(f["x"]).view(B, T, Hp * Wp, C)
+    args = (bf(f["table"]), bf(f["t"]), bf(f["w"]), bf(f["b"]))
+    for (H, W) in ((8, 8), (7, 5)):
+        whole = ops.final_layer(x.reshape(B * n, C), *args, B, T, Hp, Wp, H, W, (1, 2, 2), 8)
+        for P in (3, 4):
+            Sl = -(-(Hp * Wp) // P)
+            toks = []
+            for r in range(P):
+                xs = torch.zeros(B, T, Sl, C, dtype=torch.bfloat16, device=dev())
+                valid = max(0, min(Sl, Hp * Wp - r * Sl))
+                xs[:, :, :valid] = x[:, :, r * Sl:r * Sl + valid]
+                toks.append(ops.final_layer_tokens(xs.view(B * T * Sl, C), *args, B, T, Sl))
+            out = ops.unpatchify_tokens(torch.stack(toks).contiguous(), P, B, T, Sl, Hp, Wp, H, W, (1, 2, 2), 8)
+            assert torch.equal(out, whole), f"P={P} {H}x{W}: sharded final layer differs from the whole-frame one"
+
+
 def test_cfg_euler_and_add(ops):
     g = torch.Generator().manual_seed(8)
     z = torch.randn(1, 4, 3, 8, 8, generator=g)
@@ -531,6 +570,55 @@ def test_stdit3_forward_golden():
     # second call hits the text/kv caches and must give the same answer
     out2 = m(i["x"], i["timestep"], i["y"], mask=i["mask"], fps=i["fps"], height=i["height"], width=i["width"])
     assert torch.equal(out.cpu(), out2.cpu())
+
+
+def test_stdit3_launch_program_replay_equals_eager():
+    """Launch programs (videosys_amd/program.py, vsys_program_run): a step recorded once and replayed through the C loop must give
+    the bits of the step issued launch by launch from Python — across changing inputs and timesteps (they live in the program's
+    device buffers), and per PAB decision pattern (each pattern is its own program; a pattern seen for the first time is
+    recorded while it runs eagerly)."""
+    from videosys_amd import pab
+
+    fx = load_golden("stdit3_pab_small.pt")
+    i = fx["inputs"]
+    kw = dict(mask=i["mask"], fps=i["fps"], height=i["height"], width=i["width"])
+    g = torch.Generator().manual_seed(77)
+    xs = [i["x"]] + [torch.randn(i["x"].shape, generator=g).to(torch.bfloat16).float() for _ in range(3)]
+    ts = [900.0, 640.0, 333.0, 120.0]
+
+    def run(use_programs, with_pab):
+        m = _small_model(fx)
+        m.use_programs = use_programs
+        outs = []
+        if with_pab:
+            p = fx["pab"]
+            pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=list(p["spatial"][:2]), spatial_range=p["spatial"][2],
+                                              temporal_broadcast=True, temporal_threshold=list(p["temporal"][:2]), temporal_range=p["temporal"][2],
+                                              cross_broadcast=True, cross_threshold=list(p["cross"][:2]), cross_range=p["cross"][2]))
+            pab.update_steps(fx["steps"])
+        try:
+            if with_pab:
+                for rep in range(2):          # the schedule twice: the second pass replays every pattern of the first
+                    m.reset_pab_state()
+                    for t in fx["timesteps"]:
+                        outs.append(m(i["x"], torch.tensor([t, t]), i["y"], **kw).float().cpu())
+            else:
+                for x, t in zip(xs, ts):
+                    outs.append(m(x, torch.tensor([t, t]), i["y"], **kw).float().cpu())
+        finally:
+            pab.set_pab_manager(None)
+        torch.cuda.synchronize()
+        return outs, dict(m.program_stats)
+
+    for with_pab in (False, True):
+        eager, st0 = run(False, with_pab)
+        prog, st1 = run(True, with_pab)
+        assert st0["replayed"] == 0 and st0["recorded"] == 0
+        assert st1["replayed"] >= (len(fx["timesteps"]) if with_pab else 3), st1
+        for k, (a, b) in enumerate(zip(eager, prog)):
+            assert torch.equal(a, b), f"pab={with_pab} call {k}: replayed step differs from the eager step ({st1})"
+        if not with_pab:   # the outputs handed back are the caller's: a later replay must not overwrite them
+            assert not torch.equal(prog[0], prog[1])
 
 
 def test_stdit3_pab_golden():

@@ -315,9 +315,11 @@ def test_dsp_eight_ranks_in_process_equals_single_and_oracle(frames, hl, wl):
             m.enable_parallel(parallel_mgr=_rank_manager(group, P, r), overlap=overlap)
             m._scatter, m._switch = scatter, order
             assert m._overlap == overlap
-            out = m(x, t, yy, **kw)
+            out = m(x, t, yy, **kw)        # recorded (launch program, program.py) ...
+            out2 = m(x, t, yy, **kw)       # ... and replayed: collectives and cross-stream events re-issued from the log
             torch.cuda.synchronize()
-            res.append(bool(torch.equal(out, out_single)))
+            assert m.program_stats["replayed"] >= 1
+            res.append(bool(torch.equal(out, out_single)) and bool(torch.equal(out2, out_single)))
         S_full = (Hl // 2) * (Wl // 2)
         nfr = {v: __import__("videosys_amd.dsp", fromlist=["x"]).frames_per_rank(2, T, P, v) for v in ("flat", "sample")}
         return res, nfr, m._switch_order(1, 2 * T, S_full)

@@ -62,6 +62,12 @@ SIGNATURES = {
     "vsys_vae_first_im2col": [_ptr, _i64, _i64, _i64, _i64, _i64, _ptr, _ptr, _ptr],
     "vsys_extract_planar": [_ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr],
     "vsys_softmax_rows": [_ptr, _ptr, _i64, _i64, _i64, _ptr],
+    "vsys_patch_embed_shard": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_final_layer_tokens": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "vsys_unpatchify_tokens": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
+    # launch programs (no trailing stream: the stream table is an argument)
+    "vsys_program_op_info": [_int, _ptr, _ptr],
+    "vsys_program_run": [_ptr, _i64, _ptr, _i64, _ptr],
 }
 
 _lib = None

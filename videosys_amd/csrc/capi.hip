@@ -180,7 +180,18 @@ int vsys_patch_embed(const void* z_f32, int64_t Bz, const void* w, const void* b
   if (!z_f32 || !w || !bias || !pos || !out) return VSYS_ERR_ARG;
   if (!fits_int(B) || !fits_int(T) || !fits_int(H) || !fits_int(W) || !fits_int(C) || ph <= 0 || pw <= 0) return VSYS_ERR_SHAPE;
   return launch_patch_embed(reinterpret_cast<const float*>(z_f32), (int)Bz, B16(w), B16(bias), B16(pos), B16(out), (int)B,
-                            (int)Cin, (int)T, (int)H, (int)W, (int)ph, (int)pw, (int)C, S(stream));
+                            (int)Cin, (int)T, (int)H, (int)W, (int)ph, (int)pw, (int)C, 0, -1, S(stream));
+}
+
+int vsys_patch_embed_shard(const void* z_f32, int64_t Bz, const void* w, const void* bias, const void* pos, void* out, int64_t B,
+                           int64_t Cin, int64_t T, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t C, int64_t s0, int64_t Sl,
+                           void* stream) {
+  if (!z_f32 || !w || !bias || !pos || !out) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(T) || !fits_int(H) || !fits_int(W) || !fits_int(C) || ph <= 0 || pw <= 0 || !fits_int(s0) ||
+      !fits_int(Sl))
+    return VSYS_ERR_SHAPE;
+  return launch_patch_embed(reinterpret_cast<const float*>(z_f32), (int)Bz, B16(w), B16(bias), B16(pos), B16(out), (int)B,
+                            (int)Cin, (int)T, (int)H, (int)W, (int)ph, (int)pw, (int)C, (int)s0, (int)Sl, S(stream));
 }
 
 int vsys_final_layer(const void* x, const void* table, const void* tvec, const void* w, const void* bias, void* out_f32,
@@ -189,7 +200,26 @@ int vsys_final_layer(const void* x, const void* table, const void* tvec, const v
   if (!x || !table || !tvec || !w || !bias || !out_f32) return VSYS_ERR_ARG;
   if (!fits_int(B) || !fits_int(T) || !fits_int(Hp) || !fits_int(Wp) || !fits_int(C)) return VSYS_ERR_SHAPE;
   return launch_final_layer(B16(x), B16(table), B16(tvec), B16(w), B16(bias), reinterpret_cast<float*>(out_f32), (int)B,
-                            (int)T, (int)Hp, (int)Wp, (int)H, (int)W, (int)ph, (int)pw, (int)Cout, (int)C, eps, S(stream));
+                            (int)T, (int)Hp, (int)Wp, (int)H, (int)W, (int)ph, (int)pw, (int)Cout, (int)C, eps, -1, nullptr, S(stream));
+}
+
+int vsys_final_layer_tokens(const void* x, const void* table, const void* tvec, const void* w, const void* bias, void* tokens_f32,
+                            int64_t B, int64_t T, int64_t Sl, int64_t n_out, int64_t C, float eps, void* stream) {
+  if (!x || !table || !tvec || !w || !bias || !tokens_f32) return VSYS_ERR_ARG;
+  if (!fits_int(B) || !fits_int(T) || !fits_int(Sl) || !fits_int(C) || n_out <= 0 || n_out > 64) return VSYS_ERR_SHAPE;
+  // (ph, pw, Cout) = (1, 1, n_out): the token-major form needs only their product
+  return launch_final_layer(B16(x), B16(table), B16(tvec), B16(w), B16(bias), nullptr, (int)B, (int)T, 1, (int)Sl, 1, 1, 1, 1,
+                            (int)n_out, (int)C, eps, (int)Sl, reinterpret_cast<float*>(tokens_f32), S(stream));
+}
+
+int vsys_unpatchify_tokens(const void* tokens_f32, void* out_f32, int64_t P, int64_t B, int64_t T, int64_t Sl, int64_t Hp,
+                           int64_t Wp, int64_t H, int64_t W, int64_t ph, int64_t pw, int64_t Cout, void* stream) {
+  if (!tokens_f32 || !out_f32) return VSYS_ERR_ARG;
+  if (!fits_int(P) || !fits_int(B) || !fits_int(T) || !fits_int(Sl) || !fits_int(Hp) || !fits_int(Wp) || !fits_int(H) || !fits_int(W) ||
+      ph <= 0 || pw <= 0 || Cout <= 0 || Hp * ph < H || Wp * pw < W)
+    return VSYS_ERR_SHAPE;
+  return launch_unpatchify_tokens(reinterpret_cast<const float*>(tokens_f32), reinterpret_cast<float*>(out_f32), (int)P, (int)B, (int)T,
+                                  (int)Sl, (int)Hp, (int)Wp, (int)H, (int)W, (int)ph, (int)pw, (int)Cout, S(stream));
 }
 
 int vsys_cfg_euler_step(void* z_f32, const void* model_out_f32, int64_t Bz, int64_t Cin, int64_t Cout, int64_t thw,

@@ -305,19 +305,25 @@ __global__ void timestep_embedding_kernel(const float* __restrict__ t, bf16_t* _
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, int Bz, const bf16_t* __restrict__ w,
                                                           const bf16_t* __restrict__ bias, const bf16_t* __restrict__ pos,
                                                           bf16_t* __restrict__ out, int B, int Cin, int T, int H, int W,
-                                                          int ph, int pw, int C) {
+                                                          int ph, int pw, int C, int s0, int Sl) {
+  // out rows are the tokens s0 .. s0 + Sl - 1 of every (b, t) (the whole frame: s0 = 0, Sl = S); tokens past S are zero rows
+  // (the zero padding of split_sequence, comm.py:148-167)
   const int Hp = (H + ph - 1) / ph, Wp = (W + pw - 1) / pw;
   const int S = Hp * Wp;
   const int cchunks = C >> 3;
-  const int64_t total = (int64_t)B * T * S * cchunks;
+  const int64_t total = (int64_t)B * T * Sl * cchunks;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int cc = (int)(i % cchunks);
   const int64_t tok = i / cchunks;
-  const int s = (int)(tok % S);
-  const int t = (int)((tok / S) % T);
-  const int b = (int)(tok / ((int64_t)S * T));
+  const int s = s0 + (int)(tok % Sl);
+  const int t = (int)((tok / Sl) % T);
+  const int b = (int)(tok / ((int64_t)Sl * T));
   const int bz = b % Bz;
+  if (s >= S) {
+    *reinterpret_cast<uint4*>(out + tok * C + cc * 8) = make_uint4(0, 0, 0, 0);
+    return;
+  }
   const int hp = s / Wp, wp = s - hp * Wp;
   float acc[8];
   {
@@ -375,9 +381,11 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const bf16_t* __restri
                                                           const bf16_t* __restrict__ tvec, const bf16_t* __restrict__ w,
                                                           const bf16_t* __restrict__ bias, float* __restrict__ out,
                                                           int B, int T, int Hp, int Wp, int H, int W, int ph, int pw,
-                                                          int Cout, int C, float eps) {
+                                                          int Cout, int C, float eps, int Sl, float* __restrict__ tokens) {
+  // x rows: [B, T, Sl, C] (Sl = S for the whole sequence).  tokens != null: the NOUT values of a row go to tokens[row][NOUT]
+  // (the S-shard of a sequence-parallel rank; vsys_unpatchify_tokens scatters the gathered rows) instead of to the pixels.
   const int lane = threadIdx.x & 63;
-  const int S = Hp * Wp;
+  const int S = Sl;
   const int64_t rows = (int64_t)B * T * S;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -447,6 +455,10 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const bf16_t* __restri
     d = wave_sum(d);
     if (lane == 0) {
       d = bf2f(f2bf(d + bf2f(bias[n])));  // Linear output is bf16, then .to(float32)
+      if (tokens != nullptr) {
+        tokens[row * NOUT + n] = d;
+        continue;
+      }
       // "(T_p H_p W_p C_out)" ordering of the channel axis, T_p = 1
       const int co = n % Cout;
       const int dx = (n / Cout) % pw, dy = n / (Cout * pw);
@@ -454,6 +466,23 @@ __global__ __launch_bounds__(256) void final_layer_kernel(const bf16_t* __restri
       if (hh < H && ww2 < W) out[((((int64_t)b * Cout + co) * T + t) * H + hh) * W + ww2] = d;
     }
   }
+}
+
+// unpatchify of gathered token rows: tok [P][B][T][Sl][NOUT] fp32 (rank r holds tokens r*Sl .. of every (b, t); tokens >= Hp*Wp
+// are padding) -> out[B, Cout, T, H, W] fp32, "(T_p H_p W_p C_out)" channel order, cropped (open_sora_transformer_3d.py:634-658)
+__global__ void unpatchify_tokens_kernel(const float* __restrict__ tok, float* __restrict__ out, int P, int B, int T, int Sl,
+                                         int Hp, int Wp, int H, int W, int ph, int pw, int Cout) {
+  const int NOUT = ph * pw * Cout;
+  const int64_t total = (int64_t)B * Cout * T * H * W;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ww = (int)(i % W), hh = (int)((i / W) % H), t = (int)((i / ((int64_t)W * H)) % T);
+  const int co = (int)((i / ((int64_t)W * H * T)) % Cout), b = (int)(i / ((int64_t)W * H * T * Cout));
+  const int hp = hh / ph, dy = hh - hp * ph, wp = ww / pw, dx = ww - wp * pw;
+  const int s = hp * Wp + wp;
+  const int r = s / Sl, j = s - r * Sl;
+  const int n = (dy * pw + dx) * Cout + co;
+  out[i] = tok[((((int64_t)r * B + b) * T + t) * Sl + j) * NOUT + n];
 }
 
 // RFLOW step: pred = model_out[:, :Cin] ; v = uncond + g*(cond - uncond) ; z += v*dt    (cond = batch half 0)
@@ -671,32 +700,47 @@ int launch_timestep_embedding(const float* t, bf16_t* out, int B, int dim, hipSt
 }
 
 int launch_patch_embed(const float* x, int Bz, const bf16_t* w, const bf16_t* bias, const bf16_t* pos, bf16_t* out, int B,
-                       int Cin, int T, int H, int W, int ph, int pw, int C, hipStream_t stream) {
-  if (C % 8 || Bz <= 0) return VSYS_ERR_SHAPE;
+                       int Cin, int T, int H, int W, int ph, int pw, int C, int s0, int Sl, hipStream_t stream) {
+  if (C % 8 || Bz <= 0 || s0 < 0) return VSYS_ERR_SHAPE;
   const int Hp = (H + ph - 1) / ph, Wp = (W + pw - 1) / pw;
-  const int64_t total = (int64_t)B * T * Hp * Wp * (C / 8);
+  if (Sl < 0) Sl = Hp * Wp;   // the whole frame
+  const int64_t total = (int64_t)B * T * Sl * (C / 8);
   if (total <= 0) return 0;
+  if ((total + 255) / 256 > 0x7fffffff) return VSYS_ERR_SHAPE;
   hipLaunchKernelGGL(patch_embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, x, Bz, w, bias, pos, out,
-                     B, Cin, T, H, W, ph, pw, C);
+                     B, Cin, T, H, W, ph, pw, C, s0, Sl);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_unpatchify_tokens(const float* tok, float* out, int P, int B, int T, int Sl, int Hp, int Wp, int H, int W, int ph,
+                             int pw, int Cout, hipStream_t stream) {
+  if (P <= 0 || Sl <= 0 || (int64_t)P * Sl < (int64_t)Hp * Wp) return VSYS_ERR_SHAPE;
+  const int64_t total = (int64_t)B * Cout * T * H * W;
+  if (total <= 0) return 0;
+  if ((total + 255) / 256 > 0x7fffffff) return VSYS_ERR_SHAPE;
+  hipLaunchKernelGGL(unpatchify_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, tok, out, P, B, T, Sl,
+                     Hp, Wp, H, W, ph, pw, Cout);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
 int launch_final_layer(const bf16_t* x, const bf16_t* table, const bf16_t* tvec, const bf16_t* w, const bf16_t* bias,
                        float* out, int B, int T, int Hp, int Wp, int H, int W, int ph, int pw, int Cout, int C, float eps,
-                       hipStream_t stream) {
+                       int Sl, float* tokens, hipStream_t stream) {
   if (C % 8 != 0 || C > 64 * 8 * 4) return VSYS_ERR_SHAPE;
-  const int64_t rows = (int64_t)B * T * Hp * Wp;
+  if (Sl < 0) Sl = Hp * Wp;
+  if (tokens == nullptr && Sl != Hp * Wp) return VSYS_ERR_ARG;   // pixels can only be addressed from whole frames
+  const int64_t rows = (int64_t)B * T * Sl;
   if (rows <= 0) return 0;
   const unsigned grid = (unsigned)((rows + 3) / 4);
   if (C <= 64 * 8 * 2)
     hipLaunchKernelGGL(final_layer_kernel<2>, dim3(grid), dim3(256), 0, stream, x, table, tvec, w, bias, out, B, T, Hp, Wp,
-                       H, W, ph, pw, Cout, C, eps);
+                       H, W, ph, pw, Cout, C, eps, Sl, tokens);
   else if (C <= 64 * 8 * 3)
     hipLaunchKernelGGL(final_layer_kernel<3>, dim3(grid), dim3(256), 0, stream, x, table, tvec, w, bias, out, B, T, Hp, Wp,
-                       H, W, ph, pw, Cout, C, eps);
+                       H, W, ph, pw, Cout, C, eps, Sl, tokens);
   else
     hipLaunchKernelGGL(final_layer_kernel<4>, dim3(grid), dim3(256), 0, stream, x, table, tvec, w, bias, out, B, T, Hp, Wp,
-                       H, W, ph, pw, Cout, C, eps);
+                       H, W, ph, pw, Cout, C, eps, Sl, tokens);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

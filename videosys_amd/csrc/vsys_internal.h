@@ -115,10 +115,12 @@ int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* sc
 int launch_mod_table(const bf16_t* table, const bf16_t* t_mlp, bf16_t* out, int nblk, int B, int C6, hipStream_t stream);
 int launch_timestep_embedding(const float* t, bf16_t* out, int B, int dim, hipStream_t stream);
 int launch_patch_embed(const float* x, int Bz, const bf16_t* w, const bf16_t* bias, const bf16_t* pos, bf16_t* out, int B,
-                       int Cin, int T, int H, int W, int ph, int pw, int C, hipStream_t stream);
+                       int Cin, int T, int H, int W, int ph, int pw, int C, int s0, int Sl, hipStream_t stream);  // Sl < 0: whole frame
+int launch_unpatchify_tokens(const float* tok, float* out, int P, int B, int T, int Sl, int Hp, int Wp, int H, int W, int ph,
+                             int pw, int Cout, hipStream_t stream);
 int launch_final_layer(const bf16_t* x, const bf16_t* table, const bf16_t* tvec, const bf16_t* w, const bf16_t* bias,
                        float* out, int B, int T, int Hp, int Wp, int H, int W, int ph, int pw, int Cout, int C, float eps,
-                       hipStream_t stream);
+                       int Sl, float* tokens, hipStream_t stream);   // Sl < 0, tokens = null: whole frames -> pixels
 int launch_cfg_euler(float* z, const float* model_out, int Bz, int Cin, int Cout, int64_t thw, float guidance, float dt,
                      hipStream_t stream);
 int launch_cfg_axpby(float* z, const float* model_out, int Bz, int Cin, int Cout, int64_t thw, float guidance, float c_z,

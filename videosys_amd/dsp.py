@@ -43,15 +43,33 @@ def group_rank(group) -> int:
 
 
 def all_to_all_single(recv, send, group):
-    if hasattr(group, "all_to_all_single"):
-        return group.all_to_all_single(recv, send)
-    return dist.all_to_all_single(recv, send, group=group)
+    """Stream-ordered all-to-all on torch's current stream.  A host-side action: under a launch-program recorder it is logged
+    and re-issued on every replay (program.host_call); the buffers are the SequenceParallel object's resident staging buffers."""
+    from . import program
+
+    def issue():
+        with COMM_TIMER.comm():
+            if hasattr(group, "all_to_all_single"):
+                group.all_to_all_single(recv, send)
+            else:
+                dist.all_to_all_single(recv, send, group=group)
+
+    program.keep(recv), program.keep(send)
+    program.host_call(issue)
 
 
 def all_gather_into_tensor(out, x, group):
-    if hasattr(group, "all_gather_into_tensor"):
-        return group.all_gather_into_tensor(out, x)
-    return dist.all_gather_into_tensor(out, x, group=group)
+    from . import program
+
+    def issue():
+        with COMM_TIMER.comm():
+            if hasattr(group, "all_gather_into_tensor"):
+                group.all_gather_into_tensor(out, x)
+            else:
+                dist.all_gather_into_tensor(out, x, group=group)
+
+    program.keep(out), program.keep(x)
+    program.host_call(issue)
 
 
 def initialize(rank=0, world_size=1, init_method=None, backend: Optional[str] = None):
@@ -299,8 +317,7 @@ class SequenceParallel:
     def gather(self, x, S):
         B, T, Sl, C = x.shape
         recv = self._buf("gather_recv", (self.P, B, T, Sl, C), x)
-        with COMM_TIMER.comm():
-            all_gather_into_tensor(recv.view(self.P * B, T, Sl, C), x.contiguous(), self.group)
+        all_gather_into_tensor(recv.view(self.P * B, T, Sl, C), x.contiguous(), self.group)
         ops, shape = plan_gather(B, T, Sl, S, C, self.P)
         out = torch.empty(shape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, ops)
@@ -314,8 +331,7 @@ class SequenceParallel:
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
-        with COMM_TIMER.comm():
-            all_to_all_single(recv, send, self.group)
+        all_to_all_single(recv, send, self.group)
         if out is None:
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)
         self.exec(recv, out, unpack)
@@ -330,8 +346,7 @@ class SequenceParallel:
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)
         self.exec(x, send, pack)
-        with COMM_TIMER.comm():
-            all_to_all_single(recv, send, self.group)
+        all_to_all_single(recv, send, self.group)
         if out is None:
             assert chunk is None, "a chunked switch writes part of the frames: the caller owns the output buffer"
             out = torch.empty(oshape, dtype=x.dtype, device=x.device)

@@ -9,7 +9,7 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, program
 
 EPI_BIAS, EPI_BIAS_GELU, EPI_GATE_RES = 0, 1, 2
 ACT_NONE, ACT_SILU, ACT_GELU_TANH = 0, 1, 2
@@ -18,11 +18,26 @@ VT_ROWS = 96
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else t.data_ptr()
+    if t is None:
+        return None
+    if program.active() is not None:
+        program.keep(t)          # a recorded launch holds this address: the program keeps the tensor alive
+    return t.data_ptr()
 
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def _call(name: str, *args):
+    """One C-ABI launch on torch's current stream (``args`` = the entry point's arguments without the trailing stream); under a
+    launch-program recorder (program.py) the launch is also logged for replay."""
+    lib = _lib.load()
+    s = torch.cuda.current_stream()
+    rec = program.active()
+    if rec is not None:
+        rec.launch(name, args, _lib.SIGNATURES[name][:-1], s)
+    _lib.check(getattr(lib, name)(*args, s.cuda_stream), name)
 
 
 def _chk(*ts):
@@ -51,9 +66,9 @@ def gemm(x, w, bias=None, *, epilogue=EPI_BIAS, gate=None, gate_stride=0, rows_p
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     assert out.stride(1) == 1
     lib = _lib.load()
-    _lib.check(lib.vsys_gemm_bf16(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, epilogue,
+    _call("vsys_gemm_bf16", _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, epilogue,
                                   _p(gate), gate_stride, rows_per_sample, _p(res), res.stride(0) if res is not None else 0,
-                                  _p(aux), aux.stride(0) if aux is not None else 0, _stream()), "vsys_gemm_bf16")
+                                  _p(aux), aux.stride(0) if aux is not None else 0)
     return out
 
 
@@ -66,8 +81,8 @@ def linear_small(x, w, bias=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.vsys_linear_small(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, act_in,
-                                     act_out, _stream()), "vsys_linear_small")
+    _call("vsys_linear_small", _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, act_in,
+                                     act_out)
     return out
 
 
@@ -80,8 +95,7 @@ def adaln_modulate(x, shift, scale, rows_per_sample, mod_stride, eps=1e-6, out=N
     if out is None:
         out = torch.empty_like(x)
     lib = _lib.load()
-    _lib.check(lib.vsys_adaln_modulate(_p(x), _p(shift), _p(scale), _p(out), rows, C, rows_per_sample, mod_stride, eps,
-                                       _stream()), "vsys_adaln_modulate")
+    _call("vsys_adaln_modulate", _p(x), _p(shift), _p(scale), _p(out), rows, C, rows_per_sample, mod_stride, eps)
     return out
 
 
@@ -94,7 +108,7 @@ def mod_table(table, t_mlp, out=None):
     if out is None:
         out = torch.empty(nblk, B, C6, dtype=torch.bfloat16, device=table.device)
     lib = _lib.load()
-    _lib.check(lib.vsys_mod_table(_p(table), _p(t_mlp), _p(out), nblk, B, C6, _stream()), "vsys_mod_table")
+    _call("vsys_mod_table", _p(table), _p(t_mlp), _p(out), nblk, B, C6)
     return out
 
 
@@ -104,7 +118,7 @@ def timestep_embedding(t_f32, dim=256):
     B = t_f32.numel()
     out = torch.empty(B, dim, dtype=torch.bfloat16, device=t_f32.device)
     lib = _lib.load()
-    _lib.check(lib.vsys_timestep_embedding(_p(t_f32), _p(out), B, dim, _stream()), "vsys_timestep_embedding")
+    _call("vsys_timestep_embedding", _p(t_f32), _p(out), B, dim)
     return out
 
 
@@ -119,8 +133,39 @@ def patch_embed(z_f32, w, bias, pos, B, patch, C):
     Hp, Wp = -(-H // ph), -(-W // pw)
     out = torch.empty(B, T, Hp * Wp, C, dtype=torch.bfloat16, device=z_f32.device)
     lib = _lib.load()
-    _lib.check(lib.vsys_patch_embed(_p(z_f32), Bz, _p(w), _p(bias), _p(pos), _p(out), B, Cin, T, H, W, ph, pw, C, _stream()),
-               "vsys_patch_embed")
+    _call("vsys_patch_embed", _p(z_f32), Bz, _p(w), _p(bias), _p(pos), _p(out), B, Cin, T, H, W, ph, pw, C)
+    return out
+
+
+def patch_embed_shard(z_f32, w, bias, pos, B, patch, C, s0, Sl):
+    """The tokens s0 .. s0+Sl-1 of every (b, t) only: bf16 [B, T, Sl, C]; tokens past Hp*Wp are zero rows (sequence padding)."""
+    _chk(z_f32, w, bias, pos)
+    _bf16(w, bias, pos)
+    assert z_f32.dtype == torch.float32 and z_f32.is_contiguous() and w.is_contiguous() and pos.is_contiguous()
+    Bz, Cin, T, H, W = z_f32.shape
+    assert patch[0] == 1
+    out = torch.empty(B, T, Sl, C, dtype=torch.bfloat16, device=z_f32.device)
+    _call("vsys_patch_embed_shard", _p(z_f32), Bz, _p(w), _p(bias), _p(pos), _p(out), B, Cin, T, H, W, patch[1], patch[2], C, s0, Sl)
+    return out
+
+
+def final_layer_tokens(x, table, tvec, w, bias, B, T, Sl, eps=1e-6):
+    """T2IFinalLayer on the local rows [B*T*Sl, C] -> fp32 [B, T, Sl, n_out] (n_out = rows of the linear = ph*pw*Cout)."""
+    _chk(x, table, tvec, w, bias)
+    _bf16(x, table, tvec, w, bias)
+    assert x.is_contiguous() and w.is_contiguous() and table.is_contiguous() and tvec.is_contiguous()
+    C, n_out = x.shape[-1], w.shape[0]
+    out = torch.empty(B, T, Sl, n_out, dtype=torch.float32, device=x.device)
+    _call("vsys_final_layer_tokens", _p(x), _p(table), _p(tvec), _p(w), _p(bias), _p(out), B, T, Sl, n_out, C, eps)
+    return out
+
+
+def unpatchify_tokens(tokens, P, B, T, Sl, Hp, Wp, H, W, patch, Cout):
+    """tokens fp32 [P, B, T, Sl, ph*pw*Cout] (gathered S-shards) -> fp32 [B, Cout, T, H, W]."""
+    _chk(tokens)
+    assert tokens.dtype == torch.float32 and tokens.is_contiguous() and tokens.numel() == P * B * T * Sl * patch[1] * patch[2] * Cout
+    out = torch.empty(B, Cout, T, H, W, dtype=torch.float32, device=tokens.device)
+    _call("vsys_unpatchify_tokens", _p(tokens), _p(out), P, B, T, Sl, Hp, Wp, H, W, patch[1], patch[2], Cout)
     return out
 
 
@@ -131,8 +176,8 @@ def final_layer(x, table, tvec, w, bias, B, T, Hp, Wp, H, W, patch, Cout, eps=1e
     C = x.shape[-1]
     out = torch.empty(B, Cout, T, H, W, dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.vsys_final_layer(_p(x), _p(table), _p(tvec), _p(w), _p(bias), _p(out), B, T, Hp, Wp, H, W, patch[1],
-                                    patch[2], Cout, C, eps, _stream()), "vsys_final_layer")
+    _call("vsys_final_layer", _p(x), _p(table), _p(tvec), _p(w), _p(bias), _p(out), B, T, Hp, Wp, H, W, patch[1],
+                                    patch[2], Cout, C, eps)
     return out
 
 
@@ -145,8 +190,7 @@ def cfg_euler_step(z_f32, model_out_f32, guidance, dt):
     assert model_out_f32.shape[0] == 2 * Bz
     thw = z_f32[0, 0].numel()
     lib = _lib.load()
-    _lib.check(lib.vsys_cfg_euler_step(_p(z_f32), _p(model_out_f32), Bz, Cin, Cout, thw, float(guidance), float(dt), _stream()),
-               "vsys_cfg_euler_step")
+    _call("vsys_cfg_euler_step", _p(z_f32), _p(model_out_f32), Bz, Cin, Cout, thw, float(guidance), float(dt))
     return z_f32
 
 
@@ -172,7 +216,7 @@ def add_bcast_rows(x, e, group, period):
     assert x.is_contiguous() and e.is_contiguous() and x.shape[-1] == e.shape[-1] and e.shape[0] >= period
     rows = x.numel() // x.shape[-1]
     lib = _lib.load()
-    _lib.check(lib.vsys_add_bcast_rows(_p(x), _p(e), rows, x.shape[-1], group, period, _stream()), "vsys_add_bcast_rows")
+    _call("vsys_add_bcast_rows", _p(x), _p(e), rows, x.shape[-1], group, period)
     return x
 
 
@@ -181,7 +225,7 @@ def add_rows(x, y):
     _bf16(x, y)
     assert x.is_contiguous() and y.is_contiguous() and x.numel() == y.numel()
     lib = _lib.load()
-    _lib.check(lib.vsys_add_rows(_p(x), _p(y), x.numel(), _stream()), "vsys_add_rows")
+    _call("vsys_add_rows", _p(x), _p(y), x.numel())
     return x
 
 
@@ -206,7 +250,7 @@ def copy_4d_batch(src, dst, descs):
         part = descs[i:i + 16]
         flat = [int(v) for d in part for v in d]
         arr = (ctypes.c_int64 * len(flat))(*flat)
-        _lib.check(lib.vsys_copy_4d_batch(_p(src), _p(dst), len(part), arr, _stream()), "vsys_copy_4d_batch")
+        _call("vsys_copy_4d_batch", _p(src), _p(dst), len(part), arr)
 
 
 def kv_pad_len(kv_len: int) -> int:
@@ -228,8 +272,8 @@ def attn_prep_kv(k, v, k_norm_w, kp, vt, batch, heads, kv_len, eps=1e-6):
     kv_pad = kp.shape[2]
     assert vt.shape[3] == kv_pad and vt.shape[2] == VT_ROWS
     lib = _lib.load()
-    _lib.check(lib.vsys_attn_prep_kv(_p(k), k.stride(0), _p(v), v.stride(0), _p(k_norm_w), _p(kp), _p(vt), batch, heads,
-                                     kv_len, kv_pad, eps, _stream()), "vsys_attn_prep_kv")
+    _call("vsys_attn_prep_kv", _p(k), k.stride(0), _p(v), v.stride(0), _p(k_norm_w), _p(kp), _p(vt), batch, heads,
+                                     kv_len, kv_pad, eps)
 
 
 def flash_attn(q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
@@ -239,8 +283,8 @@ def flash_attn(q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
     assert q.stride(1) == 1 and out.stride(1) == 1
     kv_pad = kp.shape[2]
     lib = _lib.load()
-    _lib.check(lib.vsys_flash_attn_d72(_p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
-                                       q_len, kv_len, kv_pad, eps, _stream()), "vsys_flash_attn_d72")
+    _call("vsys_flash_attn_d72", _p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
+                                       q_len, kv_len, kv_pad, eps)
     return out
 
 
@@ -253,8 +297,8 @@ def attn_temporal(qkv, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, B, T, S, 
         assert rope_cos.dtype == torch.float32 and rope_cos.is_contiguous() and rope_cos.shape == (T, HEAD_DIM)
         assert rope_sin.dtype == torch.float32 and rope_sin.is_contiguous() and rope_sin.shape == (T, HEAD_DIM)
     lib = _lib.load()
-    _lib.check(lib.vsys_attn_temporal_d72(_p(qkv), qkv.stride(0), C, _p(q_norm_w), _p(k_norm_w), _p(rope_cos), _p(rope_sin),
-                                          _p(out), out.stride(0), B, T, S, heads, eps, _stream()), "vsys_attn_temporal_d72")
+    _call("vsys_attn_temporal_d72", _p(qkv), qkv.stride(0), C, _p(q_norm_w), _p(k_norm_w), _p(rope_cos), _p(rope_sin),
+                                          _p(out), out.stride(0), B, T, S, heads, eps)
     return out
 
 
@@ -267,10 +311,10 @@ def gemm_gate2(x, w, bias, gate, gate_stride, rows_per_sample, seg_split, gate_a
     M, K = x.shape
     N = w.shape[0]
     lib = _lib.load()
-    _lib.check(lib.vsys_gemm_bf16_gate2(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(gate),
+    _call("vsys_gemm_bf16_gate2", _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(gate),
                                         gate_stride, rows_per_sample, seg_split, gate_alt, _p(res),
                                         res.stride(0) if res is not None else 0, _p(aux),
-                                        aux.stride(0) if aux is not None else 0, _stream()), "vsys_gemm_bf16_gate2")
+                                        aux.stride(0) if aux is not None else 0)
     return out
 
 
@@ -282,8 +326,8 @@ def ln_modulate(x, ln_w, ln_b, shift, scale, rows_per_sample, mod_stride=0, seg_
     if out is None:
         out = torch.empty_like(x)
     lib = _lib.load()
-    _lib.check(lib.vsys_ln_modulate(_p(x), _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(out), rows, C, rows_per_sample, mod_stride,
-                                    seg_split, mod_alt, eps, _stream()), "vsys_ln_modulate")
+    _call("vsys_ln_modulate", _p(x), _p(ln_w), _p(ln_b), _p(shift), _p(scale), _p(out), rows, C, rows_per_sample, mod_stride,
+                                    seg_split, mod_alt, eps)
     return out
 
 
@@ -293,8 +337,7 @@ def gate_add_rows(x, y, gate, rows_per_sample, gate_stride, seg_split=0, gate_al
     assert x.is_contiguous() and y.is_contiguous() and x.shape == y.shape
     rows, C = x.shape
     lib = _lib.load()
-    _lib.check(lib.vsys_gate_add_rows(_p(x), _p(y), _p(gate), rows, C, rows_per_sample, gate_stride, seg_split, gate_alt, _stream()),
-               "vsys_gate_add_rows")
+    _call("vsys_gate_add_rows", _p(x), _p(y), _p(gate), rows, C, rows_per_sample, gate_stride, seg_split, gate_alt)
     return x
 
 
@@ -335,9 +378,8 @@ def attn_prep_kv64(k, v, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, bat
         assert rope_cos.dtype == torch.float32 and rope_cos.is_contiguous() and rope_sin.is_contiguous() and rope_cos.shape[1] == 64
         rope_len = rope_cos.shape[0]
     lib = _lib.load()
-    _lib.check(lib.vsys_attn_prep_kv64(_p(k), k.stride(0), _p(v), v.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin),
-                                       rope_start, rope_len, _p(kp), _p(vt), batch, heads, kv_len, kp.shape[2], eps, _stream()),
-               "vsys_attn_prep_kv64")
+    _call("vsys_attn_prep_kv64", _p(k), k.stride(0), _p(v), v.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin),
+                                       rope_start, rope_len, _p(kp), _p(vt), batch, heads, kv_len, kp.shape[2], eps)
 
 
 def flash_attn64(q, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
@@ -346,9 +388,8 @@ def flash_attn64(q, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, out, bat
     assert q.stride(1) == 1 and out.stride(1) == 1
     rope_len = 0 if rope_cos is None else rope_cos.shape[0]
     lib = _lib.load()
-    _lib.check(lib.vsys_flash_attn_d64(_p(q), q.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin), rope_start, rope_len,
-                                       _p(kp), _p(vt), _p(out), out.stride(0), batch, heads, q_len, kv_len, kp.shape[2], eps,
-                                       _stream()), "vsys_flash_attn_d64")
+    _call("vsys_flash_attn_d64", _p(q), q.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin), rope_start, rope_len,
+                                       _p(kp), _p(vt), _p(out), out.stride(0), batch, heads, q_len, kv_len, kp.shape[2], eps)
     return out
 
 

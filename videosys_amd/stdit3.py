@@ -27,7 +27,7 @@ from typing import Dict, Optional
 
 import torch
 
-from . import dsp, ops, pab
+from . import dsp, ops, pab, program
 from .utils import same_tensor
 
 
@@ -142,6 +142,11 @@ class STDiT3:
         self._fps_cache = {}
         self._ws = {}
         self._hidden_tap = None   # test hook: callable(pair_index, x_rows) after every (spatial, temporal) block pair
+        # launch programs (program.py): a step is recorded once per (geometry, PAB decision pattern, parallel layout) and replayed
+        # through vsys_program_run afterwards; VSYS_PROGRAMS=0 issues every launch from Python every step
+        self.use_programs = os.environ.get("VSYS_PROGRAMS", "1") != "0"
+        self._programs = {}
+        self.program_stats = dict(recorded=0, replayed=0, eager=0)
         # attribute paths the reference's callers read (scheduling_rflow_open_sora.py:221, pipeline_open_sora.py:295)
         self.x_embedder = SimpleNamespace(proj=SimpleNamespace(weight=torch.empty(0, dtype=dtype)))
         self.y_embedder = SimpleNamespace(y_embedding=None)
@@ -171,6 +176,7 @@ class STDiT3:
         self.y_embedder.y_embedding = self.w["y_embedder.y_embedding"]
         self._text_cache = None
         self._rope_cache = {}
+        self._programs = {}
         return self
 
     def expected_keys(self):
@@ -205,6 +211,7 @@ class STDiT3:
             if enable_cp and sp_size % 2 == 0:   # "update cfg parallel" (:470-475): the CFG pair goes to two rank groups
                 sp_size, cp_size = sp_size // 2, 2
             self.parallel_manager = dsp.ParallelManager(dp_size or 1, cp_size, sp_size)
+        self._programs = {}
         if self.parallel_manager.sp_size > 1:
             kw = {} if copy_executor is None else {"copy_executor": copy_executor}
             self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
@@ -273,6 +280,7 @@ class STDiT3:
                 and (mask is None or c["mask_version"] == mask._version)):
             return c
         w = self.w
+        self._programs = {}   # recorded steps hold the previous prompt's K/V addresses
         B, _, L, Cc = y.shape
         C, H = self.hidden_size, self.num_heads
         yb = y.to(device=self.device, dtype=self.dtype).reshape(B * L, Cc).contiguous()
@@ -309,8 +317,9 @@ class STDiT3:
         return self._text_cache
 
     def reset_text_cache(self):
-        """Forget the per-prompt text projections (and their references to the prompt tensors)."""
+        """Forget the per-prompt text projections (and their references to the prompt tensors) and the recorded steps."""
         self._text_cache = None
+        self._programs = {}
 
     # ------------------------------------------------------------------ forward
     @torch.no_grad()
@@ -332,66 +341,139 @@ class STDiT3:
             x, timestep, y, fps, height, width, mask = (rows(v) for v in (x, timestep, y, fps, height, width, mask))
         B, _, Tx, Hx, Wx = x.shape
         T, Hp, Wp = self.get_dynamic_size(x)
-        S = Hp * Wp
         dev = self.device
 
-        # ---- per-step vectors (tiny): t, fps, t_mlp and all modulation rows
-        # timestep.to(dtype) (:562) then .float() inside the embedder.  The sampler hands timesteps over as HOST tensors,
-        # so the integer the PAB policy needs is available without a device sync.
+        # ---- host-side, per step: the timestep (the sampler hands timesteps over as HOST tensors, so the integer the PAB policy
+        # needs is available without a device sync; timestep.to(dtype) (:562) then .float() inside the embedder), the PAB
+        # decisions of every block, and the step-invariant tables (all cached: text K/V, position table, fps embedding, RoPE)
         ts_host = timestep.detach().to("cpu").to(self.dtype).float()
-        ts = ts_host.to(dev)
-        t = self._embed_vec(ts, "t_embedder")
+        timestep_int = int(ts_host[0]) if pab.enable_pab() else None
+        valid_depth = kwargs.get("valid_depth", self.depth)
+        plan = self._pab_plan(timestep_int, all_timesteps, valid_depth)
+        txt = self._encode_text(y, mask)
+        pos = self._pos(Hp, Wp, height[0], width[0])
         fkey = tuple(float(v) for v in fps.reshape(-1).tolist()) + (B,)
         if fkey not in self._fps_cache:
             f = fps.to(dev).float().reshape(-1)
             if f.numel() != B:
                 f = f.repeat(B // f.numel())
             self._fps_cache[fkey] = self._embed_vec(f, "fps_embedder")
-        ops.add_rows(t, self._fps_cache[fkey])
+        self._rope(T)
+        static = (txt, pos, self._fps_cache[fkey])
+
+        mlp_action = plan is not None and any(d[2] or d[3] for d in plan)   # stores / replays host-side dict entries: eager
+        if not (self.use_programs and self._hidden_tap is None and not mlp_action):
+            self.program_stats["eager"] += 1
+            xz = x.to(device=dev, dtype=torch.float32).contiguous()
+            out = self._forward_device(xz, ts_host.to(dev), static, plan, timestep_int, valid_depth, cp)
+        else:
+            sp = self._sp
+            key = (B, Tx, Hx, Wx, float(height[0]), float(width[0]), fkey, valid_depth, cp,
+                   None if plan is None else tuple(d[:2] for d in plan),
+                   None if sp is None else (sp.P, sp.rank, self._scatter, self._switch, self._overlap))
+            ent = self._programs.get(key)
+            if ent is not None:       # replay: refresh the two per-step inputs, ONE C call per launch segment
+                prog, xin, tin, out = ent
+                xin.copy_(x, non_blocking=True)
+                tin.copy_(ts_host, non_blocking=True)
+                prog.run()
+                self.program_stats["replayed"] += 1
+                out = out.clone()     # the program owns its output buffer; callers keep what they are handed
+            else:                     # first time for this key: run eagerly under the recorder
+                xin = torch.empty(B, x.shape[1], Tx, Hx, Wx, dtype=torch.float32, device=dev)
+                tin = torch.empty(B, dtype=torch.float32, device=dev)
+                xin.copy_(x)
+                tin.copy_(ts_host)
+                with program.Recorder() as rec:
+                    out = self._forward_device(xin, tin, static, plan, timestep_int, valid_depth, cp)
+                prog = rec.finish()
+                if prog is not None:
+                    self._programs[key] = (prog, xin, tin, out)
+                    self.program_stats["recorded"] += 1
+                    out = out.clone()
+                else:
+                    self.program_stats["eager"] += 1
+        return out
+
+    def _pab_plan(self, timestep_int, all_timesteps, valid_depth):
+        """The PAB decisions of every block of this step, made up front in the order the reference makes them inside its blocks
+        (attention, cross, MLP per block: open_sora_transformer_3d.py:186-190,230-234,244-250) with the same per-block counters.
+        None when PAB is off; else per block (broadcast_attn, broadcast_cross, broadcast_mlp, store_mlp, skip_range)."""
+        if not pab.enable_pab():
+            return None
+        plan = []
+        mlp_on = pab.PAB_MANAGER.config.mlp_broadcast
+        if mlp_on and all_timesteps is None:
+            raise ValueError("PAB mlp_broadcast needs the sampler's schedule: call the model with all_timesteps=[...]")
+        ats = [int(v) for v in all_timesteps] if mlp_on else None
+        for i in range(2 * valid_depth):
+            st = self.states[i]
+            fn = pab.if_broadcast_temporal if st.temporal else pab.if_broadcast_spatial
+            b_attn, st.attn_count = fn(timestep_int, st.attn_count)
+            b_cross, st.cross_count = pab.if_broadcast_cross(timestep_int, st.cross_count)
+            b_mlp, b_next, rng = False, False, None
+            if mlp_on:
+                b_mlp, st.mlp_count, b_next, rng = pab.if_broadcast_mlp(timestep_int, st.mlp_count, st.block_idx, ats,
+                                                                         is_temporal=st.temporal)
+            plan.append((bool(b_attn), bool(b_cross), bool(b_mlp), bool(b_next), rng))
+        return plan
+
+    def _forward_device(self, xz, ts, static, plan, timestep_int, valid_depth, cp):
+        """Everything of a step that runs on the device, from resident inputs: xz fp32 [B, C_in, T, H, W], ts fp32 [B]."""
+        w, C = self.w, self.hidden_size
+        txt, pos, fps_emb = static
+        B, _, Tx, Hx, Wx = xz.shape
+        T, Hp, Wp = self.get_dynamic_size(xz)
+        S = Hp * Wp
+        dev = self.device
+        pm = self.parallel_manager
+
+        # ---- per-step vectors (tiny): t, fps, t_mlp and all modulation rows
+        t = self._embed_vec(ts, "t_embedder")
+        ops.add_rows(t, fps_emb)
         t_mlp = ops.linear_small(t, w["t_block.1.weight"], w["t_block.1.bias"], act_in=ops.ACT_SILU)  # [B, 6C]
         mod = ops.mod_table(w["_all_tables"], t_mlp)  # [2*depth, B, 6C]
 
-        txt = self._encode_text(y, mask)
-
-        # ---- x embed (+ pos)
-        pos = self._pos(Hp, Wp, height[0], width[0])
-        xz = x.to(device=dev, dtype=torch.float32).contiguous()
-        xe = ops.patch_embed(xz, w["x_embedder.proj.weight"], w["x_embedder.proj.bias"], pos, B, self.patch_size, C)
-
+        # ---- x embed (+ pos).  Sequence parallel: split_sequence(x, dim=2) (:598-603) keeps tokens rank*Sl .. of every frame, so
+        # only those are embedded (the reference embeds the whole frame on every rank and slices)
         sp = self._sp
         S_full = S
         if sp is not None:
-            xe = sp.split(xe)  # [B, T, S/P, C]
-            S = xe.shape[2]
+            S = -(-S_full // sp.P)
+            xe = ops.patch_embed_shard(xz, w["x_embedder.proj.weight"], w["x_embedder.proj.bias"], pos, B, self.patch_size, C,
+                                       sp.rank * S, S)   # [B, T, S/P, C], zero rows past the frame's last token
+        else:
+            xe = ops.patch_embed(xz, w["x_embedder.proj.weight"], w["x_embedder.proj.bias"], pos, B, self.patch_size, C)
         xcur = xe.view(B * T * S, C)
 
-        timestep_int = int(ts_host[0]) if pab.enable_pab() else None
-        valid_depth = kwargs.get("valid_depth", self.depth)
         for d in range(valid_depth):
             for i in (2 * d, 2 * d + 1):
-                xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, timestep_int, all_timesteps)
+                xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, None if plan is None else plan[i], timestep_int)
             if self._hidden_tap is not None:
                 self._hidden_tap(d, xcur)
 
         if sp is not None:
-            xg = sp.gather(xcur.view(B, T, S, C), S_full)
-            xcur = xg.view(B * T * S_full, C)
-            S = S_full
-
-        out = ops.final_layer(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
-                              w["final_layer.linear.bias"], B, T, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
+            # gather_sequence (:615-619) + final layer + unpatchify: the final layer is per token, so it runs on the local rows and
+            # its 32 fp32 values per token are gathered (0.6 MB per rank at config 2) instead of the 1152-wide hidden state (11 MB)
+            tok = ops.final_layer_tokens(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
+                                         w["final_layer.linear.bias"], B, T, S)
+            allt = torch.empty(sp.P, *tok.shape, dtype=tok.dtype, device=dev)
+            dsp.all_gather_into_tensor(allt, tok, sp.group)
+            out = ops.unpatchify_tokens(allt, sp.P, B, T, S, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
+        else:
+            out = ops.final_layer(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
+                                  w["final_layer.linear.bias"], B, T, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
         if cp > 1:  # gather_sequence(x, cp_group, dim=0) (:621)
-            import torch.distributed as dist
-
             parts = torch.empty(cp * B, *out.shape[1:], dtype=out.dtype, device=dev)
-            dist.all_gather_into_tensor(parts, out.contiguous(), group=pm.cp_group)
+            dsp.all_gather_into_tensor(parts, out.contiguous(), pm.cp_group)
             out = parts
         return out
 
     __call__ = forward
 
-    def _block(self, i, x, mod_i, txt, B, T, S, S_full, timestep_int, all_timesteps):
-        """STDiT3Block.forward (open_sora_transformer_3d.py:162-286). x: [B*T*S, C] (S = local shard), updated in place."""
+    def _block(self, i, x, mod_i, txt, B, T, S, S_full, decisions, timestep_int):
+        """STDiT3Block.forward (open_sora_transformer_3d.py:162-286). x: [B*T*S, C] (S = local shard), updated in place.
+        ``decisions`` = this block's entry of _pab_plan (None: PAB off)."""
         w, C, H = self.w, self.hidden_size, self.num_heads
         p = self.block_prefix(i)
         st = self.states[i]
@@ -400,14 +482,11 @@ class STDiT3:
         C6 = 6 * C
         shift_msa, scale_msa, gate_msa = mod_i[0, 0:C], mod_i[0, C:2 * C], mod_i[0, 2 * C:3 * C]
         shift_mlp, scale_mlp, gate_mlp = mod_i[0, 3 * C:4 * C], mod_i[0, 4 * C:5 * C], mod_i[0, 5 * C:6 * C]
-        use_pab = pab.enable_pab()
+        use_pab = decisions is not None
+        broadcast_attn, broadcast_cross, broadcast_mlp, broadcast_next, skip_range = decisions or (False, False, False, False, None)
         sp = self._sp
 
         # ---------------- self attention
-        broadcast_attn = False
-        if use_pab:
-            fn = pab.if_broadcast_temporal if temporal else pab.if_broadcast_spatial
-            broadcast_attn, st.attn_count = fn(timestep_int, st.attn_count)
         if broadcast_attn:
             ops.add_rows(x, st.last_attn)
         else:
@@ -434,9 +513,6 @@ class STDiT3:
                      gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
 
         # ---------------- cross attention (no norm, no modulation, no gate)
-        broadcast_cross = False
-        if use_pab:
-            broadcast_cross, st.cross_count = pab.if_broadcast_cross(timestep_int, st.cross_count)
         if broadcast_cross:
             ops.add_rows(x, st.last_cross)
         else:
@@ -454,13 +530,6 @@ class STDiT3:
         # ---------------- MLP (+ PAB MLP broadcast, open_sora_transformer_3d.py:232-280 / pab_mgr.py:93-174: inside a configured
         # window the block replays gate_mlp * mlp(...) of the window's first timestep).  ``all_timesteps`` reaches the blocks
         # here; the reference's STDiT3.forward forgets to pass it on and raises TypeError with mlp_broadcast=True.
-        broadcast_mlp, broadcast_next, skip_range = False, False, None
-        if use_pab and pab.PAB_MANAGER.config.mlp_broadcast:
-            if all_timesteps is None:
-                raise ValueError("PAB mlp_broadcast needs the sampler's schedule: call the model with all_timesteps=[...]")
-            ats = [int(v) for v in all_timesteps]
-            broadcast_mlp, st.mlp_count, broadcast_next, skip_range = pab.if_broadcast_mlp(timestep_int, st.mlp_count, st.block_idx,
-                                                                                           ats, is_temporal=temporal)
         if broadcast_mlp:
             slab = pab.get_mlp_output(skip_range, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal)
             ops.add_rows(x, slab)
@@ -539,18 +608,21 @@ class STDiT3:
             sp.to_spatial_shard(attend(0, xt, Bc, Tc), Tv, S, out=out)
             return back.view(B * T * S, C)
 
-        main = torch.cuda.current_stream()
-        ev_in = main.record_event()
+        # Cross-stream ordering is host-side work (event record / wait): under a launch-program recorder each of these runs again
+        # on every replay (program.host_call), on the stream that is current here.
+        ev_in, ev_done = torch.cuda.Event(), [torch.cuda.Event(), torch.cuda.Event()]
+        program.host_call(lambda: ev_in.record())                       # main stream: xm (or q|k|v) is ready
         xts = [None, None]
         for i, (x4, ck, Bc, Tc, out) in enumerate(chunks):   # phase 1: both first exchanges
             with torch.cuda.stream(self._side[i]):
-                self._side[i].wait_event(ev_in)
+                program.host_call(lambda: torch.cuda.current_stream().wait_event(ev_in))
                 xts[i] = sp.to_temporal_shard(x4, S_full, tag=f"_{i}", chunk=ck, out=self._buf(f"sp_xt{i}", (Bc, Tc, S_full, wide)))
         for i, (x4, ck, Bc, Tc, out) in enumerate(chunks):   # phase 2: per-chunk attention, then the exchange back
             with torch.cuda.stream(self._side[i]):
                 ao = attend(i, xts[i], Bc, Tc)
                 sp.to_spatial_shard(ao, x4.shape[1], S, out=out, tag=f"_{i}", chunk=ck, Tp=Tp if ck is not None else None)
-                main.wait_event(self._side[i].record_event())
+                program.host_call(lambda e=ev_done[i]: e.record())
+            program.host_call(lambda e=ev_done[i]: torch.cuda.current_stream().wait_event(e))   # main waits for the chunk
         return back.view(B * T * S, C)
 
     def _switch_order(self, B, T, S_full):
