@@ -50,8 +50,8 @@ def _stdit3_worker(rank, world, port, outdir, T, HW):
         out = model(x, t, y, **kw).float().cpu()
         out2 = model(x, t, y, **kw).float().cpu()
         # the default: comm/compute overlap — the two CFG samples on two side streams, collectives issued A1, B1, A2, B2
-        model.enable_parallel(1, world, False)
-        assert model._overlap and model._side is not None and model._switch_order(2, T, (HW // 2) ** 2) == "activations"
+        model.enable_parallel(1, world, False, overlap=True)
+        assert model._overlap is True and model._side is not None and model._switch_order(2, T, (HW // 2) ** 2) == "activations"
         out3 = model(x, t, y, **kw).float().cpu()
         out4 = model(x, t, y, **kw).float().cpu()
         torch.cuda.synchronize()

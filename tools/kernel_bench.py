@@ -38,6 +38,10 @@ def main():
     ap.add_argument("--vendor", action="store_true", help="also time torch.nn.functional.linear (hipBLASLt / rocBLAS) on the four "
                     "GEMM shapes: a yardstick only, never on the product path")
     args = ap.parse_args()
+    if args.rows != 38912 and args.only != "gemm":
+        print(f"[kernel_bench] --rows {args.rows}: the attention / row-wise section is sized for the 38912 rows of config 2; GEMMs only",
+              flush=True)
+        args.only = "gemm"
     import __graft_entry__ as ge
 
     ge.build()

@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
 __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
     const bf16_t* __restrict__ qkv, int64_t row_stride, int C, const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, bf16_t* __restrict__ out, int64_t out_stride, int B, int T,
-    int S, int heads, float eps, float scale) {
+    int S, int heads, float eps, float scale, int hsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
@@ -73,7 +73,12 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
   for (int i = lane * 16; i < VT_BYTES; i += 64 * 16) *reinterpret_cast<uint4*>(vt + i) = make_uint4(0, 0, 0, 0);
   __syncthreads();
 
-  const int64_t bs = blockIdx.x;
+  // hsplit workgroups share a pixel token: workgroup (bs, hg) owns the heads hg*hpg .. hg*hpg + hpg - 1 (small grids: one rank
+  // of a sequence-parallel run has B*S = 256 tokens, one workgroup per CU would leave a wave per SIMD walking four heads serially)
+  const int64_t bs = blockIdx.x / hsplit;
+  const int hg = (int)(blockIdx.x - bs * hsplit);
+  const int hpg = (heads + hsplit - 1) / hsplit;
+  const int h_end = (hg + 1) * hpg < heads ? (hg + 1) * hpg : heads;
   const int s = (int)(bs % S), b = (int)(bs / S);
   // A-operand row m = l31 of the first product holds this key (see header); query / value rows are natural
   const int r_of_m = (l31 & 3) + 4 * (l31 >> 3);
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
     }
   };
 
-  for (int h = wave; h < heads; h += 4) {
+  for (int h = hg * hpg + wave; h < h_end; h += 4) {
     // ---- one round trip: the 4 / 5 sixteen-byte pieces of this lane's q, k and v rows
     uint4 rq[5], rk[5], rv[5];
 #pragma unroll
@@ -236,11 +241,15 @@ int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, co
                                 const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T, int S,
                                 int heads, float eps, float scale, hipStream_t stream) {
   if (T > 32 || T < 1) return VSYS_ERR_SHAPE;
-  const int64_t grid = (int64_t)B * S;
+  // fewer than ~3 workgroups per CU: split the heads of a token over 2 or 4 workgroups (every wave still owns whole heads)
+  int hsplit = 1;
+  const int64_t slots = 3LL * cu_count_this_device();
+  while (hsplit < 4 && (int64_t)B * S * hsplit < slots && heads % (hsplit * 2 * 4) == 0) hsplit *= 2;
+  const int64_t grid = (int64_t)B * S * hsplit;
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
   const int lds = LDS_HEAD + 4 * VT_BYTES;   // 40256
   hipLaunchKernelGGL(attn_temporal_d72_v3_kernel, dim3((unsigned)grid), dim3(256), lds, stream, qkv, row_stride, C, q_norm_w, k_norm_w,
-                     rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale);
+                     rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

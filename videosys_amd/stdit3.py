@@ -217,12 +217,17 @@ class STDiT3:
             self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
         else:
             self._sp = None
-        # comm/compute overlap of the two CFG samples around the spatial attention: ON by default whenever the sequence is sharded
-        # (bit-exact against the batched path with two ranks on one GPU, tests/test_gpu_sp.py); VSYS_DSP_OVERLAP=0 or
-        # overlap=False turns it off.  VSYS_DSP_SWITCH = activations | qkv | auto picks what travels (dsp.choose_spatial_switch).
+        # comm/compute overlap around the spatial attention (two chunks of frames on two side streams): overlap=True / False, or
+        # None = VSYS_DSP_OVERLAP (1 / 0 / auto, default auto).  "auto" overlaps when an exchange is big enough to be worth it:
+        # cutting a block's frames in two halves every kernel of the section and adds cross-stream events — measured on one GPU with
+        # the wire stubbed (tools/issue_time.py --dsp-rank 8): +2.0 ms per step at config 2 (12 MB per exchange, ~2 ms of wire time
+        # per step to hide at best), +2.4 ms at 720p x 128f (73 MB per exchange, ~14 ms of wire time per step).
+        # VSYS_DSP_SWITCH = activations | qkv | auto picks what travels (dsp.choose_spatial_switch).
         if overlap is None:
-            overlap = os.environ.get("VSYS_DSP_OVERLAP", "1") != "0"
-        self._overlap = bool(overlap) and self._sp is not None
+            env = os.environ.get("VSYS_DSP_OVERLAP", "auto")
+            overlap = "auto" if env == "auto" else env != "0"
+        self._overlap = overlap if self._sp is not None else False
+        self._overlap_min_bytes = int(os.environ.get("VSYS_DSP_OVERLAP_MIN_MB", "32")) << 20
         self._switch = os.environ.get("VSYS_DSP_SWITCH", "auto")
         # which frames a rank attends over: "flat" = the (sample, frame) axis scattered as one (default), "sample" = per sample
         # as the reference lays it out (comm.py:282-304); same result bit for bit, fewer padded frames on the busiest rank
@@ -230,6 +235,12 @@ class STDiT3:
         if self._scatter not in ("flat", "sample"):
             raise ValueError("VSYS_DSP_SCATTER must be flat or sample")
         self._side = [torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)] if self._overlap else None
+
+    def _overlap_on(self, frames, S_full, width):
+        """Is the two-chunk overlap used for a spatial block whose rank holds ``frames`` frames of S_full tokens, ``width`` wide?"""
+        if self._overlap == "auto":
+            return frames * S_full * width * 2 >= self._overlap_min_bytes   # bytes a rank sends in one exchange (bf16)
+        return bool(self._overlap)
 
     # ------------------------------------------------------------------ helpers
     def get_dynamic_size(self, x):
@@ -457,7 +468,7 @@ class STDiT3:
             # its 32 fp32 values per token are gathered (0.6 MB per rank at config 2) instead of the 1152-wide hidden state (11 MB)
             tok = ops.final_layer_tokens(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
                                          w["final_layer.linear.bias"], B, T, S)
-            allt = torch.empty(sp.P, *tok.shape, dtype=tok.dtype, device=dev)
+            allt = torch.empty(sp.P * B, *tok.shape[1:], dtype=tok.dtype, device=dev)   # [P][B, T, Sl, n] stacked along dim 0
             dsp.all_gather_into_tensor(allt, tok, sp.group)
             out = ops.unpatchify_tokens(allt, sp.P, B, T, S, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
         else:
@@ -480,8 +491,11 @@ class STDiT3:
         temporal = st.temporal
         N = B * T * S
         C6 = 6 * C
-        shift_msa, scale_msa, gate_msa = mod_i[0, 0:C], mod_i[0, C:2 * C], mod_i[0, 2 * C:3 * C]
-        shift_mlp, scale_mlp, gate_mlp = mod_i[0, 3 * C:4 * C], mod_i[0, 4 * C:5 * C], mod_i[0, 5 * C:6 * C]
+        _buf = self._buf
+
+        def slab(cur):   # a PAB slab the shape of x (allocated on first use)
+            return cur if cur is not None and cur.shape == x.shape else torch.empty_like(x)
+
         use_pab = decisions is not None
         broadcast_attn, broadcast_cross, broadcast_mlp, broadcast_next, skip_range = decisions or (False, False, False, False, None)
         sp = self._sp
@@ -490,22 +504,21 @@ class STDiT3:
         if broadcast_attn:
             ops.add_rows(x, st.last_attn)
         else:
-            xm = ops.adaln_modulate(x, shift_msa, scale_msa, T * S, C6, out=self._buf("xm", (N, C)))
+            xm = ops.adaln_modulate(x, shift_msa, scale_msa, T * S, C6, out=_buf("xm", (N, C)))
             aux = None
             if use_pab:
-                if st.last_attn is None or st.last_attn.shape != x.shape:
-                    st.last_attn = torch.empty_like(x)
+                st.last_attn = slab(st.last_attn)
                 aux = st.last_attn
             if temporal:
-                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (N, 3 * C)))
-                ao = self._buf("attn_out", (N, C))
+                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
+                ao = _buf("attn_out", (N, C))
                 cos, sin = self._rope(T)
                 ops.attn_temporal(qkv, C, w[p + ".attn.q_norm.weight"], w[p + ".attn.k_norm.weight"], cos, sin, ao, B, T, S, H)
             elif sp is None:
-                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv", (N, 3 * C)))
+                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
                 kp, vt = self._kv_spatial(B * T, S)
                 ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * T, H, S)
-                ao = self._buf("attn_out", (N, C))
+                ao = _buf("attn_out", (N, C))
                 ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * T, H, S, S)
             else:
                 ao = self._spatial_attn_sharded(p, xm, B, T, S, S_full)
@@ -516,13 +529,12 @@ class STDiT3:
         if broadcast_cross:
             ops.add_rows(x, st.last_cross)
         else:
-            q = ops.gemm(x, w[p + ".cross_attn.q_linear.weight"], w[p + ".cross_attn.q_linear.bias"], out=self._buf("xm", (N, C)))
-            ao = self._buf("attn_out", (N, C))
+            q = ops.gemm(x, w[p + ".cross_attn.q_linear.weight"], w[p + ".cross_attn.q_linear.bias"], out=_buf("xm", (N, C)))
+            ao = _buf("attn_out", (N, C))
             ops.flash_attn(q, None, txt["kp"][i], txt["vt"][i], ao, B, H, T * S, txt["Lk"])
             aux = None
             if use_pab:
-                if st.last_cross is None or st.last_cross.shape != x.shape:
-                    st.last_cross = torch.empty_like(x)
+                st.last_cross = slab(st.last_cross)
                 aux = st.last_cross
             ops.gemm(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], epilogue=ops.EPI_GATE_RES,
                      res=x, aux=aux, out=x)
@@ -536,10 +548,10 @@ class STDiT3:
             if timestep_int == skip_range[-1]:   # the window closed (the store dropped the entry): the slab is free again,
                 self._ws.setdefault("mlp_slab_pool", []).append(slab)   # in stream order behind the add above
             return x
-        xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, T * S, C6, out=self._buf("xm", (N, C)))
+        xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, T * S, C6, out=_buf("xm", (N, C)))
         hdim = w[p + ".mlp.fc1.weight"].shape[0]
         hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
-                        out=self._buf("mlp_h", (N, hdim)))
+                        out=_buf("mlp_h", (N, hdim)))
         aux = self._mlp_slab(x) if broadcast_next else None   # the post-gate output, written by the fc2 epilogue
         ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
                  gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
@@ -577,9 +589,10 @@ class STDiT3:
         back = self._buf("attn_back", (Bv, Tv, S, C))
 
         # the chunks: (view of the source, chunk of the frame block or None, Bc, frames per sample view)
-        if self._overlap and order != "qkv" and not flat and B == 2:
+        overlap = self._overlap_on(Bv * Tp, S_full, wide)
+        if overlap and order != "qkv" and not flat and B == 2:
             chunks = [(src4[i:i + 1], None, 1, Tp, back[i:i + 1]) for i in range(2)]
-        elif self._overlap and order != "qkv" and flat and Tp >= 2:
+        elif overlap and order != "qkv" and flat and Tp >= 2:
             h = -(-Tp // 2)
             chunks = [(src4, (0, h), Bv, h, back), (src4, (h, Tp), Bv, Tp - h, back)]
         else:
@@ -631,7 +644,7 @@ class STDiT3:
             return self._switch
         key = ("switch", B, T, S_full)
         if key not in self._ws:
-            self._ws[key] = dsp.choose_spatial_switch(B, T, S_full, self.hidden_size, self._sp.P, overlapped=self._overlap,
+            self._ws[key] = dsp.choose_spatial_switch(B, T, S_full, self.hidden_size, self._sp.P, overlapped=bool(self._overlap),
                                                       scatter="sample")["order"]   # (called with the scattered view's B, T)
         return self._ws[key]
 
