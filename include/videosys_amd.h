@@ -57,7 +57,7 @@ int vsys_device_count(void);
  * flash: 0 = default (two workgroups per CU; resident K/V for few keys; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
  *        4 = VALU temporal kernel (v2) for T <= 40; 8 / 10 = the resident-K/V kernel (all KV tiles of a
  *        (batch, head) staged once per workgroup; default for <= 320 keys and many query rows) whenever the keys fit / never;
- *        9 = online-softmax temporal kernel for every T. */
+ *        9 = online-softmax temporal kernel for every T; 12 = the head-dim-64 kernel on a two-stage K/V ring (shipped: three). */
 int vsys_tune_gemm_variant(int variant);
 int vsys_tune_flash_variant(int variant);
 

@@ -31,7 +31,7 @@ def rope_ref(x, cos, sin):
 
 
 @pytest.mark.parametrize("B,H,Lt,Lv,norm,rope", [(2, 6, 20, 300, True, True), (1, 3, 226, 130, True, False),
-                                                  (2, 4, 7, 64, False, True)])
+                                                  (2, 4, 7, 64, False, True), (1, 2, 30, 1000, True, True)])
 def test_flash_attn_d64_joint_sequence(B, H, Lt, Lv, norm, rope):
     from videosys_amd import ops
 
@@ -59,6 +59,19 @@ def test_flash_attn_d64_joint_sequence(B, H, Lt, Lv, norm, rope):
         k = torch.cat([k[:, :, :Lt], bf(rope_ref(k[:, :, Lt:], cos, sin)).float()], 2)
     ref = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v
     check(out, ref.transpose(1, 2).reshape(B * L, C), what=f"flash d64 B{B} H{H} L{Lt}+{Lv}")
+    # the shipped kernel runs a three-stage K/V ring (counted vmcnt(4), raw barrier); flash variant 12 selects the two-stage ring:
+    # the same arithmetic in the same order, so the same bits — for one tile, two tiles (no steady-state iteration) and many
+    from videosys_amd import _lib
+
+    for fv, what in ((12, "two-stage"),):
+        out3 = torch.empty_like(out)
+        try:
+            assert _lib.load().vsys_tune_flash_variant(fv) == 0
+            ops.flash_attn64(qd[:, :C], qw.to(dev()) if norm else None, qb.to(dev()) if norm else None, cd, sd, Lt, kp, vt, out3, B, H, L, L)
+            torch.cuda.synchronize()
+        finally:
+            _lib.load().vsys_tune_flash_variant(0)
+        assert torch.equal(out3, out), f"{what} ring (d64) differs from the shipped three-stage kernel"
 
 
 def test_ln_modulate_two_segments_and_plain():

@@ -1,0 +1,242 @@
+"""CPU (-m "not gpu"): the HOST control flow of the STDiT3 step — block sequencing, PAB plan, launch-program record / replay keys,
+sequence-parallel layouts with all ranks in one process — with every kernel wrapper of videosys_amd.ops replaced by a
+shape-checking stand-in that computes nothing.  TEST INFRASTRUCTURE: the stand-ins live here, the product has no CPU path
+(tests/test_host_cpu.py::test_no_cpu_fallback); what this catches is Python-level breakage (a renamed variable, a wrong shape
+handed to an op, a key that fails to separate two decision patterns) before a GPU minute is spent on it."""
+import contextlib
+
+import pytest
+import torch
+
+from oracle import stdit3_oracle as O
+
+
+def _zeros(shape, like=None, dtype=torch.bfloat16):
+    return torch.zeros(*shape, dtype=dtype)
+
+
+class FakeOps:
+    """Stand-ins with the signatures of videosys_amd.ops; each checks the shapes it is handed and returns a tensor of the
+    shape / dtype the real kernel produces.  ``calls`` counts launches by name."""
+
+    def __init__(self):
+        self.calls = {}
+
+    def _n(self, name):
+        self.calls[name] = self.calls.get(name, 0) + 1
+
+    def gemm(self, x, w, bias=None, *, epilogue=0, gate=None, gate_stride=0, rows_per_sample=0, res=None, aux=None, out=None):
+        self._n("gemm")
+        assert x.dim() == 2 and w.dim() == 2 and x.shape[1] == w.shape[1], (x.shape, w.shape)
+        M, N = x.shape[0], w.shape[0]
+        for t in (res, aux, out):
+            assert t is None or tuple(t.shape) == (M, N), (t.shape, M, N)
+        assert bias is None or bias.shape == (N,)
+        if epilogue == 2 and gate is not None:
+            assert rows_per_sample > 0 and gate.shape == (N,)
+        return out if out is not None else _zeros((M, N))
+
+    def linear_small(self, x, w, bias=None, act_in=0, act_out=0, out=None):
+        self._n("linear_small")
+        assert x.shape[1] == w.shape[1]
+        return out if out is not None else _zeros((x.shape[0], w.shape[0]))
+
+    def adaln_modulate(self, x, shift, scale, rows_per_sample, mod_stride, eps=1e-6, out=None):
+        self._n("adaln_modulate")
+        assert shift.shape == scale.shape == (x.shape[1],) and x.shape[0] % rows_per_sample == 0
+        assert out is None or out.shape == x.shape
+        return out if out is not None else torch.zeros_like(x)
+
+    def mod_table(self, table, t_mlp, out=None):
+        self._n("mod_table")
+        return _zeros((table.shape[0], t_mlp.shape[0], table.shape[1]))
+
+    def timestep_embedding(self, t, dim=256):
+        self._n("timestep_embedding")
+        assert t.dtype == torch.float32
+        return _zeros((t.numel(), dim))
+
+    def patch_embed(self, z, w, bias, pos, B, patch, C):
+        self._n("patch_embed")
+        _, _, T, H, W = z.shape
+        S = -(-H // patch[1]) * -(-W // patch[2])
+        assert pos.shape == (S, C)
+        return _zeros((B, T, S, C))
+
+    def patch_embed_shard(self, z, w, bias, pos, B, patch, C, s0, Sl):
+        self._n("patch_embed_shard")
+        return _zeros((B, z.shape[2], Sl, C))
+
+    def final_layer(self, x, table, tvec, w, bias, B, T, Hp, Wp, H, W, patch, Cout, eps=1e-6):
+        self._n("final_layer")
+        assert x.shape[0] == B * T * Hp * Wp
+        return torch.zeros(B, Cout, T, H, W)
+
+    def final_layer_tokens(self, x, table, tvec, w, bias, B, T, Sl, eps=1e-6):
+        self._n("final_layer_tokens")
+        assert x.shape[0] == B * T * Sl
+        return torch.zeros(B, T, Sl, w.shape[0])
+
+    def unpatchify_tokens(self, tokens, P, B, T, Sl, Hp, Wp, H, W, patch, Cout):
+        self._n("unpatchify_tokens")
+        assert tokens.numel() == P * B * T * Sl * patch[1] * patch[2] * Cout and P * Sl >= Hp * Wp
+        return torch.zeros(B, Cout, T, H, W)
+
+    def add_rows(self, x, y):
+        self._n("add_rows")
+        assert x.numel() == y.numel()
+        return x
+
+    def alloc_kv_buffers(self, batch, heads, kv_len, device):
+        kv_pad = (kv_len + 63) // 64 * 64
+        return _zeros((batch, heads, kv_pad, 72)), _zeros((batch, heads, 96, kv_pad))
+
+    def kv_pad_len(self, kv_len):
+        return (kv_len + 63) // 64 * 64
+
+    def attn_prep_kv(self, k, v, k_norm_w, kp, vt, batch, heads, kv_len, eps=1e-6):
+        self._n("attn_prep_kv")
+        assert k.shape[0] == v.shape[0] == batch * kv_len and kp.shape[0] == batch and kp.shape[2] >= kv_len
+
+    def flash_attn(self, q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
+        self._n("flash_attn")
+        assert q.shape[0] == out.shape[0] == batch * q_len and kp.shape[0] == batch and kp.shape[2] >= kv_len, (q.shape, batch, q_len, kp.shape)
+        return out
+
+    def attn_temporal(self, qkv, C, q_norm_w, k_norm_w, cos, sin, out, B, T, S, heads, eps=1e-6):
+        self._n("attn_temporal")
+        assert qkv.shape == (B * T * S, 3 * C) and out.shape == (B * T * S, C) and cos.shape == (T, 72)
+        return out
+
+    def cfg_euler_step(self, z, out, g, dt):
+        self._n("cfg_euler_step")
+        return z
+
+
+@contextlib.contextmanager
+def fake_ops():
+    from videosys_amd import ops
+
+    f = FakeOps()
+    names = [n for n in dir(f) if not n.startswith("_") and n != "calls"]
+    saved = {n: getattr(ops, n) for n in names}
+    for n in names:
+        setattr(ops, n, getattr(f, n))
+    try:
+        yield f
+    finally:
+        for n, v in saved.items():
+            setattr(ops, n, v)
+
+
+CFG = dict(depth=2, hidden_size=576, num_heads=8, caption_channels=64, model_max_length=16)
+
+
+def _model():
+    from videosys_amd.stdit3 import STDiT3, STDiT3Config
+
+    m = STDiT3(STDiT3Config(**CFG), device="cpu")
+    m.load_state_dict(O.synth_state_dict(**CFG, seed=3))
+    return m
+
+
+def _inputs(T=5, HW=8):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, T, HW, HW, generator=g)
+    y = torch.randn(2, 1, 16, 64, generator=g)
+    mask = torch.zeros(1, 16, dtype=torch.long)
+    mask[:, :11] = 1
+    kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([64.0, 64.0]), width=torch.tensor([64.0, 64.0]))
+    return x, y, kw
+
+
+def test_step_launch_counts_and_program_replay():
+    x, y, kw = _inputs()
+    with fake_ops() as f:
+        m = _model()
+        t = torch.tensor([500.0, 500.0])
+        out = m(x, t, y, **kw)
+        assert out.shape == (2, 8, 5, 8, 8)
+        # per block: 2 AdaLN, 6 token GEMMs, 2 attention calls (self + cross), K/V prep for spatial blocks only
+        nblk = 2 * CFG["depth"]
+        assert f.calls["adaln_modulate"] == 2 * nblk and f.calls["attn_temporal"] == CFG["depth"]
+        assert f.calls["flash_attn"] == nblk + CFG["depth"]
+        gemms_text = f.calls["gemm"] - 6 * nblk     # the once-per-prompt kv_linear projections (GEMM or small linear by shape)
+        assert gemms_text in (0, nblk)
+        before = dict(f.calls)
+        assert m.program_stats == dict(recorded=1, replayed=0, eager=0)
+        m(x, t, y, **kw)                            # same key: replayed — no Python-level launch at all
+        assert m.program_stats["replayed"] == 1 and f.calls == before
+        m(x[:, :, :3], t, y, **kw)                  # another geometry: its own program
+        assert m.program_stats["recorded"] == 2
+        m.use_programs = False
+        m(x, t, y, **kw)
+        assert m.program_stats["eager"] == 1
+        m.reset_text_cache()
+        assert not m._programs
+
+
+def test_pab_patterns_get_their_own_programs_and_mlp_steps_run_eagerly():
+    from videosys_amd import pab
+
+    x, y, kw = _inputs()
+    sched = [1000, 900, 800, 700, 600, 500, 400, 300]
+    rule = {800: {"block": [0, 1], "skip_count": 2}}
+    pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[450, 930], spatial_range=2,
+                                      temporal_broadcast=True, temporal_threshold=[450, 930], temporal_range=4,
+                                      cross_broadcast=True, cross_threshold=[450, 930], cross_range=6,
+                                      mlp_broadcast=True, mlp_spatial_broadcast_config=rule, mlp_temporal_broadcast_config=rule))
+    pab.update_steps(len(sched))
+    try:
+        with fake_ops() as f:
+            m = _model()
+            with pytest.raises(ValueError):
+                m(x, torch.tensor([900.0, 900.0]), y, **kw)       # the MLP broadcast needs the schedule
+            m.reset_pab_state()
+            patterns = []
+            for rep in range(2):
+                m.reset_pab_state()
+                for t in sched:
+                    adds = f.calls.get("add_rows", 0)
+                    m(x, torch.tensor([float(t)] * 2), y, all_timesteps=sched, **kw)
+                    if rep == 0:
+                        patterns.append(f.calls.get("add_rows", 0) - adds)
+            # steps 800 / 700 / 600 open, replay and close the MLP windows: they run eagerly, every other pattern is recorded once
+            # in the first pass and replayed in the second
+            assert m.program_stats["eager"] == 2 * 3, m.program_stats
+            assert m.program_stats["replayed"] >= len(sched) - 3, m.program_stats
+            # broadcast steps add slabs (+ the fps embedding once per eager / recorded step); a step whose decision pattern was
+            # seen before is replayed and issues nothing from Python
+            assert max(patterns) > 1 and patterns[0] == 1 and min(patterns) == 0
+            assert pab.PAB_MANAGER.config.mlp_spatial_outputs == {} and pab.PAB_MANAGER.config.mlp_temporal_outputs == {}
+            assert len(m._ws.get("mlp_slab_pool", [])) >= 1       # closed windows handed their slabs back
+    finally:
+        pab.set_pab_manager(None)
+
+
+@pytest.mark.parametrize("scatter,order", [("flat", "activations"), ("sample", "activations"), ("flat", "qkv")])
+def test_sequence_parallel_host_flow_four_ranks_in_process(scatter, order):
+    """All four ranks of a DSP group as threads (tools/local_group.py), kernels faked: every rank must walk the same collective
+    sequence (a mismatch deadlocks the barrier -> timeout error) with consistent shard shapes, and replay it from the program."""
+    from types import SimpleNamespace
+
+    from test_host_cpu import torch_copy_executor
+    from tools.local_group import LocalWorld
+
+    x, y, kw = _inputs(T=5, HW=12)        # S = 36 tokens over 4 ranks; T = 5 frames x 2 samples
+    P = 4
+
+    def rank_fn(r, group):
+        m = _model()
+        pm = SimpleNamespace(sp_size=P, cp_size=1, dp_size=1, dp_rank=0, sp_rank=r, cp_rank=0, sp_group=group, cp_group=None)
+        m.enable_parallel(parallel_mgr=pm, copy_executor=torch_copy_executor, overlap=False)
+        m._scatter, m._switch = scatter, order
+        t = torch.tensor([500.0, 500.0])
+        out = m(x, t, y, **kw)
+        out2 = m(x, t, y, **kw)
+        assert out.shape == out2.shape == (2, 8, 5, 12, 12)
+        return dict(m.program_stats)
+
+    with fake_ops():
+        stats = LocalWorld(P, timeout=60).run(rank_fn)
+    assert all(s == dict(recorded=1, replayed=1, eager=0) for s in stats), stats

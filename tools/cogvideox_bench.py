@@ -19,10 +19,15 @@ def main():
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--pab", action="store_true")
+    ap.add_argument("--flash-variant", type=int, default=0, help="vsys_tune_flash_variant id (A/B; 0 = shipped dispatch)")
     a = ap.parse_args()
     import __graft_entry__ as ge
 
     ge.build()
+    if a.flash_variant:
+        from videosys_amd import _lib
+
+        assert _lib.load().vsys_tune_flash_variant(a.flash_variant) == 0
     from videosys_amd import CogVideoXConfig, CogVideoXPABConfig, CogVideoXPipeline
 
     geo = dict(num_attention_heads=48, num_layers=42, use_rotary_positional_embeddings=True) if a.model == "5b" else \

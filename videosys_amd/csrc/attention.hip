@@ -927,11 +927,12 @@ __global__ __launch_bounds__(256) void attn_temporal_d72_v2_kernel(const bf16_t*
 static std::atomic<int> g_flash_variant_a{0};
 static unsigned long long* g_flash_dbg = nullptr;
 // 0 = shipped default (resident-K/V kernel for <= 320 keys and many query rows), 3 = three workgroups per CU, 4 / 9 = force the VALU (v2) /
-// online-softmax temporal kernels, 8 = resident-K/V kernel whenever the keys fit, 10 = never: all valid.  1 (K/V tiles not
+// online-softmax temporal kernels, 8 = resident-K/V kernel whenever the keys fit, 10 = never, 12 = the d64 kernel (CogVideoX) on its
+// two-stage K/V ring instead of the shipped three-stage one: all valid.  1 (K/V tiles not
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 8: case 9: case 10: break;
+    case 0: case 3: case 4: case 8: case 9: case 10: case 12: break;
 #ifdef VSYS_LAB
     case 1: case 2: break;
 #endif
@@ -940,6 +941,7 @@ int set_flash_variant(int v) {
   g_flash_variant_a.store(v, std::memory_order_relaxed);
   return 0;
 }
+int get_flash_variant() { return g_flash_variant_a.load(std::memory_order_relaxed); }
 void set_flash_debug_buffer(void* p) { g_flash_dbg = reinterpret_cast<unsigned long long*>(p); }
 void* get_lab_debug_buffer() { return g_flash_dbg; }
 

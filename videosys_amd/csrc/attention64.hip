@@ -136,6 +136,15 @@ struct Flash64Params {
 
 // grid: ceil(q_len/128) * batch * heads workgroups of 4 waves x 32 query rows (1-D, XCD-remapped so the q-blocks of one
 // (batch, head) share an L2).
+// NS = stages of the K/V ring: tile t + NS - 1 is requested at the top of tile t; the wait at the end of tile t is COUNTED — a wave
+// issues four 1-KiB LDS-DMA pieces per tile, so vmcnt(4 k) means "everything but my newest k tiles" = tile t + 1 has landed — and
+// the barrier is the raw s_barrier (__syncthreads() would drain the DMA queue).  An LDS-DMA piece lands ~1.1 us after issue
+// (MI355X_MICROARCH.md), longer than a wave-tile of compute: with NS = 2 (request t + 1, drain at the end of tile t) every tile
+// ended in a wait.  Measured on CogVideoX-5B (config 5, 42 blocks, one GPU; profiles/r03_cogvideox_ring.json): box A 659.8 ms per
+// step with NS = 2 vs 636.6 / 632.3 with NS = 3; box B 671.0 vs 678.4 / 676.8 (and 688 with NS = 4): the part is power-capped and
+// the boxes of the pool differ by more than the effect — NS = 3 ships on the sum of the two (-1.4 %), NS = 2 stays selectable.
+// NS x 16 KiB of LDS per workgroup, two workgroups per CU.
+template <int NS>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(Flash64Params p) {
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -252,9 +261,20 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(Flash64Params p)
   float l_run = 0.f;
 
   const int ntiles = (p.kv_len + 63) / 64;
+  constexpr int LEAD = NS - 1;   // tiles requested ahead of the one being computed
+  // wait until at most ``k`` of this wave's tile requests (4 pieces each) are outstanding; k is wave-uniform
+  auto wait_pending = [&](int k) {
+    if (k <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (k == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (k == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  };
   stage(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+#pragma unroll
+  for (int j = 1; j < LEAD; ++j)
+    if (j < ntiles) stage(j, j);                        // fly under tile 0 (no other vector-memory operation is outstanding: Q was consumed)
+  wait_pending(LEAD - 1 < ntiles - 1 ? LEAD - 1 : ntiles - 1);
+  __builtin_amdgcn_s_barrier();
   const float defer_thr = 8.0f;
 
   auto tile = [&](int t, int cur, const bool masked) {
@@ -342,17 +362,22 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(Flash64Params p)
 #undef FLASH64_VREAD
   };
 
-  for (int t = 0; t < ntiles - 1; ++t) {
-    const int cur = t & 1;
-    stage(t + 1, cur ^ 1);  // every wave finished reading buffer cur^1 before the barrier of tile t-1
-    __builtin_amdgcn_sched_barrier(0);
-    tile(t, cur, false);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  {
+    int cur = 0, nxt = LEAD % NS;   // buffer of tile t, buffer of tile t + LEAD (= the one tile t - 1 left)
+    for (int t = 0; t < ntiles - 1; ++t) {
+      if (t + LEAD < ntiles) stage(t + LEAD, nxt);   // last read during tile t - 1: every wave passed that tile's barrier
+      __builtin_amdgcn_sched_barrier(0);
+      tile(t, cur, false);
+      __builtin_amdgcn_sched_barrier(0);
+      // tiles t + 2 .. min(t + LEAD, ntiles - 1) may stay in flight; tile t + 1 must have landed ...
+      wait_pending(LEAD - 1 < ntiles - t - 2 ? LEAD - 1 : ntiles - t - 2);
+      __builtin_amdgcn_s_barrier();   // ... for every wave
+      cur = cur == NS - 1 ? 0 : cur + 1;
+      nxt = nxt == NS - 1 ? 0 : nxt + 1;
+    }
+    if (p.kv_len & 63) tile(ntiles - 1, cur, true);
+    else tile(ntiles - 1, cur, false);
   }
-  if (p.kv_len & 63) tile(ntiles - 1, (ntiles - 1) & 1, true);
-  else tile(ntiles - 1, (ntiles - 1) & 1, false);
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -403,7 +428,11 @@ int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w,
   p.nqb = (q_len + 127) / 128;
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
   if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
-  hipLaunchKernelGGL(flash_attn_d64_kernel, dim3((unsigned)nblk), dim3(256), 2 * KV_STAGE, stream, p);
+  const int fv = get_flash_variant();
+  if (fv == 12)        // A/B id (see set_flash_variant): the two-stage ring
+    hipLaunchKernelGGL(flash_attn_d64_kernel<2>, dim3((unsigned)nblk), dim3(256), 2 * KV_STAGE, stream, p);
+  else
+    hipLaunchKernelGGL(flash_attn_d64_kernel<3>, dim3((unsigned)nblk), dim3(256), 3 * KV_STAGE, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

@@ -106,6 +106,7 @@ int launch_gemm4_lab(const GemmParams& p, int abl, int persistent, hipStream_t s
 int launch_gemm2_stamp(const GemmParams& p, hipStream_t stream);  // lab: per-stage cycle stamps into p.aux (int64)
 int set_gemm_variant(int v);   // VSYS_ERR_ARG for ids this build does not contain
 int set_flash_variant(int v);
+int get_flash_variant();
 void set_flash_debug_buffer(void* p);
 void* get_lab_debug_buffer();
 int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t ldw, const bf16_t* bias, bf16_t* out,

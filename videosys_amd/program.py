@@ -158,7 +158,8 @@ class Program:
 
     def run(self):
         lib = _lib.load()
-        self._streams[0] = torch.cuda.current_stream().cuda_stream   # the main stream = whatever is current NOW
+        if self.n_launches:
+            self._streams[0] = torch.cuda.current_stream().cuda_stream   # the main stream = whatever is current NOW
         ns = len(self.stream_handles)
         for seg in self.segments:
             if isinstance(seg, tuple):

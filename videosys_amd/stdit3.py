@@ -491,6 +491,8 @@ class STDiT3:
         temporal = st.temporal
         N = B * T * S
         C6 = 6 * C
+        shift_msa, scale_msa, gate_msa = mod_i[0, 0:C], mod_i[0, C:2 * C], mod_i[0, 2 * C:3 * C]
+        shift_mlp, scale_mlp, gate_mlp = mod_i[0, 3 * C:4 * C], mod_i[0, 4 * C:5 * C], mod_i[0, 5 * C:6 * C]
         _buf = self._buf
 
         def slab(cur):   # a PAB slab the shape of x (allocated on first use)
