@@ -621,6 +621,43 @@ def test_stdit3_launch_program_replay_equals_eager():
             assert not torch.equal(prog[0], prog[1])
 
 
+def test_stdit3_pab_slab_elision_is_exact():
+    """A computed attention output is written to its PAB slab only when the block's next call will broadcast it
+    (STDiT3._pab_plan).  Keeping every output (the reference's behaviour) and keeping only the needed ones must give the same bits
+    at every step of the schedule, two videos back to back."""
+    from videosys_amd import pab
+
+    fx = load_golden("stdit3_pab_small.pt")
+    i = fx["inputs"]
+    kw = dict(mask=i["mask"], fps=i["fps"], height=i["height"], width=i["width"])
+    p = fx["pab"]
+    sched = [int(t) for t in fx["timesteps"]]
+
+    def run(elide):
+        m = _small_model(fx)
+        m.pab_elide_unused = elide
+        pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=list(p["spatial"][:2]), spatial_range=p["spatial"][2],
+                                          temporal_broadcast=True, temporal_threshold=list(p["temporal"][:2]), temporal_range=p["temporal"][2],
+                                          cross_broadcast=True, cross_threshold=list(p["cross"][:2]), cross_range=p["cross"][2]))
+        pab.update_steps(fx["steps"])
+        outs = []
+        try:
+            for rep in range(2):
+                m.reset_pab_state()
+                for t in fx["timesteps"]:
+                    outs.append(m(i["x"], torch.tensor([t, t]), i["y"], all_timesteps=sched, **kw).float().cpu())
+        finally:
+            pab.set_pab_manager(None)
+        torch.cuda.synchronize()
+        return outs
+
+    a, b = run(False), run(True)
+    for k, (u, v) in enumerate(zip(a, b)):
+        assert torch.equal(u, v), f"step {k}: eliding unused slab writes changed the result"
+    for t, ref, out in zip(fx["timesteps"], fx["outs"], b):
+        _model_check(out, ref, f"PAB (elided slabs) step t={t}")
+
+
 def test_stdit3_pab_golden():
     from videosys_amd import pab
 

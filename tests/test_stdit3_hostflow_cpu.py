@@ -240,3 +240,68 @@ def test_sequence_parallel_host_flow_four_ranks_in_process(scatter, order):
     with fake_ops():
         stats = LocalWorld(P, timeout=60).run(rank_fn)
     assert all(s == dict(recorded=1, replayed=1, eager=0) for s in stats), stats
+
+
+def test_pab_slab_elision_never_reads_a_stale_slab():
+    """STDiT3._pab_plan keeps a computed attention output only when the block's next call will broadcast it.  With elision on,
+    every broadcast must read a slab written at exactly the step it is read from when every computed output is kept (elision
+    off = the reference's behaviour): the (step, step-of-last-write) sequence of all broadcast adds must be identical, while
+    the number of slab writes drops."""
+    from videosys_amd import pab
+    from videosys_amd.rflow import RFLOW
+
+    x, y, kw = _inputs()
+    sched = RFLOW(num_sampling_steps=30, cfg_scale=7.0, use_timestep_transform=True)
+    geom = dict(height=torch.tensor([512.0]), width=torch.tensor([512.0]), num_frames=torch.tensor([64.0]))
+    ts = [int(t.to(torch.bfloat16)[0]) for t in sched.prepare_timesteps(1, geom)]
+
+    def run(elide):
+        pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[450, 930], spatial_range=2,
+                                          temporal_broadcast=True, temporal_threshold=[450, 930], temporal_range=4,
+                                          cross_broadcast=True, cross_threshold=[450, 930], cross_range=6))
+        pab.update_steps(len(ts))
+        try:
+            with fake_ops() as f:
+                m = _model()
+                m.use_programs = False          # every launch goes through the stand-ins
+                m.pab_elide_unused = elide
+                state = dict(step=-1, written={}, reads=[], writes=0)
+                real_gemm, real_add = f.gemm, f.add_rows
+
+                def gemm(x_, w, bias=None, **k):
+                    if k.get("aux") is not None:
+                        state["written"][k["aux"].data_ptr()] = state["step"]
+                        state["writes"] += 1
+                    return real_gemm(x_, w, bias, **k)
+
+                def add_rows(x_, y_):
+                    if y_.shape == x_.shape and y_.dim() == 2 and y_.shape[0] > 2:      # a slab (not the fps embedding)
+                        state["reads"].append((state["step"], state["written"].get(y_.data_ptr())))
+                    return real_add(x_, y_)
+
+                from videosys_amd import ops
+
+                ops.gemm, ops.add_rows = gemm, add_rows
+                for rep in range(2):            # two videos back to back: the counters wrap
+                    m.reset_pab_state()
+                    for i, t in enumerate(ts):
+                        state["step"] = rep * len(ts) + i
+                        m(x, torch.tensor([float(t)] * 2), y, all_timesteps=ts, **kw)
+                return state
+        finally:
+            pab.set_pab_manager(None)
+
+    keep_all, elided = run(False), run(True)
+    assert keep_all["reads"] and all(w is not None for _, w in keep_all["reads"])
+    assert elided["reads"] == keep_all["reads"], "a broadcast read a slab written at another step than the reference's"
+    assert elided["writes"] < keep_all["writes"], (elided["writes"], keep_all["writes"])
+    # an off-schedule call (timestep not on the schedule) keeps everything
+    pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[450, 930], spatial_range=2))
+    pab.update_steps(30)
+    try:
+        with fake_ops():
+            m = _model()
+            plan = m._pab_plan(555, ts, CFG["depth"])
+            assert all(d[5] and d[6] for d in plan)
+    finally:
+        pab.set_pab_manager(None)

@@ -144,6 +144,7 @@ class STDiT3:
         self._hidden_tap = None   # test hook: callable(pair_index, x_rows) after every (spatial, temporal) block pair
         # launch programs (program.py): a step is recorded once per (geometry, PAB decision pattern, parallel layout) and replayed
         # through vsys_program_run afterwards; VSYS_PROGRAMS=0 issues every launch from Python every step
+        self.pab_elide_unused = os.environ.get("VSYS_PAB_ELIDE", "1") != "0"   # see _pab_plan: slabs nobody will read are not written
         self.use_programs = os.environ.get("VSYS_PROGRAMS", "1") != "0"
         self._programs = {}
         self.program_stats = dict(recorded=0, replayed=0, eager=0)
@@ -380,7 +381,7 @@ class STDiT3:
         else:
             sp = self._sp
             key = (B, Tx, Hx, Wx, float(height[0]), float(width[0]), fkey, valid_depth, cp,
-                   None if plan is None else tuple(d[:2] for d in plan),
+                   None if plan is None else tuple(d[:2] + d[5:7] for d in plan),
                    None if sp is None else (sp.P, sp.rank, self._scatter, self._switch, self._overlap))
             ent = self._programs.get(key)
             if ent is not None:       # replay: refresh the two per-step inputs, ONE C call per launch segment
@@ -413,12 +414,30 @@ class STDiT3:
         if not pab.enable_pab():
             return None
         plan = []
-        mlp_on = pab.PAB_MANAGER.config.mlp_broadcast
+        cfg = pab.PAB_MANAGER.config
+        mlp_on = cfg.mlp_broadcast
         if mlp_on and all_timesteps is None:
             raise ValueError("PAB mlp_broadcast needs the sampler's schedule: call the model with all_timesteps=[...]")
-        ats = [int(v) for v in all_timesteps] if mlp_on else None
+        sched = [int(v) for v in all_timesteps] if all_timesteps is not None else None
+        ats = sched if mlp_on else None
+        # A computed attention output is kept (the GEMM epilogue writes the slab, +20 us per gated GEMM) only if the block's NEXT
+        # call will broadcast it: by the reference's rule (pab_mgr.py:54-91) the next call either broadcasts or recomputes, and a
+        # recompute rewrites the slab.  The next call's timestep is known when the sampler handed the schedule over and the current
+        # timestep sits on it exactly once before its end; otherwise the slab is always written (as before).  Outside the
+        # broadcast window — 12 of the 30 steps of config 3 — nothing is kept.
+        t_next = None
+        if self.pab_elide_unused and sched is not None and sched.count(timestep_int) == 1 and sched.index(timestep_int) + 1 < len(sched):
+            t_next = sched[sched.index(timestep_int) + 1]
+
+        def kept(kind, count_next):
+            if t_next is None:
+                return True
+            on, every, thr = cfg.attn_rule(kind)
+            return bool(on) and thr is not None and count_next % every != 0 and thr[0] < t_next < thr[1]
+
         for i in range(2 * valid_depth):
             st = self.states[i]
+            kind = "temporal" if st.temporal else "spatial"
             fn = pab.if_broadcast_temporal if st.temporal else pab.if_broadcast_spatial
             b_attn, st.attn_count = fn(timestep_int, st.attn_count)
             b_cross, st.cross_count = pab.if_broadcast_cross(timestep_int, st.cross_count)
@@ -426,7 +445,8 @@ class STDiT3:
             if mlp_on:
                 b_mlp, st.mlp_count, b_next, rng = pab.if_broadcast_mlp(timestep_int, st.mlp_count, st.block_idx, ats,
                                                                          is_temporal=st.temporal)
-            plan.append((bool(b_attn), bool(b_cross), bool(b_mlp), bool(b_next), rng))
+            plan.append((bool(b_attn), bool(b_cross), bool(b_mlp), bool(b_next), rng,
+                         kept(kind, st.attn_count), kept("cross", st.cross_count)))
         return plan
 
     def _forward_device(self, xz, ts, static, plan, timestep_int, valid_depth, cp):
@@ -499,7 +519,8 @@ class STDiT3:
             return cur if cur is not None and cur.shape == x.shape else torch.empty_like(x)
 
         use_pab = decisions is not None
-        broadcast_attn, broadcast_cross, broadcast_mlp, broadcast_next, skip_range = decisions or (False, False, False, False, None)
+        broadcast_attn, broadcast_cross, broadcast_mlp, broadcast_next, skip_range, keep_attn, keep_cross = \
+            decisions or (False, False, False, False, None, False, False)
         sp = self._sp
 
         # ---------------- self attention
@@ -508,7 +529,7 @@ class STDiT3:
         else:
             xm = ops.adaln_modulate(x, shift_msa, scale_msa, T * S, C6, out=_buf("xm", (N, C)))
             aux = None
-            if use_pab:
+            if use_pab and keep_attn:
                 st.last_attn = slab(st.last_attn)
                 aux = st.last_attn
             if temporal:
@@ -535,7 +556,7 @@ class STDiT3:
             ao = _buf("attn_out", (N, C))
             ops.flash_attn(q, None, txt["kp"][i], txt["vt"][i], ao, B, H, T * S, txt["Lk"])
             aux = None
-            if use_pab:
+            if use_pab and keep_cross:
                 st.last_cross = slab(st.last_cross)
                 aux = st.last_cross
             ops.gemm(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], epilogue=ops.EPI_GATE_RES,
