@@ -197,16 +197,17 @@ def main():
         # HBM/fabric bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same
         # kernels and shapes, tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json), config-2 launch mix
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_gemm_traffic.json")
-        if os.path.exists(tpath) and world == 1:
-            with open(tpath) as fh:
+        tname = next((n for n in ("r03_gemm_traffic.json", "r01_gemm_traffic.json")
+                      if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        if tname is not None and world == 1:
+            with open(os.path.join(ROOT, "profiles", tname)) as fh:
                 traffic = round(json.load(fh)["avg_bytes_per_launch_config2_mix"])
         roof = {
             "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> + vsys::gemm2_kernel<EPI> (256x192 tile, bf16 MFMA 32x32x16, shape-dispatched, all epilogues)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic if base_geo else None,
-            "traffic_source": "profiles/r01_gemm_traffic.json (committed rocprofv3 PMC passes of the same kernels and shapes; NOT "
-                              "re-measured by this run)",
+            "traffic_source": f"profiles/{tname} (committed rocprofv3 PMC passes of the same kernels and shapes with the shipped dispatch; "
+                              "NOT re-measured by this run)",
             "annotations_not_measured_by_this_run": {
                 "power_limited_mfma_ceiling_tflops": 1816.0, "source": "profiles/r01_mfma_power_ceiling.json",
                 "note": "a bare MFMA loop with operands changing every instruction sustains 1816 TFLOP/s at the 1400 W cap (2465 "
@@ -333,6 +334,8 @@ def main():
                 "steps_per_video": STEPS_PER_VIDEO, "parallelism": f"dsp{world}",
                 "not_included": "value is DiT denoising only; vae_decode / t5_encode report the other two terms of the metric beside it",
                 "algorithmic_tflop_per_step": 89.4 if args.depth == 28 and L == 300 and base_geo else None,
+                "launch_path": ("recorded launch program: " + json.dumps(model.program_stats)) if model.use_programs else "eager (every launch from Python)",
+                "dsp_layout": None if world == 1 else {"scatter": model._scatter, "overlap": str(model._overlap), "switch": model._switch},
             },
             "step_tflops": round(89.4 / step_s, 1) if args.depth == 28 and L == 300 and not args.pab and base_geo else None,
             "roofline": roof, "cpu_baseline": cpu, "vae_decode": vae, "t5_encode": t5, "dsp": dsp_info,
