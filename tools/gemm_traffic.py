@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-shape HBM/fabric traffic of the GEMM from two rocprofv3 --pmc passes of tools/pmc_gemm.py (VSYS_GEMM_ALL_SHAPES=1,
-one variant): usage  python tools/gemm_traffic.py <fetch.db> <write.db> > profiles/r01_gemm_traffic.json
+one variant): usage  python tools/gemm_traffic.py <fetch.db> <write.db> > profiles/rNN_gemm_traffic.json
 FETCH_SIZE / WRITE_SIZE are KiB; reads are doubled (gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
 streams, MI355X_MICROARCH.md section HBM); WRITE_SIZE matches the output bytes 1:1 on this kernel (269.0 MB at qkv)."""
 import json
