@@ -337,16 +337,29 @@ def encode_text(y: Tensor, mask: Optional[Tensor], sd):
     return y, y_lens
 
 
+def t_mask_select(x_mask: Tensor, x: Tensor, masked_x: Tensor, T: int, S: int) -> Tensor:
+    """t_mask_select — open_sora_transformer_3d.py:65-73,152-160: rows of frames with x_mask True keep x, the others take masked_x."""
+    B, _, C = x.shape
+    m = x_mask.to(torch.bool)[:, :, None, None]
+    return torch.where(m, x.reshape(B, T, S, C), masked_x.reshape(B, T, S, C)).reshape(B, T * S, C)
+
+
 def stdit3_block(
     x, y, t_mlp, y_lens, T, S, sd, prefix, num_heads, temporal, rope_freqs,
     pab: Optional[PABSchedule] = None, state: Optional[_BlockState] = None, timestep_int: Optional[int] = None,
-    sp_shards: int = 1, block_idx: int = 0, all_timesteps=None,
+    sp_shards: int = 1, block_idx: int = 0, all_timesteps=None, x_mask: Optional[Tensor] = None,
+    t0_mlp: Optional[Tensor] = None,
 ):
-    """STDiT3Block.forward — open_sora_transformer_3d.py:162-286 (x_mask=None path), incl. the MLP broadcast (:232-280) when the
-    schedule carries MLP rules and ``all_timesteps`` is handed down (which the reference's STDiT3.forward forgets to do)."""
+    """STDiT3Block.forward — open_sora_transformer_3d.py:162-286, incl. the MLP broadcast (:232-280) when the schedule carries
+    MLP rules and ``all_timesteps`` is handed down (which the reference's STDiT3.forward forgets to do), and the frame-wise
+    choice between the modulation of ``t`` and of timestep 0 when ``x_mask`` [B, T] is given (:181-184,198-200,220-222,
+    262-264,271-273: frames whose mask is False are conditioning frames and see the t = 0 shift / scale / gate)."""
     B, N, C = x.shape
     mods = (sd[prefix + ".scale_shift_table"][None] + t_mlp.reshape(B, 6, -1)).chunk(6, dim=1)
     shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp = mods
+    if x_mask is not None:
+        mods0 = (sd[prefix + ".scale_shift_table"][None] + t0_mlp.reshape(B, 6, -1)).chunk(6, dim=1)
+        shift_msa0, scale_msa0, gate_msa0, shift_mlp0, scale_mlp0, gate_mlp0 = mods0
 
     broadcast_attn = False
     if pab is not None and pab.enabled():
@@ -354,7 +367,10 @@ def stdit3_block(
     if broadcast_attn:
         x_m_s = state.last_attn
     else:
-        x_m = t2i_modulate(layer_norm(x), shift_msa, scale_msa)
+        normed = layer_norm(x)
+        x_m = t2i_modulate(normed, shift_msa, scale_msa)
+        if x_mask is not None:
+            x_m = t_mask_select(x_mask, x_m, t2i_modulate(normed, shift_msa0, scale_msa0), T, S)
         if temporal:
             x_m = x_m.reshape(B, T, S, C).permute(0, 2, 1, 3).reshape(B * S, T, C)
             x_m = self_attention(x_m, sd, prefix + ".attn", num_heads, rope_freqs)
@@ -364,6 +380,8 @@ def stdit3_block(
             x_m = self_attention(x_m, sd, prefix + ".attn", num_heads, None)
             x_m = x_m.reshape(B, T * S, C)
         x_m_s = gate_msa * x_m
+        if x_mask is not None:
+            x_m_s = t_mask_select(x_mask, x_m_s, gate_msa0 * x_m, T, S)
         if pab is not None and pab.enabled():
             state.last_attn = x_m_s
     x = x + x_m_s
@@ -389,17 +407,28 @@ def stdit3_block(
         if timestep_int == window[1]:
             del bank[(window[0], block_idx)]
     else:
-        x_m = t2i_modulate(layer_norm(x), shift_mlp, scale_mlp)
-        x_m_s = gate_mlp * mlp(x_m, sd, prefix + ".mlp")
+        normed = layer_norm(x)
+        x_m = t2i_modulate(normed, shift_mlp, scale_mlp)
+        if x_mask is not None:
+            x_m = t_mask_select(x_mask, x_m, t2i_modulate(normed, shift_mlp0, scale_mlp0), T, S)
+        h = mlp(x_m, sd, prefix + ".mlp")
+        x_m_s = gate_mlp * h
+        if x_mask is not None:
+            x_m_s = t_mask_select(x_mask, x_m_s, gate_mlp0 * h, T, S)
         if store:
             pab.mlp_store[temporal][(timestep_int, block_idx)] = x_m_s
     return x + x_m_s
 
 
-def final_layer(x, t, sd):
-    """T2IFinalLayer.forward — open_sora_transformer_3d.py:75-87 (x_mask=None)."""
+def final_layer(x, t, sd, x_mask=None, t0=None, T=None, S=None):
+    """T2IFinalLayer.forward — open_sora_transformer_3d.py:75-87."""
     shift, scale = (sd["final_layer.scale_shift_table"][None] + t[:, None]).chunk(2, dim=1)
     x = t2i_modulate(layer_norm(x), shift, scale)
+    if x_mask is not None:
+        # as written in the reference (:83-85) the conditioning branch normalises the ALREADY modulated x a second time
+        # (``x`` was reassigned two lines earlier): x_zero = mod0(LN(mod_t(LN(x)))).  Restated as is — the fixture pins it.
+        shift0, scale0 = (sd["final_layer.scale_shift_table"][None] + t0[:, None]).chunk(2, dim=1)
+        x = t_mask_select(x_mask, x, t2i_modulate(layer_norm(x), shift0, scale0), T, S)
     return linear(x, sd, "final_layer.linear")
 
 
@@ -413,7 +442,7 @@ def unpatchify(x, N_t, N_h, N_w, R_t, R_h, R_w, patch, c_out):
 
 
 class STDiT3Oracle:
-    """STDiT3.forward — open_sora_transformer_3d.py:539-632, sp=cp=1, fp32, x_mask=None."""
+    """STDiT3.forward — open_sora_transformer_3d.py:539-632, sp=cp=1, fp32."""
 
     def __init__(self, sd: Dict[str, Tensor], depth: int, hidden_size: int, num_heads: int,
                  patch_size=(1, 2, 2), in_channels: int = 4, input_sq_size: int = 512, pred_sigma: bool = True,
@@ -459,28 +488,37 @@ class STDiT3Oracle:
         fe = embed_mlp(timestep_embedding(f.reshape(-1).float()), sd, "fps_embedder").view(B, -1)
         t = t + fe
         t_mlp = linear(F.silu(t), sd, "t_block.1")
+        # the timestep-0 embedding conditioning frames are modulated with (:578-582); dropped by callers without x_mask
+        self._t0 = embed_mlp(timestep_embedding(torch.zeros_like(timestep).float()), sd, "t_embedder") + fe
+        self._t0_mlp = linear(F.silu(self._t0), sd, "t_block.1")
         yy, y_lens = encode_text(y.to(dt), mask, sd)
         xe = patch_embed(x.to(dt), sd, p).view(B, T, S, self.C) + pos
         return xe.reshape(B, T * S, self.C), t, t_mlp, yy, y_lens, (T, H, W, Tx, Hx, Wx)
 
     def forward(self, x, timestep, y, mask=None, fps=None, height=None, width=None, valid_depth=None,
-                return_hidden=False, all_timesteps=None):
+                return_hidden=False, all_timesteps=None, x_mask=None):
         x, t, t_mlp, yy, y_lens, (T, H, W, Tx, Hx, Wx) = self.embed(x, timestep, y, mask, fps, height, width)
         S = H * W
+        xm_kw = {}
+        t0 = None
+        if x_mask is not None:
+            x_mask = x_mask.to(self.device).to(torch.bool)
+            t0 = self._t0
+            xm_kw = dict(x_mask=x_mask, t0_mlp=self._t0_mlp)
         rope_freqs = self.sd["rope.freqs"]
         ts_int = int(timestep[0]) if self.pab is not None else None
         depth = self.depth if valid_depth is None else valid_depth
         hidden = []
         for d in range(depth):
             x = stdit3_block(x, yy, t_mlp, y_lens, T, S, self.sd, f"spatial_blocks.{d}", self.H, False, None,
-                             self.pab, self._state(("s", d)), ts_int, block_idx=d, all_timesteps=all_timesteps)
+                             self.pab, self._state(("s", d)), ts_int, block_idx=d, all_timesteps=all_timesteps, **xm_kw)
             x = stdit3_block(x, yy, t_mlp, y_lens, T, S, self.sd, f"temporal_blocks.{d}", self.H, True, rope_freqs,
-                             self.pab, self._state(("t", d)), ts_int, block_idx=d, all_timesteps=all_timesteps)
+                             self.pab, self._state(("t", d)), ts_int, block_idx=d, all_timesteps=all_timesteps, **xm_kw)
             if callable(return_hidden):   # full-depth parity tests: per-block-pair error growth without keeping 28 copies
                 return_hidden(d, x)
             elif return_hidden:
                 hidden.append(x.clone())
-        out = final_layer(x, t, self.sd)
+        out = final_layer(x, t, self.sd, x_mask, t0, T, S)
         out = unpatchify(out, T, H, W, Tx, Hx, Wx, self.patch, self.out_channels).to(torch.float32)
         return (out, hidden) if (return_hidden and not callable(return_hidden)) else out
 
@@ -518,17 +556,31 @@ def rflow_timesteps(num_sampling_steps, batch, height, width, num_frames, num_ti
 
 def rflow_sample(model, z, y, y_null, mask, fps, height, width, num_frames, num_sampling_steps=30,
                  cfg_scale=7.0, num_timesteps=1000, use_timestep_transform=True, model_dtype=torch.float32,
-                 return_all=False):
-    """RFLOW.sample — scheduling_rflow_open_sora.py:188-257 (mask=None path)."""
+                 return_all=False, cond_mask=None, noise_fn=None):
+    """RFLOW.sample — scheduling_rflow_open_sora.py:188-257.  ``cond_mask`` [B, T] float is the reference's ``mask`` argument
+    (apply_mask_strategy, pipeline_open_sora.py:825-854: 1 = generate, an edit ratio in [0, 1) = conditioning frame): a frame is
+    denoised only while mask * num_timesteps >= t (:227-236), is noised ONCE, at the step it joins (:229-236), sees the t = 0
+    modulation before that (x_mask, :232) and is put back after every update while it is still conditioning (:254-255).
+    ``noise_fn(shape)`` draws the per-step noise (default torch.randn: the reference's randn_like on the global generator)."""
     yy = torch.cat([y, y_null], 0)
+    noise_fn = noise_fn or (lambda shape: torch.randn(shape))
+    noise_added = None if cond_mask is None else (cond_mask == 1)
     timesteps = rflow_timesteps(num_sampling_steps, z.shape[0], height, width, num_frames, num_timesteps,
                                 use_timestep_transform)
     all_timesteps = [int(t.to(model_dtype).item()) for t in timesteps]
     zs = []
     for i, t in enumerate(timesteps):
+        extra = {"all_timesteps": all_timesteps} if getattr(getattr(model, "pab", None), "mlp_enabled", lambda: False)() else {}
+        if cond_mask is not None:
+            x0 = z.clone()
+            tp = 1 - t.float() / num_timesteps                       # RFlowScheduler.add_noise (:144-161)
+            x_noise = tp[:, None, None, None, None] * x0 + (1 - tp)[:, None, None, None, None] * noise_fn(x0.shape)
+            upper = (cond_mask * num_timesteps) >= t.unsqueeze(1)
+            extra["x_mask"] = upper.repeat(2, 1)
+            z = torch.where((upper & ~noise_added)[:, None, :, None, None], x_noise, x0)
+            noise_added = upper
         z_in = torch.cat([z, z], 0)
         tt = torch.cat([t, t], 0).to(model_dtype)  # STDiT3.forward casts timestep to model dtype (:562)
-        extra = {"all_timesteps": all_timesteps} if getattr(getattr(model, "pab", None), "mlp_enabled", lambda: False)() else {}
         out = model(z_in, tt, yy, mask=mask, fps=torch.cat([fps, fps]), height=torch.cat([height, height]),
                     width=torch.cat([width, width]), **extra)
         pred = out.to(z.device).chunk(2, dim=1)[0]  # the model may run on another device (GPU-as-checker)
@@ -537,6 +589,8 @@ def rflow_sample(model, z, y, y_null, mask, fps, height, width, num_frames, num_
         dt = timesteps[i] - timesteps[i + 1] if i < len(timesteps) - 1 else timesteps[i]
         dt = dt / num_timesteps
         z = z + v_pred * dt[:, None, None, None, None]
+        if cond_mask is not None:
+            z = torch.where(upper[:, None, :, None, None], z, x0)
         if return_all:
             zs.append(z.clone())
     return (z, zs, all_timesteps) if return_all else z

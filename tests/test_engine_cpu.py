@@ -60,7 +60,9 @@ def test_engine_driver_failure_with_peers_blocked_in_a_collective(monkeypatch):
         t0 = time.time()
         with pytest.raises(KeyError, match="bad prompt on rank 0"):
             eng.generate(1, mode="raise_peers_in_collective", who=0)
-        assert time.time() - t0 < 30
+        assert time.time() - t0 < 90          # grace (3 s) + teardown; generous, the suite may share the box with other work
+        for p in eng.workers:                 # terminated workers are reaped asynchronously
+            p.join(timeout=20)
         assert all(not p.is_alive() for p in eng.workers)
         with pytest.raises(RuntimeError, match="engine is dead"):
             eng.generate(1)

@@ -439,8 +439,7 @@ def test_open_sora_prompt_preparation():
     assert P.prepare_prompt("|0| a beautiful day |2| a rainy day", aes=None, loop_i=0) == "a beautiful day"
     assert P.prepare_prompt("|0| a beautiful day |2| a rainy day", aes=None, loop_i=2) == "a rainy day"
     assert P.prepare_prompt('A cat{"reference_path": "", "mask_strategy": ""}', aes=None) == "a cat"
-    with pytest.raises(NotImplementedError):
-        P.prepare_prompt('A cat{"reference_path": "x.png"}')
+    assert P.prepare_prompt('A cat{"reference_path": "x.png", "mask_strategy": "0"}', aes=None) == "a cat"   # the tail is generate()'s
     with pytest.raises(AssertionError):
         P.prepare_prompt('A cat{"foo": 1}')
 
@@ -628,3 +627,75 @@ def test_streamk_plan_not_split_when_no_partial_round(lab_lib):
     assert _streamk_plan(512, 18, 256)[0] is None      # whole rounds only
     assert _streamk_plan(200, 18, 256)[0] is None      # fewer tiles than workgroups
     assert _streamk_plan(912, 3, 256)[0] is None       # K loop too short to cut
+
+
+# ---------------------------------------------------------------------------------------------------- Open-Sora conditioning
+def test_mask_strategy_helpers_match_the_reference():
+    """open_sora_condition.py against values minted from the reference's own functions (oracle/make_golden_xmask.py:
+    pipeline_open_sora.py:795-854)."""
+    from conftest import load_golden
+    from videosys_amd import open_sora_condition as K
+
+    fx = load_golden("stdit3_xmask_small.pt")
+    for v, p, m, want in fx["nearest"]:
+        assert K.find_nearest_point(v, p, m) == want, (v, p, m)
+    for c in fx["mask_strategy"]:
+        assert K.parse_mask_strategy(c["ms"]) == [list(g) for g in c["parsed"]], c["ms"]
+        z = c["z_in"].clone()
+        masks = K.apply_mask_strategy(z, c["refs"], [c["ms"]], c["loop_i"], align=c["align"])
+        assert torch.equal(z, c["z_out"]), c["ms"]
+        assert torch.equal(masks, c["masks"]), (c["ms"], masks, c["masks"])
+    assert K.apply_mask_strategy(torch.zeros(1, 4, 5, 2, 2), [], [], 0) is None
+    with pytest.raises(AssertionError):
+        K.parse_mask_strategy("0,0,0,0,1,0,9")
+
+
+def test_conditioning_prompt_and_loop_helpers(tmp_path):
+    from videosys_amd import open_sora_condition as K
+
+    texts, refs, ms = K.extract_json_from_prompts(['a cat {"reference_path": "a.png;b.png", "mask_strategy": "0;0,1,0,-1,1"}', "plain"],
+                                                  ["", "x.png"], ["", ""])
+    assert texts == ["a cat ", "plain"] and refs == ["a.png;b.png", "x.png"] and ms == ["0;0,1,0,-1,1", ""]
+    with pytest.raises(AssertionError):
+        K.extract_json_from_prompts(['p {"bogus": 1}'], [""], [""])
+    with pytest.raises(AssertionError):
+        K.extract_json_from_prompts(['p {"a": 1} {"b": 2}'], [""], [""])
+    assert K.dframe_to_frame(5) == 17 and K.dframe_to_frame(10) == 34
+    with pytest.raises(AssertionError):
+        K.dframe_to_frame(4)
+    # append_generated (:857-871): the continuation rule, for a sample without and one with earlier references / strategy
+    enc = lambda v: torch.full((v.shape[0], 4, 5, 2, 2), 7.0)
+    r0 = torch.zeros(4, 1, 2, 2)
+    refs, ms = K.append_generated(enc, torch.zeros(2, 3, 17, 16, 16), [None, [r0]], ["", "0"], 1, 5, 0.25)
+    assert len(refs[0]) == 1 and len(refs[1]) == 2 and refs[1][0] is r0 and float(refs[1][1].mean()) == 7.0
+    assert ms == ["1,0,-5,0,5,0.25", "0;1,1,-5,0,5,0.25"]
+    # the strategy it wrote pastes the last 5 latent frames of the new reference over the first 5 of the next z
+    z = torch.zeros(2, 4, 15, 2, 2)
+    masks = K.apply_mask_strategy(z, [[torch.arange(10.0).view(1, 10, 1, 1).expand(4, 10, 2, 2)], refs[1]], ms, 1, align=5)
+    assert z[0, 0, :5, 0, 0].tolist() == [5.0, 6.0, 7.0, 8.0, 9.0] and float(z[0, :, 5:].abs().max()) == 0
+    assert masks[0].tolist() == [0.25] * 5 + [1.0] * 10
+    # references: latents pass through, pixels go through the encoder, an image file is resized to cover + centre-cropped
+    from PIL import Image
+    import numpy as np
+
+    arr = np.zeros((40, 100, 3), dtype=np.uint8)
+    arr[:, :50, 0] = 255
+    path = str(tmp_path / "ref.png")
+    Image.fromarray(arr).save(path)
+    pix = K.read_from_path(path, (32, 32))
+    assert pix.shape == (3, 1, 32, 32) and float(pix.min()) >= -1 and float(pix.max()) <= 1
+    assert float(pix[0, 0, :, :12].mean()) > 0.9 and float(pix[0, 0, :, 20:].mean()) < -0.9   # 100x40 -> 80x32 -> crop 24..56
+    seen = []
+
+    def enc2(v):
+        seen.append(tuple(v.shape))
+        return torch.zeros(v.shape[0], 4, 1, 4, 4)
+
+    lat = torch.ones(4, 3, 4, 4)
+    out = K.collect_references_batch(["", path, [lat, torch.zeros(3, 17, 32, 32)]], enc2, (32, 32))
+    assert out[0] == [] and out[1][0].shape == (4, 1, 4, 4) and out[2][0] is lat and out[2][1].shape == (4, 1, 4, 4)
+    assert seen == [(1, 3, 1, 32, 32), (1, 3, 17, 32, 32)]
+    with pytest.raises(NotImplementedError):
+        K.read_from_path("clip.mp4", (32, 32))
+    with pytest.raises(RuntimeError):
+        K.collect_references_batch([path], None, (32, 32))

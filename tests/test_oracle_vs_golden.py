@@ -131,6 +131,43 @@ def test_rflow_small():
     assert [int(t.to(torch.bfloat16).item()) for t in ts30] == fx["ts30_c2_bf16_int"]
 
 
+def test_stdit3_xmask_small():
+    """x_mask conditioning (open_sora_transformer_3d.py:181-184,198-200,220-222,262-273,578-582 + T2IFinalLayer :75-87)."""
+    fx = load_golden("stdit3_xmask_small.pt")
+    model, _ = _small_model(fx)
+    i = fx["inputs"]
+    kw = dict(mask=i["mask"], fps=i["fps"], height=i["height"], width=i["width"])
+    out = model.forward(i["x"], i["timestep"], i["y"], x_mask=fx["x_mask"], **kw)
+    close(out, fx["out"], 2e-4, 2e-4)
+    out1 = model.forward(i["x"], i["timestep"], i["y"], x_mask=torch.ones(2, 5, dtype=torch.bool), **kw)
+    close(out1, fx["out_all_true"], 2e-4, 2e-4)
+    close(out1, model.forward(i["x"], i["timestep"], i["y"], **kw), 1e-6, 1e-6)   # an all-True mask is no mask
+    assert float((fx["out"] - fx["out_all_true"]).abs().max()) > 0.5             # and the fixture's mask does matter
+
+
+def test_rflow_masked_small():
+    """Mask-conditioned sampling (scheduling_rflow_open_sora.py:215-236,254-255): the oracle draws the per-step noise from the
+    same seeded global generator the reference's randn_like used."""
+    fx = load_golden("stdit3_xmask_small.pt")
+    model, _ = _small_model(fx)
+    s = fx["sample"]
+    seen = []
+
+    def spy(*a, **k):
+        seen.append(k["x_mask"].clone())
+        return model(*a, **k)
+
+    torch.manual_seed(s["noise_seed"])
+    z, zs, all_ts = O.rflow_sample(spy, s["z0"], s["y"], s["y_null"], s["mask"], s["fps"], s["height"], s["width"],
+                                   s["num_frames"], num_sampling_steps=s["steps"], cfg_scale=s["cfg_scale"], return_all=True,
+                                   cond_mask=s["cond_mask"])
+    assert all_ts == s["all_timesteps"]
+    assert torch.equal(torch.stack(seen), s["x_masks"])
+    close(z, s["z_out"], 5e-4, 5e-4)
+    assert torch.equal(z[:, :, 0], s["z0"][:, :, 0])          # the held reference frame comes back untouched
+    assert not torch.equal(z[:, :, 1], s["z0"][:, :, 1])      # the edited frame joined (ratio 0.6) and moved
+
+
 def test_pab_schedule_c2():
     with open(os.path.join(GOLDEN, "pab_schedule_c2.json")) as f:
         g = json.load(f)

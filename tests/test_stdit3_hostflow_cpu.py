@@ -242,6 +242,70 @@ def test_sequence_parallel_host_flow_four_ranks_in_process(scatter, order):
     assert all(s == dict(recorded=1, replayed=1, eager=0) for s in stats), stats
 
 
+def test_x_mask_runs_eagerly_with_one_modulation_row_per_frame():
+    """Conditioning mask (open_sora_transformer_3d.py:181-184,578-582): the modulation table gets one row per (sample, frame),
+    every modulated / gated launch addresses it with one frame's rows per modulation row, the final layer runs twice (the
+    t and the t = 0 branch, T2IFinalLayer :82-85), and no launch program is recorded for such a step."""
+    from types import SimpleNamespace
+
+    from test_host_cpu import torch_copy_executor
+    from tools.local_group import LocalWorld
+
+    x, y, kw = _inputs(T=5, HW=12)
+    xm = torch.tensor([[1, 0, 1, 1, 0], [0, 1, 1, 0, 1]], dtype=torch.bool)
+    t = torch.tensor([500.0, 500.0])
+    with fake_ops() as f:
+        m = _model()
+        seen = []
+        real_adaln, real_gemm, real_mod = f.adaln_modulate, f.gemm, f.mod_table
+        from videosys_amd import ops
+
+        def adaln(x_, shift, scale, rows_per_sample, mod_stride, **k):
+            seen.append(("adaln", rows_per_sample, mod_stride))
+            return real_adaln(x_, shift, scale, rows_per_sample, mod_stride, **k)
+
+        def gemm(x_, w, bias=None, **k):
+            if k.get("gate") is not None:
+                seen.append(("gate", k["rows_per_sample"], k["gate_stride"]))
+            return real_gemm(x_, w, bias, **k)
+
+        def mod_table(table, t_mlp, out=None):
+            seen.append(("mod", t_mlp.shape[0]))
+            return real_mod(table, t_mlp, out)
+
+        ops.adaln_modulate, ops.gemm, ops.mod_table = adaln, gemm, mod_table
+        out = m(x, t, y, x_mask=xm, **kw)
+        assert out.shape == (2, 8, 5, 12, 12)
+        assert m.program_stats == dict(recorded=0, replayed=0, eager=1)
+        C, S = CFG["hidden_size"], 36
+        assert ("mod", 2 * 5) in seen
+        blk = [e for e in seen if e[0] in ("adaln", "gate") and e[2] == 6 * C]
+        assert len(blk) == 4 * 2 * CFG["depth"] and all(e[1] == S for e in blk), blk
+        assert ("adaln", 5 * S, 2 * C) in seen           # the final layer's first modulation, per sample
+        assert f.calls["final_layer"] == 2
+        with pytest.raises(ValueError):
+            m(x, t, y, x_mask=xm[:, :4], **kw)
+        seen.clear()
+        m(x, t, y, **kw)                                  # without a mask: per-sample rows again, recorded as a program
+        assert ("mod", 2) in seen and all(e[1] == 5 * S for e in seen if e[0] in ("adaln", "gate"))
+        assert m.program_stats["recorded"] == 1
+
+    P = 4
+
+    def rank_fn(r, group):
+        mm = _model()
+        pm = SimpleNamespace(sp_size=P, cp_size=1, dp_size=1, dp_rank=0, sp_rank=r, cp_rank=0, sp_group=group, cp_group=None)
+        mm.enable_parallel(parallel_mgr=pm, copy_executor=torch_copy_executor, overlap=False)
+        o = mm(x, t, y, x_mask=xm, **kw)
+        assert o.shape == (2, 8, 5, 12, 12)
+        return dict(mm.program_stats)
+
+    with fake_ops() as f:
+        stats = LocalWorld(P, timeout=60).run(rank_fn)
+        assert f.calls["final_layer_tokens"] == 2 * P
+    assert all(s == dict(recorded=0, replayed=0, eager=1) for s in stats), stats
+
+
 def test_pab_slab_elision_never_reads_a_stale_slab():
     """STDiT3._pab_plan keeps a computed attention output only when the block's next call will broadcast it.  With elision on,
     every broadcast must read a slab written at exactly the step it is read from when every computed output is kept (elision
@@ -305,3 +369,45 @@ def test_pab_slab_elision_never_reads_a_stale_slab():
             assert all(d[5] and d[6] for d in plan)
     finally:
         pab.set_pab_manager(None)
+
+
+def test_rflow_mask_bookkeeping_matches_the_reference():
+    """RFLOW.sample(mask=...) with the model and the Euler kernel faked (zero velocity): the x_mask of every step equals what
+    the reference's sampler handed ITS model on the same schedule (fixture minted by oracle/make_golden_xmask.py), a held frame
+    comes back untouched, a frame with edit ratio 0.6 is noised exactly once — at the first step with t <= 600, to that step's
+    level — and an all-True step drops the mask so the plain (program) path runs."""
+    from types import SimpleNamespace
+
+    from conftest import load_golden
+    from videosys_amd.rflow import RFLOW
+
+    s = load_golden("stdit3_xmask_small.pt")["sample"]
+    seen = []
+
+    class Model:
+        device = torch.device("cpu")
+        x_embedder = SimpleNamespace(proj=SimpleNamespace(weight=torch.zeros(1, dtype=torch.float32)))
+
+        def __call__(self, z_in, t, **k):
+            seen.append(k.get("x_mask"))
+            return torch.zeros(z_in.shape[0], 8, *z_in.shape[2:])
+
+    margs = dict(y=s["y"], mask=s["mask"], height=s["height"], width=s["width"], num_frames=s["num_frames"], fps=s["fps"])
+    sched = RFLOW(num_sampling_steps=s["steps"], cfg_scale=s["cfg_scale"], use_timestep_transform=True)
+    g = torch.Generator().manual_seed(3)
+    noises = [torch.randn(s["z0"].shape, generator=g) for _ in range(s["steps"])]
+    it = iter(noises)
+    with fake_ops():
+        z = sched.sample(Model(), s["z0"], margs, s["y_null"], mask=s["cond_mask"], noise_fn=lambda shape: next(it))
+        assert [m.tolist() for m in seen] == [m.tolist() for m in s["x_masks"]]
+        ts = sched.prepare_timesteps(1, margs)
+        join = next(i for i, t in enumerate(ts) if float(t[0]) <= 600.0)
+        keep = 1 - float(ts[join][0]) / 1000
+        assert torch.equal(z[:, :, 0], s["z0"][:, :, 0]) and torch.equal(z[:, :, 2:], s["z0"][:, :, 2:])
+        torch.testing.assert_close(z[:, :, 1], keep * s["z0"][:, :, 1] + (1 - keep) * noises[join][:, :, 1], rtol=1e-6, atol=1e-6)
+        seen.clear()
+        it = iter(noises)
+        sched.sample(Model(), s["z0"], margs, s["y_null"], mask=torch.tensor([[0.99, 1.0, 1.0, 1.0, 1.0]]), noise_fn=lambda shape: next(it))
+        assert seen[0] is not None and seen[0].tolist() == [[False, True, True, True, True]] * 2 and all(m is None for m in seen[1:])
+        with pytest.raises(ValueError):
+            sched.sample(Model(), s["z0"], margs, s["y_null"], mask=torch.ones(1, 4))

@@ -233,18 +233,16 @@ class OpenSoraPipeline(StagedOffloadMixin):
     def prepare_prompt(cls, prompt: str, aes: Optional[float] = 6.5, flow: Optional[float] = None, camera_motion=None,
                        loop_i: int = 0) -> str:
         """What generate() feeds the tokenizer for loop ``loop_i`` (pipeline_open_sora.py:548-615, 705-792): an optional JSON
-        tail (``{"reference_path": ..., "mask_strategy": ...}`` — conditioning, outside the MI355X hot path) is split off, a
-        ``|0| text |k| text`` schedule is resolved to the segment that covers the loop, the score tags the Open-Sora 1.2
-        checkpoints were trained with are appended, and the text is lower-cased."""
+        tail (``{"reference_path": ..., "mask_strategy": ...}``, consumed by generate() through
+        open_sora_condition.extract_json_from_prompts) is split off, a ``|0| text |k| text`` schedule is resolved to the segment
+        that covers the loop, the score tags the Open-Sora 1.2 checkpoints were trained with are appended, and the text is
+        lower-cased."""
         import json
 
         text, brace, tail = prompt.partition("{")
         if brace:
-            extra = json.loads(brace + tail)
-            unknown = set(extra) - {"reference_path", "mask_strategy"}
+            unknown = set(json.loads(brace + tail)) - {"reference_path", "mask_strategy"}
             assert not unknown, f"Invalid key: {sorted(unknown)[0]}"
-            if any(extra.values()):
-                raise NotImplementedError("reference / mask-strategy conditioning is outside the MI355X hot path")
         if text.startswith("|0|"):
             fields = text.split("|")[1:]            # start, text, start, text, ...
             starts = [int(v) for v in fields[0::2]]
@@ -263,51 +261,91 @@ class OpenSoraPipeline(StagedOffloadMixin):
                  verbose: bool = True, *, height: Optional[int] = None, width: Optional[int] = None,
                  prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
                  fps: float = 24.0, output_type: str = "auto"):
-        """pipeline_open_sora.py:426-656 for plain text-to-video, with the reference's positional / keyword call shape:
+        """pipeline_open_sora.py:426-656 with the reference's positional / keyword call shape:
         ``engine.generate(prompt, resolution="480p", aspect_ratio="9:16", num_frames="2s")`` (examples/open_sora/sample.py).
 
         Geometry comes from the reference's vocabulary (open_sora_geometry.get_image_size / get_num_frames); keyword-only
         ``height=`` / ``width=`` override it — an extension, needed because the reference's own tables cannot name 512x512
-        (("512", "1:1") fails its assert).  ``prompt_embeds`` / ``prompt_mask`` bypass the text encoder.  Image / video
-        conditioning (``refs``, ``ms``, ``loop`` > 1) is outside the MI355X hot path and raises."""
+        (("512", "1:1") fails its assert).  ``prompt_embeds`` / ``prompt_mask`` bypass the text encoder.
+
+        Image / video conditioning (:528-535,607-645): ``refs`` names the reference clips of the prompt (';'-separated image
+        paths as in the reference, or a list of paths / pixel tensors [3, T, H, W] in [-1, 1] / latents [4, T, h, w]), ``ms`` the
+        mask strategy that pastes their latent frames into the start noise (open_sora_condition.py); both may also arrive as a
+        JSON tail of the prompt.  ``loop`` > 1 generates that many clips, each one conditioned on the last
+        ``condition_frame_length`` latent frames of the previous (encoded again by the VAE), and returns them joined in time with
+        the overlap removed.  (As written, the reference's ``video_clips[i][:, dframe_to_frame(...):]`` / ``torch.cat(dim=1)``
+        at :641-643 slice and join the CHANNEL axis of [B, C, T, H, W] clips, which drops every clip after the first; the
+        time axis — what the upstream Open-Sora code these lines come from operates on — is used here.)"""
+        from . import open_sora_condition as K
         from . import open_sora_geometry as G
         from .utils import set_seed
 
-        if loop != 1 or ms or refs:
-            raise NotImplementedError("reference / mask-strategy conditioning and multi-loop generation are outside the MI355X hot path")
         image_size = (int(height), int(width)) if height is not None and width is not None else G.get_image_size(resolution, aspect_ratio)
         num_frames = G.get_num_frames(num_frames)
         seed = set_seed(seed)   # -1 draws a fresh seed on rank 0 and broadcasts it (core/pipeline/pipeline.py _set_seed)
-        if prompt_embeds is None:
-            if self.text_encoder is None:
-                raise RuntimeError("no text encoder attached: pass prompt_embeds=[B,1,L,4096] (+ prompt_mask), or give "
-                                   "OpenSoraConfig(text_encoder=<local T5 checkpoint directory>)")
-            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
-            prompts = [self.prepare_prompt(q, aes=aes, flow=flow, camera_motion=camera_motion) for q in prompts]
-            self._enter_stage("text_encoder")
-            prompt_embeds, prompt_mask = self.text_encoder(prompts[0] if len(prompts) == 1 else prompts)
-        self._enter_stage("transformer")
+
+        # ---- conditioning inputs: one entry per prompt (:528-535)
+        prompts = None if prompt is None else ([prompt] if isinstance(prompt, str) else list(prompt))
+        n = len(prompts) if prompts is not None else prompt_embeds.shape[0]
+        per_prompt = lambda v: list(v) if isinstance(v, (list, tuple)) and len(v) == n and not torch.is_tensor(v) \
+            and all(isinstance(e, (str, list, tuple, type(None))) for e in v) else [v] * n
+        ms_list = per_prompt(ms if ms is not None else "")
+        ref_list = per_prompt(refs if refs is not None else "")
+        if prompts is not None:
+            _, ref_list, ms_list = K.extract_json_from_prompts(prompts, ref_list, ms_list)
+        conditioned = loop != 1 or any(ms_list) or any(len(r) > 0 for r in ref_list if r is not None)
+        vae = self.vae_decoder
+        encode = getattr(vae, "encode", None)
+        if loop > 1 and (vae is None or encode is None or output_type == "latent"):
+            raise RuntimeError("loop > 1 conditions every clip on the decoded + re-encoded previous one: it needs the VAE attached")
+        if conditioned:
+            self._enter_stage("vae")
+        refs_x = K.collect_references_batch(ref_list, encode, image_size) if conditioned else None
+
         pab.update_steps(self._config.num_sampling_steps)
-        self.transformer.reset_pab_state()
-        self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
-        B = prompt_embeds.shape[0]
         T, Hl, Wl = get_latent_size(num_frames, *image_size)
         g = torch.Generator(device="cpu")
         g.manual_seed(seed)
-        z = torch.randn(B, self.transformer.in_channels, T, Hl, Wl, generator=g, dtype=torch.float32)
-        z = z.to(torch.bfloat16).float()  # the reference draws z in bf16 (pipeline_open_sora.py:622-624)
-        # the conditioning scalars are tensors of the MODEL dtype, as in the reference (data_process.py:798-805): 854 is 856 there
-        margs = dict(y=prompt_embeds, mask=prompt_mask)
-        margs.update(G.prepare_multi_resolution_info(B, image_size, num_frames, fps, dtype=self.transformer.dtype))
-        y_null = self.null(B)
-        samples = self.scheduler.sample(self.transformer, z, margs, y_null, device=self._device, progress=verbose)
-        if self.vae_decoder is None or output_type == "latent":
-            self._enter_stage(None)
+        clips = []
+        samples = None
+        for loop_i in range(loop):
+            if prompt_embeds is None or (loop_i > 0 and prompts is not None):
+                if self.text_encoder is None:
+                    raise RuntimeError("no text encoder attached: pass prompt_embeds=[B,1,L,4096] (+ prompt_mask), or give "
+                                       "OpenSoraConfig(text_encoder=<local T5 checkpoint directory>)")
+                texts = [self.prepare_prompt(q, aes=aes, flow=flow, camera_motion=camera_motion, loop_i=loop_i) for q in prompts]
+                self._enter_stage("text_encoder")
+                prompt_embeds, prompt_mask = self.text_encoder(texts[0] if len(texts) == 1 else texts)
+            if loop_i > 0:   # the clip just decoded becomes a reference of every sample (:613-617)
+                self._enter_stage("vae")
+                refs_x, ms_list = K.append_generated(encode, clips[-1], refs_x, ms_list, loop_i, condition_frame_length,
+                                                     condition_frame_edit)
+            self._enter_stage("transformer")
+            self.transformer.reset_pab_state()
+            self.transformer.reset_text_cache()   # per-prompt projections never outlive a sampling run
+            B = prompt_embeds.shape[0]
+            z = torch.randn(B, self.transformer.in_channels, T, Hl, Wl, generator=g, dtype=torch.float32)
+            z = z.to(torch.bfloat16).float()  # the reference draws z in bf16 (pipeline_open_sora.py:622-624)
+            # the conditioning scalars are tensors of the MODEL dtype, as in the reference (data_process.py:798-805): 854 is 856 there
+            margs = dict(y=prompt_embeds, mask=prompt_mask)
+            margs.update(G.prepare_multi_resolution_info(B, image_size, num_frames, fps, dtype=self.transformer.dtype))
+            masks = None
+            if conditioned:
+                masks = K.apply_mask_strategy(z, [[r.to("cpu", torch.float32) for r in rs] for rs in refs_x], ms_list, loop_i, align=align)
+                if masks is not None and bool((masks == 1).all()):
+                    masks = None      # nothing pasted for this loop: the plain sampler (an all-one mask changes no value)
+            samples = self.scheduler.sample(self.transformer, z, margs, self.null(B), device=self._device, progress=verbose,
+                                            mask=masks)
+            if vae is None or output_type == "latent":
+                break
+            self._enter_stage("vae")
+            clips.append(vae(samples.to(torch.bfloat16), num_frames=num_frames))
+        self._enter_stage(None)
+        if not clips:
             out = VideoSysPipelineOutput(video=samples)
             return out if return_dict else (samples,)
-        self._enter_stage("vae")
-        video = self.vae_decoder(samples.to(torch.bfloat16), num_frames=num_frames)
-        self._enter_stage(None)
+        skip = K.dframe_to_frame(condition_frame_length) if loop > 1 else 0
+        video = clips[0] if loop == 1 else torch.cat([clips[0]] + [c[:, :, skip:] for c in clips[1:]], dim=2)
         video = (video.clamp(-1, 1) * 0.5 + 0.5).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
         return VideoSysPipelineOutput(video=video) if return_dict else (video,)
 

@@ -47,9 +47,13 @@ class RFLOW:
 
     @torch.no_grad()
     def sample(self, model, z, model_args, y_null, device=None, mask=None, guidance_scale=None, progress=True,
-               verbose=False):
-        if mask is not None:
-            raise NotImplementedError("mask-conditioned sampling (image/video conditioning) is outside the MI355X hot path")
+               verbose=False, noise_fn=None):
+        """``mask`` [B, T] (float; open_sora_condition.apply_mask_strategy) conditions the sampling on frames already present in
+        ``z`` (:215-236,254-255): a frame is denoised only from the step on at which mask * num_timesteps >= t; until then the
+        model sees it with the timestep-0 modulation (``x_mask``) and every update puts it back; at the step it joins it is
+        noised to that step's level, once.  The mask and the per-step decisions live on the host (B*T values), only the boolean
+        frame masks travel.  ``noise_fn(shape)`` draws that noise (fp32, host or device); default: torch.randn on the global
+        CPU generator, one draw per step like the reference's randn_like, so a seed reproduces a run."""
         if guidance_scale is None:
             guidance_scale = self.cfg_scale
         model_args = dict(model_args)
@@ -63,7 +67,24 @@ class RFLOW:
             if k in fwd_args and fwd_args[k] is not None and fwd_args[k].shape[0] == B:
                 fwd_args[k] = torch.cat([fwd_args[k], fwd_args[k]], 0)
         z = z.to(device=model.device, dtype=torch.float32).contiguous().clone()
+        if mask is not None:
+            cond = mask.detach().to("cpu", torch.float32)
+            if tuple(cond.shape) != (B, z.shape[2]):
+                raise ValueError(f"mask must be [B, T] = [{B}, {z.shape[2]}], got {tuple(cond.shape)}")
+            noise_added = cond == 1
+            frames = lambda m: m.to(z.device)[:, None, :, None, None]
         for i, t in enumerate(timesteps):
+            if mask is not None:
+                x0 = z.clone()
+                upper = (cond * self.num_timesteps) >= t.unsqueeze(1)            # frames that are being denoised at this step
+                noise = noise_fn(x0.shape) if noise_fn is not None else torch.randn(x0.shape, dtype=torch.float32)
+                joining = upper & ~noise_added
+                if bool(joining.any()):
+                    keep = (1 - t.float() / self.num_timesteps).to(z.device)[:, None, None, None, None]   # add_noise, :144-161
+                    z = torch.where(frames(joining), keep * x0 + (1 - keep) * noise.to(z.device, torch.float32), x0)
+                noise_added = upper
+                # (an all-True mask selects the modulation of t for every frame — the plain step, which replays its launch program)
+                fwd_args["x_mask"] = None if bool(upper.all()) else upper.repeat(2, 1)
             z_in = torch.cat([z, z], 0)
             tt = torch.cat([t, t], 0)
             out = model(z_in, tt, **fwd_args)
@@ -72,4 +93,6 @@ class RFLOW:
                 raise NotImplementedError("per-sample step sizes (mixed geometries in one batch) are not supported")
             dt = float(dt[0]) / self.num_timesteps
             ops.cfg_euler_step(z, out, guidance_scale, dt)
+            if mask is not None and not bool(upper.all()):
+                z = torch.where(frames(upper), z, x0)
         return z

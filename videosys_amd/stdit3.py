@@ -16,7 +16,10 @@ Differences from the reference that do not change results (SURVEY.md §7 "hard p
   * PAB decisions use the host-side integer timestep (no ``int(timestep[0])`` device sync per block);
   * ``all_timesteps`` IS forwarded to the blocks (the reference forgets to: SURVEY.md §0.9), so ``mlp_broadcast=True`` — the
     default of OpenSoraPABConfig — works here instead of raising TypeError;
-  * x_mask (image/video conditioning masks) is not supported on this path and raises NotImplementedError.
+  * x_mask (image / video conditioning, :181-184,198-200,220-222,262-273,578-582): the reference computes both modulations of
+    every row and picks per frame with torch.where; here the modulation VECTOR is picked per (sample, frame) up front and the
+    kernels run with one frame's rows per modulation row — the same selection without the second pass.  Such steps are issued
+    eagerly (no launch program): the mask changes from step to step.
 """
 from __future__ import annotations
 
@@ -337,8 +340,6 @@ class STDiT3:
     @torch.no_grad()
     def forward(self, x, timestep, y, all_timesteps=None, mask=None, x_mask=None, fps=None, height=None, width=None,
                 **kwargs):
-        if x_mask is not None:
-            raise NotImplementedError("x_mask (reference/mask conditioning) is outside the MI355X hot path")
         w, C, H = self.w, self.hidden_size, self.num_heads
         # === Split batch === (:545-557): rank group cp_rank keeps its rows of every per-sample input
         pm = self.parallel_manager
@@ -350,10 +351,14 @@ class STDiT3:
             Bl = Bfull // cp
             sl = slice(pm.cp_rank * Bl, (pm.cp_rank + 1) * Bl)
             rows = lambda v: v[sl] if (torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == Bfull) else v
-            x, timestep, y, fps, height, width, mask = (rows(v) for v in (x, timestep, y, fps, height, width, mask))
+            x, timestep, y, fps, height, width, mask, x_mask = (rows(v) for v in (x, timestep, y, fps, height, width, mask, x_mask))
         B, _, Tx, Hx, Wx = x.shape
         T, Hp, Wp = self.get_dynamic_size(x)
         dev = self.device
+        if x_mask is not None:   # [B, T] bool: False = conditioning frame (sees the timestep-0 modulation, :181-184,578-582)
+            if tuple(x_mask.shape) != (B, T):
+                raise ValueError(f"x_mask must be [B, T] = [{B}, {T}], got {tuple(x_mask.shape)}")
+            x_mask = x_mask.to(device=dev, dtype=torch.bool).contiguous()
 
         # ---- host-side, per step: the timestep (the sampler hands timesteps over as HOST tensors, so the integer the PAB policy
         # needs is available without a device sync; timestep.to(dtype) (:562) then .float() inside the embedder), the PAB
@@ -374,10 +379,11 @@ class STDiT3:
         static = (txt, pos, self._fps_cache[fkey])
 
         mlp_action = plan is not None and any(d[2] or d[3] for d in plan)   # stores / replays host-side dict entries: eager
-        if not (self.use_programs and self._hidden_tap is None and not mlp_action):
+        # (a conditioning mask changes from step to step and selects rows with torch ops: the step is issued eagerly)
+        if not (self.use_programs and self._hidden_tap is None and not mlp_action and x_mask is None):
             self.program_stats["eager"] += 1
             xz = x.to(device=dev, dtype=torch.float32).contiguous()
-            out = self._forward_device(xz, ts_host.to(dev), static, plan, timestep_int, valid_depth, cp)
+            out = self._forward_device(xz, ts_host.to(dev), static, plan, timestep_int, valid_depth, cp, x_mask)
         else:
             sp = self._sp
             key = (B, Tx, Hx, Wx, float(height[0]), float(width[0]), fkey, valid_depth, cp,
@@ -449,8 +455,9 @@ class STDiT3:
                          kept(kind, st.attn_count), kept("cross", st.cross_count)))
         return plan
 
-    def _forward_device(self, xz, ts, static, plan, timestep_int, valid_depth, cp):
-        """Everything of a step that runs on the device, from resident inputs: xz fp32 [B, C_in, T, H, W], ts fp32 [B]."""
+    def _forward_device(self, xz, ts, static, plan, timestep_int, valid_depth, cp, x_mask=None):
+        """Everything of a step that runs on the device, from resident inputs: xz fp32 [B, C_in, T, H, W], ts fp32 [B];
+        x_mask bool [B, T] on the device or None."""
         w, C = self.w, self.hidden_size
         txt, pos, fps_emb = static
         B, _, Tx, Hx, Wx = xz.shape
@@ -463,7 +470,17 @@ class STDiT3:
         t = self._embed_vec(ts, "t_embedder")
         ops.add_rows(t, fps_emb)
         t_mlp = ops.linear_small(t, w["t_block.1.weight"], w["t_block.1.bias"], act_in=ops.ACT_SILU)  # [B, 6C]
-        mod = ops.mod_table(w["_all_tables"], t_mlp)  # [2*depth, B, 6C]
+        t0 = None
+        if x_mask is not None:
+            # conditioning frames are modulated with the embedding of timestep 0 (:578-582).  The blocks choose between the two
+            # modulations per frame with torch.where on the modulated / gated activations (t_mask_select, :152-160); choosing the
+            # modulation VECTOR per (sample, frame) and running every kernel with "rows per sample" = the rows of one frame is
+            # the same selection, bit for bit: the table below has one row per (sample, frame).
+            t0 = self._embed_vec(torch.zeros_like(ts), "t_embedder")
+            ops.add_rows(t0, fps_emb)
+            t0_mlp = ops.linear_small(t0, w["t_block.1.weight"], w["t_block.1.bias"], act_in=ops.ACT_SILU)
+            t_mlp = torch.where(x_mask[:, :, None], t_mlp[:, None, :], t0_mlp[:, None, :]).reshape(B * T, -1).contiguous()
+        mod = ops.mod_table(w["_all_tables"], t_mlp)  # [2*depth, B, 6C]  (x_mask: [2*depth, B*T, 6C])
 
         # ---- x embed (+ pos).  Sequence parallel: split_sequence(x, dim=2) (:598-603) keeps tokens rank*Sl .. of every frame, so
         # only those are embedded (the reference embeds the whole frame on every rank and slices)
@@ -479,21 +496,33 @@ class STDiT3:
 
         for d in range(valid_depth):
             for i in (2 * d, 2 * d + 1):
-                xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, None if plan is None else plan[i], timestep_int)
+                xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, None if plan is None else plan[i], timestep_int,
+                                   rps=S if x_mask is not None else T * S)
             if self._hidden_tap is not None:
                 self._hidden_tap(d, xcur)
 
+        fin = (w["final_layer.scale_shift_table"], w["final_layer.linear.weight"], w["final_layer.linear.bias"])
+        x_zero = None
+        if x_mask is not None:
+            # T2IFinalLayer with a mask (:82-85): as written there the conditioning branch normalises the ALREADY modulated x a
+            # second time, x_zero = mod_0(LN(mod_t(LN(x)))) — kept, the golden fixture pins it.  mod_t(LN(x)) is one AdaLN
+            # launch; the fused final-layer kernel then runs on it with the timestep-0 vector, and the frames are chosen below.
+            ss = fin[0][None] + t[:, None]                         # bf16 [B, 2, C]: shift | scale of t
+            x_zero = ops.adaln_modulate(xcur, ss[0, 0], ss[0, 1], T * S, 2 * C, out=self._buf("xm", (B * T * S, C)))
         if sp is not None:
             # gather_sequence (:615-619) + final layer + unpatchify: the final layer is per token, so it runs on the local rows and
             # its 32 fp32 values per token are gathered (0.6 MB per rank at config 2) instead of the 1152-wide hidden state (11 MB)
-            tok = ops.final_layer_tokens(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
-                                         w["final_layer.linear.bias"], B, T, S)
+            tok = ops.final_layer_tokens(xcur, fin[0], t, fin[1], fin[2], B, T, S)
+            if x_mask is not None:
+                tok = torch.where(x_mask[:, :, None, None], tok, ops.final_layer_tokens(x_zero, fin[0], t0, fin[1], fin[2], B, T, S))
             allt = torch.empty(sp.P * B, *tok.shape[1:], dtype=tok.dtype, device=dev)   # [P][B, T, Sl, n] stacked along dim 0
             dsp.all_gather_into_tensor(allt, tok, sp.group)
             out = ops.unpatchify_tokens(allt, sp.P, B, T, S, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
         else:
-            out = ops.final_layer(xcur, w["final_layer.scale_shift_table"], t, w["final_layer.linear.weight"],
-                                  w["final_layer.linear.bias"], B, T, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
+            out = ops.final_layer(xcur, fin[0], t, fin[1], fin[2], B, T, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
+            if x_mask is not None:
+                out0 = ops.final_layer(x_zero, fin[0], t0, fin[1], fin[2], B, T, Hp, Wp, Hx, Wx, self.patch_size, self.out_channels)
+                out = torch.where(x_mask[:, None, :, None, None], out, out0)
         if cp > 1:  # gather_sequence(x, cp_group, dim=0) (:621)
             parts = torch.empty(cp * B, *out.shape[1:], dtype=out.dtype, device=dev)
             dsp.all_gather_into_tensor(parts, out.contiguous(), pm.cp_group)
@@ -502,9 +531,11 @@ class STDiT3:
 
     __call__ = forward
 
-    def _block(self, i, x, mod_i, txt, B, T, S, S_full, decisions, timestep_int):
+    def _block(self, i, x, mod_i, txt, B, T, S, S_full, decisions, timestep_int, rps=None):
         """STDiT3Block.forward (open_sora_transformer_3d.py:162-286). x: [B*T*S, C] (S = local shard), updated in place.
-        ``decisions`` = this block's entry of _pab_plan (None: PAB off)."""
+        ``decisions`` = this block's entry of _pab_plan (None: PAB off).  ``rps``: rows that share one modulation row of ``mod_i``
+        — a sample's T*S rows, or one frame's S rows when a conditioning mask picks the modulation per frame."""
+        rps = T * S if rps is None else rps
         w, C, H = self.w, self.hidden_size, self.num_heads
         p = self.block_prefix(i)
         st = self.states[i]
@@ -527,7 +558,7 @@ class STDiT3:
         if broadcast_attn:
             ops.add_rows(x, st.last_attn)
         else:
-            xm = ops.adaln_modulate(x, shift_msa, scale_msa, T * S, C6, out=_buf("xm", (N, C)))
+            xm = ops.adaln_modulate(x, shift_msa, scale_msa, rps, C6, out=_buf("xm", (N, C)))
             aux = None
             if use_pab and keep_attn:
                 st.last_attn = slab(st.last_attn)
@@ -546,7 +577,7 @@ class STDiT3:
             else:
                 ao = self._spatial_attn_sharded(p, xm, B, T, S, S_full)
             ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
-                     gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
+                     gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
 
         # ---------------- cross attention (no norm, no modulation, no gate)
         if broadcast_cross:
@@ -571,13 +602,13 @@ class STDiT3:
             if timestep_int == skip_range[-1]:   # the window closed (the store dropped the entry): the slab is free again,
                 self._ws.setdefault("mlp_slab_pool", []).append(slab)   # in stream order behind the add above
             return x
-        xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, T * S, C6, out=_buf("xm", (N, C)))
+        xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, rps, C6, out=_buf("xm", (N, C)))
         hdim = w[p + ".mlp.fc1.weight"].shape[0]
         hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
                         out=_buf("mlp_h", (N, hdim)))
         aux = self._mlp_slab(x) if broadcast_next else None   # the post-gate output, written by the fc2 epilogue
         ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
-                 gate_stride=C6, rows_per_sample=T * S, res=x, aux=aux, out=x)
+                 gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
         if broadcast_next:
             pab.save_mlp_output(timestep=timestep_int, block_idx=st.block_idx, ff_output=aux, is_temporal=temporal)
         return x
