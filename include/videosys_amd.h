@@ -263,6 +263,13 @@ int vsys_gn_apply(const void* x, const int64_t* grid_src, void* y, const int64_t
  * (modules/upsampling.py:42-49): 2T-1 frames, frame 0 stays single. */
 int vsys_regrid(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t up,
                 int64_t tmode, void* stream);
+/* Strided pick, destination (t, h, w) = source (t * t_stride + t_first, h * s_stride + s_first, w * s_stride + s_first): the
+ * strided convolutions of the VAE ENCODERS are their stride-1 convolution (vsys_conv_bf16) sampled — diffusers Downsample2D
+ * (pad (0, 1, 0, 1) + 3 x 3 stride 2; third-party, called from autoencoder_kl_open_sora.py:503-520) at (2i + 1, 2j + 1) of the
+ * pad-1 conv, the stride-(2, 1, 1) CausalConv3d of the temporal encoder (autoencoder_kl_open_sora.py:107-125,229-236) at frame
+ * 2t + 1 of the two-front-frames conv. */
+int vsys_subsample(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t t_stride,
+                   int64_t s_stride, int64_t t_first, int64_t s_first, void* stream);
 /* CogVideoXSpatialNorm3D + SiLU (autoencoder_kl_cogvideox.py:165-178,275-276): y = silu(GN(x) * Y + B); yb = [conv_y(zq) |
  * conv_b(zq)] computed at LATENT resolution, rows (n, zt, zh, zw) of 2C columns; the latent voxel of (t, h, w) follows
  * F.interpolate(zq, size=f.shape) including the first-frame split for odd frame counts.  stats from vsys_gn_stats. */

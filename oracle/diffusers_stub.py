@@ -490,22 +490,93 @@ class _VaeDecoder(nn.Module):
         return self.conv_out(self.conv_act(self.conv_norm_out(x)))
 
 
+class _VaeDownsample2D(nn.Module):
+    """Downsample2D(use_conv=True, padding=0): F.pad(x, (0, 1, 0, 1)) (right / bottom only) then a 3x3 stride-2 conv."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+
+
+class _VaeDownEncoderBlock2D(nn.Module):
+    def __init__(self, in_channels, out_channels, num_layers, add_downsample):
+        super().__init__()
+        self.resnets = nn.ModuleList([_VaeResnetBlock2D(in_channels if i == 0 else out_channels, out_channels)
+                                      for i in range(num_layers)])
+        self.downsamplers = nn.ModuleList([_VaeDownsample2D(out_channels)]) if add_downsample else None
+
+    def forward(self, x):
+        for r in self.resnets:
+            x = r(x)
+        if self.downsamplers is not None:
+            x = self.downsamplers[0](x)
+        return x
+
+
+class _VaeEncoder(nn.Module):
+    """diffusers.models.autoencoders.vae.Encoder (double_z=True): conv_in -> down_blocks (block_out_channels, layers_per_block
+    resnets each, downsample on all but the last) -> mid_block -> conv_norm_out -> SiLU -> conv_out (2 * latent channels)."""
+
+    def __init__(self, in_channels=3, out_channels=4, block_out_channels=(128, 256, 512, 512), layers_per_block=2):
+        super().__init__()
+        self.conv_in = nn.Conv2d(in_channels, block_out_channels[0], 3, padding=1)
+        self.down_blocks = nn.ModuleList()
+        out_ch = block_out_channels[0]
+        for i, ch in enumerate(block_out_channels):
+            prev, out_ch = out_ch, ch
+            self.down_blocks.append(_VaeDownEncoderBlock2D(prev, out_ch, layers_per_block, i != len(block_out_channels) - 1))
+        self.mid_block = _VaeMidBlock(block_out_channels[-1])
+        self.conv_norm_out = nn.GroupNorm(32, block_out_channels[-1], eps=1e-6)
+        self.conv_act = nn.SiLU()
+        self.conv_out = nn.Conv2d(block_out_channels[-1], 2 * out_channels, 3, padding=1)
+
+    def forward(self, x):
+        x = self.conv_in(x)
+        for b in self.down_blocks:
+            x = b(x)
+        return self.conv_out(self.conv_act(self.conv_norm_out(self.mid_block(x))))
+
+
+class _DiagonalGaussian:
+    """diffusers.models.autoencoders.vae.DiagonalGaussianDistribution: moments = [mean | logvar] along dim 1, logvar clamped to
+    [-30, 20], sample() = mean + exp(0.5 logvar) * randn."""
+
+    def __init__(self, parameters):
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.std = torch.exp(0.5 * self.logvar)
+
+    def sample(self, generator=None):
+        return self.mean + self.std * torch.randn(self.mean.shape, generator=generator, dtype=self.mean.dtype)
+
+    def mode(self):
+        return self.mean
+
+
 class AutoencoderKL(nn.Module):
-    """Decode side of diffusers.models.AutoencoderKL at the SDXL-VAE config the reference loads
+    """diffusers.models.AutoencoderKL at the SDXL-VAE config the reference loads
     ("PixArt-alpha/pixart_sigma_sdxlvae_T5_diffusers", subfolder "vae": block_out_channels (128, 256, 512, 512),
-    layers_per_block 2, latent_channels 4, norm_num_groups 32): decode(z) = decoder(post_quant_conv(z)).  The encoder is not
-    restated (the hot path never encodes).  ``from_pretrained`` returns randomly initialised weights (no network here)."""
+    layers_per_block 2, latent_channels 4, norm_num_groups 32): decode(z) = decoder(post_quant_conv(z)); encode(x).latent_dist =
+    DiagonalGaussian(quant_conv(encoder(x))).  ``from_pretrained`` returns randomly initialised weights (no network here)."""
 
     def __init__(self, block_out_channels=(128, 256, 512, 512), layers_per_block=2, latent_channels=4):
         super().__init__()
         self.config = SimpleNamespace(latent_channels=latent_channels, block_out_channels=tuple(block_out_channels),
                                       layers_per_block=layers_per_block, scaling_factor=0.13025)
+        self.encoder = _VaeEncoder(3, latent_channels, block_out_channels, layers_per_block)
+        self.quant_conv = nn.Conv2d(2 * latent_channels, 2 * latent_channels, 1)
         self.post_quant_conv = nn.Conv2d(latent_channels, latent_channels, 1)
         self.decoder = _VaeDecoder(latent_channels, 3, block_out_channels, layers_per_block)
 
     @classmethod
     def from_pretrained(cls, *args, **kwargs):
         return cls()
+
+    def encode(self, x, return_dict=True):
+        return SimpleNamespace(latent_dist=_DiagonalGaussian(self.quant_conv(self.encoder(x))))
 
     def decode(self, z, return_dict=True):
         return SimpleNamespace(sample=self.decoder(self.post_quant_conv(z)))

@@ -241,7 +241,7 @@ def build_reference_opensora_vae(state_dict=None, dtype=torch.float32, micro_fra
     if state_dict is not None:
         missing, unexpected = model.load_state_dict(state_dict, strict=False)
         assert not unexpected, unexpected
-        assert all("encoder" in k or "quant_conv" in k or k in ("scale", "shift") for k in missing), missing
+        assert all("encoder" in k or ".quant_conv" in k or k in ("scale", "shift") for k in missing), missing
     return model.to(dtype).eval()
 
 

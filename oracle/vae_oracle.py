@@ -13,6 +13,11 @@ Restates, function by function, from a flat reference-keyed state dict:
     ResnetBlock2D / Upsample2D — THIRD-PARTY, not vendored in the reference tree and not installable here: restated from the
     published source; **parity unpinned** for these leaves.
 
+Encode side (image / video conditioning, SURVEY.md §8 "callers either side"): VideoAutoencoderPipeline.encode :653-670,
+VAE_Temporal.encode :441-451 + Encoder.forward :258-272 (construction :203-256; the strided CausalConv3d :107-118),
+DiagonalGaussianDistribution :21-40, VideoAutoencoderKL.encode :503-520; and the THIRD-PARTY diffusers AutoencoderKL.encode /
+vae.Encoder / DownEncoderBlock2D / Downsample2D (restated, **parity unpinned**, as above).
+
 Pinning: tests/test_vae_cpu.py checks this file against the reference's own classes (imported through oracle/ref_loader.py
 with the diffusers leaves stubbed) when /root/reference is present, and against tests/golden/opensora_vae_small.pt (minted by
 oracle/make_golden_vae.py from the reference classes) everywhere.
@@ -127,3 +132,85 @@ def decode(sd, z, num_frames, micro_frame_size=17, micro_batch_size=4):
         out.append(spatial_decode(sd, x[i:i + micro_batch_size] / SD_SCALE))
     x = torch.cat(out, 0)
     return x.view(B, T, 3, x.shape[-2], x.shape[-1]).permute(0, 2, 1, 3, 4).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------- encode
+def gaussian_sample(moments, noise):
+    """DiagonalGaussianDistribution(moments).sample() with the noise handed in: mean + exp(0.5 clamp(logvar, -30, 20)) * noise
+    (autoencoder_kl_open_sora.py:21-40; the diffusers class of the 2-D VAE is the same arithmetic)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * noise
+
+
+def spatial_encode_moments(sd, x):
+    """diffusers AutoencoderKL.encode up to the distribution parameters, SDXL-VAE config: conv_in, 4 down blocks of 2 resnets
+    (128, 256, 512, 512; pad-right/bottom + 3x3 stride-2 conv after the first three), mid (resnet, attention, resnet),
+    GroupNorm, SiLU, conv_out (8 channels), quant_conv.  x [N, 3, H, W] -> [N, 8, H/8, W/8]."""
+    s = "spatial_vae.module."
+    e = s + "encoder."
+    x = F.conv2d(x, sd[e + "conv_in.weight"], sd[e + "conv_in.bias"], padding=1)
+    for i in range(4):
+        for j in range(2):
+            x = _resnet_2d(sd, f"{e}down_blocks.{i}.resnets.{j}", x)
+        k = f"{e}down_blocks.{i}.downsamplers.0.conv"
+        if (k + ".weight") in sd:
+            x = F.conv2d(F.pad(x, (0, 1, 0, 1)), sd[k + ".weight"], sd[k + ".bias"], stride=2)
+    x = _resnet_2d(sd, e + "mid_block.resnets.0", x)
+    x = _attn_2d(sd, e + "mid_block.attentions.0", x)
+    x = _resnet_2d(sd, e + "mid_block.resnets.1", x)
+    x = F.conv2d(F.silu(_gn(x, sd, e + "conv_norm_out", 1e-6)), sd[e + "conv_out.weight"], sd[e + "conv_out.bias"], padding=1)
+    return F.conv2d(x, sd[s + "quant_conv.weight"], sd[s + "quant_conv.bias"])
+
+
+def strided_causal_conv3d(x, w, b, t_stride):
+    """CausalConv3d with strides (t_stride, 1, 1) (:107-118): (kt - 1) + (1 - t_stride) zero frames in front."""
+    kt, kh, kw = w.shape[2:]
+    x = F.pad(x, (kw // 2, kw // 2, kh // 2, kh // 2, (kt - 1) + (1 - t_stride), 0), mode="constant")
+    return F.conv3d(x, w, b, stride=(t_stride, 1, 1))
+
+
+def temporal_encode_moments(sd, x):
+    """VAE_Temporal.encode :441-451 up to the distribution parameters (VAE_Temporal_SD geometry :465-478): zero frames in front
+    up to a multiple of 4, conv_in, 4 x 4 ResBlocks at 128 / 256 / 256 / 512 channels with a stride-2-in-time conv after the
+    second and third group (temporal_downsample (False, True, True): the first slot is an Identity), 4 ResBlocks, GroupNorm,
+    SiLU, 1x1x1 conv to 8 channels, quant_conv.  x [B, 4, T, h, w] -> [B, 8, ceil(T/4), h, w]."""
+    t = "temporal_vae."
+    T = x.shape[2]
+    tpad = 0 if T % 4 == 0 else 4 - T % 4
+    x = F.pad(x, (0, 0, 0, 0, tpad, 0))
+    e = t + "encoder."
+    x = causal_conv3d(x, sd[e + "conv_in.conv.weight"], None)
+    for i in range(4):
+        for j in range(4):
+            x = res_block_3d(sd, f"{e}block_res_blocks.{i}.{j}", x)
+        k = f"{e}conv_blocks.{i}.conv"
+        if i < 3 and (k + ".weight") in sd:
+            x = strided_causal_conv3d(x, sd[k + ".weight"], sd[k + ".bias"], 2)
+    for i in range(4):
+        x = res_block_3d(sd, f"{e}res_blocks.{i}", x)
+    x = causal_conv3d(F.silu(_gn(x, sd, e + "norm1", 1e-5)), sd[e + "conv2.conv.weight"], sd[e + "conv2.conv.bias"])
+    return causal_conv3d(x, sd[t + "quant_conv.conv.weight"], sd[t + "quant_conv.conv.bias"])
+
+
+@torch.no_grad()
+def encode(sd, x, noise_fn=None, micro_frame_size=17, micro_batch_size=4):
+    """VideoAutoencoderPipeline.encode :653-670 (cal_loss False) + VideoAutoencoderKL.encode :503-520: x [B, 3, T, H, W] in
+    [-1, 1] -> normalised latents [B, 4, Tz, H/8, W/8].  ``noise_fn(shape)`` is drawn once per 2-D micro batch of frames and
+    once per temporal micro batch, in that order — the order of the reference's randn calls (default torch.randn)."""
+    noise_fn = noise_fn or (lambda shape: torch.randn(shape))
+    dt = x.dtype
+    B, _, T, H, W = x.shape
+    fr = x.permute(0, 2, 1, 3, 4).reshape(B * T, 3, H, W)
+    lat = []
+    for i in range(0, fr.shape[0], micro_batch_size):
+        m = spatial_encode_moments(sd, fr[i:i + micro_batch_size])
+        lat.append(gaussian_sample(m, noise_fn(m[:, :4].shape).to(dt)) * SD_SCALE)
+    x_z = torch.cat(lat, 0).view(B, T, 4, H // 8, W // 8).permute(0, 2, 1, 3, 4)
+    zs = []
+    for i in range(0, T, micro_frame_size):
+        m = temporal_encode_moments(sd, x_z[:, :, i:i + micro_frame_size]).to(dt)
+        zs.append(gaussian_sample(m, noise_fn(m[:, :4].shape).to(dt)))
+    z = torch.cat(zs, dim=2)
+    scale = torch.tensor(SCALE)[None, :, None, None, None].to(dt)
+    shift = torch.tensor(SHIFT)[None, :, None, None, None].to(dt)
+    return (z - shift) / scale

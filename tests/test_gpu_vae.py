@@ -233,3 +233,106 @@ def test_autoencoder_kl_decoder_matches_oracle():
     assert got.dtype == torch.uint8 and tuple(got.shape) == (1, 3, 64, 96, 3)
     diff = (got.float() - want).abs()
     assert diff.mean().item() < 1.5 and (diff > 12).float().mean().item() < 1e-3, (diff.mean().item(), diff.max().item())
+
+
+# ---------------------------------------------------------------------------------------------------- encode side
+def test_subsample_is_the_strided_conv():
+    """vsys_subsample on the stride-1 conv = the encoders' strided convolutions (diffusers Downsample2D: pad (0, 1, 0, 1) + 3x3
+    stride 2; CausalConv3d with strides (2, 1, 1): one zero frame in front) — against torch on bf16-rounded operands."""
+    from videosys_amd import ops
+    from videosys_amd.ops import VaeGrid
+    from videosys_amd.vae_open_sora import OpenSoraVAE, _conv_w
+
+    g = torch.Generator().manual_seed(2)
+    vae = OpenSoraVAE.__new__(OpenSoraVAE)
+    vae.device, vae._padded = dev(), {}
+    for n, T, H, W, cin, cout, kt, st, ss in ((3, 1, 12, 8, 128, 128, 1, 1, 2), (1, 8, 6, 5, 256, 256, 3, 2, 1)):
+        x = bfr(torch.randn(n, cin, T, H, W, generator=g))
+        shape = (cout, cin, 3, 3, 3) if kt == 3 else (cout, cin, 3, 3)
+        w = bfr(torch.randn(shape, generator=g) / math.sqrt(cin * 9 * kt))
+        b = bfr(torch.randn(cout, generator=g) * 0.1)
+        if kt == 1:
+            ref = F.conv2d(F.pad(x[:, :, 0], (0, 1, 0, 1)), w, b, stride=2)[:, :, None]
+        else:
+            ref = F.conv3d(F.pad(x, (1, 1, 1, 1, 1, 0)), w, b, stride=(2, 1, 1))
+        gd = VaeGrid(n, T, H, W, 0, 0)
+        _, rows = to_rows(x, gd)
+        cv = type("C", (), dict(kt=kt, ks=3, cin=cin, cout=cout, w=_conv_w(w.to(dev())), b=b.to(torch.bfloat16).to(dev())))()
+        out, g2 = vae._strided_conv(rows.contiguous(), gd, cv, st, ss)
+        assert (g2.T, g2.H, g2.W) == tuple(ref.shape[2:])
+        check(from_rows(out, g2, cout), ref, what=f"strided conv kt={kt}")
+
+
+def test_opensora_vae_encode_matches_reference_golden():
+    """OpenSoraVAE.encode against the fixture minted from the reference's VideoAutoencoderPipeline.encode: the two encoders'
+    distribution parameters at the bf16 floor (rel rms <= 1.5 x the reference's own bf16 run, cosine >= 0.999), and the
+    sampled, normalised latents against the fp32 reference on the same seeded noise."""
+    from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict
+
+    gold = load_golden("opensora_vae_encode_small.pt")
+    vae = OpenSoraVAE(synth_state_dict(gold["seed"], encoder=True), device=dev())
+    assert vae.has_encoder
+    rms = lambda t: t.pow(2).mean().sqrt().item()
+
+    def floor_check(out, ref, ref16, what):
+        floor, mine = rms(ref16.float() - ref) / rms(ref), rms(out - ref) / rms(ref)
+        cos = F.cosine_similarity(out.flatten(), ref.flatten(), dim=0).item()
+        assert mine <= 1.5 * floor + 1e-3 and cos >= 0.999, f"{what}: rel rms {mine:.4f} vs floor {floor:.4f}, cosine {cos:.5f}"
+
+    fr = gold["x"][0].permute(1, 0, 2, 3)[:4]                                     # [4 frames, 3, 32, 48]
+    m2d = vae._spatial_encode(fr.permute(1, 0, 2, 3).to(torch.bfloat16).to(dev()).contiguous()).float().cpu()   # [8, 4, 4, 6]
+    floor_check(m2d.permute(1, 0, 2, 3), gold["frames4_moments"], gold["frames4_moments_bf16"], "2-D encoder moments")
+    mt = vae._temporal_encode(gold["xz17"][0].to(torch.bfloat16).to(dev()).contiguous()).float().cpu()          # [8, 5, 4, 6]
+    floor_check(mt[None], gold["xz17_moments"], gold["xz17_moments_bf16"], "temporal encoder moments")
+
+    torch.manual_seed(gold["noise_seed"])
+    z = vae.encode(gold["x"].to(dev())).float().cpu()
+    ref = gold["z_fp32"]
+    assert z.shape == ref.shape
+    e = rms(z - ref) / rms(ref)
+    cos = F.cosine_similarity(z.flatten(), ref.flatten(), dim=0).item()
+    assert e <= 0.06 and cos >= 0.998, f"encode latents vs reference fp32: rel rms {e:.4f}, cosine {cos:.5f}"
+    torch.manual_seed(gold["noise_seed"])
+    assert torch.equal(z, vae.encode(gold["x"].to(dev())).float().cpu())        # buffers reused: same bits
+    with pytest.raises(RuntimeError):
+        OpenSoraVAE(synth_state_dict(gold["seed"]), device=dev()).encode(gold["x"].to(dev()))
+
+
+def test_open_sora_pipeline_image_conditioning_and_loop():
+    """generate() with a reference image and a mask strategy (pipeline_open_sora.py:528-535,607-645): the reference frame is
+    encoded by the VAE, pasted over latent frame 0 and HELD through the sampling (mask 0), so the returned latents carry it bit
+    for bit; with ``loop=2`` the second clip starts from the re-encoded tail of the first and the clips are joined in time."""
+    from videosys_amd import OpenSoraConfig, OpenSoraPipeline
+    from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict
+
+    tcfg = dict(depth=1, hidden_size=576, num_heads=8, caption_channels=64, model_max_length=16)
+    vae = OpenSoraVAE(synth_state_dict(7, encoder=True), device=dev())
+    pipe = OpenSoraPipeline(OpenSoraConfig(transformer="synthetic:3", num_sampling_steps=3, transformer_config=tcfg), device=dev(),
+                            vae_decoder=vae)
+    g = torch.Generator().manual_seed(0)
+    emb = torch.randn(1, 1, 16, 64, generator=g).to(torch.bfloat16)
+    mask = torch.ones(1, 16, dtype=torch.long)
+    img = (torch.rand(3, 1, 64, 96, generator=g) * 2 - 1)
+    kw = dict(prompt_embeds=emb, prompt_mask=mask, height=64, width=96, num_frames=34, seed=1)
+    plain = pipe.generate(output_type="latent", **kw).video
+    lat = pipe.generate(output_type="latent", refs=[img], ms="0", **kw).video
+    torch.manual_seed(1)                                                         # generate() seeds the global generator with ``seed``
+    ref_lat = vae.encode(img[None].to(dev()))                                    # ... so this is the posterior draw it made: [1, 4, 1, 8, 12]
+    assert tuple(lat.shape) == tuple(plain.shape) == (1, 4, 10, 8, 12)
+    assert torch.equal(lat[:, :, :1].cpu(), ref_lat.cpu().to(torch.float32))
+    assert not torch.equal(lat[:, :, 1:].cpu(), plain[:, :, 1:].cpu())           # the others saw it through the attention
+    assert pipe.transformer.program_stats["eager"] >= 3                          # masked steps are issued eagerly
+    # the same reference handed over as a JSON tail of a prompt needs the text encoder; as latents it needs no encoder at all
+    lat2 = pipe.generate(output_type="latent", refs=[ref_lat[0].cpu()], ms="0", **kw).video
+    assert torch.equal(lat2.cpu(), lat.cpu())
+    # two loops: the second clip holds the re-encoded last 5 latent frames of the first (17 pixel frames) and generates 5 more
+    video = pipe.generate(loop=2, condition_frame_length=5, **kw).video
+    assert video.dtype == torch.uint8 and tuple(video.shape) == (1, 34 + 34 - 17, 64, 96, 3)
+    first = pipe.generate(**kw).video
+    assert torch.equal(video[:, :34], first)
+    with pytest.raises(RuntimeError):
+        pipe.generate(loop=2, output_type="latent", **kw)
+    dec_only = OpenSoraPipeline(OpenSoraConfig(transformer="synthetic:3", vae="synthetic:7", num_sampling_steps=2, transformer_config=tcfg),
+                                device=dev())
+    with pytest.raises(RuntimeError):
+        dec_only.generate(refs=[img], ms="0", **kw)                              # pixel reference, VAE without encoder weights

@@ -84,3 +84,87 @@ def test_vae_oracle_matches_live_reference_class():
     out = VO.decode(sd, z, 38)
     assert out.shape == ref.shape == (1, 3, 38, 32, 48)
     assert (out - ref).abs().max().item() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------- encode side
+def test_vae_encode_oracle_matches_reference_golden():
+    """oracle/vae_oracle.py encode against the fixture minted from the reference's VideoAutoencoderPipeline.encode
+    (oracle/make_golden_vae_encode.py): the two encoders' distribution parameters and the sampled, normalised latents (same
+    seeded noise stream)."""
+    from oracle import vae_oracle as VO
+    from oracle.make_golden import sd_checksum
+    from videosys_amd.vae_open_sora import synth_state_dict
+
+    gold = load_golden("opensora_vae_encode_small.pt")
+    sd = synth_state_dict(gold["seed"], encoder=True)
+    assert sd_checksum(sd) == gold["sd_checksum"]
+    fr = gold["x"][0].permute(1, 0, 2, 3)
+    assert (VO.spatial_encode_moments(sd, fr[:4]) - gold["frames4_moments"]).abs().max().item() < 1e-4
+    assert (VO.temporal_encode_moments(sd, gold["xz17"]) - gold["xz17_moments"]).abs().max().item() < 1e-4
+    torch.manual_seed(gold["noise_seed"])
+    z = VO.encode(sd, gold["x"])
+    assert z.shape == gold["z_fp32"].shape == (1, 4, 6, 4, 6)
+    assert (z - gold["z_fp32"]).abs().max().item() < 1e-4
+
+
+def test_encoder_param_inventory_matches_reference():
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present on this box")
+    from videosys_amd.vae_open_sora import decoder_param_shapes, encoder_param_shapes, synth_state_dict
+
+    model = ref_loader.build_reference_opensora_vae()
+    ref = {k: tuple(v.shape) for k, v in model.state_dict().items() if "encoder" in k or ".quant_conv" in k}
+    assert encoder_param_shapes() == ref
+    a, b = synth_state_dict(5), synth_state_dict(5, encoder=True)
+    assert set(b) == set(decoder_param_shapes()) | set(encoder_param_shapes())
+    assert all(torch.equal(a[k], b[k]) for k in a)          # decode-side weights do not depend on the flag
+
+
+def test_vae_encode_oracle_matches_live_reference_class():
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present on this box")
+    from oracle import vae_oracle as VO
+    from videosys_amd.vae_open_sora import synth_state_dict
+
+    sd = synth_state_dict(21, encoder=True)
+    model = ref_loader.build_reference_opensora_vae(sd)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 3, 5, 16, 24, generator=g).clamp(-1, 1)     # two samples, one 5-frame micro batch (3 pad frames)
+    torch.manual_seed(99)
+    with torch.no_grad():
+        ref = model.encode(x)
+    torch.manual_seed(99)
+    out = VO.encode(sd, x)
+    assert out.shape == ref.shape == (2, 4, 2, 2, 3)
+    assert (out - ref).abs().max().item() < 1e-4
+
+
+def test_vae_encode_host_flow_on_emulated_kernels():
+    """The host composition of OpenSoraVAE.encode — grids, zero borders, the stride-1-conv-then-sample form of the five strided
+    convolutions, the padded 8-channel heads, micro batching, noise order — run on CPU with every kernel wrapper replaced by a
+    torch restatement of its contract (tests/vae_cpu_emul.py), against the oracle: the moments of both encoders at bf16-storage
+    accuracy, the sampled latents on the same seeded noise."""
+    from oracle import vae_oracle as VO
+    from vae_cpu_emul import cpu_vae, emulated_vae_ops
+    from videosys_amd.vae_open_sora import synth_state_dict
+
+    gold = load_golden("opensora_vae_encode_small.pt")
+    sd = synth_state_dict(gold["seed"], encoder=True)
+    rel = lambda a, b: ((a.float() - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt()).item()
+    with emulated_vae_ops():
+        vae = cpu_vae(sd)
+        fr = gold["x"][0].permute(1, 0, 2, 3)[:4]
+        m2d = vae._spatial_encode(fr.permute(1, 0, 2, 3).to(torch.bfloat16).contiguous()).float().permute(1, 0, 2, 3)
+        assert rel(m2d, gold["frames4_moments"]) <= 1.5 * rel(gold["frames4_moments_bf16"], gold["frames4_moments"]) + 1e-3
+        mt = vae._temporal_encode(gold["xz17"][0].to(torch.bfloat16).contiguous()).float()[None]
+        assert rel(mt, gold["xz17_moments"]) <= 1.5 * rel(gold["xz17_moments_bf16"], gold["xz17_moments"]) + 1e-3
+        torch.manual_seed(gold["noise_seed"])
+        z = vae._encode(gold["x"], lambda shape: torch.randn(shape))
+    assert z.shape == gold["z_fp32"].shape
+    assert rel(z, gold["z_fp32"]) <= 0.06, rel(z, gold["z_fp32"])
+    cos = torch.nn.functional.cosine_similarity(z.flatten(), gold["z_fp32"].flatten(), dim=0).item()
+    assert cos >= 0.998, cos

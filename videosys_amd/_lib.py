@@ -56,6 +56,7 @@ SIGNATURES = {
     "vsys_gn_stats": [_ptr, _ptr, _i64, _i64, _i64, _f32, _ptr, _i64, _ptr, _ptr],
     "vsys_gn_apply": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _int, _ptr],
     "vsys_regrid": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_subsample": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "vsys_spatial_norm_apply": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "vsys_blend_edge": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "vsys_d2s_time": [_ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr],

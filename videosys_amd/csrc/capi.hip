@@ -396,6 +396,15 @@ int vsys_regrid(const void* x, const int64_t* grid_src, void* y, const int64_t* 
   return launch_regrid(B16(x), gs, B16(y), gd, (int)N, (int)C, (int)up, (int)tmode, S(stream));
 }
 
+int vsys_subsample(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t t_stride,
+                   int64_t s_stride, int64_t t_first, int64_t s_first, void* stream) {
+  VaeGrid gs, gd;
+  if (!x || !y || !to_grid(grid_src, gs) || !to_grid(grid_dst, gd)) return VSYS_ERR_ARG;
+  if (!fits_int(N) || !fits_int(C) || !fits_int(t_stride) || !fits_int(s_stride) || !fits_int(t_first) || !fits_int(s_first))
+    return VSYS_ERR_SHAPE;
+  return launch_subsample(B16(x), gs, B16(y), gd, (int)N, (int)C, (int)t_stride, (int)s_stride, (int)t_first, (int)s_first, S(stream));
+}
+
 int vsys_spatial_norm_apply(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C,
                             int64_t groups, const void* stats_f32, const void* gamma, const void* beta, const void* yb, int64_t zT,
                             int64_t zH, int64_t zW, void* stream) {

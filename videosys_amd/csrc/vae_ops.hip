@@ -139,6 +139,26 @@ __global__ __launch_bounds__(256) void regrid_kernel(const bf16_t* __restrict__ 
   }
 }
 
+// strided pick: destination (t, h, w) = source (t * st + t0, h * ss + s0, w * ss + s0).  A strided convolution is the stride-1
+// convolution sampled: diffusers Downsample2D (F.pad(0, 1, 0, 1) + 3 x 3 stride-2 conv, the SD VAE encoder) = the pad-1 stride-1
+// conv at (2i + 1, 2j + 1); the causal stride-(2, 1, 1) CausalConv3d of the temporal encoder (one front pad frame,
+// autoencoder_kl_open_sora.py:107-118) = the two-front-frames stride-1 conv at frame 2t + 1.
+__global__ __launch_bounds__(256) void subsample_kernel(const bf16_t* __restrict__ x, VaeGrid gs, bf16_t* __restrict__ y, VaeGrid gd,
+                                                        int C, int st, int ss, int t0, int s0, int N) {
+  const int nch = C >> 3;
+  const int64_t total = (int64_t)N * gd.T * gd.H * gd.W * nch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int ch = (int)(i % nch);
+    int64_t pos = i / nch;
+    const int w = (int)(pos % gd.W); pos /= gd.W;
+    const int h = (int)(pos % gd.H); pos /= gd.H;
+    const int t = (int)(pos % gd.T);
+    const int n = (int)(pos / gd.T);
+    *reinterpret_cast<uint4*>(y + grid_row(gd, n, t, h, w) * C + ch * 8) =
+        *reinterpret_cast<const uint4*>(x + grid_row(gs, n, t * st + t0, h * ss + s0, w * ss + s0) * C + ch * 8);
+  }
+}
+
 // "B (C ts) T H W -> B C (T ts) H W", ts = 2 (reference autoencoder_kl_open_sora.py:362-368): source channel 2c + s of frame
 // t becomes channel c of frame 2t + s.  Thread = 16 source channels -> 8 channels of each of the two frames.
 __global__ __launch_bounds__(256) void d2s_time_kernel(const bf16_t* __restrict__ x, VaeGrid gs, bf16_t* __restrict__ y, VaeGrid gd,
@@ -382,6 +402,17 @@ int launch_regrid(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& 
     return VSYS_ERR_SHAPE;
   hipLaunchKernelGGL(regrid_kernel, dim3(grid_for((int64_t)N * gd.T * gd.H * gd.W * (C >> 3))), dim3(256), 0, stream, x, gs, y, gd, C, up,
                      tmode, N);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_subsample(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int st, int ss, int t0, int s0,
+                     hipStream_t stream) {
+  if (N <= 0) return 0;
+  if (!grid_ok(gs) || !grid_ok(gd) || C % 8 != 0 || st < 1 || ss < 1 || t0 < 0 || s0 < 0 || gd.T <= 0 || gd.H <= 0 || gd.W <= 0 ||
+      (gd.T - 1) * st + t0 >= gs.T || (gd.H - 1) * ss + s0 >= gs.H || (gd.W - 1) * ss + s0 >= gs.W)
+    return VSYS_ERR_SHAPE;
+  hipLaunchKernelGGL(subsample_kernel, dim3(grid_for((int64_t)N * gd.T * gd.H * gd.W * (C >> 3))), dim3(256), 0, stream, x, gs, y, gd, C,
+                     st, ss, t0, s0, N);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

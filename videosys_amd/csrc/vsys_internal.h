@@ -77,6 +77,8 @@ int launch_gn_stats(const bf16_t* x, const VaeGrid& g, int N, int C, int groups,
 int launch_gn_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int groups, const float* stats,
                     const bf16_t* gamma, const bf16_t* beta, int act, hipStream_t stream);
 int launch_regrid(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int up, int tmode, hipStream_t stream);
+int launch_subsample(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int st, int ss, int t0, int s0,
+                     hipStream_t stream);
 int launch_spatial_norm_apply(const bf16_t* x, const VaeGrid& gs, bf16_t* y, const VaeGrid& gd, int N, int C, int groups,
                               const float* stats, const bf16_t* gamma, const bf16_t* beta, const bf16_t* yb, int zT, int zH, int zW,
                               hipStream_t stream);

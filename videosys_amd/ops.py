@@ -489,6 +489,16 @@ def regrid(x, gs: VaeGrid, y, gd: VaeGrid, C, up=0, tmode=0):
     return y
 
 
+def subsample(x, gs: VaeGrid, y, gd: VaeGrid, C, t_stride=1, s_stride=1, t_first=0, s_first=0):
+    """y[(t, h, w) of gd] = x[(t * t_stride + t_first, h * s_stride + s_first, w * s_stride + s_first) of gs] (strided convs)."""
+    _chk(x, y)
+    _bf16(x, y)
+    assert x.shape[0] == gs.rows and y.shape[0] == gd.rows and x.is_contiguous() and y.is_contiguous()
+    _lib.check(_lib.load().vsys_subsample(_p(x), gs._c, _p(y), gd._c, gs.n, C, t_stride, s_stride, t_first, s_first, _stream()),
+               "vsys_subsample")
+    return y
+
+
 def spatial_norm_silu(x, gs: VaeGrid, y, gd: VaeGrid, C, gamma, beta, yb, zdims, eps=1e-6, groups=32):
     """y[interior of gd] = silu(GroupNorm(x) * Y + B) with [Y | B] = yb rows over the latent grid zdims = (zT, zH, zW)."""
     _chk(x, y, gamma, beta, yb)

@@ -204,8 +204,8 @@ class OpenSoraPipeline(StagedOffloadMixin):
         reference's keys) or "synthetic:<seed>"; a hub id cannot be fetched here, so it leaves the pipeline latent-only."""
         from .vae_open_sora import OpenSoraVAE, synth_state_dict as vae_synth
 
-        if isinstance(name, str) and name.startswith("synthetic:"):
-            return OpenSoraVAE(vae_synth(int(name.split(":", 1)[1])), device=self._device)
+        if isinstance(name, str) and name.startswith(("synthetic:", "synthetic-full:")):   # -full: with the encoders (conditioning)
+            return OpenSoraVAE(vae_synth(int(name.split(":", 1)[1]), encoder=name.startswith("synthetic-full:")), device=self._device)
         if isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "model.safetensors")):
             from safetensors.torch import load_file
 
@@ -295,9 +295,12 @@ class OpenSoraPipeline(StagedOffloadMixin):
             _, ref_list, ms_list = K.extract_json_from_prompts(prompts, ref_list, ms_list)
         conditioned = loop != 1 or any(ms_list) or any(len(r) > 0 for r in ref_list if r is not None)
         vae = self.vae_decoder
-        encode = getattr(vae, "encode", None)
+        encode = None
+        if getattr(vae, "has_encoder", False):
+            encode = lambda v: vae.encode(v.to(self._device))      # pixels [B, 3, T, H, W] in [-1, 1] -> latents (seeded: set_seed)
         if loop > 1 and (vae is None or encode is None or output_type == "latent"):
-            raise RuntimeError("loop > 1 conditions every clip on the decoded + re-encoded previous one: it needs the VAE attached")
+            raise RuntimeError("loop > 1 conditions every clip on the decoded + re-encoded previous one: it needs a VAE with "
+                               "encoder weights attached and pixel output")
         if conditioned:
             self._enter_stage("vae")
         refs_x = K.collect_references_batch(ref_list, encode, image_size) if conditioned else None

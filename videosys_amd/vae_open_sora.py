@@ -1,4 +1,4 @@
-"""Open-Sora v1.2 VAE decode on MI355X.
+"""Open-Sora v1.2 VAE on MI355X: decode and, for image / video conditioning, encode.
 
 Mirrors the decode side of the reference ``VideoAutoencoderPipeline`` (videosys/models/autoencoders/
 autoencoder_kl_open_sora.py:620-735, factory ``OpenSoraVAE_V1_2`` :738-761):
@@ -14,12 +14,21 @@ GroupNorm/SiLU, upsampling, depth-to-space and the first/last small-channel laye
 single-head d = 512 mid-block attention is three batched GEMMs + a row softmax.  State-dict keys are the reference's
 (``temporal_vae.decoder.*``, ``spatial_vae.module.decoder.*``) so the real checkpoints drop in.
 
+``encode`` (reference :653-670, VAE_Temporal.encode :441-451, VideoAutoencoderKL.encode :503-520) is what the pipeline's
+conditioning needs (reference frames, ``loop`` > 1): the 2-D SDXL encoder per frame, then the temporal encoder per 17-frame
+micro batch, each followed by a draw from its diagonal Gaussian.  It runs on the same kernels; the three stride-2 convolutions of
+the 2-D encoder and the two stride-2-in-time causal convolutions of the temporal encoder are computed as the stride-1
+convolution sampled at the odd positions (vsys_subsample) — 4x / 2x the arithmetic of a strided kernel on those five layers of
+a path that runs once per conditioning clip, in exchange for no new convolution kernel.  Encoder weights are optional: a
+checkpoint without ``*.encoder.*`` keys gives a decode-only object.
+
 There is no CPU path: without the HIP library / a GPU every call raises.
 """
 from __future__ import annotations
 
 import math
-from typing import Dict, List, Optional
+from types import SimpleNamespace
+from typing import Callable, Dict, List, Optional
 
 import torch
 
@@ -92,6 +101,7 @@ class OpenSoraVAE:
 
     micro_frame_size = 17
     micro_batch_size = 4
+    has_encoder = False
     out_channels = 4
     shift = (-0.10, 0.34, 0.27, 0.98)   # OpenSoraVAE_V1_2, autoencoder_kl_open_sora.py:756-757
     scale = (3.85, 2.32, 2.33, 3.06)
@@ -110,6 +120,10 @@ class OpenSoraVAE:
         self._padded: Dict[tuple, tuple] = {}
         self._init_temporal(state_dict, dev)
         self._init_spatial(state_dict, dev, "spatial_vae.module.")
+        self.has_encoder = "temporal_vae.encoder.conv_in.conv.weight" in state_dict and \
+            "spatial_vae.module.encoder.conv_in.weight" in state_dict
+        if self.has_encoder:
+            self._init_encoders(state_dict, dev)
 
     def _init_temporal(self, sd, dev):
         # ---- temporal VAE (VAE_Temporal_SD: filters 128, multipliers (1,2,2,4), 4 res blocks, temporal up (F,T,T))
@@ -150,6 +164,48 @@ class OpenSoraVAE:
             self.s_up.append((res, _Conv(sd, upk, dev) if (upk + ".weight") in sd else None))
         self.s_norm = _Norm(sd, d + "conv_norm_out", dev, 1e-6)
         self.s_out = _Conv(sd, d + "conv_out", dev, n_pad=128)
+
+    def _init_encoders(self, sd, dev):
+        """Encode side: diffusers vae.Encoder + quant_conv under ``spatial_vae.module.`` and Encoder (:177-272) + quant_conv under
+        ``temporal_vae.``.  The two 8-channel heads (conv_out / conv2, then the 1x1 quant convs) are padded to the 128-column tile."""
+        e = "spatial_vae.module.encoder."
+        w_in = sd[e + "conv_in.weight"].to(dev)                                     # [128, 3, 3, 3]: RGB + one zero channel
+        w_in = torch.cat([w_in, torch.zeros_like(w_in[:, :1])], 1)
+        self.e_conv_in_w = _conv_w(w_in, None, 64)                                  # K = 9 * 4 = 36 -> 64
+        self.e_conv_in_b = _vec(sd[e + "conv_in.bias"].to(dev))
+        self.e_down = []
+        for i in range(4):
+            res = [_Res(sd, f"{e}down_blocks.{i}.resnets.{j}", dev, False) for j in range(2)]
+            dk = f"{e}down_blocks.{i}.downsamplers.0.conv"
+            self.e_down.append((res, _Conv(sd, dk, dev) if (dk + ".weight") in sd else None))
+        self.e_mid = [_Res(sd, f"{e}mid_block.resnets.{i}", dev, False) for i in range(2)]
+        self.e_attn = self._attn_weights(sd, e + "mid_block.attentions.0.", dev)
+        self.e_norm = _Norm(sd, e + "conv_norm_out", dev, 1e-6)
+        self.e_out = _Conv(sd, e + "conv_out", dev, n_pad=128)
+        q = "spatial_vae.module.quant_conv"
+        self.e_quant_w = _conv_w(sd[q + ".weight"].to(dev), 128, 128)
+        self.e_quant_b = _vec(sd[q + ".bias"].to(dev), 128)
+        t = "temporal_vae.encoder."
+        self.te_conv_in_w = _conv_w(sd[t + "conv_in.conv.weight"].to(dev), None, 128)   # K = 27 * 4 = 108 -> 128, no bias
+        self.te_blocks = [[_Res(sd, f"{t}block_res_blocks.{i}.{j}", dev, True) for j in range(4)] for i in range(4)]
+        self.te_down = {i: _Conv(sd, f"{t}conv_blocks.{i}.conv", dev) for i in range(3) if f"{t}conv_blocks.{i}.conv.weight" in sd}
+        self.te_res = [_Res(sd, f"{t}res_blocks.{i}", dev, True) for i in range(4)]
+        self.te_norm = _Norm(sd, t + "norm1", dev, 1e-5)
+        self.te_out = _Conv(sd, t + "conv2.conv", dev, n_pad=128)                       # 1x1x1, 512 -> 8
+        q = "temporal_vae.quant_conv.conv"
+        self.te_quant_w = _conv_w(sd[q + ".weight"].to(dev), 128, 128)
+        self.te_quant_b = _vec(sd[q + ".bias"].to(dev), 128)
+
+    @staticmethod
+    def _attn_weights(sd, a, dev):
+        """The single-head mid-block attention of the 2-D VAE: (norm, wq, bq, wk, bk, wv, wo, bo') with the value bias folded
+        into the output bias (softmax rows sum to 1: P (V + 1 b_v^T) = P V + b_v)."""
+        bf = lambda k: sd[k].to(dev).to(torch.bfloat16).contiguous()
+        wo = bf(a + "to_out.0.weight")
+        bo = sd[a + "to_out.0.bias"].to(dev).float() + wo.float() @ bf(a + "to_v.bias").float()
+        return SimpleNamespace(a_norm=_Norm(sd, a + "group_norm", dev, 1e-6), a_wq=bf(a + "to_q.weight"), a_bq=bf(a + "to_q.bias"),
+                               a_wk=bf(a + "to_k.weight"), a_bk=bf(a + "to_k.bias"), a_wv=bf(a + "to_v.weight"), a_wo=wo,
+                               a_bo=bo.to(torch.bfloat16))
 
     # ------------------------------------------------------------------------------------------------ sizes
     def get_temporal_latent_size(self, t: int) -> int:
@@ -235,8 +291,8 @@ class OpenSoraVAE:
         return g.T - tpad
 
     # ------------------------------------------------------------------------------------------------ 2-D decoder
-    def _attention(self, x, g: VaeGrid):
-        """diffusers Attention (1 head, d = C = 512) with residual; x rows over g -> dense rows whose per-frame stride is the
+    def _attention(self, x, g: VaeGrid, aw=None):
+        """diffusers Attention (1 head, d = C = 512) with residual (``aw``: another mid block's weights, default the decoder's); x rows over g -> dense rows whose per-frame stride is the
         token count rounded up to the 128-column GEMM tile (pad rows are zero on input, finite junk on output)."""
         C, L, n = 512, g.H * g.W, g.n
         Lp = (L + 127) // 128 * 128
@@ -248,12 +304,13 @@ class OpenSoraVAE:
                     torch.zeros(gdn.rows, C, dtype=torch.bfloat16, device=self.device))
             self._padded[key] = bufs
         hn, xd = bufs
-        ops.group_norm(x, g, hn, gdn, C, self.a_norm.g, self.a_norm.b, self.a_norm.eps, False)
+        A = aw if aw is not None else self
+        ops.group_norm(x, g, hn, gdn, C, A.a_norm.g, A.a_norm.b, A.a_norm.eps, False)
         ops.regrid(x, g, xd, gdn, C)
-        q = ops.gemm128(hn, self.a_wq, self.a_bq)
-        k = ops.gemm128(hn, self.a_wk, self.a_bk)
+        q = ops.gemm128(hn, A.a_wq, A.a_bq)
+        k = ops.gemm128(hn, A.a_wk, A.a_bk)
         vt = torch.empty(n, C, Lp, dtype=torch.bfloat16, device=self.device)   # V^T per frame = W_v X^T (pad columns = 0)
-        ops.gemm128(self.a_wv, hn.view(n, Lp, C), out=vt, batch=n, batch_a=0, batch_w=Lp * C, batch_o=C * Lp, M=C)
+        ops.gemm128(A.a_wv, hn.view(n, Lp, C), out=vt, batch=n, batch_a=0, batch_w=Lp * C, batch_o=C * Lp, M=C)
         o = torch.empty(n * Lp, C, dtype=torch.bfloat16, device=self.device)
         step = max(1, min(n, (1 << 28) // (Lp * Lp)))          # <= 1 GiB of fp32 scores at a time
         for f in range(0, n, step):
@@ -264,7 +321,7 @@ class OpenSoraVAE:
             p = ops.softmax_rows(s, n=L)
             ops.gemm128(p, vt[f:f + m], out=o[f * Lp:(f + m) * Lp].view(m, Lp, C), batch=m, batch_a=Lp * Lp, batch_w=C * Lp,
                         batch_o=Lp * C, M=Lp)
-        return ops.gemm128(o, self.a_wo, self.a_bo, res=xd), gdn
+        return ops.gemm128(o, A.a_wo, A.a_bo, res=xd), gdn
 
     def _spatial_decode(self, xz: torch.Tensor, out: torch.Tensor, f0: int, in_scale: float = 1.0 / _SD_SCALE):
         """xz planar bf16 [4, F, H, W] -> out[3, f0:f0+F, 8H, 8W].  VideoAutoencoderKL.decode :522-538 + diffusers Decoder."""
@@ -314,6 +371,117 @@ class OpenSoraVAE:
                 self._spatial_decode(xz[:, f:f + m].contiguous(), vid, f)
             outs.append(vid)
         return torch.stack(outs, 0)
+
+
+    # ------------------------------------------------------------------------------------------------ encode
+    _IDENT = [1.0] * 4 + [0.0] * 4 + [1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0] + [0.0] * 4   # first-layer params: x as is
+
+    def _strided_conv(self, x, g: VaeGrid, cv: "_Conv", t_stride: int, s_stride: int):
+        """3x3(x3) convolution with stride (t_stride, s_stride, s_stride) in the encoders' padding conventions: the stride-1
+        convolution over the zero-bordered grid, sampled at the odd positions (module docstring)."""
+        tf = cv.kt - 1
+        gp = VaeGrid(g.n, g.T, g.H, g.W, 1, tf)
+        xp = self._padded_buf(gp, cv.cin)
+        ops.regrid(x, g, xp, gp, cv.cin)
+        y = ops.conv(xp, gp, cv.w, cv.b, cv.cin, cv.kt, cv.ks)
+        g2 = VaeGrid(g.n, g.T // t_stride, g.H // s_stride, g.W // s_stride, 0, 0)
+        out = torch.empty(g2.rows, cv.cout, dtype=torch.bfloat16, device=self.device)
+        ops.subsample(y, gp.conv_out(), out, g2, cv.cout, t_stride, s_stride, t_stride - 1, s_stride - 1)
+        return out, g2
+
+    def _spatial_encode(self, pix: torch.Tensor) -> torch.Tensor:
+        """pix planar bf16 [3, F, H, W] in [-1, 1] -> moments planar bf16 [8, F, H/8, W/8] (mean | logvar) of the 2-D VAE:
+        diffusers AutoencoderKL.encode up to the distribution, VideoAutoencoderKL.encode :503-520."""
+        _, F, H, W = pix.shape
+        z4 = torch.cat([pix, torch.zeros_like(pix[:1])], 0).contiguous()
+        a = ops.vae_first_im2col(z4, 1, 64, self._IDENT)
+        g = VaeGrid(F, 1, H, W, 0, 0)
+        x = ops.gemm128(a, self.e_conv_in_w, self.e_conv_in_b)
+        for res, down in self.e_down:
+            for r in res:
+                x, g = self._resblock(x, g, r)
+            if down is not None:
+                x, g = self._strided_conv(x, g, down, 1, 2)
+        x, g = self._resblock(x, g, self.e_mid[0])
+        x, g = self._attention(x, g, self.e_attn)
+        x, g = self._resblock(x, g, self.e_mid[1])
+        h, gh = self._norm_act(x, g, self.e_norm, 512, 0)
+        y = ops.conv(h, gh, self.e_out.w, self.e_out.b, 512, 1, 3)           # 8 of 128 columns carry the head
+        m = ops.gemm128(y, self.e_quant_w, self.e_quant_b)                  # quant_conv (1x1) on those 8
+        out = torch.empty(8, F, H // 8, W // 8, dtype=torch.bfloat16, device=self.device)
+        ops.extract_planar(m, gh.conv_out(), 8, 0, out, 0)
+        return out
+
+    def _temporal_encode(self, xz: torch.Tensor) -> torch.Tensor:
+        """xz planar bf16 [4, T, h, w] (T <= micro_frame_size frames of 2-D latents) -> moments planar bf16 [8, ceil(T/4), h, w]:
+        VAE_Temporal.encode :441-451 up to the distribution (zero frames in FRONT up to a multiple of 4, Encoder :258-272)."""
+        _, T, H, W = xz.shape
+        tpad = 0 if T % 4 == 0 else 4 - T % 4
+        if tpad:
+            xz = torch.cat([torch.zeros(4, tpad, H, W, dtype=xz.dtype, device=xz.device), xz], 1)
+        Tp = T + tpad
+        a = ops.vae_first_im2col(xz.contiguous(), 3, 128, self._IDENT)
+        g = VaeGrid(1, Tp, H, W, 0, 0)
+        x = ops.gemm128(a, self.te_conv_in_w, None)
+        for i in range(4):
+            for r in self.te_blocks[i]:
+                x, g = self._resblock(x, g, r)
+            if i in self.te_down:
+                x, g = self._strided_conv(x, g, self.te_down[i], 2, 1)
+        for r in self.te_res:
+            x, g = self._resblock(x, g, r)
+        h, gh = self._norm_act(x, g, self.te_norm, 512, 0, dense=True)
+        y = ops.gemm128(h, self.te_out.w, self.te_out.b)
+        m = ops.gemm128(y, self.te_quant_w, self.te_quant_b)
+        out = torch.empty(8, g.T, H, W, dtype=torch.bfloat16, device=self.device)
+        ops.extract_planar(m, gh, 8, 0, out, 0)
+        return out
+
+    @staticmethod
+    def _sample(moments: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
+        """DiagonalGaussianDistribution.sample (:21-40) on planar moments [8, ...] with the noise handed in -> fp32 [4, ...]."""
+        mean, logvar = moments[:4].float(), moments[4:].float()
+        return mean + torch.exp(0.5 * logvar.clamp(-30.0, 20.0)) * noise
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, noise_fn: Optional[Callable] = None, frames_per_launch: Optional[int] = None) -> torch.Tensor:
+        """video [B, 3, T, H, W] in [-1, 1] -> normalised latents [B, 4, Tz, H/8, W/8] fp32 (autoencoder_kl_open_sora.py:653-670,
+        cal_loss False).  ``noise_fn(shape)`` supplies the standard-normal draws of the two posteriors ([B', 4, h, w] per 2-D
+        micro batch of ``micro_batch_size`` frames, then [B, 4, tz, h, w] per temporal micro batch — the reference's order);
+        default torch.randn on the CPU generator."""
+        if not self.has_encoder:
+            raise RuntimeError("this OpenSoraVAE was built from a checkpoint without encoder weights (decode only)")
+        if not x.is_cuda:
+            raise RuntimeError("OpenSoraVAE.encode needs a HIP device tensor (no CPU path)")
+        return self._encode(x, noise_fn)
+
+    def _encode(self, x, noise_fn):
+        B, C, T, H, W = x.shape
+        assert C == 3 and H % 8 == 0 and W % 8 == 0, (C, H, W)
+        noise_fn = noise_fn or (lambda shape: torch.randn(shape, dtype=torch.float32))
+        dev = self.device
+        h, w = H // 8, W // 8
+        # 2-D VAE over the (B T) frames in micro batches (:509-518)
+        fr = x.to(torch.bfloat16).permute(0, 2, 1, 3, 4).reshape(B * T, 3, H, W)
+        mb = self.micro_batch_size or B * T
+        lat = torch.empty(B * T, 4, h, w, dtype=torch.float32, device=dev)
+        for i in range(0, B * T, mb):
+            n = min(mb, B * T - i)
+            m = self._spatial_encode(fr[i:i + n].permute(1, 0, 2, 3).contiguous())             # [8, n, h, w]
+            nz = noise_fn((n, 4, h, w)).to(dev, torch.float32).permute(1, 0, 2, 3)
+            lat[i:i + n] = (self._sample(m, nz) * _SD_SCALE).permute(1, 0, 2, 3)
+        x_z = lat.view(B, T, 4, h, w).permute(0, 2, 1, 3, 4).to(torch.bfloat16)                  # [B, 4, T, h, w]
+        # temporal VAE per micro batch of frames (:659-665)
+        step = self.micro_frame_size or T
+        zs = []
+        for i in range(0, T, step):
+            ms = torch.stack([self._temporal_encode(x_z[b, :, i:i + step].contiguous()) for b in range(B)], 0)   # [B, 8, tz, h, w]
+            nz = noise_fn((B, 4, ms.shape[2], h, w)).to(dev, torch.float32)
+            zs.append(torch.stack([self._sample(ms[b], nz[b]) for b in range(B)], 0))
+        z = torch.cat(zs, dim=2)
+        scale = torch.tensor(self.scale, device=dev)[None, :, None, None, None]
+        shift = torch.tensor(self.shift, device=dev)[None, :, None, None, None]
+        return (z - shift) / scale
 
     __call__ = decode
 
@@ -429,12 +597,90 @@ def decoder_param_shapes() -> Dict[str, tuple]:
     return p
 
 
-def synth_state_dict(seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Deterministic random decode-side weights (bf16-representable fp32): conv / linear weights N(0, 1/fan_in), biases
-    N(0, 0.02), norm scales 1 + N(0, 0.1), norm shifts N(0, 0.1).  No checkpoint can be fetched here (no network)."""
-    g = torch.Generator().manual_seed(seed)
+def encoder_param_shapes() -> Dict[str, tuple]:
+    """Names and shapes of every encode-side parameter of the reference VideoAutoencoderPipeline (checked against the reference's
+    own state_dict in tests/test_vae_cpu.py): the diffusers vae.Encoder + quant_conv and the temporal Encoder (:177-256) +
+    quant_conv."""
+    p: Dict[str, tuple] = {}
+
+    def norm(name, c):
+        p[name + ".weight"] = (c,)
+        p[name + ".bias"] = (c,)
+
+    def conv2(name, ci, co, k):
+        p[name + ".weight"] = (co, ci, k, k)
+        p[name + ".bias"] = (co,)
+
+    def res2(name, ci, co):
+        norm(name + ".norm1", ci); conv2(name + ".conv1", ci, co, 3)
+        norm(name + ".norm2", co); conv2(name + ".conv2", co, co, 3)
+        if ci != co:
+            conv2(name + ".conv_shortcut", ci, co, 1)
+
+    s = "spatial_vae.module."
+    e = s + "encoder."
+    conv2(e + "conv_in", 3, 128, 3)
+    prev = 128
+    for i, co in enumerate((128, 256, 512, 512)):
+        for j in range(2):
+            res2(f"{e}down_blocks.{i}.resnets.{j}", prev, co)
+            prev = co
+        if i < 3:
+            conv2(f"{e}down_blocks.{i}.downsamplers.0.conv", co, co, 3)
+    res2(e + "mid_block.resnets.0", 512, 512)
+    a = e + "mid_block.attentions.0."
+    norm(a + "group_norm", 512)
+    for n in ("to_q", "to_k", "to_v", "to_out.0"):
+        p[a + n + ".weight"] = (512, 512)
+        p[a + n + ".bias"] = (512,)
+    res2(e + "mid_block.resnets.1", 512, 512)
+    norm(e + "conv_norm_out", 512)
+    conv2(e + "conv_out", 512, 8, 3)
+    conv2(s + "quant_conv", 8, 8, 1)
+
+    def conv3(name, ci, co, k, bias):
+        p[name + ".conv.weight"] = (co, ci, k, k, k)
+        if bias:
+            p[name + ".conv.bias"] = (co,)
+
+    def res3(name, ci, co):
+        norm(name + ".norm1", ci); conv3(name + ".conv1", ci, co, 3, False)
+        norm(name + ".norm2", co); conv3(name + ".conv2", co, co, 3, False)
+        if ci != co:
+            conv3(name + ".conv3", ci, co, 1, False)
+
+    t = "temporal_vae."
+    e = t + "encoder."
+    conv3(e + "conv_in", 4, 128, 3, False)
+    prev = 128
+    for i in range(4):
+        f = 128 * (1, 2, 2, 4)[i]
+        for j in range(4):
+            res3(f"{e}block_res_blocks.{i}.{j}", prev, f)
+            prev = f
+        if i < 3 and (False, True, True)[i]:
+            conv3(f"{e}conv_blocks.{i}", prev, f, 3, True)
+    for i in range(4):
+        res3(f"{e}res_blocks.{i}", 512, 512)
+    norm(e + "norm1", 512)
+    conv3(e + "conv2", 512, 8, 1, True)
+    conv3(t + "quant_conv", 8, 8, 1, True)
+    return p
+
+
+def synth_state_dict(seed: int = 0, encoder: bool = False) -> Dict[str, torch.Tensor]:
+    """Deterministic random weights (bf16-representable fp32): conv / linear weights N(0, 1/fan_in), biases N(0, 0.02), norm
+    scales 1 + N(0, 0.1), norm shifts N(0, 0.1).  No checkpoint can be fetched here (no network).  The decode-side values do
+    not depend on ``encoder`` (the encode-side ones come from their own generator)."""
+    sd = _synth(decoder_param_shapes(), torch.Generator().manual_seed(seed))
+    if encoder:
+        sd.update(_synth(encoder_param_shapes(), torch.Generator().manual_seed(seed + 7919)))
+    return sd
+
+
+def _synth(shapes, g) -> Dict[str, torch.Tensor]:
     sd = {}
-    for k, shp in decoder_param_shapes().items():
+    for k, shp in shapes.items():
         is_norm = ".norm" in k or "group_norm" in k or "conv_norm_out" in k
         if k.endswith(".weight") and len(shp) >= 2:
             fan_in = 1
