@@ -91,6 +91,7 @@ def subsample(x, gs, y, gd, C, t_stride=1, s_stride=1, t_first=0, s_first=0):
 
 
 def extract_planar(x, g, nc, tskip, out, f0):
+    assert 1 <= nc <= 4 and x.stride(0) % 4 == 0 and out.is_contiguous()       # the kernel's contract
     v = _interior(x, g, nc)                                                    # [n, T, H, W, nc]
     fr = v.reshape(g.n * g.T, g.H, g.W, nc)[tskip:]
     out[:, f0:f0 + fr.shape[0]] = fr.permute(3, 0, 1, 2)

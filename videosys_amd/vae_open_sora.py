@@ -409,7 +409,8 @@ class OpenSoraVAE:
         y = ops.conv(h, gh, self.e_out.w, self.e_out.b, 512, 1, 3)           # 8 of 128 columns carry the head
         m = ops.gemm128(y, self.e_quant_w, self.e_quant_b)                  # quant_conv (1x1) on those 8
         out = torch.empty(8, F, H // 8, W // 8, dtype=torch.bfloat16, device=self.device)
-        ops.extract_planar(m, gh.conv_out(), 8, 0, out, 0)
+        ops.extract_planar(m, gh.conv_out(), 4, 0, out[:4], 0)               # mean   (the kernel moves <= 4 channels a call)
+        ops.extract_planar(m[:, 4:], gh.conv_out(), 4, 0, out[4:], 0)        # logvar
         return out
 
     def _temporal_encode(self, xz: torch.Tensor) -> torch.Tensor:
@@ -434,7 +435,8 @@ class OpenSoraVAE:
         y = ops.gemm128(h, self.te_out.w, self.te_out.b)
         m = ops.gemm128(y, self.te_quant_w, self.te_quant_b)
         out = torch.empty(8, g.T, H, W, dtype=torch.bfloat16, device=self.device)
-        ops.extract_planar(m, gh, 8, 0, out, 0)
+        ops.extract_planar(m, gh, 4, 0, out[:4], 0)
+        ops.extract_planar(m[:, 4:], gh, 4, 0, out[4:], 0)
         return out
 
     @staticmethod
