@@ -228,11 +228,26 @@ int vsys_gather_rows(const void* table, const void* ids_i64, void* out, int64_t 
 int vsys_rms_norm_rows(const void* x, const void* w, void* y, int64_t rows, int64_t C, float eps, void* stream);
 /* T5DenseGatedActDense: out[r, f] = bf16(gelu_new(h[r, f])) * h[r, F + f], h = [wi_0 x | wi_1 x] of 2F columns. */
 int vsys_geglu(const void* h, void* out, int64_t rows, int64_t F, void* stream);
+/* Finish of a split-K, transposed skinny linear (few activation rows against a large weight — T5 at 300 tokens: every weight byte
+ * is used for 300 MACs, so the layer is a weight stream): the GEMM ran as vsys_conv_bf16 with the WEIGHT as the row operand, the
+ * activations as the 128-column operand and S slices of K in the batch dimension, leaving part_f32[s][n][m] (row pitch ldp >= M,
+ * slice pitch slab elements); out[m][n] = bf16(sum_s part[s][n][m]) (+ res[m][n], added after the rounding).
+ * Replaces the tail of nn.Linear inside transformers' T5Attention / T5DenseGatedActDense (third-party; call sites
+ * pipeline_open_sora.py:269-287). */
+int vsys_splitk_reduce_t(const void* part_f32, int64_t nsplit, int64_t slab, int64_t ldp, const void* res, int64_t ldr, void* out, int64_t ldo,
+                         int64_t M, int64_t N, void* stream);
 /* T5Attention (encoder self-attention, d_kv = 64, no score scaling): softmax_j(q_i k_j + relbias[h][j - i + L - 1]) v over the
  * first klen[b] keys.  qkv rows (b, l) of row_stride elements, q | k | v at column 0 | inner | 2 inner, head h at h*64;
  * relbias fp32 [heads, 2L-1]; klen int32 [B] on the device; L <= 512. */
 int vsys_t5_attention(const void* qkv, int64_t row_stride, int64_t inner, const void* relbias_f32, const void* klen_i32, void* out,
                       int64_t out_stride, int64_t B, int64_t L, int64_t heads, void* stream);
+/* The same attention on the matrix pipe, ONE sample per call (its own key length kv_len <= L): the head_dim-64 flash kernel with
+ * an additive (head, key - query) logit bias.  qkv bf16 rows [L, 3*inner] (q | k | v, head h at h*64); bias_f32 [heads, bias_ld]
+ * holds log2(e) * T5Attention.compute_bias, entry of (h, key - query) at bias_center + key - query, padded by the caller so that
+ * every key < 64*ceil(L/64) and query < 128*ceil(L/128) stays inside (bias_center >= 128*ceil(L/128) - 1, bias_ld >= bias_center +
+ * 64*ceil(L/64)); kp / vt: workspaces of heads * 64*ceil(L/64) * 64 bf16 each (the K / V^T layouts of vsys_attn_prep_kv64). */
+int vsys_t5_attention_mfma(const void* qkv, int64_t row_stride, int64_t inner, const void* bias_f32, int64_t bias_ld, int64_t bias_center,
+                           int64_t kv_len, void* kp, void* vt, void* out, int64_t out_stride, int64_t L, int64_t heads, void* stream);
 
 /* ---- VAE decode (VideoAutoencoderPipeline.decode, autoencoder_kl_open_sora.py:672-695) --------------
  * Activations are channels-last bf16 row matrices over a grid; a grid is described by int64 g[6] = {T, H, W, pad, tf,

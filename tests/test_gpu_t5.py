@@ -61,14 +61,51 @@ def test_t5_attention_matches_torch(B, L, H, lens):
     ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * L, inner)
     out = ops.t5_attention(qkv.to(torch.bfloat16).to(dev()), rel.to(dev()), klen.to(dev()), B, L, H)
     check(out, ref, what="t5 attention")
+    # the matrix-pipe form (d64 flash kernel + relative-position bias hook): same reference, valid query rows
+    L1 = L - 1
+    center = (L + 127) // 128 * 128 - 1
+    tab = torch.zeros(H, center + (L + 63) // 64 * 64)
+    tab[:, center - L1:center + L] = rel * math.log2(math.e)
+    out2 = ops.t5_attention_mfma(qkv.to(torch.bfloat16).to(dev()), tab.to(dev()), center, lens, B, L, H)
+    check(out2, ref, what="t5 attention (mfma)")
 
 
-def test_t5_encoder_matches_transformers_golden():
+@pytest.mark.parametrize("M,N,K,nsplit,res", [(300, 512, 2048, None, True), (300, 768, 1024, 1, False), (77, 256, 4096, 8, True),
+                                               (600, 1024, 512, 2, False), (128, 4096, 4096, None, True)])
+def test_linear_skinny_matches_torch(M, N, K, nsplit, res):
+    """The weight-streaming linear (transposed split-K GEMM + vsys_splitk_reduce_t) against torch on bf16-rounded operands; rows
+    past M of the padded activation buffer are poisoned with NaN: they must not reach any result row."""
+    from videosys_amd import ops
+
+    g = torch.Generator().manual_seed(M + N + K)
+    Mp = (M + 127) // 128 * 128
+    x = torch.full((Mp, K), float("nan"))
+    x[:M] = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    r = torch.randn(Mp, N, generator=g) if res else None
+    xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    ref = xb[:M].float() @ wb.float().t()
+    if res:
+        ref = ref.to(torch.bfloat16).float() + r[:M].to(torch.bfloat16).float()
+    out = ops.linear_skinny(xb.to(dev()), M, wb.to(dev()), res=None if r is None else r.to(torch.bfloat16).to(dev()), nsplit=nsplit)
+    assert out.shape == (Mp, N)
+    check(out[:M], ref, what=f"linear_skinny {M}x{N}x{K} split {nsplit}")
+    if res:   # in place on the residual stream, as the encoder uses it
+        rr = r.to(torch.bfloat16).to(dev())
+        out2 = ops.linear_skinny(xb.to(dev()), M, wb.to(dev()), res=rr, out=rr, nsplit=nsplit)
+        assert out2.data_ptr() == rr.data_ptr() and torch.equal(out2[:M], out[:M])
+
+
+@pytest.mark.parametrize("skinny,mfma", [(True, True), (False, True), (True, False)])
+def test_t5_encoder_matches_transformers_golden(skinny, mfma):
     from videosys_amd.t5 import T5Encoder, synth_state_dict
 
     gold = load_golden("t5_small.pt")
     cfg = gold["cfg"]
     enc = T5Encoder(device=dev(), **cfg).load_state_dict(synth_state_dict(seed=gold["seed"], **cfg))
+    enc.mfma_attention = mfma         # False: the VALU attention kernel
+    if not skinny:
+        enc.skinny_rows = 0           # the many-rows path (direct 128-column GEMMs)
     out = enc(gold["ids"], gold["mask"]).last_hidden_state.float().cpu()
     ref = gold["out_fp32"]
     keep = gold["mask"].bool()                        # padded query positions are junk in every implementation

@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=300)
     ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--ab", action="store_true", help="also time the direct (many-rows) GEMM path in the same process, interleaved")
     args = ap.parse_args()
     from videosys_amd.t5 import T5Encoder
 
@@ -28,11 +29,27 @@ def main():
     out = enc(ids, mask).last_hidden_state
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
-    ts = []
-    for _ in range(args.iters):
+    def timed():
         torch.cuda.synchronize(); t0 = time.perf_counter()
         enc(ids, mask)
-        torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    ts = []
+    modes = {"direct_gemm+valu_attention": (0, False), "weight_streaming+valu_attention": (enc.skinny_rows, False)}
+    ab = {k: [] for k in modes}
+    keep = (enc.skinny_rows, enc.mfma_attention)
+    for _ in range(args.iters):
+        ts.append(timed())
+        if args.ab:   # the earlier forms in the same process, interleaved
+            for k, (rows, mf) in modes.items():
+                enc.skinny_rows, enc.mfma_attention = rows, mf
+                timed()
+                ab[k].append(timed())
+            enc.skinny_rows, enc.mfma_attention = keep
+            timed()
+    if args.ab:
+        print(json.dumps({**{k + "_sec": round(min(v), 5) for k, v in ab.items()}, "shipped_sec": round(min(ts), 5)}))
     params = sum(v.numel() for k, v in enc.w.items())
     flops = 2.0 * args.batch * args.tokens * (params - enc.w["emb"].numel())
     print(json.dumps({"workload": f"T5-v1.1-XXL encoder, batch {args.batch} x {args.tokens} tokens", "sec": round(min(ts), 5),

@@ -132,6 +132,9 @@ struct Flash64Params {
   bf16_t* out; int64_t out_stride;
   int heads, q_len, kv_len, kv_pad, nqb;
   float eps;
+  // BIAS kernels only: additive logit bias that depends on (head, key - query) — T5's relative-position bias — as an fp32
+  // table in the exp2 domain, entry of (h, j - i) at bias[h * bias_ld + bias_center + j - i]
+  const float* bias; int bias_ld, bias_center;
 };
 
 // grid: ceil(q_len/128) * batch * heads workgroups of 4 waves x 32 query rows (1-D, XCD-remapped so the q-blocks of one
@@ -144,7 +147,7 @@ struct Flash64Params {
 // step with NS = 2 vs 636.6 / 632.3 with NS = 3; box B 671.0 vs 678.4 / 676.8 (and 688 with NS = 4): the part is power-capped and
 // the boxes of the pool differ by more than the effect — NS = 3 ships on the sum of the two (-1.4 %), NS = 2 stays selectable.
 // NS x 16 KiB of LDS per workgroup, two workgroups per CU.
-template <int NS>
+template <int NS, bool BIAS = false>
 __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(Flash64Params p) {
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -302,6 +305,19 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(Flash64Params p)
     FLASH64_VREAD(vf0, 0);
     __builtin_amdgcn_sched_barrier(0);
 
+    if constexpr (BIAS) {
+      // element (kt, r) of this lane is key t*64 + kt*32 + 16*hi + r against query q0 + l31: 16 consecutive table entries per kt.
+      // The BIAS caller leaves K UNSCALED (T5 logits are large — no 1/sqrt(d) — and a log2(e) folded into bf16 K would cost 2^-9
+      // of each of them): the accumulators are q k - m in natural units (minit is kept in natural units too) and move to the
+      // exp2 domain here, in the same fma that adds the bias.
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int idx = p.bias_center + (t * 64 + kt * 32 + 16 * hi + r) - (q0 + l31);
+          s[kt][r] = __builtin_fmaf(s[kt][r], 1.4426950408889634f, p.bias[(int64_t)h * p.bias_ld + idx]);
+        }
+    }
     if (masked) {
       const int lim = p.kv_len - (t * 64 + 16 * hi);
 #pragma unroll
@@ -325,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(Flash64Params p)
       const float alpha = __builtin_amdgcn_exp2f(-delta);
       l_run *= alpha;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) minit[r] -= delta;
+      for (int r = 0; r < 16; ++r) minit[r] -= BIAS ? delta * 0.6931471805599453f : delta;   // (BIAS: natural units, see above)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -401,16 +417,47 @@ __global__ __launch_bounds__(256, 2) void flash_attn_d64_kernel(Flash64Params p)
 
 }  // namespace
 
-int launch_attn_prep_kv64(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* ln_w,
-                          const bf16_t* ln_b, const float* rope_cos, const float* rope_sin, int rope_start, int rope_len,
-                          bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps, hipStream_t stream) {
+static int prep_kv64(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* ln_w, const bf16_t* ln_b,
+                     const float* rope_cos, const float* rope_sin, int rope_start, int rope_len, bf16_t* kp, bf16_t* vt, int batch,
+                     int heads, int kv_len, int kv_pad, float eps, float kscale, hipStream_t stream) {
   if (batch <= 0 || heads <= 0 || kv_len <= 0) return 0;
   if (kv_pad % 64 != 0 || kv_pad < kv_len || (k_stride % 8) || (v_stride % 8)) return VSYS_ERR_SHAPE;
   if ((rope_cos == nullptr) != (rope_sin == nullptr)) return VSYS_ERR_ARG;
   dim3 grid(kv_pad / 64, batch * heads);
   hipLaunchKernelGGL(attn_prep_kv64_kernel, grid, dim3(256), 0, stream, k, k_stride, v, v_stride, ln_w, ln_b, rope_cos, rope_sin,
-                     rope_start, rope_len, kp, vt, heads, kv_len, kv_pad, eps,
-                     0.125f * 1.4426950408889634f /* 64^-0.5 * log2(e) */);
+                     rope_start, rope_len, kp, vt, heads, kv_len, kv_pad, eps, kscale);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_attn_prep_kv64(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* ln_w,
+                          const bf16_t* ln_b, const float* rope_cos, const float* rope_sin, int rope_start, int rope_len,
+                          bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps, hipStream_t stream) {
+  return prep_kv64(k, k_stride, v, v_stride, ln_w, ln_b, rope_cos, rope_sin, rope_start, rope_len, kp, vt, batch, heads, kv_len, kv_pad,
+                   eps, 0.125f * 1.4426950408889634f /* 64^-0.5 * log2(e) */, stream);
+}
+
+// T5 self-attention (transformers T5Attention.forward, third-party; the encoder every pipeline calls once per prompt): no
+// 1/sqrt(d) scaling, additive relative-position bias, keys >= kv_len masked.  One sample per call (its own key length): the K/V
+// layouts of its heads are written by the d64 prep kernel (K unscaled), the d64 flash kernel runs with the BIAS hook.
+// bias: fp32 [heads, bias_ld] in the exp2 domain, entry of (h, key - query) at bias_center + key - query; the caller pads the
+// table so that every (key < kv_pad, query < 128 * ceil(L / 128)) index is inside it.
+int launch_t5_attention_mfma(const bf16_t* qkv, int64_t row_stride, int inner, const float* bias, int bias_ld, int bias_center,
+                             int kv_len, bf16_t* kp, bf16_t* vt, bf16_t* out, int64_t out_stride, int L, int heads,
+                             hipStream_t stream) {
+  if (L <= 0 || heads <= 0) return 0;
+  if (inner != heads * 64 || kv_len <= 0 || kv_len > L || (row_stride % 8) || (out_stride % 4) || bias == nullptr) return VSYS_ERR_SHAPE;
+  const int kv_pad = (L + 63) / 64 * 64, qpad = (L + 127) / 128 * 128;
+  if (bias_center < qpad - 1 || bias_ld < bias_center + kv_pad) return VSYS_ERR_SHAPE;
+  const int rc = prep_kv64(qkv + inner, row_stride, qkv + 2 * inner, row_stride, nullptr, nullptr, nullptr, nullptr, 0, 0, kp, vt, 1, heads,
+                           L, kv_pad, 0.f, 1.0f, stream);
+  if (rc != 0) return rc;
+  Flash64Params p;
+  p.q = qkv; p.q_stride = row_stride; p.ln_w = nullptr; p.ln_b = nullptr; p.rope_cos = nullptr; p.rope_sin = nullptr;
+  p.rope_start = 0; p.rope_len = 0; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
+  p.heads = heads; p.q_len = L; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = 0.f;
+  p.nqb = (L + 127) / 128;
+  p.bias = bias; p.bias_ld = bias_ld; p.bias_center = bias_center;
+  hipLaunchKernelGGL((flash_attn_d64_kernel<3, true>), dim3((unsigned)(p.nqb * heads)), dim3(256), 3 * KV_STAGE, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
@@ -426,6 +473,7 @@ int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w,
   p.rope_start = rope_start; p.rope_len = rope_len; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
   p.nqb = (q_len + 127) / 128;
+  p.bias = nullptr; p.bias_ld = 0; p.bias_center = 0;
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
   if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
   const int fv = get_flash_variant();

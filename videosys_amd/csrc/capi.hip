@@ -315,6 +315,23 @@ int vsys_geglu(const void* h, void* out, int64_t rows, int64_t F, void* stream) 
   return launch_geglu(B16(h), B16(out), rows, (int)F, S(stream));
 }
 
+int vsys_t5_attention_mfma(const void* qkv, int64_t row_stride, int64_t inner, const void* bias_f32, int64_t bias_ld, int64_t bias_center,
+                           int64_t kv_len, void* kp, void* vt, void* out, int64_t out_stride, int64_t L, int64_t heads, void* stream) {
+  if (!qkv || !bias_f32 || !kp || !vt || !out) return VSYS_ERR_ARG;
+  if (!fits_int(inner) || !fits_int(bias_ld) || !fits_int(bias_center) || !fits_int(kv_len) || !fits_int(L) || !fits_int(heads))
+    return VSYS_ERR_SHAPE;
+  return launch_t5_attention_mfma(B16(qkv), row_stride, (int)inner, reinterpret_cast<const float*>(bias_f32), (int)bias_ld,
+                                  (int)bias_center, (int)kv_len, B16(kp), B16(vt), B16(out), out_stride, (int)L, (int)heads, S(stream));
+}
+
+int vsys_splitk_reduce_t(const void* part_f32, int64_t nsplit, int64_t slab, int64_t ldp, const void* res, int64_t ldr, void* out, int64_t ldo,
+                         int64_t M, int64_t N, void* stream) {
+  if (!part_f32 || !out) return VSYS_ERR_ARG;
+  if (!fits_int(nsplit) || !fits_int(ldp) || !fits_int(M) || !fits_int(N)) return VSYS_ERR_SHAPE;
+  return launch_splitk_reduce_t(reinterpret_cast<const float*>(part_f32), (int)nsplit, slab, (int)ldp, B16(res), ldr, B16(out), ldo, (int)M,
+                                (int)N, S(stream));
+}
+
 int vsys_t5_attention(const void* qkv, int64_t row_stride, int64_t inner, const void* relbias_f32, const void* klen_i32, void* out,
                       int64_t out_stride, int64_t B, int64_t L, int64_t heads, void* stream) {
   if (!qkv || !relbias_f32 || !klen_i32 || !out) return VSYS_ERR_ARG;

@@ -143,6 +143,55 @@ __global__ __launch_bounds__(256) void t5_attention_kernel(const bf16_t* __restr
   }
 }
 
+// Split-K epilogue of the skinny (few rows, weight-streaming) linears: the GEMM ran TRANSPOSED and in S slices of K —
+// part[s][n][m] = sum over slice s of W[n][k] x[m][k] (fp32, conv_bf16.hip with the weight as the row operand so that a weight
+// panel is fetched from HBM once) — and this kernel finishes it: out[m][n] = bf16(sum_s part[s][n][m]) (+ res[m][n],
+// added after the rounding like the GEMM epilogues do).  Tile 64 n x 64 m through LDS: 16-byte reads along m, 16-byte writes along n.
+__global__ __launch_bounds__(256) void splitk_reduce_t_kernel(const float* __restrict__ part, int S, int64_t slab, int ldp,
+                                                              const bf16_t* __restrict__ res, int64_t ldr, bf16_t* __restrict__ out,
+                                                              int64_t ldo, int M, int N) {
+  __shared__ float tile[64][68];
+  const int t = threadIdx.x;
+  const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+  {
+    const int mq = t & 15, nr = t >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int nl = nr + 16 * i;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + nl < N && m0 + 4 * mq < ldp) {
+        const float* src = part + (int64_t)(n0 + nl) * ldp + m0 + 4 * mq;
+        for (int s = 0; s < S; ++s) {
+          const float4 v = *reinterpret_cast<const float4*>(src + s * slab);
+          a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+      }
+      *reinterpret_cast<float4*>(&tile[nl][4 * mq]) = a;
+    }
+  }
+  __syncthreads();
+  {
+    const int nc = t & 7, mr = t >> 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int ml = mr + 32 * i;
+      const int m = m0 + ml, n = n0 + 8 * nc;
+      if (m < M && n < N) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = tile[8 * nc + e][ml];
+        if (res != nullptr) {
+          float r[8];
+          unpack8(*reinterpret_cast<const uint4*>(res + (int64_t)m * ldr + n), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e])) + r[e];
+        }
+        *reinterpret_cast<uint4*>(out + (int64_t)m * ldo + n) = pack8(v);
+      }
+    }
+  }
+}
+
 inline unsigned stream_grid(int64_t items) {
   int64_t b = (items + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -171,6 +220,16 @@ int launch_geglu(const bf16_t* h, bf16_t* out, int64_t rows, int F, hipStream_t 
   if (rows <= 0) return 0;
   if (F % 8 != 0) return VSYS_ERR_SHAPE;
   hipLaunchKernelGGL(geglu_kernel, dim3(stream_grid(rows * (F >> 3))), dim3(256), 0, stream, h, out, rows, F);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_splitk_reduce_t(const float* part, int S, int64_t slab, int ldp, const bf16_t* res, int64_t ldr, bf16_t* out, int64_t ldo,
+                           int M, int N, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (S < 1 || S > 64 || N % 8 != 0 || ldp % 4 != 0 || ldp < M || slab < (int64_t)N * ldp || (ldo % 8) || (res && (ldr % 8)))
+    return VSYS_ERR_SHAPE;
+  hipLaunchKernelGGL(splitk_reduce_t_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, stream, part, S, slab, ldp, res, ldr, out,
+                     ldo, M, N);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

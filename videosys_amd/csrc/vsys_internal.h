@@ -96,6 +96,11 @@ int launch_rms_norm_rows(const bf16_t* x, const bf16_t* w, bf16_t* y, int64_t ro
 int launch_geglu(const bf16_t* h, bf16_t* out, int64_t rows, int F, hipStream_t stream);
 int launch_t5_attention(const bf16_t* qkv, int64_t row_stride, int inner, const float* relbias, const int* klen, bf16_t* out,
                         int64_t out_stride, int B, int L, int heads, hipStream_t stream);
+int launch_splitk_reduce_t(const float* part, int S, int64_t slab, int ldp, const bf16_t* res, int64_t ldr, bf16_t* out, int64_t ldo,
+                           int M, int N, hipStream_t stream);
+int launch_t5_attention_mfma(const bf16_t* qkv, int64_t row_stride, int inner, const float* bias, int bias_ld, int bias_center,
+                             int kv_len, bf16_t* kp, bf16_t* vt, bf16_t* out, int64_t out_stride, int L, int heads,
+                             hipStream_t stream);
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream);

@@ -447,12 +447,14 @@ def conv(a, grid: VaeGrid, w, bias, cin, kt, ks, out=None, res=None):
     return out
 
 
-def gemm128(a, w, bias=None, res=None, out=None, out_f32=None, out_scale=1.0, batch=1, batch_a=0, batch_w=0, batch_o=0, M=None):
-    """Plain C = A W^T (+ bias, + res) on the 128-column tile kernel; batch > 1 strides the operands (elements)."""
+def gemm128(a, w, bias=None, res=None, out=None, out_f32=None, out_scale=1.0, batch=1, batch_a=0, batch_w=0, batch_o=0, M=None, K=None):
+    """Plain C = A W^T (+ bias, + res) on the 128-column tile kernel; batch > 1 strides the operands (elements).  ``K``: contract
+    over the first K columns only (with batch strides along K: a split-K run, one K slice per batch entry)."""
     _chk(a, w, bias, res, out, out_f32)
     _bf16(a, w, bias, res, out)
     M = a.shape[0] if M is None else M
-    N, K = w.shape[-2], a.shape[-1]   # (a batched w is [batch, N, K]; also when the batch happens to be 1)
+    N = w.shape[-2]                   # (a batched w is [batch, N, K]; also when the batch happens to be 1)
+    K = a.shape[-1] if K is None else K
     if out is None and out_f32 is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     o = out if out is not None else out_f32
@@ -570,6 +572,70 @@ def softmax_rows(s_f32, n=None, out=None):
 
 
 # ------------------------------------------------------------------------------------------------ T5 encoder
+def t5_attention_mfma(qkv, bias_pad, center, lens, B, L, heads, out=None, ws=None):
+    """T5 self-attention on the matrix pipe (the head_dim-64 flash kernel with a (head, key - query) bias), one launch pair per
+    sample.  qkv bf16 [B*L, 3*inner]; bias_pad fp32 [heads, ld]: log2(e) * relative-position bias of (h, key - query) at column
+    center + key - query (t5.padded_bias_table); lens: the B key lengths (host ints); ws: (kp, vt) workspaces."""
+    _chk(qkv, bias_pad, out)
+    _bf16(qkv, out)
+    inner = heads * 64
+    assert qkv.shape == (B * L, 3 * inner) and qkv.stride(1) == 1 and bias_pad.dtype == torch.float32 and bias_pad.is_contiguous()
+    assert bias_pad.shape[0] == heads and len(lens) == B
+    kv_pad = (L + 63) // 64 * 64
+    if out is None:
+        out = torch.empty(B * L, inner, dtype=torch.bfloat16, device=qkv.device)
+    if ws is None:
+        ws = (torch.empty(heads * kv_pad * 64, dtype=torch.bfloat16, device=qkv.device),
+              torch.empty(heads * kv_pad * 64, dtype=torch.bfloat16, device=qkv.device))
+    lib = _lib.load()
+    for b in range(B):
+        q_b, o_b = qkv[b * L:(b + 1) * L], out[b * L:(b + 1) * L]
+        _lib.check(lib.vsys_t5_attention_mfma(_p(q_b), qkv.stride(0), inner, _p(bias_pad), bias_pad.shape[1], center, int(lens[b]),
+                                              _p(ws[0]), _p(ws[1]), _p(o_b), out.stride(0), L, heads, _stream()), "vsys_t5_attention_mfma")
+    return out
+
+
+def skinny_split(N, Mp, K):
+    """K slices for linear_skinny, from the measured sweep at the T5-XXL shapes (tools/skinny_probe.py, profiles/
+    r03_t5_skinny_probe.jsonl): with >= 144 (weight panel, activation tile) workgroups one slice is already best (each further
+    slice is another N x Mp fp32 round trip: qkv 92 / 84 / 81 us GEMM but 9 / 11 / 15 us reduce at 1 / 2 / 4 slices, wi 100 / 100 /
+    107); with 48 (the N = 4096 linears) four slices win (o 76 -> 34 us, wo 207 -> 67 us).  Rule: slices = the power of two that
+    brings the workgroup count closest to 192, slices of >= 1024 columns."""
+    tiles = ((N + 255) // 256) * (Mp // 128)
+    s = 1
+    while tiles * s < 128 and s < 8 and K % (64 * s) == 0 and K // (2 * s) >= 1024:
+        s *= 2
+    return s
+
+
+def linear_skinny(x, M, w, res=None, out=None, nsplit=None, part=None):
+    """out[:M] = x[:M] @ w^T (+ res[:M]) for FEW rows against a large weight (T5 at 300 tokens: 300 MACs per weight element, a
+    weight stream).  x bf16 [Mp, K] with Mp % 128 == 0 (rows >= M are never looked at in the result), w bf16 [N, K].
+    The GEMM runs transposed — the weight is the row operand of the 128-column kernel, so a 256-row weight panel is fetched
+    from HBM once and its Mp / 128 activation tiles are neighbours in tile order — and in ``nsplit`` slices of K (one per
+    batch entry) to put >= 512 workgroups on the chip; vsys_splitk_reduce_t sums the fp32 slices, transposes back, rounds, adds
+    the residual.  ``part``: fp32 workspace of >= nsplit * N * Mp elements (allocated when None)."""
+    _chk(x, w, res, out, part)
+    _bf16(x, w, res, out)
+    Mp, K = x.shape
+    N = w.shape[0]
+    assert Mp % 128 == 0 and M <= Mp and w.shape[1] == K and x.is_contiguous() and w.is_contiguous()
+    nsplit = skinny_split(N, Mp, K) if nsplit is None else nsplit
+    assert K % nsplit == 0 and (K // nsplit) % 32 == 0
+    Ks = K // nsplit
+    if part is None:
+        part = torch.empty(nsplit * N * Mp, dtype=torch.float32, device=x.device)
+    assert part.dtype == torch.float32 and part.numel() >= nsplit * N * Mp and part.is_contiguous()
+    pv = part[:nsplit * N * Mp].view(nsplit, N, Mp)
+    gemm128(w, x, out_f32=pv, batch=nsplit, batch_a=Ks, batch_w=Ks, batch_o=N * Mp, M=N, K=Ks)
+    if out is None:
+        out = torch.empty(Mp, N, dtype=torch.bfloat16, device=x.device)
+    assert out.shape[1] == N and out.stride(1) == 1 and (res is None or (res.shape[1] == N and res.stride(1) == 1))
+    _lib.check(_lib.load().vsys_splitk_reduce_t(_p(pv), nsplit, N * Mp, Mp, _p(res), res.stride(0) if res is not None else 0, _p(out),
+                                                out.stride(0), M, N, _stream()), "vsys_splitk_reduce_t")
+    return out
+
+
 def gather_rows(table, ids):
     _chk(table, ids)
     _bf16(table)

@@ -7,6 +7,11 @@ pipeline_cogvideox.py:211-247; pipeline_latte.py).  State-dict keys are the HF o
 Per layer: RMS-norm -> fused q|k|v GEMM -> attention with the additive relative-position bias (bucketed on the host exactly
 like T5Attention._relative_position_bucket, shared by all layers) and the key-padding mask -> o GEMM (+ residual in the
 epilogue) -> RMS-norm -> fused wi_0|wi_1 GEMM -> gelu_new(a) * b -> wo GEMM (+ residual).  No CPU path.
+
+A prompt is a few hundred rows against 4.7 B weights: every weight element is used for ~300 MACs, the encoder is a weight
+stream.  Up to ``skinny_rows`` rows the linears therefore run as ops.linear_skinny (weight as the row operand, split over K,
+fp32 slices summed and transposed back by vsys_splitk_reduce_t): every weight panel leaves HBM once and >= 256 workgroups pull
+on it, instead of 64 - 320 workgroups that each re-stream the activations.
 """
 from __future__ import annotations
 
@@ -40,6 +45,17 @@ def relative_bias_table(rel_weight: torch.Tensor, L: int, num_buckets: int = 32,
     return rel_weight.float()[bucket].t().contiguous()
 
 
+def padded_bias_table(rel_weight: torch.Tensor, L: int, num_buckets: int = 32, max_distance: int = 128):
+    """(table fp32 [heads, ld], center) for ops.t5_attention_mfma: log2(e) * bias of relative position d = key - query at column
+    center + d, zero outside |d| <= L - 1, wide enough for every (key < 64 ceil(L/64), query < 128 ceil(L/128)) the kernel's
+    tiles touch (those positions are masked or discarded, the reads must only stay inside the table)."""
+    center = (L + 127) // 128 * 128 - 1
+    ld = center + (L + 63) // 64 * 64
+    t = torch.zeros(rel_weight.shape[1], ld, dtype=torch.float32)
+    t[:, center - (L - 1):center + L] = relative_bias_table(rel_weight, L, num_buckets, max_distance) * math.log2(math.e)
+    return t.contiguous(), center
+
+
 class T5Encoder:
     def __init__(self, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64, vocab_size=32128,
                  relative_attention_num_buckets=32, relative_attention_max_distance=128, layer_norm_epsilon=1e-6, device="cuda"):
@@ -57,6 +73,9 @@ class T5Encoder:
         self.device, self.dtype = dev, torch.bfloat16
         self.w: Dict[str, torch.Tensor] = {}
         self._bias_cache: Dict[int, torch.Tensor] = {}
+        self.skinny_rows = 1024            # B * L up to which the linears take the weight-streaming path
+        self.mfma_attention = True         # False: the one-wave-per-query-row VALU kernel (kept for A/B and as the checker's twin)
+        self._ws: Dict[tuple, torch.Tensor] = {}
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor]):
         c = self.config
@@ -123,18 +142,69 @@ class T5Encoder:
                     raise NotImplementedError("attention_mask must be a prefix of ones per sample")
         klen = torch.tensor(lens, dtype=torch.int32, device=self.device)
         ids = input_ids.reshape(-1).to(device=self.device, dtype=torch.int64).contiguous()
-        x = ops.gather_rows(w["emb"], ids)                                  # [B*L, d_model]
         bias = self._relbias(L)
+        self._lens = lens
+        if B * L <= self.skinny_rows:
+            return self._forward_skinny(ids, bias, klen, B, L)
+        x = ops.gather_rows(w["emb"], ids)                                  # [B*L, d_model]
         h = torch.empty_like(x)
         for i in range(c.num_layers):
             ops.rms_norm_rows(x, w[f"{i}.ln0"], c.layer_norm_epsilon, out=h)
             qkv = ops.gemm128(h, w[f"{i}.qkv"])
-            ao = ops.t5_attention(qkv, bias, klen, B, L, c.num_heads)
+            ao = self._attention(qkv, bias, klen, B, L)
             x = ops.gemm128(ao, w[f"{i}.o"], res=x)
             ops.rms_norm_rows(x, w[f"{i}.ln1"], c.layer_norm_epsilon, out=h)
             g = ops.geglu(ops.gemm128(h, w[f"{i}.wi"]))
             x = ops.gemm128(g, w[f"{i}.wo"], res=x)
         out = ops.rms_norm_rows(x, w["ln_f"], c.layer_norm_epsilon)
+        return SimpleNamespace(last_hidden_state=out.view(B, L, c.d_model))
+
+    def _attention(self, qkv, bias, klen, B, L, out=None):
+        c = self.config
+        if not self.mfma_attention:
+            return ops.t5_attention(qkv, bias, klen, B, L, c.num_heads, out=out)
+        key = ("pad", L)
+        if key not in self._bias_cache:
+            t, center = padded_bias_table(self._rel, L, c.relative_attention_num_buckets, c.relative_attention_max_distance)
+            self._bias_cache[key] = (t.to(self.device), center)
+        t, center = self._bias_cache[key]
+        kv_pad = (L + 63) // 64 * 64
+        ws = (self._buf("t5_kp", (c.num_heads * kv_pad * 64,)), self._buf("t5_vt", (c.num_heads * kv_pad * 64,)))
+        return ops.t5_attention_mfma(qkv, t, center, self._lens, B, L, c.num_heads, out=out, ws=ws)
+
+    def _buf(self, name, shape, dtype=torch.bfloat16):
+        t = self._ws.get((name, shape, dtype))
+        if t is None:
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
+            self._ws[(name, shape, dtype)] = t
+        return t
+
+    def _forward_skinny(self, ids, bias, klen, B, L):
+        """The same layer sequence on row-padded buffers ([Mp, .], Mp = rows rounded up to the 128-column tile; rows >= M are
+        never read into a result) with the weight-streaming linears."""
+        c, w = self.config, self.w
+        M = B * L
+        Mp = (M + 127) // 128 * 128
+        inner = c.num_heads * c.d_kv
+        x = self._buf("x", (Mp, c.d_model))
+        h = self._buf("h", (Mp, c.d_model))
+        qkv = self._buf("qkv", (Mp, 3 * inner))
+        ao = self._buf("ao", (Mp, inner))
+        hw = self._buf("wi", (Mp, 2 * c.d_ff))
+        g = self._buf("g", (Mp, c.d_ff))
+        shapes = ((3 * inner, c.d_model), (c.d_model, inner), (2 * c.d_ff, c.d_model), (c.d_model, c.d_ff))
+        part = self._buf("part", (max(ops.skinny_split(n, Mp, k) * n * Mp for n, k in shapes),), torch.float32)
+        x[:M].copy_(ops.gather_rows(w["emb"], ids))
+        for i in range(c.num_layers):
+            ops.rms_norm_rows(x[:M], w[f"{i}.ln0"], c.layer_norm_epsilon, out=h[:M])
+            ops.linear_skinny(h, M, w[f"{i}.qkv"], out=qkv, part=part)
+            self._attention(qkv[:M], bias, klen, B, L, out=ao[:M])
+            ops.linear_skinny(ao, M, w[f"{i}.o"], res=x, out=x, part=part)
+            ops.rms_norm_rows(x[:M], w[f"{i}.ln1"], c.layer_norm_epsilon, out=h[:M])
+            ops.linear_skinny(h, M, w[f"{i}.wi"], out=hw, part=part)
+            ops.geglu(hw[:M], out=g[:M])
+            ops.linear_skinny(g, M, w[f"{i}.wo"], res=x, out=x, part=part)
+        out = ops.rms_norm_rows(x[:M], w["ln_f"], c.layer_norm_epsilon)
         return SimpleNamespace(last_hidden_state=out.view(B, L, c.d_model))
 
     __call__ = forward
