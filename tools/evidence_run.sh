@@ -19,3 +19,6 @@ timeout 900 python bench.py --steps 30 --warmup 30 --pab --no-cpu-baseline --no-
 timeout 900 python bench.py --geometry 720p128f --steps 3 --warmup 1 > gpurun_out/ev/bench_720p.log 2>&1; tail -1 gpurun_out/ev/bench_720p.log | cut -c150-330
 timeout 600 python tools/issue_time.py > gpurun_out/ev/issue_1.log 2>&1; tail -1 gpurun_out/ev/issue_1.log
 timeout 600 python tools/issue_time.py --dsp-rank 8 --sweep > gpurun_out/ev/issue_dsp8.log 2>&1; tail -4 gpurun_out/ev/issue_dsp8.log
+timeout 300 python tools/t5_bench.py --ab --iters 5 > gpurun_out/ev/t5_ab.log 2>&1; tail -2 gpurun_out/ev/t5_ab.log | cut -c1-200
+(cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ev/t5prof -o t5 -- python $R/tools/t5_bench.py --iters 5 > $R/gpurun_out/ev/t5prof.log 2>&1)
+python tools/prof_summary.py $(find gpurun_out/ev/t5prof -name "*.db" | head -1) "# rocprofv3 --kernel-trace --stats -- python tools/t5_bench.py --iters 5   (T5-v1.1-XXL encoder, 300 tokens, 6 forward passes in the trace; round-3 final tree)" > gpurun_out/ev/t5_kernel_stats.txt 2>&1; head -8 gpurun_out/ev/t5_kernel_stats.txt | cut -c1-60,100-170
