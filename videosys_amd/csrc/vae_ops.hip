@@ -56,17 +56,30 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 }
 
 // pass 2: one wave per (n, group): fold the block partials in double (fixed lane assignment + butterfly: deterministic),
-// emit mean and 1/sqrt(var + eps)
+// emit mean and 1/sqrt(var + eps).  A lane's items are fetched eight at a time BEFORE they are added (the partials were written by
+// another kernel a moment ago: every read is an L2 miss, and a load-add-load-add chain took 35-100 us per launch — 16 ms of a
+// 64-frame decode — for a few KB of data; the order of the additions is unchanged).
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ partial, int nblk, int C, int groups,
                                                          int64_t count_per_channel, float eps, float* __restrict__ stats) {
   const int idx = blockIdx.x;
   const int n = idx / groups, grp = idx - n * groups;
   const int hpg = (C / groups) >> 2;  // 4-channel half chunks per group
+  const int items = nblk * hpg;
+  const float* base = partial + ((int64_t)n * nblk * (C >> 2) + grp * hpg) * 2;
   double s = 0.0, q = 0.0;
-  for (int i = threadIdx.x; i < nblk * hpg; i += 64) {
-    const int b = i / hpg, k = i - b * hpg;
-    const float2 v = *reinterpret_cast<const float2*>(partial + (((int64_t)n * nblk + b) * (C >> 2) + grp * hpg + k) * 2);
-    s += v.x; q += v.y;
+  for (int i0 = threadIdx.x; i0 < items; i0 += 64 * 8) {
+    float2 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 64 * u;
+      v[u] = make_float2(0.f, 0.f);
+      if (i < items) {
+        const int b = i / hpg, k = i - b * hpg;
+        v[u] = *reinterpret_cast<const float2*>(base + ((int64_t)b * (C >> 2) + k) * 2);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s += v[u].x; q += v[u].y; }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); q += __shfl_xor(q, o, 64); }
