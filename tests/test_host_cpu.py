@@ -430,7 +430,7 @@ def test_open_sora_prompt_preparation():
     text_preprocessing of the reference (pipeline_open_sora.py:548-615,705-792) for the text-to-video case."""
     from videosys_amd.pipeline_open_sora import OpenSoraPipeline as P
 
-    assert P.prepare_prompt("  A Sunset over the SEA ") == "a sunset over the sea  aesthetic score: 6.5."   # tag appended, THEN stripped
+    assert P.prepare_prompt("  A Sunset over the SEA ") == "a sunset over the sea aesthetic score: 6.5."   # tag appended, THEN cleaned
     assert P.prepare_prompt("A cat") == "a cat aesthetic score: 6.5."
     assert P.prepare_prompt("A cat", aes=None) == "a cat"
     assert P.prepare_prompt("A cat", aes=7, flow=3.25, camera_motion="pan right") == \
@@ -442,6 +442,27 @@ def test_open_sora_prompt_preparation():
     assert P.prepare_prompt('A cat{"reference_path": "x.png", "mask_strategy": "0"}', aes=None) == "a cat"   # the tail is generate()'s
     with pytest.raises(AssertionError):
         P.prepare_prompt('A cat{"foo": 1}')
+
+
+def test_caption_cleaner_matches_the_reference():
+    """caption.py against outputs minted from the reference's own _clean_caption / text_preprocessing
+    (oracle/make_golden_caption.py; pipeline_open_sora.py:298-424): one application, the double application the pipeline uses,
+    and the plain lower-case + strip form."""
+    import json
+
+    from conftest import GOLDEN
+    from videosys_amd import caption as C
+
+    with open(os.path.join(GOLDEN, "clean_caption_cases.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) >= 20
+    for c in cases:
+        assert C.clean_caption(c["in"]) == c["once"], c["in"]
+        assert C.text_preprocessing(c["in"]) == c["twice"], c["in"]
+        assert C.text_preprocessing(c["in"], False) == c["plain"], c["in"]
+    # html step (bs4 absent here: the standard library's html.parser, which is bs4's backend for features="html.parser")
+    assert C.clean_caption("a <b>bold</b> claim &lt;3") == "a bold claim <3"
+    assert C.BAD_PUNCT.sub(" ", "a#b\\c/d*e") == "a b c d e"
 
 
 def test_videosys_alias_package_exports_reference_names():

@@ -225,9 +225,12 @@ class OpenSoraPipeline(StagedOffloadMixin):
         return self.transformer.y_embedder.y_embedding[None].repeat(n, 1, 1)[:, None]
 
     @staticmethod
-    def text_preprocessing(text: str) -> str:
-        """pipeline_open_sora.py:417-424 without ``clean_caption`` (ftfy / bs4 are not in this image): lower-case + strip."""
-        return text.lower().strip()
+    def text_preprocessing(text: str, use_text_preprocessing: bool = True) -> str:
+        """pipeline_open_sora.py:417-424: the training-time caption cleaner applied twice (caption.py; its html / mojibake steps
+        use bs4 / ftfy when they are installed and standard-library equivalents otherwise), or lower-case + strip."""
+        from .caption import text_preprocessing
+
+        return text_preprocessing(text, use_text_preprocessing)
 
     @classmethod
     def prepare_prompt(cls, prompt: str, aes: Optional[float] = 6.5, flow: Optional[float] = None, camera_motion=None,
