@@ -68,11 +68,26 @@ def main():
     me = SimpleNamespace()
     me._basic_clean = funcs["_basic_clean"]
     me._clean_caption = lambda c: funcs["_clean_caption"](me, c)
+    # LattePipeline: the diffusers IFPipeline copy (pipeline_latte.py:185-189 bad_punct_regex, :519-650)
+    lpath = "/root/reference/videosys/pipelines/latte/pipeline_latte.py"
+    lns = dict(ns)
+    lat = SimpleNamespace()
+    for node in ast.parse(open(lpath).read()).body:
+        if isinstance(node, ast.ClassDef) and node.name == "LattePipeline":
+            for item in node.body:
+                if isinstance(item, ast.Assign) and getattr(item.targets[0], "id", None) == "bad_punct_regex":
+                    exec(compile(ast.Module([item], []), lpath, "exec"), lns)
+                    lat.bad_punct_regex = lns["bad_punct_regex"]
+                if isinstance(item, ast.FunctionDef) and item.name in ("_clean_caption", "_text_preprocessing"):
+                    exec(compile(ast.Module([item], []), lpath, "exec"), lns)
+    lat._clean_caption = lambda c: lns["_clean_caption"](lat, c)
     out = []
     for c in CASES:
         assert "<" not in c.replace("<person>", "") and "&" not in c
         out.append({"in": c, "once": me._clean_caption(c), "twice": funcs["text_preprocessing"](me, c),
-                    "plain": funcs["text_preprocessing"](me, c, False)})
+                    "plain": funcs["text_preprocessing"](me, c, False),
+                    "latte_twice": lns["_text_preprocessing"](lat, c, clean_caption=True)[0],
+                    "latte_plain": lns["_text_preprocessing"](lat, c, clean_caption=False)[0]})
     with open(os.path.join(ROOT, "tests", "golden", "clean_caption_cases.json"), "w") as fh:
         json.dump(out, fh, ensure_ascii=False, indent=1)
     for o in out[:6]:

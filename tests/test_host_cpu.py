@@ -460,6 +460,9 @@ def test_caption_cleaner_matches_the_reference():
         assert C.clean_caption(c["in"]) == c["once"], c["in"]
         assert C.text_preprocessing(c["in"]) == c["twice"], c["in"]
         assert C.text_preprocessing(c["in"], False) == c["plain"], c["in"]
+        # LattePipeline._text_preprocessing (the diffusers IFPipeline copy: no strip inside the ftfy / unescape step)
+        assert C.text_preprocessing(c["in"], True, mid_strip=False) == c["latte_twice"], c["in"]
+        assert C.text_preprocessing(c["in"], False, mid_strip=False) == c["latte_plain"], c["in"]
     # html step (bs4 absent here: the standard library's html.parser, which is bs4's backend for features="html.parser")
     assert C.clean_caption("a <b>bold</b> claim &lt;3") == "a bold claim <3"
     assert C.BAD_PUNCT.sub(" ", "a#b\\c/d*e") == "a b c d e"

@@ -107,19 +107,22 @@ def _html_text(s: str) -> str:
         return "".join(p.parts)
 
 
-def basic_clean(text: str) -> str:
-    """_basic_clean (:298-302)."""
+def basic_clean(text: str, strip: bool = True) -> str:
+    """_basic_clean (:298-302).  ``strip=False``: the inline form of LattePipeline._clean_caption (pipeline_latte.py:617-618), which
+    does not strip at this point."""
     try:
         import ftfy
 
         text = ftfy.fix_text(text)
     except ImportError:
         text = unicodedata.normalize("NFC", text)
-    return html.unescape(html.unescape(text)).strip()
+    text = html.unescape(html.unescape(text))
+    return text.strip() if strip else text
 
 
-def clean_caption(caption) -> str:
-    """_clean_caption (:304-415), one application."""
+def clean_caption(caption, mid_strip: bool = True) -> str:
+    """_clean_caption (:304-415), one application.  ``mid_strip=False`` = LattePipeline._clean_caption (pipeline_latte.py:534-650:
+    the same rule sequence, copied from diffusers' IFPipeline, without the strip inside the ftfy / unescape step)."""
     s = ul.unquote_plus(str(caption)).strip().lower()
     for pat, rep in _PRE_HTML:
         s = pat.sub(rep, s)
@@ -128,14 +131,15 @@ def clean_caption(caption) -> str:
         s = pat.sub(rep, s)
     if len(_DASHES.findall(s)) > 3:           # this-is-my-cute-cat / this_is_my_cute_cat
         s = _DASHES.sub(" ", s)
-    s = basic_clean(s)
+    s = basic_clean(s, mid_strip)
     for pat, rep in _POST:
         s = pat.sub(rep, s)
     return s.strip()
 
 
-def text_preprocessing(text: str, use_text_preprocessing: bool = True) -> str:
-    """text_preprocessing (:417-424): the cleaner twice (as at training time), or lower-case + strip."""
+def text_preprocessing(text: str, use_text_preprocessing: bool = True, mid_strip: bool = True) -> str:
+    """text_preprocessing (:417-424; LattePipeline._text_preprocessing, pipeline_latte.py:519-531): the cleaner twice (as at training
+    time), or lower-case + strip."""
     if use_text_preprocessing:
-        return clean_caption(clean_caption(text))
+        return clean_caption(clean_caption(text, mid_strip), mid_strip)
     return text.lower().strip()

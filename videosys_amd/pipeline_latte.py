@@ -179,16 +179,22 @@ class LattePipeline(StagedOffloadMixin):
                  seed: int = -1, verbose: bool = False, *, prompt_embeds: Optional[torch.Tensor] = None,
                  negative_prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
                  negative_mask: Optional[torch.Tensor] = None, latents: Optional[torch.Tensor] = None,
-                 video_length: int = 16, height: int = 512, width: int = 512, output_type: str = "auto"):
+                 video_length: int = 16, height: int = 512, width: int = 512, output_type: str = "auto",
+                 clean_caption: bool = True):
         """pipeline_latte.py:675-900 for text-to-video: CFG batch [negative | prompt], learned-sigma half dropped,
         DDIM eta = 0.  ``height/width/video_length`` are the reference's hard-coded 512/512/16 by default (:764-766);
-        BASELINE config 1 (256x256) passes them explicitly."""
+        BASELINE config 1 (256x256) passes them explicitly.  ``clean_caption`` (default True as :692): prompt and negative prompt
+        go through _text_preprocessing (:519-531: the IF caption cleaner twice, caption.py) before the tokenizer."""
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, L, 4096]")
+            from .caption import text_preprocessing
+
+            prep = lambda t: [text_preprocessing(v, clean_caption, mid_strip=False) for v in t] if isinstance(t, (list, tuple)) \
+                else text_preprocessing(t, clean_caption, mid_strip=False)
             self._enter_stage("text_encoder")
-            prompt_embeds, prompt_mask = self.text_encoder(prompt)
-            negative_prompt_embeds, negative_mask = self.text_encoder(negative_prompt)
+            prompt_embeds, prompt_mask = self.text_encoder(prep(prompt))
+            negative_prompt_embeds, negative_mask = self.text_encoder(prep(negative_prompt))
         if guidance_scale <= 1.0:
             raise NotImplementedError("the MI355X path runs the classifier-free-guidance batch (guidance_scale > 1)")
         from .utils import set_seed
