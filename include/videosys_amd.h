@@ -241,6 +241,15 @@ int vsys_splitk_reduce_t(const void* part_f32, int64_t nsplit, int64_t slab, int
  * relbias fp32 [heads, 2L-1]; klen int32 [B] on the device; L <= 512. */
 int vsys_t5_attention(const void* qkv, int64_t row_stride, int64_t inner, const void* relbias_f32, const void* klen_i32, void* out,
                       int64_t out_stride, int64_t B, int64_t L, int64_t heads, void* stream);
+/* The weight-streaming linear on the 256 x 384 tile (one 8-wave workgroup per CU): part_f32[s][m][n] = sum over K slice s of
+ * x[m][k] w[n][k] for m < rows (x holds rows_padded rows, a multiple of 384; the rows past the real ones are multiplied but not
+ * stored), n < N, nsplit slices of ceil(K / 32 / nsplit) * 32 columns (the last one takes what is left; K % 32 == 0).  Every 256-row weight panel is read by exactly one workgroup.  vsys_splitk_reduce then
+ * gives out[m][n] = bf16(sum_s part[s][m][n]) (+ res[m][n] after the rounding), slab = rows_padded * N, ldp = N.
+ * Replaces nn.Linear inside transformers' T5 stack at a few hundred rows (third-party; call sites pipeline_open_sora.py:269-287). */
+int vsys_gemm_skinny_slices(const void* w, int64_t ldw, const void* x, int64_t ldx, void* part_f32, int64_t rows, int64_t rows_padded,
+                            int64_t N, int64_t K, int64_t nsplit, void* stream);
+int vsys_splitk_reduce(const void* part_f32, int64_t nsplit, int64_t slab, int64_t ldp, const void* res, int64_t ldr, void* out, int64_t ldo,
+                       int64_t M, int64_t N, void* stream);
 /* The same attention on the matrix pipe, ONE sample per call (its own key length kv_len <= L): the head_dim-64 flash kernel with
  * an additive (head, key - query) logit bias.  qkv bf16 rows [L, 3*inner] (q | k | v, head h at h*64); bias_f32 [heads, bias_ld]
  * holds log2(e) * T5Attention.compute_bias, entry of (h, key - query) at bias_center + key - query, padded by the caller so that

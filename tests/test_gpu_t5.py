@@ -70,15 +70,17 @@ def test_t5_attention_matches_torch(B, L, H, lens):
     check(out2, ref, what="t5 attention (mfma)")
 
 
-@pytest.mark.parametrize("M,N,K,nsplit,res", [(300, 512, 2048, None, True), (300, 768, 1024, 1, False), (77, 256, 4096, 8, True),
-                                               (600, 1024, 512, 2, False), (128, 4096, 4096, None, True)])
-def test_linear_skinny_matches_torch(M, N, K, nsplit, res):
+@pytest.mark.parametrize("M,N,K,nsplit,res,pad", [(300, 512, 2048, None, True, 384), (300, 768, 1024, 1, False, 384), (77, 256, 4096, 8, True, 128),
+                                                   (600, 1024, 512, 2, False, 128), (128, 4096, 4096, None, True, 128),
+                                                   (600, 1000, 1024, 2, True, 384), (300, 4096, 10240, None, True, 384),
+                                                   (300, 1024, 4096, 3, True, 384), (200, 512, 1056, 5, False, 384)])
+def test_linear_skinny_matches_torch(M, N, K, nsplit, res, pad):
     """The weight-streaming linear (transposed split-K GEMM + vsys_splitk_reduce_t) against torch on bf16-rounded operands; rows
     past M of the padded activation buffer are poisoned with NaN: they must not reach any result row."""
     from videosys_amd import ops
 
     g = torch.Generator().manual_seed(M + N + K)
-    Mp = (M + 127) // 128 * 128
+    Mp = (M + pad - 1) // pad * pad     # 384: the 256 x 384 tile (one workgroup per weight panel); 128: the 128-column kernel
     x = torch.full((Mp, K), float("nan"))
     x[:M] = torch.randn(M, K, generator=g)
     w = torch.randn(N, K, generator=g) / math.sqrt(K)

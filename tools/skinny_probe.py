@@ -14,12 +14,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=300)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--narrow", action="store_true", help="the 128-column kernel form (panel shared by three column-tile workgroups)")
     args = ap.parse_args()
     from videosys_amd import _lib, ops
 
     dev = torch.device("cuda:0")
     M = args.rows
-    Mp = (M + 127) // 128 * 128
+    Mp = (M + 383) // 384 * 384
     g = torch.Generator(device=dev).manual_seed(0)
     for name, N, K in (("qkv", 12288, 4096), ("o", 4096, 4096), ("wi", 20480, 4096), ("wo", 4096, 10240)):
         x = (torch.randn(Mp, K, generator=g, device=dev)).to(torch.bfloat16)
@@ -27,9 +28,10 @@ def main():
         ws = [(torch.randn(N, K, generator=g, device=dev) / K ** 0.5).to(torch.bfloat16) for _ in range(6)]
         res = torch.zeros(Mp, N, dtype=torch.bfloat16, device=dev)
         out = torch.empty(Mp, N, dtype=torch.bfloat16, device=dev)
-        row = {"shape": f"{name} {M}x{N}x{K}", "weight_mb": round(N * K * 2 / 1e6, 1), "auto_split": ops.skinny_split(N, Mp, K)}
-        for S in (1, 2, 4, 8):
-            if K % (S * 32) or K // S < 256:
+        row = {"shape": f"{name} {M}x{N}x{K}", "form": "128-column kernel" if args.narrow else "256x384 tile", "weight_mb": round(N * K * 2 / 1e6, 1),
+               "auto_split": ops.skinny_split(N, Mp, K, wide=not args.narrow)}
+        for S in ((1, 2, 4, 8) if args.narrow else (2, 3, 4, 5, 8, 10, 16)):
+            if (args.narrow and K % (S * 32)) or K // S < 256:
                 continue
             part = torch.empty(S * N * Mp, dtype=torch.float32, device=dev)
             pv = part.view(S, N, Mp)
@@ -38,11 +40,18 @@ def main():
             for it in range(args.iters):
                 w = ws[it % len(ws)]
                 e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                st = torch.cuda.current_stream().cuda_stream
                 e[0].record()
-                ops.gemm128(w, x, out_f32=pv, batch=S, batch_a=Ks, batch_w=Ks, batch_o=N * Mp, M=N, K=Ks)
-                e[1].record()
-                _lib.check(_lib.load().vsys_splitk_reduce_t(pv.data_ptr(), S, N * Mp, Mp, res.data_ptr(), res.stride(0), out.data_ptr(),
-                                                            out.stride(0), M, N, torch.cuda.current_stream().cuda_stream), "reduce")
+                if args.narrow:
+                    ops.gemm128(w, x, out_f32=pv, batch=S, batch_a=Ks, batch_w=Ks, batch_o=N * Mp, M=N, K=Ks)
+                    e[1].record()
+                    _lib.check(_lib.load().vsys_splitk_reduce_t(pv.data_ptr(), S, N * Mp, Mp, res.data_ptr(), res.stride(0), out.data_ptr(),
+                                                                out.stride(0), M, N, st), "reduce")
+                else:
+                    _lib.check(_lib.load().vsys_gemm_skinny_slices(w.data_ptr(), K, x.data_ptr(), K, part.data_ptr(), M, Mp, N, K, S, st), "gemm")
+                    e[1].record()
+                    _lib.check(_lib.load().vsys_splitk_reduce(part.data_ptr(), S, Mp * N, N, res.data_ptr(), res.stride(0), out.data_ptr(),
+                                                              out.stride(0), M, N, st), "reduce")
                 e[2].record()
                 torch.cuda.synchronize()
                 tg.append(e[0].elapsed_time(e[1]) * 1e3)

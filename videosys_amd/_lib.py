@@ -49,6 +49,8 @@ SIGNATURES = {
     "vsys_gather_rows": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "vsys_rms_norm_rows": [_ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr],
     "vsys_geglu": [_ptr, _ptr, _i64, _i64, _ptr],
+    "vsys_gemm_skinny_slices": [_ptr, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _i64, _i64, _ptr],
+    "vsys_splitk_reduce": [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     "vsys_t5_attention_mfma": [_ptr, _i64, _i64, _ptr, _i64, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "vsys_splitk_reduce_t": [_ptr, _i64, _i64, _i64, _ptr, _i64, _ptr, _i64, _i64, _i64, _ptr],
     "vsys_t5_attention": [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr],

@@ -65,7 +65,7 @@ int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.gate = B16(gate); p.gate_stride = gate_sample_stride; p.res = B16(res); p.ldr = ldr; p.aux = B16(aux); p.ldaux = ldaux;
   p.rows_per_sample = (int)rows_per_sample;
-  p.seg_split = 0; p.gate_alt = 0;
+  p.seg_split = 0; p.gate_alt = 0; p.ks = 0; p.out32 = nullptr; p.slab = 0; p.ldo32 = 0;
   if (epilogue != VSYS_EPI_GATE_RES && (gate || res || aux)) return VSYS_ERR_ARG;
   return launch_gemm(p, epilogue, S(stream));
 }
@@ -82,7 +82,7 @@ int vsys_gemm_bf16_gate2(const void* x, int64_t ldx, const void* w, int64_t ldw,
   p.M = (int)M; p.N = (int)N; p.K = (int)K;
   p.gate = B16(gate); p.gate_stride = gate_sample_stride; p.res = B16(res); p.ldr = ldr; p.aux = B16(aux); p.ldaux = ldaux;
   p.rows_per_sample = (int)rows_per_sample;
-  p.seg_split = (int)seg_split; p.gate_alt = gate_alt;
+  p.seg_split = (int)seg_split; p.gate_alt = gate_alt; p.ks = 0; p.out32 = nullptr; p.slab = 0; p.ldo32 = 0;
   return launch_gemm(p, VSYS_EPI_GATE_RES, S(stream));
 }
 
@@ -313,6 +313,30 @@ int vsys_geglu(const void* h, void* out, int64_t rows, int64_t F, void* stream) 
   if (!h || !out) return VSYS_ERR_ARG;
   if (!fits_int(F)) return VSYS_ERR_SHAPE;
   return launch_geglu(B16(h), B16(out), rows, (int)F, S(stream));
+}
+
+int vsys_gemm_skinny_slices(const void* w, int64_t ldw, const void* x, int64_t ldx, void* part_f32, int64_t rows, int64_t rows_padded,
+                            int64_t N, int64_t K, int64_t nsplit, void* stream) {
+  if (!w || !x || !part_f32) return VSYS_ERR_ARG;
+  if (!fits_int(rows_padded) || !fits_int(N) || !fits_int(K) || !fits_int(nsplit) || nsplit < 1 || K % 32 != 0 || rows < 1 || rows > rows_padded)
+    return VSYS_ERR_SHAPE;
+  GemmParams p;
+  p.A = B16(w); p.lda = ldw; p.W = B16(x); p.ldw = ldx; p.bias = nullptr; p.out = nullptr; p.ldo = 0;
+  p.M = (int)N; p.N = (int)rows_padded; p.K = (int)K;
+  p.gate = nullptr; p.gate_stride = 0; p.res = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.rows_per_sample = (int)rows;
+  p.seg_split = 0; p.gate_alt = 0;
+  p.ks = (int)(((K / 32 + nsplit - 1) / nsplit) * 32);   // k-tiles dealt out evenly, the last slice takes what is left
+  if ((int64_t)p.ks * (nsplit - 1) >= K) return VSYS_ERR_SHAPE;
+  p.out32 = reinterpret_cast<float*>(part_f32); p.slab = rows_padded * N; p.ldo32 = N;
+  return launch_gemm2_slices(p, (int)nsplit, S(stream));
+}
+
+int vsys_splitk_reduce(const void* part_f32, int64_t nsplit, int64_t slab, int64_t ldp, const void* res, int64_t ldr, void* out, int64_t ldo,
+                       int64_t M, int64_t N, void* stream) {
+  if (!part_f32 || !out) return VSYS_ERR_ARG;
+  if (!fits_int(nsplit) || !fits_int(M) || !fits_int(N)) return VSYS_ERR_SHAPE;
+  return launch_splitk_reduce(reinterpret_cast<const float*>(part_f32), (int)nsplit, slab, ldp, B16(res), ldr, B16(out), ldo, (int)M, (int)N,
+                              S(stream));
 }
 
 int vsys_t5_attention_mfma(const void* qkv, int64_t row_stride, int64_t inner, const void* bias_f32, int64_t bias_ld, int64_t bias_center,

@@ -57,7 +57,17 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // tile order: same W-resident raster as gemm_bf16.hip (column groups of 6 inside 8 row-panel groups)
   const int nbn = p.N / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // EPI_F32_SLICES: the 1-D grid is (K slice, tile) in slice-major order, so the contiguous run of it that xcd_remap gives an
+  // XCD holds one or two K slices: the activation columns of a slice (384 x ks bf16, < 1 MB) stay in that XCD's L2 while its
+  // weight panels stream through — every workgroup re-reads them, and with the slices spread over all XCDs each L2 saw ALL of
+  // the activations (3-8 MB against 4 MB of L2) next to the weight stream
+  int kslice = 0;
+  if constexpr (EPI == EPI_F32_SLICES) {
+    const int ntile = ((p.M + BM - 1) / BM) * nbn;
+    kslice = tile / ntile;
+    tile -= kslice * ntile;
+  }
   int bm, bn;
   if (nbn > 6) {
     const int nbm = (p.M + BM - 1) / BM;
@@ -106,13 +116,15 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)col0 * p.ldw), 0,
                                                         (int)(b_bytes < 0x7fffffff ? b_bytes : 0x7fffffff), 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  // EPI_F32_SLICES: blockIdx.y picks a K slice of p.ks columns; every other epilogue walks the whole K
+  const int kbase2 = EPI == EPI_F32_SLICES ? kslice * p.ks * 2 : 0;
   auto dma_a = [&](int i, int t, int slot) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(smem + slot * A_SLOT + (wave_u * (16 * NA) + i * 16) * 64), 16, a_off[i],
-                                             t * (BK * 2), 0, 0);
+                                             kbase2 + t * (BK * 2), 0, 0);
   };
   auto dma_w = [&](int i, int t, int slot) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(smem + W_BASE + slot * W_SLOT + (wave_u * 48 + i * 16) * 64), 16,
-                                             b_off[i], t * (BK * 2), 0, 0);
+                                             b_off[i], kbase2 + t * (BK * 2), 0, 0);
   };
 
   // ---- fragment read offsets: row r, k-step ks: logical chunk 2ks + hi at physical chunk ^ ((r>>2)&3); all fragment rows of
@@ -129,7 +141,8 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nt = p.K / BK;
+  // (slices: the last one may be shorter — K need not divide evenly)
+  const int nt = (EPI == EPI_F32_SLICES ? (p.ks < p.K - kslice * p.ks ? p.ks : p.K - kslice * p.ks) : p.K) / BK;
 #pragma unroll
   for (int i = 0; i < NA; ++i) dma_a(i, 0, 0);
 #pragma unroll
@@ -251,6 +264,29 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     sw = sw1;
   }
 
+  if constexpr (EPI == EPI_F32_SLICES) {
+    // fp32 K-slice partials straight from the accumulators, stored TRANSPOSED: the row operand is the weight (row = output
+    // feature n), the column operand the few activation rows (column = m), and the consumer wants [m][n].  For a fixed
+    // accumulator register the 32 lanes of a half wave hold 32 consecutive n of one m: a 128-byte segment per store.
+    float* o32 = p.out32 + (int64_t)kslice * p.slab;
+    const int ncol0 = col0 + wn * 96;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int n = row0 + wm * 128 + i * 32 + l31;
+      if (n < p.M) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = ncol0 + j * 32 + 8 * g + 4 * hi + r;
+              if (m < p.rows_per_sample) o32[(int64_t)m * p.ldo32 + n] = acc[i][j][4 * g + r];   // (rows_per_sample = real activation rows)
+            }
+      }
+    }
+    return;
+  }
   // ---- epilogue in two passes of 64 rows per wave (m-blocks {0,1}, then {2,3}); the per-wave LDS image is private to the
   // wave, so only wave-local ordering is needed between its writes and reads (the barrier above covers the staging reads)
   char* st = smem + wave * OUT_WAVE_BYTES;
@@ -411,6 +447,26 @@ int launch_gemm2_stamp(const GemmParams& p_, hipStream_t stream) {
 }
 
 #endif  // VSYS_LAB
+
+// Weight-streaming linears (few activation rows against a large weight: ops.linear_skinny, T5 at 300 tokens).  The WEIGHT is the
+// row operand "A" [M = features, K], the activations the column operand "W" [N = rows padded to 384, K]: on the 256 x 384 tile a
+// weight panel is read by exactly one workgroup and ALL activation rows ride along (2.5 x the weight bytes through LDS instead
+// of 4.2 x on the 128-column kernel), K is cut in ``slices`` so that ~one workgroup per CU pulls on HBM, and every
+// slice leaves fp32 partials out32[s][n_row = activation row][feature] for vsys_splitk_reduce.
+int launch_gemm2_slices(const GemmParams& p, int slices, hipStream_t stream) {
+  using G = G2<4>;
+  if (p.M <= 0) return 0;
+  if (p.N % G::BN != 0 || slices < 1 || slices > 65535 || p.ks <= 0 || p.ks % BK != 0 || p.K % BK != 0 || (int64_t)p.ks * slices < p.K ||
+      (int64_t)p.ks * (slices - 1) >= p.K || p.out32 == nullptr || (p.lda % 8) || (p.ldw % 8) || p.rows_per_sample <= 0)
+    return VSYS_ERR_SHAPE;
+  if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 768 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
+  const int nbm = (p.M + BM - 1) / BM, nbn = p.N / G::BN;
+  static std::atomic<unsigned long long> attr_seen{0};
+  if (first_use_on_this_device(attr_seen))
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_F32_SLICES, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+  hipLaunchKernelGGL((gemm2_kernel<EPI_F32_SLICES, 4>), dim3(nbm * nbn * slices), dim3(G::NT), G::LDS_BYTES, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
 
 // wide = 0: 256 x 192 tile, two workgroups per CU (variant 20); wide = 1: 256 x 384 tile, one 8-wave workgroup per CU (variant 30)
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream) {

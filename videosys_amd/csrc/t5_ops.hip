@@ -192,6 +192,32 @@ __global__ __launch_bounds__(256) void splitk_reduce_t_kernel(const float* __res
   }
 }
 
+// The same finish for slices that are already [s][m][n] (launch_gemm2_slices): out[m][n] = bf16(sum_s part[s][m][n]) (+ res[m][n]);
+// thread = 8 consecutive n.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int64_t slab, int64_t ldp,
+                                                            const bf16_t* __restrict__ res, int64_t ldr, bf16_t* __restrict__ out,
+                                                            int64_t ldo, int M, int N) {
+  const int nch = N >> 3;
+  const int64_t total = (int64_t)M * nch;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / nch;
+    const int n = (int)(i - m * nch) * 8;
+    const float* src = part + m * ldp + n;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(src + s * slab), b = *reinterpret_cast<const float4*>(src + s * slab + 4);
+      v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (res != nullptr) {
+      float r[8];
+      unpack8(*reinterpret_cast<const uint4*>(res + m * ldr + n), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bf2f(f2bf(v[e])) + r[e];
+    }
+    *reinterpret_cast<uint4*>(out + m * ldo + n) = pack8(v);
+  }
+}
+
 inline unsigned stream_grid(int64_t items) {
   int64_t b = (items + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -229,6 +255,16 @@ int launch_splitk_reduce_t(const float* part, int S, int64_t slab, int ldp, cons
   if (S < 1 || S > 64 || N % 8 != 0 || ldp % 4 != 0 || ldp < M || slab < (int64_t)N * ldp || (ldo % 8) || (res && (ldr % 8)))
     return VSYS_ERR_SHAPE;
   hipLaunchKernelGGL(splitk_reduce_t_kernel, dim3((N + 63) / 64, (M + 63) / 64), dim3(256), 0, stream, part, S, slab, ldp, res, ldr, out,
+                     ldo, M, N);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+int launch_splitk_reduce(const float* part, int S, int64_t slab, int64_t ldp, const bf16_t* res, int64_t ldr, bf16_t* out, int64_t ldo,
+                         int M, int N, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (S < 1 || S > 64 || N % 8 != 0 || ldp % 4 != 0 || ldp < N || slab < (int64_t)M * ldp || (ldo % 8) || (res && (ldr % 8)))
+    return VSYS_ERR_SHAPE;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(stream_grid((int64_t)M * (N >> 3))), dim3(256), 0, stream, part, S, slab, ldp, res, ldr, out,
                      ldo, M, N);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }

@@ -35,7 +35,8 @@ inline int cu_count_this_device() {
   return n;
 }
 
-enum { EPI_BIAS = VSYS_EPI_BIAS, EPI_BIAS_GELU = VSYS_EPI_BIAS_GELU, EPI_GATE_RES = VSYS_EPI_GATE_RES };
+enum { EPI_BIAS = VSYS_EPI_BIAS, EPI_BIAS_GELU = VSYS_EPI_BIAS_GELU, EPI_GATE_RES = VSYS_EPI_GATE_RES,
+       EPI_F32_SLICES = 100 /* internal (gemm2_bf16.hip): fp32 K-slice partials, see launch_gemm2_slices */ };
 enum { ACT_NONE = VSYS_ACT_NONE, ACT_SILU = VSYS_ACT_SILU, ACT_GELU_TANH = VSYS_ACT_GELU_TANH };
 
 struct GemmParams {
@@ -51,6 +52,9 @@ struct GemmParams {
   // CogVideoX joint [text | video] rows: rows whose position inside the sample is < seg_split take their gate vector
   // gate_alt elements further on (enc_gate vs gate of CogVideoXLayerNormZero); 0 = one gate per sample
   int seg_split; int64_t gate_alt;
+  // EPI_F32_SLICES only (launch_gemm2_slices): K slice length, fp32 output [slices][N][M] (element (m, n) of slice s at
+  // out32[s * slab + n * ldo32 + m]: "A" is the weight here, so this is activation-row-major)
+  int ks; float* out32; int64_t slab, ldo32;
 };
 
 // implicit-GEMM convolution / 128-column GEMM (conv_bf16.hip).  A points at the row that tap (0,0,0) reads for output row 0.
@@ -98,12 +102,15 @@ int launch_t5_attention(const bf16_t* qkv, int64_t row_stride, int inner, const 
                         int64_t out_stride, int B, int L, int heads, hipStream_t stream);
 int launch_splitk_reduce_t(const float* part, int S, int64_t slab, int ldp, const bf16_t* res, int64_t ldr, bf16_t* out, int64_t ldo,
                            int M, int N, hipStream_t stream);
+int launch_splitk_reduce(const float* part, int S, int64_t slab, int64_t ldp, const bf16_t* res, int64_t ldr, bf16_t* out, int64_t ldo,
+                         int M, int N, hipStream_t stream);
 int launch_t5_attention_mfma(const bf16_t* qkv, int64_t row_stride, int inner, const float* bias, int bias_ld, int bias_center,
                              int kv_len, bf16_t* kp, bf16_t* vt, bf16_t* out, int64_t out_stride, int L, int heads,
                              hipStream_t stream);
 
 int launch_gemm(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream);
+int launch_gemm2_slices(const GemmParams& p, int slices, hipStream_t stream);
 int launch_gemm3(const GemmParams& p, int epi, hipStream_t stream);
 // ping-pong wave groups (gemm4_bf16.hip); persistent = 1: one workgroup per CU walks the tiles, 2: + stream-K tail
 int launch_gemm4(const GemmParams& p, int epi, int persistent, hipStream_t stream);

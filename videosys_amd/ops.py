@@ -595,12 +595,20 @@ def t5_attention_mfma(qkv, bias_pad, center, lens, B, L, heads, out=None, ws=Non
     return out
 
 
-def skinny_split(N, Mp, K):
-    """K slices for linear_skinny, from the measured sweep at the T5-XXL shapes (tools/skinny_probe.py, profiles/
-    r03_t5_skinny_probe.jsonl): with >= 144 (weight panel, activation tile) workgroups one slice is already best (each further
-    slice is another N x Mp fp32 round trip: qkv 92 / 84 / 81 us GEMM but 9 / 11 / 15 us reduce at 1 / 2 / 4 slices, wi 100 / 100 /
-    107); with 48 (the N = 4096 linears) four slices win (o 76 -> 34 us, wo 207 -> 67 us).  Rule: slices = the power of two that
-    brings the workgroup count closest to 192, slices of >= 1024 columns."""
+def skinny_split(N, Mp, K, wide=None):
+    """K slices for linear_skinny.  Wide path (Mp a multiple of 384: the 256 x 384 tile, ONE workgroup per CU): the largest slice
+    count that keeps (weight panels) x (activation tiles) x slices within one round of 256 workgroups, slices of >= 512 columns
+    (a multiple of 32).  128-column path (tools/skinny_probe.py, profiles/r03_t5_skinny_probe.jsonl): one slice with >= 144
+    workgroups, else the power of two that brings the count closest to 192, slices of >= 1024 columns."""
+    wide = (Mp % 384 == 0) if wide is None else wide
+    if wide:
+        tiles = ((N + 255) // 256) * (Mp // 384)
+        best = 1
+        for s in range(2, 33):   # (slices need not divide K: k-tiles of 32 are dealt out evenly, the last slice takes what is left)
+            ks = -(-(K // 32) // s) * 32
+            if tiles * s <= 256 and ks >= 512 and ks * (s - 1) < K:
+                best = s
+        return best
     tiles = ((N + 255) // 256) * (Mp // 128)
     s = 1
     while tiles * s < 128 and s < 8 and K % (64 * s) == 0 and K // (2 * s) >= 1024:
@@ -608,31 +616,43 @@ def skinny_split(N, Mp, K):
     return s
 
 
-def linear_skinny(x, M, w, res=None, out=None, nsplit=None, part=None):
+def linear_skinny(x, M, w, res=None, out=None, nsplit=None, part=None, wide=None):
     """out[:M] = x[:M] @ w^T (+ res[:M]) for FEW rows against a large weight (T5 at 300 tokens: 300 MACs per weight element, a
-    weight stream).  x bf16 [Mp, K] with Mp % 128 == 0 (rows >= M are never looked at in the result), w bf16 [N, K].
-    The GEMM runs transposed — the weight is the row operand of the 128-column kernel, so a 256-row weight panel is fetched
-    from HBM once and its Mp / 128 activation tiles are neighbours in tile order — and in ``nsplit`` slices of K (one per
-    batch entry) to put >= 512 workgroups on the chip; vsys_splitk_reduce_t sums the fp32 slices, transposes back, rounds, adds
-    the residual.  ``part``: fp32 workspace of >= nsplit * N * Mp elements (allocated when None)."""
+    weight stream).  x bf16 [Mp, K] (rows >= M are never looked at in the result), w bf16 [N, K].  The GEMM runs with the WEIGHT
+    as the row operand and K cut in ``nsplit`` slices, leaving fp32 partials that a reduce kernel sums, rounds and adds the
+    residual to (in place on the residual stream if asked).
+      * Mp % 384 == 0 (``wide``): the 256 x 384 tile of gemm2_bf16.hip — every 256-row weight panel is read by ONE workgroup
+        together with all activation rows (vsys_gemm_skinny_slices, partials [s][m][n], vsys_splitk_reduce);
+      * Mp % 128 == 0: the 128-column kernel of conv_bf16.hip — a panel is shared by its Mp / 128 column-tile workgroups
+        (partials [s][n][m], vsys_splitk_reduce_t transposes back).
+    ``part``: fp32 workspace of >= nsplit * N * Mp elements (allocated when None)."""
     _chk(x, w, res, out, part)
     _bf16(x, w, res, out)
     Mp, K = x.shape
     N = w.shape[0]
-    assert Mp % 128 == 0 and M <= Mp and w.shape[1] == K and x.is_contiguous() and w.is_contiguous()
-    nsplit = skinny_split(N, Mp, K) if nsplit is None else nsplit
-    assert K % nsplit == 0 and (K // nsplit) % 32 == 0
+    wide = (Mp % 384 == 0) if wide is None else wide
+    assert Mp % (384 if wide else 128) == 0 and M <= Mp and w.shape[1] == K and x.is_contiguous() and w.is_contiguous()
+    nsplit = skinny_split(N, Mp, K, wide) if nsplit is None else nsplit
+    assert K % 32 == 0 and (wide or (K % nsplit == 0 and (K // nsplit) % 32 == 0))
     Ks = K // nsplit
     if part is None:
         part = torch.empty(nsplit * N * Mp, dtype=torch.float32, device=x.device)
     assert part.dtype == torch.float32 and part.numel() >= nsplit * N * Mp and part.is_contiguous()
-    pv = part[:nsplit * N * Mp].view(nsplit, N, Mp)
-    gemm128(w, x, out_f32=pv, batch=nsplit, batch_a=Ks, batch_w=Ks, batch_o=N * Mp, M=N, K=Ks)
     if out is None:
         out = torch.empty(Mp, N, dtype=torch.bfloat16, device=x.device)
     assert out.shape[1] == N and out.stride(1) == 1 and (res is None or (res.shape[1] == N and res.stride(1) == 1))
-    _lib.check(_lib.load().vsys_splitk_reduce_t(_p(pv), nsplit, N * Mp, Mp, _p(res), res.stride(0) if res is not None else 0, _p(out),
-                                                out.stride(0), M, N, _stream()), "vsys_splitk_reduce_t")
+    lib = _lib.load()
+    ldr = res.stride(0) if res is not None else 0
+    if wide:
+        _lib.check(lib.vsys_gemm_skinny_slices(_p(w), w.stride(0), _p(x), x.stride(0), _p(part), M, Mp, N, K, nsplit, _stream()),
+                   "vsys_gemm_skinny_slices")
+        _lib.check(lib.vsys_splitk_reduce(_p(part), nsplit, Mp * N, N, _p(res), ldr, _p(out), out.stride(0), M, N, _stream()),
+                   "vsys_splitk_reduce")
+        return out
+    pv = part[:nsplit * N * Mp].view(nsplit, N, Mp)
+    gemm128(w, x, out_f32=pv, batch=nsplit, batch_a=Ks, batch_w=Ks, batch_o=N * Mp, M=N, K=Ks)
+    _lib.check(lib.vsys_splitk_reduce_t(_p(pv), nsplit, N * Mp, Mp, _p(res), ldr, _p(out), out.stride(0), M, N, _stream()),
+               "vsys_splitk_reduce_t")
     return out
 
 

@@ -180,11 +180,11 @@ class T5Encoder:
         return t
 
     def _forward_skinny(self, ids, bias, klen, B, L):
-        """The same layer sequence on row-padded buffers ([Mp, .], Mp = rows rounded up to the 128-column tile; rows >= M are
+        """The same layer sequence on row-padded buffers ([Mp, .], Mp = rows rounded up to the 384-column tile; rows >= M are
         never read into a result) with the weight-streaming linears."""
         c, w = self.config, self.w
         M = B * L
-        Mp = (M + 127) // 128 * 128
+        Mp = (M + 383) // 384 * 384        # the 256 x 384 tile of ops.linear_skinny
         inner = c.num_heads * c.d_kv
         x = self._buf("x", (Mp, c.d_model))
         h = self._buf("h", (Mp, c.d_model))
