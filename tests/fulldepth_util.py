@@ -55,12 +55,15 @@ def opensora_models(depth=28, seed=1234, device="cuda:0"):
     return hip, ref, floor, y_null
 
 
-def opensora_one_step(hip, ref, floor, y_null, z, y, mask, geom, t_value=700.0):
-    """One CFG-batched forward at one timestep: output + per-block-pair hidden-state error growth."""
+def opensora_one_step(hip, ref, floor, y_null, z, y, mask, geom, t_value=700.0, x_mask=None):
+    """One CFG-batched forward at one timestep: output + per-block-pair hidden-state error growth.  ``x_mask`` [2, T] bool: the
+    conditioning-mask form of the step (frames with False see the timestep-0 modulation)."""
     x = torch.cat([z, z], 0)
     yy = torch.cat([y, y_null], 0)
     t = torch.tensor([t_value, t_value]).to(torch.bfloat16).float()   # STDiT3.forward casts timestep to the model dtype (:562)
     kw = dict(mask=mask, fps=geom["fps"].repeat(2), height=geom["height"].repeat(2), width=geom["width"].repeat(2))
+    if x_mask is not None:
+        kw["x_mask"] = x_mask
     ref_h = []
     out_ref = ref.forward(x, t, yy, return_hidden=lambda d, h: ref_h.append(h.detach().clone()), **kw)
     rows = []
@@ -78,19 +81,32 @@ def opensora_one_step(hip, ref, floor, y_null, z, y, mask, geom, t_value=700.0):
     return dict(out_hip=stats(out_hip, out_ref), out_floor=stats(out_floor, out_ref), per_pair=rows)
 
 
-def opensora_rflow(hip, ref, floor, y_null, z, y, mask, geom, steps=3, cfg_scale=7.0):
-    """RFLOW.sample through the product sampler vs the oracle sampler around ref / floor (same bf16 timesteps)."""
+def opensora_rflow(hip, ref, floor, y_null, z, y, mask, geom, steps=3, cfg_scale=7.0, cond_mask=None):
+    """RFLOW.sample through the product sampler vs the oracle sampler around ref / floor (same bf16 timesteps).  ``cond_mask``
+    [1, T] float: mask-conditioned sampling (frames of ``z`` with a value < 1 are conditioning frames), same noise in all three."""
     from oracle import stdit3_oracle as O
     from videosys_amd.rflow import RFLOW
 
     sched = RFLOW(num_sampling_steps=steps, cfg_scale=cfg_scale, use_timestep_transform=True)
     margs = dict(y=y, mask=mask, **geom)
-    z_hip = sched.sample(hip, z, margs, y_null).float().cpu()
+    extra, okw = {}, {}
+    if cond_mask is not None:
+        g = torch.Generator().manual_seed(99)
+        noises = [torch.randn(z.shape, generator=g) for _ in range(steps)]
+        fn = lambda: (lambda it: (lambda shape: next(it)))(iter(noises))
+        extra = dict(mask=cond_mask, noise_fn=fn())
+    z_hip = sched.sample(hip, z, margs, y_null, **extra).float().cpu()
     res = {}
     for name, m in (("ref", ref), ("floor", floor)):
+        if cond_mask is not None:
+            okw = dict(cond_mask=cond_mask, noise_fn=fn())
         res[name] = O.rflow_sample(m, z, y, y_null, mask, geom["fps"], geom["height"], geom["width"], geom["num_frames"],
-                                   num_sampling_steps=steps, cfg_scale=cfg_scale, model_dtype=torch.bfloat16)
-    return dict(steps=steps, z_hip=stats(z_hip, res["ref"]), z_floor=stats(res["floor"], res["ref"]))
+                                   num_sampling_steps=steps, cfg_scale=cfg_scale, model_dtype=torch.bfloat16, **okw)
+    out = dict(steps=steps, z_hip=stats(z_hip, res["ref"]), z_floor=stats(res["floor"], res["ref"]))
+    if cond_mask is not None:
+        held = cond_mask[0] == 0
+        out["held_frames_bit_exact"] = bool(torch.equal(z_hip[:, :, held], z[:, :, held].float().cpu()))
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ Latte, config 1

@@ -55,6 +55,31 @@ def test_config2_rflow_three_steps(opensora):
     assert not why, f"config 2 latents after 3 RFLOW steps: {why}"
 
 
+def test_config2_conditioned_step_and_sampling_full_depth(opensora):
+    """Image / video conditioning at the config-2 size and depth: (a) one step with a conditioning mask (latent frames 0-4 held:
+    they see the timestep-0 modulation, incl. the final layer's twice-normalised branch) with the per-pair error growth; (b)
+    five mask-conditioned RFLOW steps (frames 0-2 held, frames 3-4 joining at t <= 600, same noise in the product and in both
+    oracles): latents at the floor tolerance, held frames bit for bit."""
+    hip, ref, floor, y_null = opensora
+    z, y, mask, geom = U.opensora_inputs(T=19, HW=64, L=300)
+    xm = torch.ones(2, 19, dtype=torch.bool)
+    xm[:, :5] = False
+    r = U.opensora_one_step(hip, ref, floor, y_null, z, y, mask, geom, t_value=700.0, x_mask=xm)
+    _report("config2 one step with x_mask", r)
+    why = U.verdict(r["out_hip"], r["out_floor"])
+    assert not why, f"config 2 output with x_mask: {why}"
+    for row in r["per_pair"]:
+        assert row["hip_rel_rms"] <= 1.5 * row["floor_rel_rms"], f"hidden state after pair {row['pair']} (x_mask): {row}"
+    cond = torch.ones(1, 19)
+    cond[0, :3] = 0.0
+    cond[0, 3:5] = 0.6
+    r2 = U.opensora_rflow(hip, ref, floor, y_null, z, y, mask, geom, steps=5, cond_mask=cond)
+    _report("config2 conditioned rflow x5", r2)
+    assert r2["held_frames_bit_exact"]
+    why = U.verdict(r2["z_hip"], r2["z_floor"])
+    assert not why, f"config 2 latents after 5 mask-conditioned RFLOW steps: {why}"
+
+
 def test_config3_pab_thirty_steps_reduced_frames(opensora):
     hip, ref, floor, y_null = opensora
     z, y, mask, geom = U.opensora_inputs(T=5, HW=64, L=120)
