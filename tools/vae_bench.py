@@ -57,8 +57,25 @@ def main():
     ap.add_argument("--hw", type=int, default=64)
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--fpl", type=int, default=16)
+    ap.add_argument("--encode", type=int, default=0, help="N > 0: time OpenSoraVAE.encode of N frames (image / video conditioning) instead")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.encode:
+        vae = OpenSoraVAE(synth_state_dict(0, encoder=True), device=dev, frames_per_launch=args.fpl)
+        x = (torch.rand(1, 3, args.encode, args.hw * 8, args.hw * 8, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)
+        noise = lambda shape: torch.zeros(shape)      # (the posterior draw itself is not what is timed)
+        zz = vae.encode(x, noise_fn=noise)
+        torch.cuda.synchronize()
+        assert torch.isfinite(zz).all()
+        ts = []
+        for _ in range(args.iters):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            vae.encode(x, noise_fn=noise)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print(json.dumps({"workload": f"OpenSoraVAE.encode {args.encode} frames {args.hw * 8}x{args.hw * 8} -> latent {list(zz.shape)}",
+                          "sec_per_encode": round(min(ts), 4), "all": [round(t, 4) for t in ts],
+                          "max_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)}))
+        return
     vae = OpenSoraVAE(synth_state_dict(0), device=dev, frames_per_launch=args.fpl)
     Tz = vae.get_latent_size((args.frames, args.hw * 8, args.hw * 8))[0]
     z = torch.randn(1, 4, Tz, args.hw, args.hw, generator=torch.Generator().manual_seed(0)).to(dev)
