@@ -67,3 +67,30 @@ def test_relative_bias_table_matches_transformers_compute_bias():
     tab = relative_bias_table(sd["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"], L)
     idx = (torch.arange(L)[None, :] - torch.arange(L)[:, None]) + L - 1      # j - i + L - 1
     assert torch.equal(tab[:, idx], want)
+
+
+def test_skinny_split_rule_and_padded_bias_table():
+    """Host side of the weight-streaming T5 path: the K-slice rule (256 x 384 tile form: panels x slices within one round of 256
+    workgroups, slices of >= 512 columns, K need not divide; 128-column form: the measured rule) and the padded relative-position
+    table of the matrix-pipe attention (every index a tile can form stays inside; the real entries equal the plain table)."""
+    import math
+
+    from videosys_amd.ops import skinny_split
+    from videosys_amd.t5 import padded_bias_table, relative_bias_table
+
+    # T5-XXL at 300 tokens (rows padded to 384): qkv, o, wi, wo
+    assert [skinny_split(n, 384, k) for n, k in ((12288, 4096), (4096, 4096), (20480, 4096), (4096, 10240))] == [5, 8, 3, 16]
+    for n, k in ((12288, 4096), (4096, 4096), (20480, 4096), (4096, 10240), (1024, 512), (256, 64)):
+        s = skinny_split(n, 384, k)
+        ks = -(-(k // 32) // s) * 32
+        assert s >= 1 and ks * (s - 1) < k <= ks * s and (s == 1 or ks >= 512) and ((n + 255) // 256) * s <= max(256, (n + 255) // 256)
+    assert [skinny_split(n, 384, k, wide=False) for n, k in ((12288, 4096), (4096, 4096), (20480, 4096), (4096, 10240))] == [1, 4, 1, 4]
+    g = torch.Generator().manual_seed(0)
+    for L, H in ((300, 4), (77, 2), (128, 3), (1, 2)):
+        rel = torch.randn(32, H, generator=g)
+        t, center = padded_bias_table(rel, L)
+        qpad, kpad = (L + 127) // 128 * 128, (L + 63) // 64 * 64
+        assert center >= qpad - 1 and t.shape == (H, center + kpad)        # min index center - (qpad - 1) >= 0, max center + kpad - 1
+        plain = relative_bias_table(rel, L)
+        assert torch.allclose(t[:, center - (L - 1):center + L], plain * math.log2(math.e))
+        assert float(t[:, :center - (L - 1)].abs().sum()) == 0 and float(t[:, center + L:].abs().sum()) == 0
