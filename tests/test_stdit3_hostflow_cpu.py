@@ -411,3 +411,30 @@ def test_rflow_mask_bookkeeping_matches_the_reference():
         assert seen[0] is not None and seen[0].tolist() == [[False, True, True, True, True]] * 2 and all(m is None for m in seen[1:])
         with pytest.raises(ValueError):
             sched.sample(Model(), s["z0"], margs, s["y_null"], mask=torch.ones(1, 4))
+
+
+def test_skip_y_embedder_takes_projected_text_and_lengths():
+    """config.skip_y_embedder (open_sora_transformer_3d.py:585-590): y arrives projected and packed, mask carries the per-sample
+    token counts (a list, as the training data loader hands them over): the caption MLP is not run, the K/V cache is built from y."""
+    from videosys_amd.stdit3 import STDiT3, STDiT3Config
+
+    x, _, kw = _inputs()
+    kw = dict(kw)
+    with fake_ops() as f:
+        m = STDiT3(STDiT3Config(skip_y_embedder=True, **CFG), device="cpu")
+        m.load_state_dict(O.synth_state_dict(**CFG, seed=3))
+        y = torch.randn(1, 2 * 11, CFG["hidden_size"])
+        kw["mask"] = [11, 11]
+        before = f.calls.get("linear_small", 0)
+        out = m(x, torch.tensor([500.0, 500.0]), y, **kw)
+        assert out.shape == (2, 8, 5, 8, 8)
+        used = f.calls.get("linear_small", 0) - before
+        m2 = _model()
+        before = f.calls.get("linear_small", 0)
+        _, y_raw, kw_raw = _inputs()
+        m2(x, torch.tensor([500.0, 500.0]), y_raw, **kw_raw)
+        assert f.calls.get("linear_small", 0) - before >= used + 2      # the two caption-projection linears are the difference
+        m(x, torch.tensor([500.0, 500.0]), y, **kw)                      # same y, same lengths: the text cache holds, program replays
+        assert m.program_stats["replayed"] == 1
+        with pytest.raises(ValueError):
+            m(x, torch.tensor([500.0, 500.0]), y, **dict(kw, mask=[10, 12]))

@@ -291,13 +291,31 @@ class STDiT3:
         different prompt once the caching allocator recycles the block; ``reset_text_cache()`` (called by the pipeline at the
         start of every generate()) drops it explicitly."""
         c = self._text_cache
+        skip = bool(getattr(self.config, "skip_y_embedder", False))
+        if skip and mask is not None and not torch.is_tensor(mask):
+            mask = torch.tensor([int(v) for v in mask], dtype=torch.long)   # y_lens handed over as a list (:586-588)
+            if c is not None and c.get("lens_key") == tuple(mask.tolist()) and same_tensor(c["y"], y) and c["y_version"] == y._version:
+                return c
         if (c is not None and same_tensor(c["y"], y) and c["y_version"] == y._version and same_tensor(c["mask"], mask)
                 and (mask is None or c["mask_version"] == mask._version)):
             return c
         w = self.w
         self._programs = {}   # recorded steps hold the previous prompt's K/V addresses
-        B, _, L, Cc = y.shape
         C, H = self.hidden_size, self.num_heads
+        if skip:
+            # config.skip_y_embedder (:585-590): ``y`` is ALREADY the y_embedder output, packed [1, sum(y_lens), C], and ``mask``
+            # carries the per-sample token counts — the caption projection is skipped, the rest is the same
+            if mask is None:
+                raise ValueError("skip_y_embedder=True needs the per-sample text lengths in ``mask``")
+            y_lens = [int(v) for v in mask.reshape(-1).tolist()]
+            if len(set(y_lens)) != 1:
+                raise ValueError("cross-attention needs equal text lengths per sample (as the reference's torch_impl view does)")
+            B = len(y_lens)
+            yp = y.to(device=self.device, dtype=self.dtype).reshape(-1, C).contiguous()
+            if yp.shape[0] != sum(y_lens):
+                raise ValueError(f"y holds {yp.shape[0]} tokens, y_lens sum to {sum(y_lens)}")
+            return self._text_kv(y, mask, yp, y_lens, B, lens_key=tuple(y_lens))
+        B, _, L, Cc = y.shape
         yb = y.to(device=self.device, dtype=self.dtype).reshape(B * L, Cc).contiguous()
         h = ops.linear_small(yb, w["y_embedder.y_proj.fc1.weight"], w["y_embedder.y_proj.fc1.bias"], act_out=ops.ACT_GELU_TANH)
         ye = ops.linear_small(h, w["y_embedder.y_proj.fc2.weight"], w["y_embedder.y_proj.fc2.bias"]).view(B, L, C)
@@ -314,6 +332,11 @@ class STDiT3:
         else:
             y_lens = [L] * B
             yp = ye.reshape(B * L, C)
+        return self._text_kv(y, mask, yp, y_lens, B)
+
+    def _text_kv(self, y, mask, yp, y_lens, B, lens_key=None):
+        """Every block's kv_linear(y) and its attention layouts from the packed text tokens yp [B * Lk, C]; fills the cache."""
+        w, C, H = self.w, self.hidden_size, self.num_heads
         Lk = y_lens[0]
         nblk = 2 * self.depth
         kv_pad = ops.kv_pad_len(Lk)
@@ -328,7 +351,7 @@ class STDiT3:
                 ops.linear_small(yp, w[p + ".weight"], w[p + ".bias"], out=kv)
             ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kps[i], vts[i], B, H, Lk)
         self._text_cache = dict(y=y, y_version=y._version, mask=mask, mask_version=None if mask is None else mask._version,
-                                y_lens=y_lens, kp=kps, vt=vts, Lk=Lk)
+                                y_lens=y_lens, kp=kps, vt=vts, Lk=Lk, lens_key=lens_key)
         return self._text_cache
 
     def reset_text_cache(self):
