@@ -438,3 +438,52 @@ def test_skip_y_embedder_takes_projected_text_and_lengths():
         assert m.program_stats["replayed"] == 1
         with pytest.raises(ValueError):
             m(x, torch.tensor([500.0, 500.0]), y, **dict(kw, mask=[10, 12]))
+
+
+def test_generate_conditioning_and_loop_host_flow():
+    """OpenSoraPipeline.generate with references, a mask strategy and loop = 2 on CPU — kernels and the VAE faked — checks the
+    host sequence of pipeline_open_sora.py:528-535,607-645: references are collected (latents pass through, pixels are encoded),
+    the strategy is pasted into the start noise and held frames come back untouched, the second loop is conditioned on the
+    re-encoded tail of the first clip and the clips are joined in time with the 17-frame overlap removed."""
+    from videosys_amd import OpenSoraConfig
+    from videosys_amd.pipeline_open_sora import OpenSoraPipeline
+
+    class FakeVAE:
+        has_encoder = True
+
+        def __init__(self):
+            self.encoded, self.decoded = [], []
+
+        def encode(self, v):                       # [B, 3, T, H, W] -> [B, 4, ceil-ish(T / 17 * 5), H / 8, W / 8]
+            self.encoded.append(tuple(v.shape))
+            T = v.shape[2]
+            tz = (T // 17) * 5 + (-(-(T % 17) // 4) if T % 17 else 0)
+            return torch.full((v.shape[0], 4, tz, v.shape[3] // 8, v.shape[4] // 8), 0.5)
+
+        def __call__(self, z, num_frames):
+            self.decoded.append(tuple(z.shape))
+            return torch.zeros(z.shape[0], 3, num_frames, z.shape[3] * 8, z.shape[4] * 8)
+
+    with fake_ops():
+        vae = FakeVAE()
+        pipe = OpenSoraPipeline(OpenSoraConfig(transformer="synthetic:3", num_sampling_steps=3, transformer_config=CFG), device="cpu",
+                                text_encoder=None, vae_decoder=vae)
+        emb = torch.randn(1, 1, 16, 64)
+        pm = torch.ones(1, 16, dtype=torch.long)
+        kw = dict(prompt_embeds=emb, prompt_mask=pm, height=64, width=64, num_frames=34, seed=3, verbose=False)
+        lat_ref = torch.full((4, 2, 8, 8), 2.0)
+        out = pipe.generate(output_type="latent", refs=[lat_ref], ms="0,0,0,0,2,0", align=None, **kw).video
+        assert tuple(out.shape) == (1, 4, 10, 8, 8) and vae.encoded == []
+        assert torch.equal(out[0, :, :2].cpu(), lat_ref)                     # held (mask 0): pasted in, never touched by the sampler
+        img = torch.zeros(3, 1, 64, 64)
+        out = pipe.generate(output_type="latent", refs=[img], ms="0", **kw).video
+        assert vae.encoded == [(1, 3, 1, 64, 64)] and float(out[0, :, 0].mean()) == 0.5
+        vae.encoded.clear()
+        video = pipe.generate(loop=2, condition_frame_length=5, **kw).video
+        assert vae.encoded == [(1, 3, 34, 64, 64)] and len(vae.decoded) == 2
+        assert video.dtype == torch.uint8 and tuple(video.shape) == (1, 34 + 34 - 17, 64, 64, 3)
+        with pytest.raises(RuntimeError):
+            pipe.generate(loop=2, output_type="latent", **kw)
+        vae.has_encoder = False
+        with pytest.raises(RuntimeError):
+            pipe.generate(refs=[img], ms="0", **kw)
