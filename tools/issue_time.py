@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--depth", type=int, default=28)
     ap.add_argument("--sweep", action="store_true", help="with --dsp-rank: every (scatter, overlap) setting in one process")
     ap.add_argument("--program", type=int, default=-1, help="1 / 0: force the recorded launch program on / off (default: model default)")
+    ap.add_argument("--x-mask", type=int, default=0, help="N > 0: the conditioned step — the first N latent frames are conditioning frames (x_mask False)")
     args = ap.parse_args()
     from videosys_amd import ops
     from videosys_amd.stdit3 import STDiT3, STDiT3Config, synth_state_dict
@@ -58,6 +59,10 @@ def main():
     mask = torch.ones(1, 300, dtype=torch.long)
     kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([HH * 8.0] * 2), width=torch.tensor([WW * 8.0] * 2))
     t = torch.tensor([500.0, 500.0])
+    if args.x_mask:
+        xm = torch.ones(2, T, dtype=torch.bool)
+        xm[:, :args.x_mask] = False
+        kw["x_mask"] = xm
 
     def step():
         out = model(torch.cat([z, z], 0), t, y, **kw)
@@ -86,7 +91,9 @@ def main():
                        frames_on_this_rank_padded=dsp.frames_per_rank(2, T, args.dsp_rank, model._scatter),
                        ideal_frames=round(2 * T / args.dsp_rank, 3), wire="stubbed (device copy recv <- send)")
         if hasattr(model, "use_programs"):
-            rec["launch_program"] = bool(model.use_programs)
+            rec["launch_program"] = bool(model.use_programs) and not args.x_mask
+        if args.x_mask:
+            rec["x_mask_conditioning_frames"] = args.x_mask
         print(json.dumps(rec), flush=True)
 
     if args.sweep and args.dsp_rank > 1:
