@@ -122,8 +122,23 @@ def main():
     kv = rnd(600, 2 * C)
     kpc, vtc = ops.alloc_kv_buffers(2, H, 300, dev)
     ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kpc, vtc, 2, H, 300)
-    ms = timeit(lambda: ops.flash_attn(x, None, kpc, vtc, ao, 2, H, 19456, 300), args.reps)
-    res["flash_cross_L300"] = [(ms, 4.0 * 2 * H * 19456 * 300 * 72 / (ms * 1e-3) / 1e12)]
+    for rd in range(args.rounds):
+        for fv in [int(v) for v in args.flash_variants.split(',')]:
+            assert lib.vsys_tune_flash_variant(fv) == 0
+            ms = timeit(lambda: ops.flash_attn(x, None, kpc, vtc, ao, 2, H, 19456, 300), args.reps)
+            res.setdefault("flash_cross_L300" + (f"_v{fv}" if fv else ""), []).append((ms, 4.0 * 2 * H * 19456 * 300 * 72 / (ms * 1e-3) / 1e12))
+    lib.vsys_tune_flash_variant(0)
+    # every flash variant must give the default's bits (they differ in schedule only)
+    ref_s, ref_c = torch.empty_like(ao), torch.empty_like(ao)
+    ops.flash_attn(qkv[:, :C], qw, kp, vt, ref_s, 38, H, 1024, 1024)
+    ops.flash_attn(x, None, kpc, vtc, ref_c, 2, H, 19456, 300)
+    for fv in sorted(set(int(v) for v in args.flash_variants.split(',')) - {0}):
+        lib.vsys_tune_flash_variant(fv)
+        o1, o2 = torch.empty_like(ao), torch.empty_like(ao)
+        ops.flash_attn(qkv[:, :C], qw, kp, vt, o1, 38, H, 1024, 1024)
+        ops.flash_attn(x, None, kpc, vtc, o2, 2, H, 19456, 300)
+        print(f"  check flash variant {fv} == default: spatial {bool(torch.equal(o1, ref_s))}, cross {bool(torch.equal(o2, ref_c))}")
+    lib.vsys_tune_flash_variant(0)
     freqs = 1.0 / (10000 ** (torch.arange(0, 72, 2).float() / 72))
     ang = torch.einsum("p,f->pf", torch.arange(19).float(), freqs).repeat_interleave(2, -1)
     cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
