@@ -39,9 +39,10 @@ extern "C" {
 #define VSYS_ACT_SILU      1
 #define VSYS_ACT_GELU_TANH 2
 
+/* Library identity and error text — no reference counterpart (the reference is pure Python and has no FFI). */
 int vsys_abi_version(void);
 const char* vsys_strerror(int code);
-/* number of HIP devices visible to the library (fails loudly instead of falling back when 0) */
+/* number of HIP devices visible to the library (fails loudly instead of falling back when 0); no reference counterpart */
 int vsys_device_count(void);
 
 /* Kernel selection for A/B measurement and for the schedule-equivalence tests — NOT part of the per-call data path: the
@@ -57,7 +58,8 @@ int vsys_device_count(void);
  * flash: 0 = default (two workgroups per CU; resident K/V for few keys; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
  *        4 = VALU temporal kernel (v2) for T <= 40; 8 / 10 = the resident-K/V kernel (all KV tiles of a
  *        (batch, head) staged once per workgroup; default for <= 320 keys and many query rows) whenever the keys fit / never;
- *        9 = online-softmax temporal kernel for every T; 12 = the head-dim-64 kernel on a two-stage K/V ring (shipped: three). */
+ *        9 = online-softmax temporal kernel for every T; 12 = the head-dim-64 kernel on a two-stage K/V ring (shipped: three).
+ * No reference counterpart (measurement tooling). */
 int vsys_tune_gemm_variant(int variant);
 int vsys_tune_flash_variant(int variant);
 
@@ -200,7 +202,8 @@ int vsys_attn_prep_kv64(const void* k, int64_t k_stride, const void* v, int64_t 
                         const void* rope_cos_f32, const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, void* kp,
                         void* vt, int64_t batch, int64_t heads, int64_t kv_len, int64_t kv_pad, float eps, void* stream);
 
-/* softmax(q k^T / 8) v for head_dim 64, non-causal, with the q side of the processor above (LayerNorm + RoPE) applied on
+/* softmax(q k^T / 8) v for head_dim 64, non-causal (F.scaled_dot_product_attention in CogVideoXAttnProcessor2_0,
+ * cogvideox_transformer_3d.py:151-158), with the q side of the processor above (LayerNorm + RoPE, :108-149) applied on
  * the fly.  q(b,s,h) at q + (b*q_len + s)*q_stride + h*64; out likewise. */
 int vsys_flash_attn_d64(const void* q, int64_t q_stride, const void* ln_w, const void* ln_b, const void* rope_cos_f32,
                         const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, const void* kp, const void* vt, void* out,
@@ -222,11 +225,13 @@ int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* 
 
 /* ---- T5 text encoder (T5EncoderModel of transformers, third-party; called once per prompt at pipeline_open_sora.py:269-287,
  * pipeline_cogvideox.py:211-247, pipeline_latte.py) — the linears are vsys_conv_bf16 with one tap. */
-/* out[i, :] = table[ids[i], :] (nn.Embedding; ids int64 on the device, clamped to [0, vocab)). */
+/* out[i, :] = table[ids[i], :] (nn.Embedding = T5Stack.embed_tokens, transformers, third-party; ids int64 on the device, clamped
+ * to [0, vocab)). */
 int vsys_gather_rows(const void* table, const void* ids_i64, void* out, int64_t n, int64_t C, int64_t vocab, void* stream);
-/* T5LayerNorm: y = w * bf16(x * rsqrt(mean(x^2) + eps)), fp32 statistics, C <= 8192. */
+/* T5LayerNorm (transformers modeling_t5.py, third-party): y = w * bf16(x * rsqrt(mean(x^2) + eps)), fp32 statistics, C <= 8192. */
 int vsys_rms_norm_rows(const void* x, const void* w, void* y, int64_t rows, int64_t C, float eps, void* stream);
-/* T5DenseGatedActDense: out[r, f] = bf16(gelu_new(h[r, f])) * h[r, F + f], h = [wi_0 x | wi_1 x] of 2F columns. */
+/* T5DenseGatedActDense (transformers modeling_t5.py, third-party): out[r, f] = bf16(gelu_new(h[r, f])) * h[r, F + f],
+ * h = [wi_0 x | wi_1 x] of 2F columns. */
 int vsys_geglu(const void* h, void* out, int64_t rows, int64_t F, void* stream);
 /* Finish of a split-K, transposed skinny linear (few activation rows against a large weight — T5 at 300 tokens: every weight byte
  * is used for 300 MACs, so the layer is a weight stream): the GEMM ran as vsys_conv_bf16 with the WEIGHT as the row operand, the
@@ -236,7 +241,8 @@ int vsys_geglu(const void* h, void* out, int64_t rows, int64_t F, void* stream);
  * pipeline_open_sora.py:269-287). */
 int vsys_splitk_reduce_t(const void* part_f32, int64_t nsplit, int64_t slab, int64_t ldp, const void* res, int64_t ldr, void* out, int64_t ldo,
                          int64_t M, int64_t N, void* stream);
-/* T5Attention (encoder self-attention, d_kv = 64, no score scaling): softmax_j(q_i k_j + relbias[h][j - i + L - 1]) v over the
+/* T5Attention (transformers modeling_t5.py, third-party; encoder self-attention, d_kv = 64, no score scaling):
+ * softmax_j(q_i k_j + relbias[h][j - i + L - 1]) v over the
  * first klen[b] keys.  qkv rows (b, l) of row_stride elements, q | k | v at column 0 | inner | 2 inner, head h at h*64;
  * relbias fp32 [heads, 2L-1]; klen int32 [B] on the device; L <= 512. */
 int vsys_t5_attention(const void* qkv, int64_t row_stride, int64_t inner, const void* relbias_f32, const void* klen_i32, void* out,
@@ -250,7 +256,8 @@ int vsys_gemm_skinny_slices(const void* w, int64_t ldw, const void* x, int64_t l
                             int64_t N, int64_t K, int64_t nsplit, void* stream);
 int vsys_splitk_reduce(const void* part_f32, int64_t nsplit, int64_t slab, int64_t ldp, const void* res, int64_t ldr, void* out, int64_t ldo,
                        int64_t M, int64_t N, void* stream);
-/* The same attention on the matrix pipe, ONE sample per call (its own key length kv_len <= L): the head_dim-64 flash kernel with
+/* The same attention (T5Attention, transformers modeling_t5.py, third-party; call sites pipeline_open_sora.py:269-287) on the matrix
+ * pipe, ONE sample per call (its own key length kv_len <= L): the head_dim-64 flash kernel with
  * an additive (head, key - query) logit bias.  qkv bf16 rows [L, 3*inner] (q | k | v, head h at h*64); bias_f32 [heads, bias_ld]
  * holds log2(e) * T5Attention.compute_bias, entry of (h, key - query) at bias_center + key - query, padded by the caller so that
  * every key < 64*ceil(L/64) and query < 128*ceil(L/128) stays inside (bias_center >= 128*ceil(L/128) - 1, bias_ld >= bias_center +
@@ -279,7 +286,8 @@ int vsys_conv_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const
  * norm1/norm2): stats_f32[n][group] = (mean, 1/sqrt(var + eps)).  partial_f32 is scratch of N*nblk*(C/4)*2 floats. */
 int vsys_gn_stats(const void* x, const int64_t* grid, int64_t N, int64_t C, int64_t groups, float eps, void* partial_f32,
                   int64_t nblk, void* stats_f32, void* stream);
-/* y = act(bf16((x - mean) * rstd * gamma + beta)), act = VSYS_ACT_NONE | VSYS_ACT_SILU, interior rows of grid_dst only. */
+/* y = act(bf16((x - mean) * rstd * gamma + beta)), act = VSYS_ACT_NONE | VSYS_ACT_SILU, interior rows of grid_dst only: the
+ * GroupNorm (+ SiLU) of ResBlock.forward (autoencoder_kl_open_sora.py:152-164) / diffusers ResnetBlock2D with vsys_gn_stats. */
 int vsys_gn_apply(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t C, int64_t groups,
                   const void* stats_f32, const void* gamma, const void* beta, int act, void* stream);
 /* grid-to-grid copy of the interior; up = 1: nearest-neighbour 2x upsampling in H and W (diffusers Upsample2D before its conv).
@@ -306,7 +314,9 @@ int vsys_blend_edge(const void* a, void* b, int64_t outer, int64_t Ha, int64_t W
                     void* stream);
 /* temporal depth-to-space "B (C ts) T H W -> B C (T ts) H W", ts = 2 (autoencoder_kl_open_sora.py:362-368): x has 2*Cout channels. */
 int vsys_d2s_time(const void* x, const int64_t* grid_src, void* y, const int64_t* grid_dst, int64_t N, int64_t Cout, void* stream);
-/* First decoder layer: planar bf16 latent z[4][F][H][W] -> z*scale + shift -> 1x1 post_quant_conv -> im2col rows
+/* First decoder layer (VideoAutoencoderPipeline.decode z * scale + shift, autoencoder_kl_open_sora.py:676-677; post_quant_conv
+ * + Decoder.conv1 :459,355-357; also the encoders' first convolutions with identity parameters): planar bf16 latent
+ * z[4][F][H][W] -> z*scale + shift -> 1x1 post_quant_conv -> im2col rows
  * [F*H*W, kcols] (column = tap*4 + channel, zero padding; kt = 3: causal, two virtual zero frames in front).
  * params (HOST floats): scale[4], shift[4], pq_w[4][4], pq_b[4]. */
 int vsys_vae_first_im2col(const void* z, int64_t F, int64_t H, int64_t W, int64_t kt, int64_t kcols, const float* params,
@@ -316,7 +326,8 @@ int vsys_vae_first_im2col(const void* z, int64_t F, int64_t H, int64_t W, int64_
 int vsys_extract_planar(const void* x, const int64_t* grid, int64_t N, int64_t ldx, int64_t nc, int64_t tskip, void* out,
                         int64_t Ftot, int64_t f0, void* stream);
 /* row softmax over the first n of ld columns, fp32 [rows, ld] -> bf16 [rows, ld] with zeros in columns n..ld-1 (mid-block
- * attention of the 2-D decoder, keys padded to the 128-column tile; n % 4 == 0, ld % 4 == 0, ld <= 8192). */
+ * attention of the 2-D VAE — diffusers Attention under VideoAutoencoderKL.decode / .encode, autoencoder_kl_open_sora.py:503-538 —
+ * keys padded to the 128-column tile; n % 4 == 0, ld % 4 == 0, ld <= 8192). */
 int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64_t ld, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------------------
@@ -361,7 +372,8 @@ typedef struct vsys_cmd {
   float f[2];      /* float arguments, declaration order */
 } vsys_cmd;
 
-/* arity of an op (what the recorder must fill): 0, or VSYS_ERR_ARG for an unknown op */
+/* arity of an op (what the recorder must fill): 0, or VSYS_ERR_ARG for an unknown op.  (vsys_program_*: no reference counterpart —
+ * the reference issues every op from Python every step, open_sora_transformer_3d.py:608-613.) */
 int vsys_program_op_info(int op, int* n_int, int* n_float);
 int vsys_program_run(const vsys_cmd* cmds, int64_t n, void* const* streams, int64_t n_streams, int64_t* failed_at);
 

@@ -723,3 +723,19 @@ def test_conditioning_prompt_and_loop_helpers(tmp_path):
         K.read_from_path("clip.mp4", (32, 32))
     with pytest.raises(RuntimeError):
         K.collect_references_batch([path], None, (32, 32))
+
+
+def test_every_entry_point_of_the_header_cites_what_it_replaces():
+    """include/videosys_amd.h: the comment in front of every exported function names the reference file (``*.py:line``) it replaces,
+    says that the piece is third-party in the reference, or states that there is no reference counterpart."""
+    with open(os.path.join(ROOT, "include", "videosys_amd.h")) as fh:
+        s = fh.read()
+    missing = []
+    for m in re.finditer(r"^(?:int|const char\*|void|int64_t)\s+(vsys_\w+)\(", s, flags=re.M):
+        pre = s[:m.start()]
+        j = pre.rfind("*/")
+        i = pre.rfind("/*", 0, j)
+        c = pre[i:j].lower()
+        if not (".py" in c or "no reference counterpart" in c or "third-party" in c):
+            missing.append(m.group(1))
+    assert not missing, missing
