@@ -61,6 +61,21 @@ def test_cogvideox_sampling_golden():
     check(out, fx["out"], rel=5e-2, what=f"cogvideox {fx['steps']}-step latents")
 
 
+def test_cogvideox_without_classifier_free_guidance():
+    """guidance_scale <= 1 (pipeline_cogvideox.py:627,706-708 skipped): same latents as the CFG run whose negative prompt equals
+    the prompt (cond == uncond bit for bit, so the guidance term vanishes)."""
+    from videosys_amd import CogVideoXConfig, CogVideoXPipeline
+
+    fx = load_golden("cogvideox_sample_small.pt")
+    pipe = CogVideoXPipeline(CogVideoXConfig(model_path=f"THUDM/CogVideoX-5b@synthetic:{fx['seed']}",
+                                             transformer_config=fx["cfg"]), device=dev())
+    kw = dict(prompt_embeds=fx["pos"], latents=fx["latents"], height=64, width=96, num_frames=9, num_inference_steps=fx["steps"],
+              output_type="latent")
+    a = pipe.generate(negative_prompt_embeds=fx["pos"], guidance_scale=fx["guidance"], **kw).video
+    b = pipe.generate(guidance_scale=1.0, **kw).video
+    assert torch.equal(a, b) and torch.isfinite(b).all()
+
+
 def test_cogvideox_pab_golden():
     from videosys_amd import pab
 

@@ -67,6 +67,21 @@ def test_latte_sampling_golden():
     check(out, fx["out"], rel=5e-2, what=f"latte {fx['steps']}-step DDIM latents")
 
 
+def test_latte_without_classifier_free_guidance():
+    """guidance_scale <= 1 (do_classifier_free_guidance False, pipeline_latte.py:749,828-831): the model runs on the prompt batch
+    alone.  The CFG run with the negative prompt EQUAL to the prompt computes uncond + g (cond - uncond) with cond == uncond bit
+    for bit, i.e. the same prediction: both runs must give the same latents exactly."""
+    from videosys_amd import LatteConfig, LattePipeline
+
+    fx = load_golden("latte_sample_small.pt")
+    pipe = LattePipeline(LatteConfig(model_path=f"synthetic:{fx['seed']}", transformer_config=fx["cfg"]), device=dev())
+    kw = dict(prompt_embeds=fx["pos"], prompt_mask=fx["pmask"], latents=fx["latents"], num_inference_steps=fx["steps"], output_type="latent")
+    a = pipe.generate(negative_prompt_embeds=fx["pos"], negative_mask=fx["pmask"], guidance_scale=fx["guidance"], **kw).video
+    b = pipe.generate(guidance_scale=1.0, **kw).video
+    assert torch.equal(a, b)
+    assert torch.isfinite(b).all() and not torch.equal(b.cpu(), fx["latents"].to(b.dtype))
+
+
 def test_latte_pab_golden():
     from videosys_amd import pab
 

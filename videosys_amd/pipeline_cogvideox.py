@@ -222,9 +222,9 @@ class CogVideoXPipeline(StagedOffloadMixin):
                 raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, 226, 4096]")
             self._enter_stage("text_encoder")
             prompt_embeds = self.text_encoder(prompt)
-            negative_prompt_embeds = self.text_encoder(negative_prompt or "")
-        if guidance_scale <= 1.0:
-            raise NotImplementedError("the MI355X path runs the classifier-free-guidance batch (guidance_scale > 1)")
+            if guidance_scale > 1.0:
+                negative_prompt_embeds = self.text_encoder(negative_prompt or "")
+        cfg = guidance_scale > 1.0        # do_classifier_free_guidance (:627): without it the model runs on the prompt batch alone
         from .utils import set_seed
 
         seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
@@ -233,7 +233,8 @@ class CogVideoXPipeline(StagedOffloadMixin):
         self.transformer.reset_pab_state()
         self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
         B = prompt_embeds.shape[0]
-        emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+        emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0) if cfg else prompt_embeds
+        nb = (2 if cfg else 1) * B
         self.scheduler.set_timesteps(num_inference_steps)
         c = self.transformer.config
         lat_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
@@ -245,12 +246,14 @@ class CogVideoXPipeline(StagedOffloadMixin):
         rope = self._prepare_rotary_positional_embeddings(height, width, z.shape[1]) if c.use_rotary_positional_embeddings else None
         zf = z.view(B, 1, -1)  # the step kernel sees [Bz, Cin = 1, thw]: CogVideoX predicts all 16 channels (no sigma half)
         for t in self.scheduler.timesteps:
-            out = self.transformer(z, emb, torch.full((2 * B,), t, dtype=torch.int64), image_rotary_emb=rope,
+            out = self.transformer(z, emb, torch.full((nb,), t, dtype=torch.int64), image_rotary_emb=rope,
                                    return_dict=False)[0]
             g_t = guidance_scale
             if use_dynamic_cfg:  # :702-705
                 g_t = 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
             c_z, c_v = self.scheduler.coeffs(t)
+            if not cfg:   # (:706-708 skipped) the step kernel combines two halves: the prediction twice at guidance 1 is the prediction
+                out, g_t = torch.cat([out, out], 0), 1.0
             ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, c_z, c_v, cond_first=False)
             z.copy_(z.to(torch.bfloat16).float())  # latents = latents.to(prompt_embeds.dtype) (:723)
         if self.vae_decoder is None or output_type in ("latent", "latents"):

@@ -194,9 +194,9 @@ class LattePipeline(StagedOffloadMixin):
                 else text_preprocessing(t, clean_caption, mid_strip=False)
             self._enter_stage("text_encoder")
             prompt_embeds, prompt_mask = self.text_encoder(prep(prompt))
-            negative_prompt_embeds, negative_mask = self.text_encoder(prep(negative_prompt))
-        if guidance_scale <= 1.0:
-            raise NotImplementedError("the MI355X path runs the classifier-free-guidance batch (guidance_scale > 1)")
+            if guidance_scale > 1.0:
+                negative_prompt_embeds, negative_mask = self.text_encoder(prep(negative_prompt))
+        cfg = guidance_scale > 1.0        # do_classifier_free_guidance (:749): without it the model runs on the prompt batch alone
         from .utils import set_seed
 
         seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
@@ -205,8 +205,12 @@ class LattePipeline(StagedOffloadMixin):
         self.transformer.reset_pab_state()
         self.transformer.reset_text_cache()   # per-prompt projections never outlive a generate()
         B = prompt_embeds.shape[0]
-        emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
-        mask = None if prompt_mask is None else torch.cat([negative_mask, prompt_mask], dim=0)
+        if cfg:
+            emb = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0)
+            mask = None if prompt_mask is None else torch.cat([negative_mask, prompt_mask], dim=0)
+        else:
+            emb, mask = prompt_embeds, prompt_mask
+        nb = (2 if cfg else 1) * B
         self.scheduler.set_timesteps(num_inference_steps)
         ts = self.scheduler.timesteps
         cin = self.transformer.in_channels
@@ -216,12 +220,14 @@ class LattePipeline(StagedOffloadMixin):
         z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
         all_ts = torch.tensor(ts)
         for t in ts:
-            tt = torch.full((2 * B,), t, dtype=torch.int64)
+            tt = torch.full((nb,), t, dtype=torch.int64)
             out = self.transformer(z, timestep=tt, all_timesteps=all_ts, encoder_hidden_states=emb,
                                    encoder_attention_mask=mask, added_cond_kwargs={"resolution": None, "aspect_ratio": None},
                                    enable_temporal_attentions=True, return_dict=False)[0]
             c_z, c_eps = self.scheduler.coeffs(t)
-            ops.cfg_linear_step(z, out, guidance_scale, c_z, c_eps, cond_first=False)
+            if not cfg:   # the step kernel combines two halves: hand it the prediction twice at guidance 1 (u + 1 (u - u) = u exactly)
+                out = torch.cat([out, out], 0)
+            ops.cfg_linear_step(z, out, guidance_scale if cfg else 1.0, c_z, c_eps, cond_first=False)
         if self.vae_decoder is None or output_type in ("latent", "latents"):
             self._enter_stage(None)
             return VideoSysPipelineOutput(video=z)
