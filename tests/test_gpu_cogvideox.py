@@ -74,6 +74,21 @@ def test_cogvideox_without_classifier_free_guidance():
     a = pipe.generate(negative_prompt_embeds=fx["pos"], guidance_scale=fx["guidance"], **kw).video
     b = pipe.generate(guidance_scale=1.0, **kw).video
     assert torch.equal(a, b) and torch.isfinite(b).all()
+    # the reference's other keywords: tuple return, a step callback that may replace the latents, a caller-owned generator
+    seen = []
+
+    def cb(p, i, t, kw_):
+        seen.append(i)
+        return {"latents": kw_["latents"]} if i else {"latents": kw_["latents"] * 0}
+
+    out = pipe.generate(guidance_scale=1.0, return_dict=False, callback_on_step_end=cb, **kw)
+    assert isinstance(out, tuple) and seen == list(range(fx["steps"])) and not torch.equal(out[0], b)
+    kw2 = {k: v for k, v in kw.items() if k != "latents"}
+    g1 = pipe.generate(guidance_scale=1.0, generator=torch.Generator().manual_seed(5), **kw2).video
+    g2 = pipe.generate(guidance_scale=1.0, generator=torch.Generator().manual_seed(5), seed=123, **kw2).video
+    assert torch.equal(g1, g2)
+    with pytest.raises(NotImplementedError):
+        pipe.generate(timesteps=[999, 500], **kw)
 
 
 def test_cogvideox_pab_golden():

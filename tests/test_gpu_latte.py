@@ -82,6 +82,43 @@ def test_latte_without_classifier_free_guidance():
     assert torch.isfinite(b).all() and not torch.equal(b.cpu(), fx["latents"].to(b.dtype))
 
 
+def test_latte_text_prompts_follow_encode_prompt_masking():
+    """Text prompts through generate() (encode_prompt, pipeline_latte.py:287-445): a single prompt's embeddings — and the negative
+    ones with them — are cut to the prompt's token count and the transformer sees no attention mask; with mask_feature=False the
+    full padded length is attended.  Checked against generate() fed the equivalent embeddings directly (bit-equal)."""
+    from videosys_amd import LatteConfig, LattePipeline
+
+    class FakeText:   # (embeddings [B, 1, 16, 64], mask [B, 16]) like t5.T5TextEncoder; deterministic in the prompt text
+        def __call__(self, prompts):
+            prompts = [prompts] if isinstance(prompts, str) else list(prompts)
+            emb, mask = [], torch.zeros(len(prompts), 16, dtype=torch.long)
+            for b, q in enumerate(prompts):
+                g = torch.Generator().manual_seed(sum(q.encode()) + 7)
+                emb.append(torch.randn(1, 16, 64, generator=g).to(torch.bfloat16))
+                mask[b, :min(len(q) + 1, 16)] = 1
+            return torch.stack(emb, 0), mask
+
+    fx = load_golden("latte_sample_small.pt")
+    te = FakeText()
+    pipe = LattePipeline(LatteConfig(model_path=f"synthetic:{fx['seed']}", transformer_config=fx["cfg"]), device=dev(), text_encoder=te)
+    kw = dict(latents=fx["latents"], num_inference_steps=fx["steps"], guidance_scale=fx["guidance"], output_type="latent")
+    a = pipe.generate(prompt="a red cat", negative_prompt="", clean_caption=False, **kw).video
+    pe, pm = te("a red cat")
+    ne, _ = te("")
+    keep = int(pm.sum())
+    assert keep == 10
+    b = pipe.generate(prompt_embeds=pe[:, 0, :keep], negative_prompt_embeds=ne[:, 0, :keep], **kw).video
+    assert torch.equal(a, b)
+    c = pipe.generate(prompt="a red cat", negative_prompt="", clean_caption=False, mask_feature=False, **kw).video
+    d = pipe.generate(prompt_embeds=pe[:, 0], negative_prompt_embeds=ne[:, 0], **kw).video
+    assert torch.equal(c, d) and not torch.equal(a, c)
+    seen = []
+    out = pipe.generate(prompt="a red cat", clean_caption=True, return_dict=False, callback=lambda i, t, z: seen.append((i, t)), callback_steps=2, **kw)
+    assert isinstance(out, tuple) and torch.equal(out[0], a) and [i for i, _ in seen] == list(range(0, fx["steps"], 2))
+    with pytest.raises(NotImplementedError):
+        pipe.generate(prompt="x", eta=0.5, **kw)
+
+
 def test_latte_pab_golden():
     from videosys_amd import pab
 

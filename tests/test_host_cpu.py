@@ -739,3 +739,27 @@ def test_every_entry_point_of_the_header_cites_what_it_replaces():
         if not (".py" in c or "no reference counterpart" in c or "third-party" in c):
             missing.append(m.group(1))
     assert not missing, missing
+
+
+def test_generate_accepts_every_keyword_of_the_reference():
+    """Every keyword of the reference's ``generate`` (Open-Sora, Latte, CogVideoX pipelines) exists on this build's ``generate``
+    (values the path cannot honour are refused with an error that says so, not with a TypeError about the keyword)."""
+    import ast
+    import inspect
+
+    ref_root = "/root/reference/videosys/pipelines"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present on this box")
+    from videosys_amd.pipeline_cogvideox import CogVideoXPipeline
+    from videosys_amd.pipeline_latte import LattePipeline
+    from videosys_amd.pipeline_open_sora import OpenSoraPipeline
+
+    for path, cls, ours in (("open_sora/pipeline_open_sora.py", "OpenSoraPipeline", OpenSoraPipeline),
+                            ("latte/pipeline_latte.py", "LattePipeline", LattePipeline),
+                            ("cogvideox/pipeline_cogvideox.py", "CogVideoXPipeline", CogVideoXPipeline)):
+        src = open(os.path.join(ref_root, path)).read()
+        fn = next(it for n in ast.parse(src).body if isinstance(n, ast.ClassDef) and n.name == cls
+                  for it in n.body if isinstance(it, ast.FunctionDef) and it.name == "generate")
+        want = [a.arg for a in fn.args.args + fn.args.kwonlyargs if a.arg != "self"]
+        have = set(inspect.signature(ours.generate).parameters)
+        assert not [a for a in want if a not in have], (cls, [a for a in want if a not in have])

@@ -215,8 +215,19 @@ class CogVideoXPipeline(StagedOffloadMixin):
                  num_inference_steps: int = 50, guidance_scale: float = 6, use_dynamic_cfg: bool = False, seed: int = -1,
                  verbose: bool = False, *, prompt_embeds: Optional[torch.Tensor] = None,
                  negative_prompt_embeds: Optional[torch.Tensor] = None, latents: Optional[torch.Tensor] = None,
-                 output_type: str = "auto"):
-        """pipeline_cogvideox.py:498-755 for text-to-video (CFG batch [negative | prompt], eta = 0)."""
+                 output_type: str = "auto", timesteps=None, num_videos_per_prompt: int = 1, eta: float = 0.0,
+                 generator: Optional[torch.Generator] = None, return_dict: bool = True, callback_on_step_end=None,
+                 callback_on_step_end_tensor_inputs=("latents",), max_sequence_length: int = 226):
+        """pipeline_cogvideox.py:498-755 for text-to-video (CFG batch [negative | prompt], eta = 0).  The reference's other
+        keywords keep their meaning where the path has them: ``generator`` draws the start latents, ``callback_on_step_end(self,
+        i, t, {"latents": ...})`` may hand back new latents (:725-734), ``return_dict=False`` returns a tuple; ``timesteps`` (a
+        custom schedule), ``eta`` != 0 and ``num_videos_per_prompt`` != 1 (the reference overrides it to 1, :603) are refused."""
+        if timesteps is not None:
+            raise NotImplementedError("custom timestep schedules: the CogVideoX DDIM schedule is set from num_inference_steps")
+        if eta != 0.0:
+            raise NotImplementedError("the scheduler step is DDIM with eta = 0 (what the reference pipeline runs)")
+        if any(k != "latents" for k in callback_on_step_end_tensor_inputs):
+            raise ValueError("callback_on_step_end_tensor_inputs: only 'latents' is a per-step tensor of this path")
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, 226, 4096]")
@@ -239,13 +250,14 @@ class CogVideoXPipeline(StagedOffloadMixin):
         c = self.transformer.config
         lat_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
         if latents is None:
-            g = torch.Generator(device="cpu").manual_seed(seed)
+            g = generator if generator is not None else torch.Generator(device="cpu").manual_seed(seed)
             latents = torch.randn(B, lat_frames, c.in_channels, height // self.vae_scale_factor_spatial,
-                                  width // self.vae_scale_factor_spatial, generator=g, dtype=torch.float32)
+                                  width // self.vae_scale_factor_spatial, generator=g, dtype=torch.float32,
+                                  device=getattr(g, "device", "cpu")).cpu()
         z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
         rope = self._prepare_rotary_positional_embeddings(height, width, z.shape[1]) if c.use_rotary_positional_embeddings else None
         zf = z.view(B, 1, -1)  # the step kernel sees [Bz, Cin = 1, thw]: CogVideoX predicts all 16 channels (no sigma half)
-        for t in self.scheduler.timesteps:
+        for step_i, t in enumerate(self.scheduler.timesteps):
             out = self.transformer(z, emb, torch.full((nb,), t, dtype=torch.int64), image_rotary_emb=rope,
                                    return_dict=False)[0]
             g_t = guidance_scale
@@ -256,17 +268,21 @@ class CogVideoXPipeline(StagedOffloadMixin):
                 out, g_t = torch.cat([out, out], 0), 1.0
             ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, c_z, c_v, cond_first=False)
             z.copy_(z.to(torch.bfloat16).float())  # latents = latents.to(prompt_embeds.dtype) (:723)
+            if callback_on_step_end is not None:   # (:725-734)
+                back = callback_on_step_end(self, step_i, t, {"latents": z})
+                if isinstance(back, dict) and back.get("latents") is not None and back["latents"] is not z:
+                    z.copy_(back["latents"].to(z.device, z.dtype))
         if self.vae_decoder is None or output_type in ("latent", "latents"):
             self._enter_stage(None)
-            return VideoSysPipelineOutput(video=z)
+            return VideoSysPipelineOutput(video=z) if return_dict else (z,)
         self._enter_stage("vae")
         frames = self.vae_decoder(z.to(torch.bfloat16))   # decode_latents (:359-364) -> [B, 3, T, H, W]
         self._enter_stage(None)
         if not torch.is_tensor(frames) or frames.dtype == torch.uint8:
-            return VideoSysPipelineOutput(video=frames)
+            return VideoSysPipelineOutput(video=frames) if return_dict else (frames,)
         # VideoProcessor.postprocess_video (diffusers, third-party) denormalises to [0, 1]; here: uint8 [B, T, H, W, C] on the CPU
         video = ((frames.float() / 2.0 + 0.5).clamp(0, 1) * 255).round().permute(0, 2, 3, 4, 1).to("cpu", torch.uint8)
-        return VideoSysPipelineOutput(video=video)
+        return VideoSysPipelineOutput(video=video) if return_dict else (video,)
 
     def save_video(self, video, output_path):
         from .utils import save_video

@@ -180,11 +180,23 @@ class LattePipeline(StagedOffloadMixin):
                  negative_prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
                  negative_mask: Optional[torch.Tensor] = None, latents: Optional[torch.Tensor] = None,
                  video_length: int = 16, height: int = 512, width: int = 512, output_type: str = "auto",
-                 clean_caption: bool = True):
+                 clean_caption: bool = True, mask_feature: bool = True, num_images_per_prompt: int = 1, eta: float = 0.0,
+                 generator: Optional[torch.Generator] = None, return_dict: bool = True, callback: Optional[Callable] = None,
+                 callback_steps: int = 1, enable_temporal_attentions: bool = True):
         """pipeline_latte.py:675-900 for text-to-video: CFG batch [negative | prompt], learned-sigma half dropped,
         DDIM eta = 0.  ``height/width/video_length`` are the reference's hard-coded 512/512/16 by default (:764-766);
         BASELINE config 1 (256x256) passes them explicitly.  ``clean_caption`` (default True as :692): prompt and negative prompt
-        go through _text_preprocessing (:519-531: the IF caption cleaner twice, caption.py) before the tokenizer."""
+        go through _text_preprocessing (:519-531: the IF caption cleaner twice, caption.py) before the tokenizer.  Text prompts
+        follow encode_prompt (:287-445): the negative prompt is encoded once per prompt at the same length, and with
+        ``mask_feature`` (default) a single prompt's embeddings — and the negative ones with them — are CUT to the prompt's token
+        count, a batch's are zeroed past each prompt's tokens; the transformer then sees no attention mask, as in the reference.
+        ``prompt_mask`` / ``negative_mask`` (an extension) apply to embeddings the caller hands over.  The remaining reference
+        keywords keep their meaning: ``generator`` draws the start latents, ``callback(i, t, latents)`` every ``callback_steps``
+        steps, ``return_dict=False`` returns a tuple, ``eta`` must be 0 (DDIM as the reference runs it), ``num_images_per_prompt`` 1."""
+        if eta != 0.0:
+            raise NotImplementedError("the scheduler step is DDIM with eta = 0 (what the reference pipeline runs)")
+        if num_images_per_prompt != 1:
+            raise NotImplementedError("num_images_per_prompt > 1: pass the prompt that many times")
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, L, 4096]")
@@ -193,9 +205,23 @@ class LattePipeline(StagedOffloadMixin):
             prep = lambda t: [text_preprocessing(v, clean_caption, mid_strip=False) for v in t] if isinstance(t, (list, tuple)) \
                 else text_preprocessing(t, clean_caption, mid_strip=False)
             self._enter_stage("text_encoder")
-            prompt_embeds, prompt_mask = self.text_encoder(prep(prompt))
-            if guidance_scale > 1.0:
-                negative_prompt_embeds, negative_mask = self.text_encoder(prep(negative_prompt))
+            flat = lambda e: e.reshape(e.shape[0], e.shape[-2], e.shape[-1])     # encoders may return [B, 1, L, d]
+            prompt_embeds, pm = self.text_encoder(prep(prompt))
+            prompt_embeds = flat(prompt_embeds)
+            nb_p = prompt_embeds.shape[0]
+            if guidance_scale > 1.0:   # uncond_tokens = [negative_prompt] * batch_size at the prompt's padded length (:391-409)
+                neg = prep(negative_prompt)
+                negative_prompt_embeds, _ = self.text_encoder([neg] * nb_p if isinstance(neg, str) else list(neg))
+                negative_prompt_embeds = flat(negative_prompt_embeds)
+            if mask_feature:           # mask_text_embeddings (:278-284, 425-442)
+                if nb_p == 1:
+                    keep = int(pm.reshape(1, -1).sum())
+                    prompt_embeds = prompt_embeds[:, :keep]
+                    if guidance_scale > 1.0:
+                        negative_prompt_embeds = negative_prompt_embeds[:, :keep]
+                else:
+                    prompt_embeds = prompt_embeds * pm.reshape(nb_p, -1, 1).to(device=prompt_embeds.device, dtype=prompt_embeds.dtype)
+            prompt_mask = negative_mask = None
         cfg = guidance_scale > 1.0        # do_classifier_free_guidance (:749): without it the model runs on the prompt batch alone
         from .utils import set_seed
 
@@ -215,26 +241,29 @@ class LattePipeline(StagedOffloadMixin):
         ts = self.scheduler.timesteps
         cin = self.transformer.in_channels
         if latents is None:
-            g = torch.Generator(device="cpu").manual_seed(seed)
-            latents = torch.randn(B, cin, video_length, height // 8, width // 8, generator=g, dtype=torch.float32)
+            g = generator if generator is not None else torch.Generator(device="cpu").manual_seed(seed)
+            latents = torch.randn(B, cin, video_length, height // 8, width // 8, generator=g, dtype=torch.float32,
+                                  device=getattr(g, "device", "cpu")).cpu()
         z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
         all_ts = torch.tensor(ts)
-        for t in ts:
+        for step_i, t in enumerate(ts):
             tt = torch.full((nb,), t, dtype=torch.int64)
             out = self.transformer(z, timestep=tt, all_timesteps=all_ts, encoder_hidden_states=emb,
                                    encoder_attention_mask=mask, added_cond_kwargs={"resolution": None, "aspect_ratio": None},
-                                   enable_temporal_attentions=True, return_dict=False)[0]
+                                   enable_temporal_attentions=enable_temporal_attentions, return_dict=False)[0]
             c_z, c_eps = self.scheduler.coeffs(t)
             if not cfg:   # the step kernel combines two halves: hand it the prediction twice at guidance 1 (u + 1 (u - u) = u exactly)
                 out = torch.cat([out, out], 0)
             ops.cfg_linear_step(z, out, guidance_scale if cfg else 1.0, c_z, c_eps, cond_first=False)
+            if callback is not None and step_i % callback_steps == 0:   # (:880-885)
+                callback(step_i, t, z)
         if self.vae_decoder is None or output_type in ("latent", "latents"):
             self._enter_stage(None)
-            return VideoSysPipelineOutput(video=z)
+            return VideoSysPipelineOutput(video=z) if return_dict else (z,)
         self._enter_stage("vae")
         video = self.vae_decoder(z)
         self._enter_stage(None)
-        return VideoSysPipelineOutput(video=video)
+        return VideoSysPipelineOutput(video=video) if return_dict else (video,)
 
     def save_video(self, video, output_path):
         from .utils import save_video
