@@ -763,3 +763,128 @@ def test_generate_accepts_every_keyword_of_the_reference():
         want = [a.arg for a in fn.args.args + fn.args.kwonlyargs if a.arg != "self"]
         have = set(inspect.signature(ours.generate).parameters)
         assert not [a for a in want if a not in have], (cls, [a for a in want if a not in have])
+
+
+def test_pipelines_and_engine_have_every_method_of_the_reference_classes():
+    """Every method / property name of the reference's pipeline classes and of its engine exists on this build's classes (a call
+    site written against the reference finds what it calls)."""
+    import ast
+
+    ref_root = "/root/reference/videosys"
+    if not os.path.isdir(ref_root):
+        pytest.skip("reference tree not present on this box")
+    from videosys_amd.engine import VideoSysEngine
+    from videosys_amd.pipeline_cogvideox import CogVideoXPipeline
+    from videosys_amd.pipeline_latte import LattePipeline
+    from videosys_amd.pipeline_open_sora import OpenSoraPipeline
+
+    internal = {"_create_pipeline"}   # runs inside the worker process here (engine._worker_main), not a method of the engine
+    for path, cls, ours in (("pipelines/open_sora/pipeline_open_sora.py", "OpenSoraPipeline", OpenSoraPipeline),
+                            ("pipelines/latte/pipeline_latte.py", "LattePipeline", LattePipeline),
+                            ("pipelines/cogvideox/pipeline_cogvideox.py", "CogVideoXPipeline", CogVideoXPipeline),
+                            ("core/engine/engine.py", "VideoSysEngine", VideoSysEngine)):
+        node = next(n for n in ast.parse(open(os.path.join(ref_root, path)).read()).body if isinstance(n, ast.ClassDef) and n.name == cls)
+        names = [it.name for it in node.body if isinstance(it, ast.FunctionDef)]
+        missing = [n for n in names if not hasattr(ours, n) and n not in internal]
+        assert not missing, (cls, missing)
+
+
+class _FakeText:
+    """(embeddings [B, 1, L, 8], mask [B, L]) like t5.T5TextEncoder; deterministic in the prompt text; records what it was asked."""
+
+    def __init__(self, L=12):
+        self.max_length, self.calls = L, []
+
+    def __call__(self, prompts):
+        prompts = [prompts] if isinstance(prompts, str) else list(prompts)
+        self.calls.append(prompts)
+        emb, mask = [], torch.zeros(len(prompts), self.max_length, dtype=torch.long)
+        for b, q in enumerate(prompts):
+            g = torch.Generator().manual_seed(sum(q.encode()) + 7)
+            emb.append(torch.randn(1, self.max_length, 8, generator=g))
+            mask[b, :min(len(q.split()) + 1, self.max_length)] = 1
+        return torch.stack(emb, 0), mask
+
+
+def test_latte_prompt_helpers_follow_the_reference():
+    """encode_prompt / mask_text_embeddings / _text_preprocessing / check_inputs / prepare_latents of LattePipeline
+    (pipeline_latte.py:278-284, 287-445, 465-531, 649-672) — host logic, no device needed."""
+    from types import SimpleNamespace
+
+    from videosys_amd.pipeline_latte import LattePipeline
+
+    pipe = object.__new__(LattePipeline)
+    pipe.text_encoder = te = _FakeText()
+    pipe.scheduler = SimpleNamespace(init_noise_sigma=1.0)
+    assert pipe._text_preprocessing("  A Cat  ") == ["a cat"] and pipe._text_preprocessing(["A", "B "], clean_caption=False) == ["a", "b"]
+    assert pipe._text_preprocessing("see www.example.com <b>A Cat</b>", clean_caption=True) == ["see a cat"]
+    # one prompt: cut to its token count, the negative with it; the negative is encoded once per prompt
+    pe, ne = pipe.encode_prompt("a red cat", "", True)
+    full, m = _FakeText()("a red cat")
+    keep = int(m.sum())
+    assert keep == 4 and pe.shape == (1, keep, 8) and ne.shape == (1, keep, 8) and torch.equal(pe, full[:, 0, :keep])
+    assert te.calls == [["a red cat"], [""]]
+    # a batch: zeroed past each prompt's tokens, full length kept; the negatives untouched
+    te.calls.clear()
+    pe, ne = pipe.encode_prompt(["a red cat", "dog"], "blurry", True)
+    full, m = _FakeText()(["a red cat", "dog"])
+    assert te.calls[1] == ["blurry", "blurry"] and pe.shape == (2, 12, 8) and ne.shape == (2, 12, 8)
+    assert torch.equal(pe, full[:, 0] * m[:, :, None]) and bool((pe[1, 2:] == 0).all()) and bool((ne[1, 2:] != 0).any())
+    # no guidance: no negative; mask_feature off: nothing cut
+    pe, ne = pipe.encode_prompt("a red cat", "", False, mask_feature=False)
+    assert ne is None and pe.shape == (1, 12, 8)
+    e4, kept = pipe.mask_text_embeddings(full[:1], m[:1])
+    assert e4.shape == (1, 1, 4, 8) and kept == 4
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 513, 512, None, 1)
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 512, 512, None, 0)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 512, 512, None, 1)
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 512, 512, None, 1, prompt_embeds=torch.zeros(1, 2, 8))
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, 512, 512, None, 1, prompt_embeds=torch.zeros(1, 2, 8), negative_prompt_embeds=torch.zeros(1, 3, 8))
+    pipe.check_inputs(None, 512, 512, None, 1, prompt_embeds=torch.zeros(1, 2, 8), negative_prompt_embeds=torch.zeros(1, 2, 8))
+    g = torch.Generator().manual_seed(3)
+    z = pipe.prepare_latents(2, 4, 16, 256, 256, torch.float32, "cpu", g)
+    assert z.shape == (2, 4, 16, 32, 32) and torch.equal(z, torch.randn(2, 4, 16, 32, 32, generator=torch.Generator().manual_seed(3)))
+    with pytest.raises(ValueError):
+        pipe.prepare_latents(2, 4, 16, 256, 256, torch.float32, "cpu", [g])
+
+
+def test_cogvideox_prompt_helpers_follow_the_reference():
+    """encode_prompt / _get_t5_prompt_embeds / check_inputs / prepare_latents of CogVideoXPipeline
+    (pipeline_cogvideox.py:211-332, 334-357, 385-434)."""
+    from types import SimpleNamespace
+
+    from videosys_amd.pipeline_cogvideox import CogVideoXPipeline
+
+    pipe = object.__new__(CogVideoXPipeline)
+    pipe.text_encoder = te = _FakeText(L=226)
+    pipe.scheduler = SimpleNamespace(init_noise_sigma=1.0)
+    pe, ne = pipe.encode_prompt(["a red cat", "dog"], None, True)
+    assert te.calls == [["a red cat", "dog"], ["", ""]] and pe.shape == ne.shape == (2, 226, 8)
+    pe, ne = pipe.encode_prompt("dog", None, False)
+    assert ne is None and pe.shape == (1, 226, 8)
+    assert pipe._get_t5_prompt_embeds("dog", num_videos_per_prompt=2).shape == (2, 226, 8)
+    with pytest.raises(TypeError):
+        pipe.encode_prompt(["a"], ("b",), True)
+    with pytest.raises(ValueError):
+        pipe.encode_prompt(["a", "b"], ["c"], True)
+    with pytest.raises(ValueError):   # the attached encoder pads to 226
+        pipe.encode_prompt("a", None, True, max_sequence_length=100)
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 480, 721, None, ["latents"])
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 480, 720, None, ["frames"])
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", 480, 720, "b", ["latents"], negative_prompt_embeds=torch.zeros(1, 2, 8))
+    pipe.check_inputs("a", 480, 720, None, ["latents", "prompt_embeds"])
+    z = pipe.prepare_latents(1, 16, 49, 480, 720, torch.float32, "cpu", torch.Generator().manual_seed(1))
+    assert z.shape == (1, 13, 16, 60, 90)
+    assert pipe.guidance_scale is None and pipe.num_timesteps == 0 and pipe.interrupt is False
+    pipe.fuse_qkv_projections()
+    assert pipe.fusing_transformer
+    pipe.unfuse_qkv_projections()
+    assert not pipe.fusing_transformer

@@ -145,6 +145,7 @@ class VideoSysEngine:
         self._tid = 0
         self._closed = False
         self._failed = None   # set when a driver-side failure forced the workers down: later calls fail fast
+        self.parallel_worker_tasks = None
         self._init_worker(config.pipeline_cls, backend)
 
     def _init_worker(self, pipeline_cls, backend):
@@ -243,6 +244,21 @@ class VideoSysEngine:
 
     def generate(self, *args, **kwargs):
         return self._run_workers("generate", *args, **kwargs)[0]
+
+    def stop_remote_worker_execution_loop(self) -> None:
+        """engine.py:103-111 of the reference: waits for worker tasks started with ``async_run_remote_workers_only``.  This engine
+        never leaves such tasks behind (every _run_workers call collects its futures, with the bounded wait after a driver-side
+        failure), so there is nothing to wait for; kept so that reference call sites run unchanged."""
+        self.parallel_worker_tasks = None
+
+    def _driver_execute_model(self, *args, **kwargs):
+        """engine.py:97-98: the call on the driver's own pipeline only (no worker is told)."""
+        return self.driver_worker.generate(*args, **kwargs)
+
+    def _wait_for_tasks_completion(self, parallel_worker_tasks: Any) -> None:
+        """engine.py:113-117: block on futures of worker tasks (``Future.result`` here, ``ResultFuture.get`` there)."""
+        for result in parallel_worker_tasks or ():
+            result.get() if hasattr(result, "get") else result.result()
 
     def save_video(self, video, output_path):
         return self.driver_worker.save_video(video, output_path)

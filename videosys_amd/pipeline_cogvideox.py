@@ -17,7 +17,7 @@ from typing import Callable, List, Optional
 import numpy as np
 import torch
 
-from .utils import StagedOffloadMixin
+from .utils import StagedOffloadMixin, check_prompt_args as _check_prompt_args, randn_tensor as _randn
 from . import ops, pab
 from .cogvideox import CogVideoXTransformer3DModel, synth_state_dict
 from .pab import PABConfig
@@ -210,6 +210,92 @@ class CogVideoXPipeline(StagedOffloadMixin):
                                                 480 // (self.vae_scale_factor_spatial * c.patch_size))
         return get_3d_rotary_pos_embed(c.attention_head_dim, crops, (gh, gw), num_frames)
 
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]   # pipeline_cogvideox.py:117-121
+    _guidance_scale, _num_timesteps, _interrupt, fusing_transformer = None, 0, False, False
+
+    guidance_scale = property(lambda self: self._guidance_scale)     # (:476-486) values of the generate() call in flight / last run
+    num_timesteps = property(lambda self: self._num_timesteps)
+    interrupt = property(lambda self: self._interrupt)
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """pipeline_cogvideox.py:367-383: the keywords the scheduler's ``step`` takes beyond (model_output, t, sample) — the DDIM step of diffusers
+        (third-party) takes both ``eta`` and ``generator``.  The step here is the fused ops.cfg_linear_step at eta = 0, which draws
+        no noise: generate() refuses another eta and uses ``generator`` for the start latents only."""
+        return {"eta": eta, "generator": generator}
+
+    def check_inputs(self, prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds=None,
+                     negative_prompt_embeds=None):
+        """pipeline_cogvideox.py:385-434: the argument combinations the reference refuses, with its ValueErrors."""
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        bad = [k for k in (callback_on_step_end_tensor_inputs or ()) if k not in self._callback_tensor_inputs]
+        if bad:
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found {bad}")
+        _check_prompt_args(prompt, negative_prompt, prompt_embeds, negative_prompt_embeds)
+
+    def prepare_latents(self, batch_size, num_channels_latents, num_frames, height, width, dtype, device, generator, latents=None):
+        """pipeline_cogvideox.py:334-357: start latents [B, (F - 1) / 4 + 1, C, h / 8, w / 8] * init_noise_sigma, drawn from
+        ``generator`` (utils.randn_tensor) unless handed in."""
+        shape = (batch_size, (num_frames - 1) // self.vae_scale_factor_temporal + 1, num_channels_latents,
+                 height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = _randn(shape, generator, dtype)
+        return latents.to(device=device) * self.scheduler.init_noise_sigma
+
+    def fuse_qkv_projections(self) -> None:
+        """pipeline_cogvideox.py:436-439.  The transformer here always runs q, k and v as one [3C, C] GEMM (cogvideox.py packs the
+        three weights at load), so there is nothing to switch; the flag is kept for call sites that toggle it."""
+        self.fusing_transformer = True
+
+    def unfuse_qkv_projections(self) -> None:
+        """pipeline_cogvideox.py:441-447 (see fuse_qkv_projections: the packed GEMM stays)."""
+        self.fusing_transformer = False
+
+    def _get_t5_prompt_embeds(self, prompt=None, num_videos_per_prompt: int = 1, max_sequence_length: int = 226, device=None,
+                              dtype=None):
+        """pipeline_cogvideox.py:211-251: prompts -> T5 states [B * num_videos_per_prompt, 226, 4096].  The attached text encoder
+        (tokenizer padded / truncated to its ``max_length`` + T5, t5.py; for this pipeline build it with
+        ``T5TextEncoder(..., max_length=226, use_attention_mask=False)``: the reference hands the encoder no attention mask, :244) takes the place of :225-244."""
+        if self.text_encoder is None:
+            raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, 226, 4096]")
+        want = getattr(self.text_encoder, "max_length", max_sequence_length)
+        if want != max_sequence_length:
+            raise ValueError(f"max_sequence_length {max_sequence_length}: the attached text encoder pads to {want}")
+        prompt = [prompt] if isinstance(prompt, str) else list(prompt)
+        e = self.text_encoder(prompt)
+        e = e[0] if isinstance(e, tuple) else e
+        e = e.reshape(len(prompt), e.shape[-2], e.shape[-1])
+        return e.repeat_interleave(num_videos_per_prompt, 0) if num_videos_per_prompt > 1 else e
+
+    def encode_prompt(self, prompt, negative_prompt=None, do_classifier_free_guidance: bool = True, num_videos_per_prompt: int = 1,
+                      prompt_embeds: Optional[torch.Tensor] = None, negative_prompt_embeds: Optional[torch.Tensor] = None,
+                      max_sequence_length: int = 226, device=None, dtype=None):
+        """pipeline_cogvideox.py:253-332 -> (prompt_embeds, negative_prompt_embeds); a string negative prompt (default "") is
+        used once per prompt of the batch, a list must have the batch's length and the prompt's type."""
+        prompt = [prompt] if isinstance(prompt, str) else prompt
+        B = len(prompt) if prompt is not None else prompt_embeds.shape[0]
+        if prompt_embeds is None:
+            prompt_embeds = self._get_t5_prompt_embeds(prompt, num_videos_per_prompt, max_sequence_length)
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            negative_prompt = negative_prompt or ""
+            negative_prompt = B * [negative_prompt] if isinstance(negative_prompt, str) else negative_prompt
+            if prompt is not None and type(prompt) is not type(negative_prompt):
+                raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} != {type(prompt)}.")
+            if B != len(negative_prompt):
+                raise ValueError(f"`negative_prompt` has batch size {len(negative_prompt)}, but `prompt` has batch size {B}")
+            negative_prompt_embeds = self._get_t5_prompt_embeds(negative_prompt, num_videos_per_prompt, max_sequence_length)
+        return prompt_embeds, negative_prompt_embeds
+
+    def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
+        """pipeline_cogvideox.py:359-364: latents [B, T, 16, h, w] -> frames [B, 3, T', H, W]; the permute and the
+        1 / scaling_factor live in vae_cogvideox.CogVideoXVAE.__call__."""
+        if self.vae_decoder is None:
+            raise RuntimeError("no VAE attached")
+        return self.vae_decoder(latents.to(torch.bfloat16))
+
     @torch.no_grad()
     def generate(self, prompt=None, negative_prompt=None, height: int = 480, width: int = 720, num_frames: int = 49,
                  num_inference_steps: int = 50, guidance_scale: float = 6, use_dynamic_cfg: bool = False, seed: int = -1,
@@ -220,25 +306,23 @@ class CogVideoXPipeline(StagedOffloadMixin):
                  callback_on_step_end_tensor_inputs=("latents",), max_sequence_length: int = 226):
         """pipeline_cogvideox.py:498-755 for text-to-video (CFG batch [negative | prompt], eta = 0).  The reference's other
         keywords keep their meaning where the path has them: ``generator`` draws the start latents, ``callback_on_step_end(self,
-        i, t, {"latents": ...})`` may hand back new latents (:725-734), ``return_dict=False`` returns a tuple; ``timesteps`` (a
+        i, t, {...})`` sees the tensors named in ``callback_on_step_end_tensor_inputs`` and may hand back new ones (:725-734), ``return_dict=False`` returns a tuple; ``timesteps`` (a
         custom schedule), ``eta`` != 0 and ``num_videos_per_prompt`` != 1 (the reference overrides it to 1, :603) are refused."""
         if timesteps is not None:
             raise NotImplementedError("custom timestep schedules: the CogVideoX DDIM schedule is set from num_inference_steps")
         if eta != 0.0:
             raise NotImplementedError("the scheduler step is DDIM with eta = 0 (what the reference pipeline runs)")
-        if any(k != "latents" for k in callback_on_step_end_tensor_inputs):
-            raise ValueError("callback_on_step_end_tensor_inputs: only 'latents' is a per-step tensor of this path")
+        self.check_inputs(prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds,
+                          negative_prompt_embeds)
+        self._guidance_scale, self._interrupt = guidance_scale, False
         if prompt_embeds is None:
             if self.text_encoder is None:
                 raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, 226, 4096]")
             self._enter_stage("text_encoder")
-            prompt_embeds = self.text_encoder(prompt)
-            if guidance_scale > 1.0:
-                negative_prompt_embeds = self.text_encoder(negative_prompt or "")
+            prompt_embeds, negative_prompt_embeds = self.encode_prompt(prompt, negative_prompt, guidance_scale > 1.0,
+                                                                       max_sequence_length=max_sequence_length)
         cfg = guidance_scale > 1.0        # do_classifier_free_guidance (:627): without it the model runs on the prompt batch alone
-        from .utils import set_seed
-
-        seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
+        seed = self._set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast; + dp_rank in a process group
         self._enter_stage("transformer")
         pab.update_steps(num_inference_steps)
         self.transformer.reset_pab_state()
@@ -248,16 +332,16 @@ class CogVideoXPipeline(StagedOffloadMixin):
         nb = (2 if cfg else 1) * B
         self.scheduler.set_timesteps(num_inference_steps)
         c = self.transformer.config
-        lat_frames = (num_frames - 1) // self.vae_scale_factor_temporal + 1
-        if latents is None:
-            g = generator if generator is not None else torch.Generator(device="cpu").manual_seed(seed)
-            latents = torch.randn(B, lat_frames, c.in_channels, height // self.vae_scale_factor_spatial,
-                                  width // self.vae_scale_factor_spatial, generator=g, dtype=torch.float32,
-                                  device=getattr(g, "device", "cpu")).cpu()
-        z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
+        if latents is None and generator is None:
+            generator = torch.Generator(device="cpu").manual_seed(seed)
+        z = self.prepare_latents(B, c.in_channels, num_frames, height, width, torch.float32, self._device, generator,
+                                 None if latents is None else latents.float()).contiguous().clone()
+        self._num_timesteps = len(self.scheduler.timesteps)
         rope = self._prepare_rotary_positional_embeddings(height, width, z.shape[1]) if c.use_rotary_positional_embeddings else None
         zf = z.view(B, 1, -1)  # the step kernel sees [Bz, Cin = 1, thw]: CogVideoX predicts all 16 channels (no sigma half)
         for step_i, t in enumerate(self.scheduler.timesteps):
+            if self._interrupt:   # (:682-683) a callback may set pipe._interrupt: the remaining steps are skipped
+                continue
             out = self.transformer(z, emb, torch.full((nb,), t, dtype=torch.int64), image_rotary_emb=rope,
                                    return_dict=False)[0]
             g_t = guidance_scale
@@ -268,15 +352,21 @@ class CogVideoXPipeline(StagedOffloadMixin):
                 out, g_t = torch.cat([out, out], 0), 1.0
             ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, c_z, c_v, cond_first=False)
             z.copy_(z.to(torch.bfloat16).float())  # latents = latents.to(prompt_embeds.dtype) (:723)
-            if callback_on_step_end is not None:   # (:725-734)
-                back = callback_on_step_end(self, step_i, t, {"latents": z})
-                if isinstance(back, dict) and back.get("latents") is not None and back["latents"] is not z:
+            if callback_on_step_end is not None:   # (:725-734) "prompt_embeds" is the [negative | prompt] batch the loop runs on
+                have = {"latents": z, "prompt_embeds": emb, "negative_prompt_embeds": negative_prompt_embeds}
+                back = callback_on_step_end(self, step_i, t, {k: have[k] for k in callback_on_step_end_tensor_inputs})
+                back = back if isinstance(back, dict) else {}
+                if back.get("latents") is not None and back["latents"] is not z:
                     z.copy_(back["latents"].to(z.device, z.dtype))
+                if back.get("prompt_embeds") is not None and back["prompt_embeds"] is not emb:
+                    emb = back["prompt_embeds"]
+                    self.transformer.reset_text_cache()
+                negative_prompt_embeds = back.get("negative_prompt_embeds", negative_prompt_embeds)
         if self.vae_decoder is None or output_type in ("latent", "latents"):
             self._enter_stage(None)
             return VideoSysPipelineOutput(video=z) if return_dict else (z,)
         self._enter_stage("vae")
-        frames = self.vae_decoder(z.to(torch.bfloat16))   # decode_latents (:359-364) -> [B, 3, T, H, W]
+        frames = self.decode_latents(z)   # (:359-364) -> [B, 3, T, H, W]
         self._enter_stage(None)
         if not torch.is_tensor(frames) or frames.dtype == torch.uint8:
             return VideoSysPipelineOutput(video=frames) if return_dict else (frames,)

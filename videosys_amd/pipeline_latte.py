@@ -15,7 +15,7 @@ from typing import Callable, List, Optional
 
 import torch
 
-from .utils import StagedOffloadMixin
+from .utils import StagedOffloadMixin, check_prompt_args as _check_prompt_args, randn_tensor as _randn
 from . import ops, pab
 from .latte import LatteT2V, synth_state_dict
 from .pab import PABConfig
@@ -95,6 +95,8 @@ class DDIMScheduler:
 
 
 class LattePipeline(StagedOffloadMixin):
+    vae_scale_factor = 8   # 2 ** (len(vae.config.block_out_channels) - 1) (pipeline_latte.py:239)
+
     def __init__(self, config: LatteConfig, device=None, text_encoder: Optional[Callable] = None,
                  vae_decoder: Optional[Callable] = None):
         self._config = config
@@ -174,6 +176,101 @@ class LattePipeline(StagedOffloadMixin):
             dp_size = world // sp_size
         self.transformer.enable_parallel(dp_size, sp_size, enable_cp)
 
+    def _text_preprocessing(self, text, clean_caption: bool = False):
+        """pipeline_latte.py:519-531: a string or a list of strings -> a list; the IF caption cleaner twice, or lower + strip."""
+        from .caption import text_preprocessing
+
+        text = [text] if not isinstance(text, (list, tuple)) else text
+        return [text_preprocessing(t, clean_caption, mid_strip=False) for t in text]
+
+    def _clean_caption(self, caption):
+        """pipeline_latte.py:534-647 (one application; no strip inside the ftfy / unescape step)."""
+        from .caption import clean_caption
+
+        return clean_caption(caption, mid_strip=False)
+
+    def mask_text_embeddings(self, emb, mask):
+        """pipeline_latte.py:278-284 on ``emb`` [B, 1, L, d], ``mask`` [B, L]: one prompt -> embeddings cut to its token count;
+        a batch -> zeroed past each prompt's tokens.  Returns (embeddings, kept length)."""
+        if emb.shape[0] == 1:
+            keep = int(mask.sum().item())
+            return emb[:, :, :keep, :], keep
+        return emb * mask[:, None, :, None].to(device=emb.device, dtype=emb.dtype), emb.shape[2]
+
+    def encode_prompt(self, prompt, negative_prompt="", do_classifier_free_guidance: bool = True, num_images_per_prompt: int = 1,
+                      device=None, prompt_embeds: Optional[torch.Tensor] = None,
+                      negative_prompt_embeds: Optional[torch.Tensor] = None, clean_caption: bool = False,
+                      mask_feature: bool = True, dtype=None):
+        """pipeline_latte.py:287-445 -> (prompt_embeds, negative_prompt_embeds) [B, L', 4096].  The negative prompt is encoded
+        once per prompt at the prompt's padded length (:391-409); with ``mask_feature`` a single prompt's embeddings — and the
+        negative ones with them — are cut to the prompt's token count, a batch's prompt embeddings are zeroed past each prompt's
+        tokens (:425-442).  The attached text encoder (tokenizer + T5, t5.py) takes the place of :331-363."""
+        if num_images_per_prompt != 1:
+            raise NotImplementedError("num_images_per_prompt > 1: pass the prompt that many times")
+        flat = lambda e: e.reshape(e.shape[0], e.shape[-2], e.shape[-1])     # encoders may return [B, 1, L, d]
+        pm = None
+        if prompt_embeds is None:
+            if self.text_encoder is None:
+                raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, L, 4096]")
+            prompt_embeds, pm = self.text_encoder(self._text_preprocessing(prompt, clean_caption))
+        prompt_embeds = flat(prompt_embeds)
+        nb = prompt_embeds.shape[0]
+        if do_classifier_free_guidance and negative_prompt_embeds is None:
+            neg = self._text_preprocessing(negative_prompt, clean_caption)
+            negative_prompt_embeds, _ = self.text_encoder(neg * nb if len(neg) == 1 else neg)
+        if not do_classifier_free_guidance:
+            negative_prompt_embeds = None
+        elif negative_prompt_embeds is not None:
+            negative_prompt_embeds = flat(negative_prompt_embeds)
+        if mask_feature and pm is not None:
+            prompt_embeds, keep = self.mask_text_embeddings(prompt_embeds[:, None], pm.reshape(nb, -1))
+            prompt_embeds = prompt_embeds[:, 0]
+            if negative_prompt_embeds is not None:
+                negative_prompt_embeds = negative_prompt_embeds[:, :keep]
+        return prompt_embeds, negative_prompt_embeds
+
+    def decode_latents(self, latents):
+        """pipeline_latte.py:916-927 / :929-948: latents [B, 4, F, h, w] -> uint8 video [B, F, H, W, 3] through the VAE the
+        pipeline was built with (``enable_vae_temporal_decoder`` chose it, :211-217); the 1 / scaling_factor and the chunking live
+        in the decoder objects (vae_open_sora.AutoencoderKLDecoder, vae_svd_temporal.AutoencoderKLTemporalDecoder)."""
+        if self.vae_decoder is None:
+            raise RuntimeError("no VAE attached")
+        return self.vae_decoder(latents)
+
+    decode_latents_with_temporal_decoder = decode_latents
+
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """pipeline_latte.py:448-463: the keywords the scheduler's ``step`` takes beyond (model_output, t, sample) — the DDIM step of diffusers
+        (third-party) takes both ``eta`` and ``generator``.  The step here is the fused ops.cfg_linear_step at eta = 0, which draws
+        no noise: generate() refuses another eta and uses ``generator`` for the start latents only."""
+        return {"eta": eta, "generator": generator}
+
+    def check_inputs(self, prompt, height, width, negative_prompt, callback_steps, prompt_embeds=None, negative_prompt_embeds=None):
+        """pipeline_latte.py:465-516: the argument combinations the reference refuses, with its ValueErrors."""
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if not isinstance(callback_steps, int) or isinstance(callback_steps, bool) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+        _check_prompt_args(prompt, negative_prompt, prompt_embeds, negative_prompt_embeds)
+
+    def prepare_latents(self, batch_size, num_channels_latents, video_length, height, width, dtype, device, generator, latents=None):
+        """pipeline_latte.py:649-672: start latents [B, C, F, h / 8, w / 8] * init_noise_sigma, drawn from ``generator`` (the
+        reference's ``randn_tensor``: on the generator's device, then moved) unless handed in."""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor, width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            latents = _randn(shape, generator, dtype)
+        return latents.to(device=device) * self.scheduler.init_noise_sigma
+
+    def decode_latents_image(self, latents):
+        """pipeline_latte.py:904-914 (``video_length`` 1): float frames [B, F, 3, H, W] in [0, 1], left on the device."""
+        if self.vae_decoder is None:
+            raise RuntimeError("no VAE attached")
+        v = self.vae_decoder.decode(latents).float()      # [B, 3, F, H, W]
+        return (v / 2.0 + 0.5).clamp(0, 1).permute(0, 2, 1, 3, 4).contiguous()
+
     @torch.no_grad()
     def generate(self, prompt=None, negative_prompt: str = "", num_inference_steps: int = 50, guidance_scale: float = 7.5,
                  seed: int = -1, verbose: bool = False, *, prompt_embeds: Optional[torch.Tensor] = None,
@@ -197,35 +294,16 @@ class LattePipeline(StagedOffloadMixin):
             raise NotImplementedError("the scheduler step is DDIM with eta = 0 (what the reference pipeline runs)")
         if num_images_per_prompt != 1:
             raise NotImplementedError("num_images_per_prompt > 1: pass the prompt that many times")
+        # (:768) the default negative_prompt "" only counts next to a text prompt: embeddings handed in come with their own negatives
+        self.check_inputs(prompt, height, width, negative_prompt if prompt is not None else None, callback_steps, prompt_embeds,
+                          negative_prompt_embeds)
         if prompt_embeds is None:
-            if self.text_encoder is None:
-                raise RuntimeError("no text encoder attached: pass prompt_embeds / negative_prompt_embeds [B, L, 4096]")
-            from .caption import text_preprocessing
-
-            prep = lambda t: [text_preprocessing(v, clean_caption, mid_strip=False) for v in t] if isinstance(t, (list, tuple)) \
-                else text_preprocessing(t, clean_caption, mid_strip=False)
             self._enter_stage("text_encoder")
-            flat = lambda e: e.reshape(e.shape[0], e.shape[-2], e.shape[-1])     # encoders may return [B, 1, L, d]
-            prompt_embeds, pm = self.text_encoder(prep(prompt))
-            prompt_embeds = flat(prompt_embeds)
-            nb_p = prompt_embeds.shape[0]
-            if guidance_scale > 1.0:   # uncond_tokens = [negative_prompt] * batch_size at the prompt's padded length (:391-409)
-                neg = prep(negative_prompt)
-                negative_prompt_embeds, _ = self.text_encoder([neg] * nb_p if isinstance(neg, str) else list(neg))
-                negative_prompt_embeds = flat(negative_prompt_embeds)
-            if mask_feature:           # mask_text_embeddings (:278-284, 425-442)
-                if nb_p == 1:
-                    keep = int(pm.reshape(1, -1).sum())
-                    prompt_embeds = prompt_embeds[:, :keep]
-                    if guidance_scale > 1.0:
-                        negative_prompt_embeds = negative_prompt_embeds[:, :keep]
-                else:
-                    prompt_embeds = prompt_embeds * pm.reshape(nb_p, -1, 1).to(device=prompt_embeds.device, dtype=prompt_embeds.dtype)
+            prompt_embeds, negative_prompt_embeds = self.encode_prompt(prompt, negative_prompt, guidance_scale > 1.0,
+                                                                       clean_caption=clean_caption, mask_feature=mask_feature)
             prompt_mask = negative_mask = None
         cfg = guidance_scale > 1.0        # do_classifier_free_guidance (:749): without it the model runs on the prompt batch alone
-        from .utils import set_seed
-
-        seed = set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast (core/pipeline/pipeline.py _set_seed)
+        seed = self._set_seed(seed)   # -1: a fresh seed per call, drawn on rank 0 and broadcast; + dp_rank in a process group
         self._enter_stage("transformer")
         pab.update_steps(num_inference_steps)
         self.transformer.reset_pab_state()
@@ -240,11 +318,10 @@ class LattePipeline(StagedOffloadMixin):
         self.scheduler.set_timesteps(num_inference_steps)
         ts = self.scheduler.timesteps
         cin = self.transformer.in_channels
-        if latents is None:
-            g = generator if generator is not None else torch.Generator(device="cpu").manual_seed(seed)
-            latents = torch.randn(B, cin, video_length, height // 8, width // 8, generator=g, dtype=torch.float32,
-                                  device=getattr(g, "device", "cpu")).cpu()
-        z = (latents.float() * self.scheduler.init_noise_sigma).to(self._device).contiguous().clone()
+        if latents is None and generator is None:
+            generator = torch.Generator(device="cpu").manual_seed(seed)
+        z = self.prepare_latents(B, cin, video_length, height, width, torch.float32, self._device, generator,
+                                 None if latents is None else latents.float()).contiguous().clone()
         all_ts = torch.tensor(ts)
         for step_i, t in enumerate(ts):
             tt = torch.full((nb,), t, dtype=torch.int64)
@@ -261,7 +338,8 @@ class LattePipeline(StagedOffloadMixin):
             self._enter_stage(None)
             return VideoSysPipelineOutput(video=z) if return_dict else (z,)
         self._enter_stage("vae")
-        video = self.vae_decoder(z)
+        # (:884-891) one frame: float image frames; else uint8 video through the decoder the config chose
+        video = self.decode_latents_image(z) if z.shape[2] == 1 and hasattr(self.vae_decoder, "decode") else self.decode_latents(z)
         self._enter_stage(None)
         return VideoSysPipelineOutput(video=video) if return_dict else (video,)
 

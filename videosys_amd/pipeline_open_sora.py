@@ -224,6 +224,33 @@ class OpenSoraPipeline(StagedOffloadMixin):
         """pipeline_open_sora.py:294-296."""
         return self.transformer.y_embedder.y_embedding[None].repeat(n, 1, 1)[:, None]
 
+    null_embed = null   # the reference's name (:294)
+
+    def get_text_embeddings(self, texts):
+        """pipeline_open_sora.py:269-287: (T5 last hidden state [B, L, 4096], attention mask [B, L]) of already cleaned texts."""
+        if self.text_encoder is None:
+            raise RuntimeError("no text encoder attached (OpenSoraConfig(text_encoder=<local T5 checkpoint directory>))")
+        self._enter_stage("text_encoder")
+        emb, mask = self.text_encoder(texts)
+        return emb.reshape(emb.shape[0], emb.shape[-2], emb.shape[-1]), mask
+
+    def encode_prompt(self, text):
+        """pipeline_open_sora.py:289-292: dict(y=[B, 1, L, 4096], mask=[B, L]) as RFLOW.sample's model_args take it."""
+        emb, mask = self.get_text_embeddings(text)
+        return dict(y=emb[:, None], mask=mask)
+
+    @staticmethod
+    def _basic_clean(text):
+        from .caption import basic_clean
+
+        return basic_clean(text)
+
+    @staticmethod
+    def _clean_caption(caption):
+        from .caption import clean_caption
+
+        return clean_caption(caption)
+
     @staticmethod
     def text_preprocessing(text: str, use_text_preprocessing: bool = True) -> str:
         """pipeline_open_sora.py:417-424: the training-time caption cleaner applied twice (caption.py; its html / mojibake steps
@@ -281,11 +308,10 @@ class OpenSoraPipeline(StagedOffloadMixin):
         time axis — what the upstream Open-Sora code these lines come from operates on — is used here.)"""
         from . import open_sora_condition as K
         from . import open_sora_geometry as G
-        from .utils import set_seed
 
         image_size = (int(height), int(width)) if height is not None and width is not None else G.get_image_size(resolution, aspect_ratio)
         num_frames = G.get_num_frames(num_frames)
-        seed = set_seed(seed)   # -1 draws a fresh seed on rank 0 and broadcasts it (core/pipeline/pipeline.py _set_seed)
+        seed = self._set_seed(seed)   # (:253-257) -1 draws a fresh seed on rank 0 and broadcasts it; + dp_rank in a process group
 
         # ---- conditioning inputs: one entry per prompt (:528-535)
         prompts = None if prompt is None else ([prompt] if isinstance(prompt, str) else list(prompt))

@@ -213,17 +213,18 @@ class T5Encoder:
 class T5TextEncoder:
     """The callable the pipelines take as ``text_encoder``: prompt(s) -> (embeddings [B, 1, L, d_model], mask [B, L])
     (pipeline_open_sora.py:269-292 get_text_embeddings / encode_prompt).  ``tokenizer`` is any HF-style tokenizer callable
-    (the sentencepiece model of "DeepFloyd/t5-v1_1-xxl" cannot be fetched here)."""
+    (the sentencepiece model of "DeepFloyd/t5-v1_1-xxl" cannot be fetched here).  ``use_attention_mask=False``: the encoder attends
+    the padding too — how CogVideoX calls it (pipelines/cogvideox/pipeline_cogvideox.py:244, ``text_encoder(input_ids)`` alone)."""
 
-    def __init__(self, encoder: T5Encoder, tokenizer, max_length: int = 300):
-        self.encoder, self.tokenizer, self.max_length = encoder, tokenizer, max_length
+    def __init__(self, encoder: T5Encoder, tokenizer, max_length: int = 300, use_attention_mask: bool = True):
+        self.encoder, self.tokenizer, self.max_length, self.use_attention_mask = encoder, tokenizer, max_length, use_attention_mask
 
     def __call__(self, prompts):
         if isinstance(prompts, str):
             prompts = [prompts]
         tok = self.tokenizer(prompts, max_length=self.max_length, padding="max_length", truncation=True, return_attention_mask=True,
                              add_special_tokens=True, return_tensors="pt")
-        emb = self.encoder(tok["input_ids"], tok["attention_mask"]).last_hidden_state
+        emb = self.encoder(tok["input_ids"], tok["attention_mask"] if self.use_attention_mask else None).last_hidden_state
         return emb[:, None], tok["attention_mask"]
 
 

@@ -25,6 +25,37 @@ def set_seed(seed, dp_rank=None):
     return seed
 
 
+def randn_tensor(shape, generator=None, dtype=None):
+    """Start noise the way the pipelines draw it (diffusers' ``randn_tensor``, third-party: drawn on the generator's device, then
+    moved by the caller): fp32 from ``generator`` — a torch.Generator, or a list of them, one per sample — else from torch's
+    global CPU stream (which set_seed seeded).  The bits do not depend on the box's GPU."""
+    if isinstance(generator, (list, tuple)):
+        z = torch.cat([torch.randn((1,) + tuple(shape[1:]), generator=g, dtype=torch.float32, device=g.device).cpu() for g in generator], 0)
+    elif generator is not None:
+        z = torch.randn(tuple(shape), generator=generator, dtype=torch.float32, device=generator.device).cpu()
+    else:
+        z = torch.randn(tuple(shape), dtype=torch.float32)
+    return z if dtype is None else z.to(dtype)
+
+
+def check_prompt_args(prompt, negative_prompt, prompt_embeds=None, negative_prompt_embeds=None):
+    """The prompt / embedding combinations the Latte and CogVideoX pipelines refuse in ``check_inputs``
+    (pipelines/latte/pipeline_latte.py:484-516, pipelines/cogvideox/pipeline_cogvideox.py:404-434), same ValueErrors."""
+    if prompt is not None and prompt_embeds is not None:
+        raise ValueError("Cannot forward both `prompt` and `prompt_embeds`. Please make sure to only forward one of the two.")
+    if prompt is None and prompt_embeds is None:
+        raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
+    if prompt is not None and not isinstance(prompt, (str, list)):
+        raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+    if prompt is not None and negative_prompt_embeds is not None:
+        raise ValueError("Cannot forward both `prompt` and `negative_prompt_embeds`. Please make sure to only forward one of the two.")
+    if negative_prompt is not None and negative_prompt_embeds is not None:
+        raise ValueError("Cannot forward both `negative_prompt` and `negative_prompt_embeds`. Please make sure to only forward one of the two.")
+    if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+        raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but got:"
+                         f" `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
+
+
 def same_tensor(a, b) -> bool:
     """True when ``b`` is ``a`` or a fresh VIEW OBJECT of exactly the same elements (same storage, offset, shape, strides) at the
     same version counter — what a per-step ``y[rows]`` slice produces under CFG parallel.  Meant for caches that HOLD ``a``:
@@ -162,3 +193,11 @@ class StagedOffloadMixin:
 
     def _after_onload(self, name):   # hook: refresh attribute aliases of weight-table entries
         pass
+
+    def _set_seed(self, seed):
+        """The pipelines' ``_set_seed`` (e.g. pipelines/open_sora/pipeline_open_sora.py:253-257): one process seeds with ``seed``,
+        a process group with ``seed + dp_rank`` — the ranks of one data-parallel replica draw the same noise, replicas differ.
+        -1 draws a fresh seed on rank 0 and broadcasts it.  Returns the seed this rank used."""
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            return set_seed(seed)
+        return set_seed(seed, self.transformer.parallel_manager.dp_rank)
