@@ -39,6 +39,18 @@ def test_t5_elementwise_kernels():
         w = bfr(1 + 0.1 * torch.randn(C, generator=g))
         ref = w * bfr(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
         check(ops.rms_norm_rows(x.to(torch.bfloat16).to(dev()), w.to(torch.bfloat16).to(dev())), ref, what=f"rms norm C={C}")
+    # the stand-alone module under the reference's name (models/modules/normalization.py LlamaRMSNorm; its own test is
+    # tests/test_rms_norm.py): any leading shape, q / k head widths
+    from videosys_amd.modules import LlamaRMSNorm
+
+    for shape in ((2, 50, 16, 72), (3, 7, 128)):
+        x = bfr(torch.randn(*shape, generator=g) * 2)
+        w = bfr(1 + 0.1 * torch.randn(shape[-1], generator=g))
+        norm = LlamaRMSNorm(shape[-1], device=dev()).load_state_dict({"weight": w})
+        ref = w * bfr(x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6))
+        out = norm(x.to(torch.bfloat16).to(dev()))
+        assert out.shape == x.shape
+        check(out.reshape(-1, shape[-1]), ref.reshape(-1, shape[-1]), what=f"LlamaRMSNorm {shape}")
     h = bfr(torch.randn(33, 2 * 512, generator=g) * 2)
     ref = bfr(F.gelu(h[:, :512], approximate="tanh")) * h[:, 512:]
     check(ops.geglu(h.to(torch.bfloat16).to(dev())), ref, what="gated gelu")

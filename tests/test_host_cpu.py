@@ -163,6 +163,33 @@ def _dsp_worker(rank, world, port, B, T, S, C, ret):
         assert torch.equal(back, local), "round trip"
         full = sp.gather(back, S)
         assert torch.equal(full, x), "gather"
+        # the function-level operators under the reference's names (comm.py), same group, against the same restatement
+        from videosys_amd import comm
+
+        with torch.no_grad():
+            pt, ps = O.dsp_pad(T, world), O.dsp_pad(S, world)
+            loc = comm.split_sequence(x, pm.sp_group, dim=2, grad_scale="down", pad=comm.get_pad("spatial"))
+            assert torch.equal(loc.float(), shards[rank]), "comm.split_sequence"
+            tsh2 = comm.all_to_all_with_pad(loc, pm.sp_group, scatter_dim=1, gather_dim=2, scatter_pad=pt, gather_pad=ps)
+            assert torch.equal(tsh2.float(), t_ref[rank]), "comm.all_to_all_with_pad"
+            back2 = comm.all_to_all_with_pad(tsh2, pm.sp_group, scatter_dim=2, gather_dim=1, scatter_pad=ps, gather_pad=pt)
+            assert torch.equal(back2, loc), "comm round trip"
+            assert torch.equal(comm.gather_sequence(back2, pm.sp_group, dim=2, grad_scale="up", pad=ps), x), "comm.gather_sequence"
+            # no pads: all_to_all_comm with negative dimensions; frames-first layout through the *_from_second_dim pair
+            e = torch.arange(2 * world * 3 * world * 2, dtype=torch.float32).view(2, world * 3, world * 2)
+            mine = comm.split_sequence(e, pm.sp_group, dim=-1)
+            sw = comm.all_to_all_comm(mine, pm.sp_group, scatter_dim=-2, gather_dim=-1)
+            assert torch.equal(sw, O.dsp_split_sequence(e, world, 1)[rank]), "comm.all_to_all_comm"
+            f = x.float().reshape(B * T, S, C)
+            fl = comm.split_from_second_dim(f, B, pm.sp_group)
+            assert torch.equal(fl, O.dsp_split_sequence(x.float(), world, 1)[rank].reshape(-1, S, C)), "split_from_second_dim"
+            assert torch.equal(comm.gather_from_second_dim(fl, B, pm.sp_group), f), "gather_from_second_dim"
+            assert torch.equal(comm.gather_sequence(mine[0], pm.sp_group, dim=0), torch.cat([v[0] for v in O.dsp_split_sequence(e, world, 2)], 0))
+        try:
+            comm.split_sequence(x.float().requires_grad_(), pm.sp_group, dim=2)
+            raise AssertionError("a tensor with a graph must be refused")
+        except NotImplementedError:
+            pass
         ret.put((rank, "ok"))
     except Exception as e:  # noqa
         import traceback
@@ -482,6 +509,66 @@ def test_videosys_alias_package_exports_reference_names():
             "print('ok')")
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-800:]
+
+
+def test_reference_module_paths_resolve_to_this_build():
+    """The submodule imports of the reference's inference examples, eval scripts and tests (``from videosys.core.pab.pab_mgr import
+    ...``) resolve through the alias table of videosys/__init__.py; with the reference tree present, every ``from videosys... import``
+    of its examples / eval / tests is checked, except the families and the training stack outside the hot path.  Subprocess: see the
+    test above."""
+    import subprocess
+    import sys
+
+    code = r"""
+import ast, glob, importlib, os
+import videosys, videosys_amd
+from videosys.core.pab.pab_mgr import PABConfig, set_pab_manager, update_steps, enable_pab, if_broadcast_spatial, get_mlp_output
+from videosys.utils.utils import save_video, set_seed, batch_func, str_to_dtype, all_exists
+from videosys.utils.test import empty_cache
+from videosys.utils.logging import init_logger
+from videosys.core.distributed.parallel_mgr import ParallelManager, initialize
+from videosys.core.distributed.comm import all_to_all_with_pad, gather_sequence, get_pad, set_pad, split_sequence, all_to_all_comm
+from videosys.core.pipeline.pipeline import VideoSysPipeline, VideoSysPipelineOutput
+from videosys.core.engine.engine import VideoSysEngine
+from videosys.schedulers.scheduling_rflow_open_sora import RFLOW, timestep_transform
+from videosys.schedulers.scheduling_ddim_cogvideox import CogVideoXDDIMScheduler
+from videosys.models.modules.normalization import LlamaRMSNorm
+from videosys.models.transformers.open_sora_transformer_3d import STDiT3_XL_2, STDiT3, STDiT3Config
+from videosys.models.transformers.latte_transformer_3d import LatteT2V
+from videosys.models.transformers.cogvideox_transformer_3d import CogVideoXTransformer3DModel
+from videosys.models.autoencoders.autoencoder_kl_open_sora import OpenSoraVAE_V1_2
+from videosys.models.autoencoders.autoencoder_kl_cogvideox import AutoencoderKLCogVideoX
+from videosys.pipelines.open_sora import OpenSoraConfig, OpenSoraPABConfig, OpenSoraPipeline
+from videosys.pipelines.open_sora.data_process import get_image_size, get_num_frames, read_from_path, prepare_multi_resolution_info
+from videosys.pipelines.latte import LatteConfig, LattePABConfig, LattePipeline
+from videosys.pipelines.cogvideox.pipeline_cogvideox import CogVideoXPipeline
+import videosys.core.pab.pab_mgr as alias
+assert alias is videosys_amd.pab and VideoSysEngine is videosys_amd.VideoSysEngine and issubclass(OpenSoraPipeline, VideoSysPipeline)
+set_pab_manager(PABConfig(cross_broadcast=True, cross_threshold=[100, 900], cross_range=2))
+assert videosys_amd.pab.PAB_MANAGER is not None and alias.PAB_MANAGER is videosys_amd.pab.PAB_MANAGER
+set_pab_manager(None)
+o = VideoSysPipelineOutput(video=7)
+assert o["video"] == 7 and o[0] == 7 and o.to_tuple() == (7,)
+ref = "/root/reference"
+skip = ("videosys.training", "videosys.core.dcp", "videosys.utils.training", "videosys.models.open_sora")
+skip_names = {"OpenSoraPlanConfig", "OpenSoraPlanV110PABConfig", "OpenSoraPlanV120PABConfig", "VchitectConfig", "VchitectPABConfig",
+              "DynamicParallelManager", "set_distributed_state", "merge_args"}
+bad, seen = [], 0
+if os.path.isdir(ref):
+    for pat in ("examples/**/*.py", "eval/**/*.py", "tests/**/*.py"):
+        for f in glob.glob(os.path.join(ref, pat), recursive=True):
+            for n in ast.walk(ast.parse(open(f).read())):
+                if isinstance(n, ast.ImportFrom) and n.module and n.module.split(".")[0] == "videosys" and not n.module.startswith(skip):
+                    m = importlib.import_module(n.module)
+                    for a in n.names:
+                        seen += 1
+                        if a.name not in skip_names and not hasattr(m, a.name):
+                            bad.append((os.path.relpath(f, ref), n.module, a.name))
+    assert seen > 50 and not bad, bad
+print("ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
 
 
 def test_torch_custom_ops_are_registered():
@@ -888,3 +975,84 @@ def test_cogvideox_prompt_helpers_follow_the_reference():
     assert pipe.fusing_transformer
     pipe.unfuse_qkv_projections()
     assert not pipe.fusing_transformer
+
+
+def test_local_checkpoint_directories_are_read_like_from_pretrained(tmp_path, monkeypatch):
+    """model_path = a local directory in the Hugging Face layout: ``transformer/config.json`` sets the geometry (a 5b checkpoint
+    under any directory name), sharded ``*.safetensors`` are merged, ``scheduler/scheduler_config.json`` and ``vae/config.json``
+    supply snr_shift_scale / scaling_factor (pipeline_cogvideox.py:146-160, pipeline_latte.py:208-217 from_pretrained calls).
+    The device models are replaced by recorders: this is the host-side loading logic only."""
+    import json
+    from types import SimpleNamespace
+
+    from safetensors.torch import save_file
+
+    from videosys_amd import pipeline_cogvideox as PC, pipeline_latte as PL, utils as U
+
+    root = tmp_path / "my_ckpt"
+    for sub in ("transformer", "scheduler", "vae"):
+        (root / sub).mkdir(parents=True)
+    (root / "transformer" / "config.json").write_text(json.dumps(dict(_class_name="CogVideoXTransformer3DModel", num_attention_heads=48,
+                                                                       num_layers=42, use_rotary_positional_embeddings=True)))
+    save_file({"a.weight": torch.ones(2)}, str(root / "transformer" / "diffusion_pytorch_model-00001-of-00002.safetensors"))
+    save_file({"b.weight": torch.zeros(3)}, str(root / "transformer" / "diffusion_pytorch_model-00002-of-00002.safetensors"))
+    (root / "scheduler" / "scheduler_config.json").write_text(json.dumps(dict(_class_name="CogVideoXDDIMScheduler", snr_shift_scale=1.0,
+                                                                              timestep_spacing="trailing")))
+    (root / "vae" / "config.json").write_text(json.dumps(dict(scaling_factor=0.7)))
+    save_file({"decoder.x": torch.ones(1)}, str(root / "vae" / "diffusion_pytorch_model.safetensors"))
+
+    cfg, sd = U.read_component(str(root), "transformer")
+    assert cfg["num_layers"] == 42 and sorted(sd) == ["a.weight", "b.weight"]
+    assert U.read_component(str(root), "missing") == ({}, None) and U.read_component("THUDM/CogVideoX-2b", "transformer") == ({}, None)
+
+    seen = {}
+
+    class FakeModel:
+        def __init__(self, num_attention_heads=30, attention_head_dim=64, num_layers=30, use_rotary_positional_embeddings=False,
+                     patch_size=2, in_channels=16, out_channels=16, text_embed_dim=4096, time_embed_dim=512, device=None, **kw):
+            self.config = SimpleNamespace(num_attention_heads=num_attention_heads, num_layers=num_layers, patch_size=patch_size,
+                                          use_rotary_positional_embeddings=use_rotary_positional_embeddings,
+                                          attention_head_dim=attention_head_dim)
+            self.parallel_manager = SimpleNamespace(dp_rank=0)
+
+        def load_state_dict(self, sd):
+            seen["sd"] = sorted(sd)
+
+    class FakeVAE:
+        def __init__(self, sd, device=None, scaling_factor=None, use_tiling=True):
+            seen["vae"] = (sorted(sd), scaling_factor)
+
+    import videosys_amd.vae_cogvideox as VC
+
+    monkeypatch.setattr(PC, "CogVideoXTransformer3DModel", FakeModel)
+    monkeypatch.setattr(VC, "CogVideoXVAE", FakeVAE)
+    pipe = PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path=str(root)), device="cpu")
+    assert pipe.transformer.config.num_layers == 42 and pipe.transformer.config.use_rotary_positional_embeddings
+    assert seen["sd"] == ["a.weight", "b.weight"] and seen["vae"] == (["decoder.x"], 0.7)
+    two_b = PC.CogVideoXDDIMScheduler(snr_shift_scale=3.0)
+    five_b = PC.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+    assert torch.equal(pipe.scheduler.alphas_cumprod, five_b.alphas_cumprod) and not torch.equal(two_b.alphas_cumprod, five_b.alphas_cumprod)
+
+    # Latte: <model_path>/transformer + vae_temporal_decoder
+    lroot = tmp_path / "latte"
+    for sub in ("transformer", "vae_temporal_decoder"):
+        (lroot / sub).mkdir(parents=True)
+    (lroot / "transformer" / "config.json").write_text(json.dumps(dict(num_layers=3, caption_channels=64, norm_num_groups=32)))
+    save_file({"w": torch.ones(1)}, str(lroot / "transformer" / "diffusion_pytorch_model.safetensors"))
+    save_file({"d": torch.ones(1)}, str(lroot / "vae_temporal_decoder" / "diffusion_pytorch_model.safetensors"))
+
+    class FakeLatte:
+        def __init__(self, num_layers=28, caption_channels=4096, video_length=16, device=None, **unused):
+            seen["latte"] = (num_layers, caption_channels, sorted(unused))
+            self.config = SimpleNamespace(num_layers=num_layers)
+            self.parallel_manager = SimpleNamespace(dp_rank=0)
+
+        def load_state_dict(self, sd):
+            seen["latte_sd"] = sorted(sd)
+
+    import videosys_amd.vae_svd_temporal as VS
+
+    monkeypatch.setattr(PL, "LatteT2V", FakeLatte)
+    monkeypatch.setattr(VS, "AutoencoderKLTemporalDecoder", lambda sd, device=None: ("svd", sorted(sd)))
+    lp = PL.LattePipeline(PL.LatteConfig(model_path=str(lroot)), device="cpu")
+    assert seen["latte"] == (3, 64, []) and seen["latte_sd"] == ["w"] and lp.vae_decoder == ("svd", ["d"])

@@ -11,17 +11,16 @@ SNR, "trailing" spacing, v-prediction, eta = 0) whose per-step CFG combine + upd
 from __future__ import annotations
 
 import math
-import os
 from typing import Callable, List, Optional
 
 import numpy as np
 import torch
 
-from .utils import StagedOffloadMixin, check_prompt_args as _check_prompt_args, randn_tensor as _randn
+from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, randn_tensor as _randn, read_component
 from . import ops, pab
 from .cogvideox import CogVideoXTransformer3DModel, synth_state_dict
 from .pab import PABConfig
-from .pipeline_open_sora import VideoSysPipelineOutput
+from .pipeline import VideoSysPipeline, VideoSysPipelineOutput
 
 
 class CogVideoXPABConfig(PABConfig):
@@ -132,7 +131,7 @@ def get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size, t
     return freqs.cos().contiguous(), freqs.sin().contiguous()
 
 
-class CogVideoXPipeline(StagedOffloadMixin):
+class CogVideoXPipeline(VideoSysPipeline):
     vae_scale_factor_spatial = 8
     vae_scale_factor_temporal = 4
 
@@ -146,23 +145,26 @@ class CogVideoXPipeline(StagedOffloadMixin):
         self._device = torch.device(device)
         name = config.model_path
         base = name.split("@", 1)[0] if isinstance(name, str) else ""
+        # <model_path>/transformer/{config.json, *.safetensors}, <model_path>/scheduler/scheduler_config.json when model_path is a
+        # local checkpoint directory (pipeline_cogvideox.py:150-160 from_pretrained); else the published geometry of the hub id +
+        # seeded weights
+        file_cfg, sd = read_component(name, "transformer")
         tcfg = dict(_GEOMETRY.get(base, {}))
+        tcfg.update(ctor_kwargs(CogVideoXTransformer3DModel.__init__, file_cfg))
         tcfg.update(config.transformer_config or {})
         self.transformer = CogVideoXTransformer3DModel(**tcfg, device=self._device)
-        st = os.path.join(name, "transformer", "diffusion_pytorch_model.safetensors") if isinstance(name, str) else ""
-        if st and os.path.exists(st):
-            from safetensors.torch import load_file
-
-            sd = load_file(st)
-        else:
+        if sd is None:
             seed = int(name.rsplit(":", 1)[1]) if isinstance(name, str) and ":" in name and name.rsplit(":", 1)[1].isdigit() else 777
             c = self.transformer.config
             sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.text_embed_dim, c.in_channels,
                                   c.out_channels, c.time_embed_dim, c.patch_size, seed=seed)
         self.transformer.load_state_dict(sd)
-        self.scheduler = CogVideoXDDIMScheduler(snr_shift_scale=1.0 if base.endswith("5b") else 3.0)
+        is_5b = base.endswith("5b") or self.transformer.config.num_layers == 42
+        sched_cfg = ctor_kwargs(CogVideoXDDIMScheduler.__init__, read_component(name, "scheduler")[0])
+        sched_cfg.setdefault("snr_shift_scale", 1.0 if is_5b else 3.0)
+        self.scheduler = CogVideoXDDIMScheduler(**sched_cfg)
         if vae_decoder is None:
-            vae_decoder = self._load_vae(config, base)
+            vae_decoder = self._load_vae(config, base, is_5b)
         self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
         self._set_parallel()
@@ -170,21 +172,19 @@ class CogVideoXPipeline(StagedOffloadMixin):
         self._init_stages(config.cpu_offload, self._device, text_encoder=getattr(self.text_encoder, "encoder", None),
                           transformer=self.transformer, vae=self.vae_decoder)
 
-    def _load_vae(self, config, base):
-        """pipeline_cogvideox.py:146-147,170-172: AutoencoderKLCogVideoX from ``<model_path>/vae`` (local safetensors) or
-        ``...@synthetic:<seed>`` random weights; tiling per ``config.vae_tiling``.  scaling_factor as published: 1.15258426 (2B),
-        0.7 (5B)."""
+    def _load_vae(self, config, base, is_5b=False):
+        """pipeline_cogvideox.py:146-147,170-172: AutoencoderKLCogVideoX from ``<model_path>/vae`` (local config.json + safetensors)
+        or ``...@synthetic:<seed>`` random weights; tiling per ``config.vae_tiling``.  scaling_factor from the checkpoint's
+        config.json, else as published: 1.15258426 (2B), 0.7 (5B)."""
         from .vae_cogvideox import CogVideoXVAE, synth_state_dict as vae_synth
 
         name = config.model_path
-        sf = 0.7 if base.endswith("5b") else 1.15258426
+        sf = 0.7 if is_5b else 1.15258426
         if isinstance(name, str) and "@synthetic:" in name:
             return CogVideoXVAE(vae_synth(int(name.rsplit(":", 1)[1])), device=self._device, scaling_factor=sf, use_tiling=config.vae_tiling)
-        st = os.path.join(name, "vae", "diffusion_pytorch_model.safetensors") if isinstance(name, str) else ""
-        if st and os.path.exists(st):
-            from safetensors.torch import load_file
-
-            return CogVideoXVAE(load_file(st), device=self._device, scaling_factor=sf, use_tiling=config.vae_tiling)
+        cfg, sd = read_component(name, "vae")
+        if sd is not None:
+            return CogVideoXVAE(sd, device=self._device, scaling_factor=cfg.get("scaling_factor", sf), use_tiling=config.vae_tiling)
         return None
 
     def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: Optional[bool] = False):

@@ -10,16 +10,15 @@ CFG combine + update is one HIP kernel (vsys_cfg_linear_step).
 from __future__ import annotations
 
 import math
-import os
 from typing import Callable, List, Optional
 
 import torch
 
-from .utils import StagedOffloadMixin, check_prompt_args as _check_prompt_args, randn_tensor as _randn
+from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, randn_tensor as _randn, read_component
 from . import ops, pab
 from .latte import LatteT2V, synth_state_dict
 from .pab import PABConfig
-from .pipeline_open_sora import VideoSysPipelineOutput
+from .pipeline import VideoSysPipeline, VideoSysPipelineOutput
 
 _MLP = {k: {"block": [0, 1, 2, 3, 4], "skip_count": 2} for k in (720, 640, 560, 480, 400)}
 
@@ -94,7 +93,7 @@ class DDIMScheduler:
         return math.sqrt(a_prev / a_t), math.sqrt(1 - a_prev) - math.sqrt(a_prev * (1 - a_t) / a_t)
 
 
-class LattePipeline(StagedOffloadMixin):
+class LattePipeline(VideoSysPipeline):
     vae_scale_factor = 8   # 2 ** (len(vae.config.block_out_channels) - 1) (pipeline_latte.py:239)
 
     def __init__(self, config: LatteConfig, device=None, text_encoder: Optional[Callable] = None,
@@ -105,15 +104,14 @@ class LattePipeline(StagedOffloadMixin):
                 raise RuntimeError("LattePipeline needs a HIP device (videosys_amd has no CPU execution path)")
             device = torch.device("cuda", torch.cuda.current_device())
         self._device = torch.device(device)
-        tcfg = dict(config.transformer_config or {})
-        self.transformer = LatteT2V(**tcfg, device=self._device)
         name = config.model_path
-        st = os.path.join(name, "transformer", "diffusion_pytorch_model.safetensors") if isinstance(name, str) else ""
-        if st and os.path.exists(st):
-            from safetensors.torch import load_file
-
-            sd = load_file(st)
-        else:
+        # <model_path>/transformer/{config.json, *.safetensors} of a local checkpoint directory (pipeline_latte.py:208-210
+        # LatteT2V.from_pretrained(model_path, subfolder="transformer", video_length=16)); else seeded weights
+        file_cfg, sd = read_component(name, "transformer")
+        tcfg = ctor_kwargs(LatteT2V.__init__, file_cfg)
+        tcfg.update(config.transformer_config or {})
+        self.transformer = LatteT2V(**tcfg, device=self._device)
+        if sd is None:
             seed = int(name.split(":", 1)[1]) if isinstance(name, str) and name.startswith("synthetic:") else 4321
             c = self.transformer.config
             sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.caption_channels, c.in_channels,
@@ -143,24 +141,16 @@ class LattePipeline(StagedOffloadMixin):
 
             if name.startswith("synthetic:"):
                 return AutoencoderKLTemporalDecoder(svd_synth(int(name.split(":", 1)[1])), device=self._device)
-            st = os.path.join(name, "vae_temporal_decoder", "diffusion_pytorch_model.safetensors")
-            if os.path.exists(st):
-                from safetensors.torch import load_file
-
-                return AutoencoderKLTemporalDecoder(load_file(st), device=self._device)
-            return None
+            sd = read_component(name, "vae_temporal_decoder")[1]
+            return AutoencoderKLTemporalDecoder(sd, device=self._device) if sd is not None else None
         from .vae_open_sora import AutoencoderKLDecoder, synth_state_dict as vae_synth
 
         if name.startswith("synthetic:"):
             pre = "spatial_vae.module."
             sd = {k[len(pre):]: v for k, v in vae_synth(int(name.split(":", 1)[1])).items() if k.startswith(pre)}
             return AutoencoderKLDecoder(sd, device=self._device)
-        st = os.path.join(name, "vae", "diffusion_pytorch_model.safetensors")
-        if os.path.exists(st):
-            from safetensors.torch import load_file
-
-            return AutoencoderKLDecoder(load_file(st), device=self._device)
-        return None
+        cfg, sd = read_component(name, "vae")
+        return AutoencoderKLDecoder(sd, device=self._device, scaling_factor=cfg.get("scaling_factor", 0.18215)) if sd is not None else None
 
     def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: Optional[bool] = False):
         """pipeline_latte.py:236-250: sp = world size unless given (then dp = world / sp)."""

@@ -12,8 +12,8 @@ locally) builds seeded random weights of the real STDiT3-XL/2 geometry.
 """
 from __future__ import annotations
 
+import glob
 import os
-from dataclasses import dataclass
 from typing import Callable, Optional
 
 import torch
@@ -21,8 +21,8 @@ import torch
 from . import pab
 from .pab import PABConfig
 from .rflow import RFLOW
-from .stdit3 import STDiT3, STDiT3Config, synth_state_dict
-from .utils import StagedOffloadMixin
+from .stdit3 import STDiT3
+from .pipeline import VideoSysPipeline, VideoSysPipelineOutput  # noqa: F401 (re-exported)
 
 
 class OpenSoraPABConfig(PABConfig):
@@ -96,13 +96,6 @@ class OpenSoraConfig:
             raise TypeError(f"unexpected OpenSoraConfig kwargs: {sorted(extra)}")
 
 
-@dataclass
-class VideoSysPipelineOutput:
-    """core/pipeline/pipeline.py:47-53."""
-
-    video: torch.Tensor
-
-
 def get_latent_size(num_frames: int, height: int, width: int):
     """OpenSoraVAE_V1_2.get_latent_size (autoencoder_kl_open_sora.py:706-717): spatial /8; time 17-frame micro
     batches compress x4 with a causal first frame: 64 frames -> 3*5 + 4 = 19."""
@@ -118,7 +111,7 @@ def get_latent_size(num_frames: int, height: int, width: int):
     return (t, height // 8, width // 8)
 
 
-class OpenSoraPipeline(StagedOffloadMixin):
+class OpenSoraPipeline(VideoSysPipeline):
     """The per-rank pipeline object the engine instantiates (engine.py:68-72) and whose ``generate`` it calls."""
 
     def __init__(self, config: OpenSoraConfig, device=None, text_encoder: Optional[Callable] = None,
@@ -129,17 +122,10 @@ class OpenSoraPipeline(StagedOffloadMixin):
                 raise RuntimeError("OpenSoraPipeline needs a HIP device (videosys_amd has no CPU execution path)")
             device = torch.device("cuda", torch.cuda.current_device())
         self._device = torch.device(device)
-        tcfg = STDiT3Config(**(config.transformer_config or {}))
-        self.transformer = STDiT3(tcfg, device=self._device)
-        name = config.transformer
-        if isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "model.safetensors")):
-            from safetensors.torch import load_file
-
-            sd = load_file(os.path.join(name, "model.safetensors"))
-        else:
-            seed = int(name.split(":", 1)[1]) if isinstance(name, str) and name.startswith("synthetic:") else 1234
-            sd = synth_state_dict(tcfg, seed=seed)
-        self.transformer.load_state_dict(sd)
+        name = config.transformer   # a local checkpoint directory or "synthetic:<seed>"; a hub id cannot be fetched: seeded weights
+        local = isinstance(name, str) and (name.startswith("synthetic:") or bool(glob.glob(os.path.join(name, "*.safetensors"))))
+        self.transformer = STDiT3.from_pretrained(name if local else "synthetic:1234", device=self._device,
+                                                  **(config.transformer_config or {}))
         self.scheduler = RFLOW(num_sampling_steps=config.num_sampling_steps, cfg_scale=config.cfg_scale,
                                use_timestep_transform=True)
         if text_encoder is None:
@@ -167,7 +153,6 @@ class OpenSoraPipeline(StagedOffloadMixin):
         """pipeline_open_sora.py:211-214: T5EncoderModel + AutoTokenizer from ``config.text_encoder`` — here a LOCAL directory
         holding the HF checkpoint (config.json, *.safetensors, tokenizer files); a hub id cannot be fetched, so the pipeline then
         expects ``prompt_embeds``."""
-        import glob
         import json
 
         if isinstance(name, str) and name.startswith("synthetic:"):
@@ -202,15 +187,12 @@ class OpenSoraPipeline(StagedOffloadMixin):
     def _load_vae(self, name):
         """OpenSoraVAE_V1_2 (autoencoder_kl_open_sora.py:738-761): a local checkpoint directory (model.safetensors with the
         reference's keys) or "synthetic:<seed>"; a hub id cannot be fetched here, so it leaves the pipeline latent-only."""
-        from .vae_open_sora import OpenSoraVAE, synth_state_dict as vae_synth
+        from .vae_open_sora import OpenSoraVAE_V1_2
 
-        if isinstance(name, str) and name.startswith(("synthetic:", "synthetic-full:")):   # -full: with the encoders (conditioning)
-            return OpenSoraVAE(vae_synth(int(name.split(":", 1)[1]), encoder=name.startswith("synthetic-full:")), device=self._device)
-        if isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "model.safetensors")):
-            from safetensors.torch import load_file
-
-            return OpenSoraVAE(load_file(os.path.join(name, "model.safetensors")), device=self._device)
-        return None
+        try:
+            return OpenSoraVAE_V1_2(from_pretrained=name, device=self._device)
+        except FileNotFoundError:
+            return None
 
     def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: bool = False):
         """pipeline_open_sora.py:253-267: dp=1, sp=world."""

@@ -751,6 +751,38 @@ class STDiT3:
             pab.PAB_MANAGER.config.mlp_temporal_outputs.clear()
 
 
+def _from_pretrained(cls, name, device="cuda", **kwargs):
+    """STDiT3.from_pretrained (open_sora_transformer_3d.py:661-663; the hub download of HF's PreTrainedModel, third-party, is not
+    available offline): ``name`` is a LOCAL checkpoint directory holding the ``*.safetensors`` file(s) (+ optional ``config.json``) with the
+    reference's keys, or ``"synthetic:<seed>"`` for seeded random weights of the configured geometry."""
+    from .utils import read_component
+
+    file_cfg, sd = read_component(name)
+    known = set(STDiT3Config().__dict__)
+    cfg = {k: (tuple(v) if isinstance(v, list) else v) for k, v in file_cfg.items() if k in known}
+    cfg.update(kwargs)
+    model = cls(STDiT3Config(**cfg), device=device)
+    if sd is None:
+        if not (isinstance(name, str) and name.startswith("synthetic:")):
+            raise FileNotFoundError(f"STDiT3.from_pretrained({name!r}): not a local checkpoint directory (*.safetensors) and not "
+                                    "'synthetic:<seed>' — hub ids cannot be fetched on this box")
+        sd = synth_state_dict(model.config, seed=int(name.split(":", 1)[1]))
+    model.load_state_dict(sd)
+    return model
+
+
+STDiT3.from_pretrained = classmethod(_from_pretrained)
+
+
+def STDiT3_XL_2(from_pretrained=None, **kwargs):
+    """open_sora_transformer_3d.py:661-667: the XL/2 geometry (depth 28, width 1152, 16 heads, patch (1, 2, 2)); weights from
+    ``from_pretrained`` (see STDiT3.from_pretrained) or left unset for the caller's ``load_state_dict``."""
+    device = kwargs.pop("device", "cuda")
+    if from_pretrained is not None:
+        return STDiT3.from_pretrained(from_pretrained, device=device, **kwargs)
+    return STDiT3(STDiT3Config(depth=28, hidden_size=1152, patch_size=(1, 2, 2), num_heads=16, **kwargs), device=device)
+
+
 def synth_state_dict(config: STDiT3Config, seed: int = 1234) -> Dict[str, torch.Tensor]:
     """Seeded random-init weights with the checkpoint's key names/shapes (no pretrained weights offline).
     Generated on the host CPU generator so every rank / the oracle see identical values."""

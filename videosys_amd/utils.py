@@ -25,6 +25,58 @@ def set_seed(seed, dp_rank=None):
     return seed
 
 
+def str_to_dtype(x: str):
+    """utils/utils.py:39-47."""
+    table = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
+    if x not in table:
+        raise RuntimeError(f"Only fp32, fp16 and bf16 are supported, but got {x}")
+    return table[x]
+
+
+def requires_grad(model, flag: bool = True) -> None:
+    """utils/utils.py:12-17, for torch modules a caller attaches; the model objects of this build hold plain HBM tables."""
+    for p in model.parameters():
+        p.requires_grad = flag
+
+
+def all_exists(paths):
+    """utils/utils.py:80-81."""
+    import os
+
+    return all(os.path.exists(path) for path in paths)
+
+
+def empty_cache(func):
+    """utils/test.py:6-13: the decorator of the reference's pipeline tests — release the caching allocator before the test."""
+    import functools
+
+    @functools.wraps(func)
+    def wrapper(*args, **kwargs):
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        return func(*args, **kwargs)
+
+    return wrapper
+
+
+def init_logger(logging_dir: str = None, master_only: bool = True):
+    """utils/logging.py:6-38: root logger at INFO with the reference's line format (+ ``<logging_dir>/log.txt``); silent on the
+    ranks other than 0 when ``master_only``."""
+    import logging
+
+    logger = logging.getLogger()
+    logger.handlers.clear()
+    if dist.is_initialized() and master_only and dist.get_rank() != 0:
+        logger.addHandler(logging.NullHandler())
+        return logger
+    extra = {}
+    if logging_dir is not None:
+        extra["handlers"] = [logging.StreamHandler(), logging.FileHandler(f"{logging_dir}/log.txt")]
+    logging.basicConfig(level=logging.INFO, format="[%(asctime)s] [%(levelname)s] [%(filename)s:%(lineno)d:%(funcName)s]   %(message)s",
+                        datefmt="%Y-%m-%d %H:%M:%S", **extra)
+    return logging.getLogger()
+
+
 def randn_tensor(shape, generator=None, dtype=None):
     """Start noise the way the pipelines draw it (diffusers' ``randn_tensor``, third-party: drawn on the generator's device, then
     moved by the caller): fp32 from ``generator`` — a torch.Generator, or a list of them, one per sample — else from torch's
@@ -54,6 +106,43 @@ def check_prompt_args(prompt, negative_prompt, prompt_embeds=None, negative_prom
     if prompt_embeds is not None and negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
         raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed directly, but got:"
                          f" `prompt_embeds` {prompt_embeds.shape} != `negative_prompt_embeds` {negative_prompt_embeds.shape}.")
+
+
+def read_component(path, subfolder=None):
+    """One component of a LOCAL checkpoint directory in the Hugging Face layout the reference's ``from_pretrained`` calls read
+    (``<path>/<subfolder>/config.json`` or ``scheduler_config.json`` + ``*.safetensors``, single file or the sharded
+    ``...-00001-of-0000N.safetensors`` set) -> (config dict, state dict or None).  ({}, None) when the directory is not there:
+    hub ids cannot be fetched on this box, the callers then fall back to their seeded synthetic weights or refuse."""
+    import glob
+    import json
+    import os
+
+    d = os.path.join(path, subfolder) if (isinstance(path, str) and subfolder) else path
+    if not (isinstance(d, str) and os.path.isdir(d)):
+        return {}, None
+    cfg = {}
+    for name in ("config.json", "scheduler_config.json"):
+        if os.path.isfile(os.path.join(d, name)):
+            with open(os.path.join(d, name)) as fh:
+                cfg = json.load(fh)
+            break
+    files = sorted(glob.glob(os.path.join(d, "*.safetensors")))
+    if not files:
+        return cfg, None
+    from safetensors.torch import load_file
+
+    sd = {}
+    for f in files:
+        sd.update(load_file(f))
+    return cfg, sd
+
+
+def ctor_kwargs(fn, cfg: dict) -> dict:
+    """The entries of a checkpoint's config.json that ``fn`` takes as keywords (bookkeeping keys such as ``_class_name`` dropped)."""
+    import inspect
+
+    names = set(inspect.signature(fn).parameters) - {"self", "device", "dtype"}
+    return {k: v for k, v in cfg.items() if k in names}
 
 
 def same_tensor(a, b) -> bool:

@@ -252,6 +252,9 @@ class CogVideoXVAE:
 
 
 # ---------------------------------------------------------------------------------------------------- synthetic weights
+AutoencoderKLCogVideoX = CogVideoXVAE   # the reference's class name (autoencoder_kl_cogvideox.py); decode side only
+
+
 def decoder_param_shapes() -> Dict[str, tuple]:
     """Decode-side parameters of the reference AutoencoderKLCogVideoX (checked against its state_dict in the CPU tests)."""
     p: Dict[str, tuple] = {}

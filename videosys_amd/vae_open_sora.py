@@ -488,6 +488,25 @@ class OpenSoraVAE:
     __call__ = decode
 
 
+def OpenSoraVAE_V1_2(micro_batch_size=4, micro_frame_size=17, from_pretrained=None, freeze_vae_2d=False, cal_loss=False, device="cuda"):
+    """autoencoder_kl_open_sora.py:731-761: the Open-Sora 1.2 video VAE (SDXL 2-D VAE + VAE_Temporal_SD, the published latent shift /
+    scale).  ``from_pretrained``: a LOCAL checkpoint directory holding ``model.safetensors`` with the reference's keys (the hub
+    download of the reference is not available offline), ``"synthetic:<seed>"`` (decoder only) or ``"synthetic-full:<seed>"``
+    (with the encoders, for image / video conditioning).  ``freeze_vae_2d`` / ``cal_loss`` are training switches with nothing to
+    act on in an inference build."""
+    from .utils import read_component
+
+    name = from_pretrained
+    if isinstance(name, str) and name.startswith(("synthetic:", "synthetic-full:")):
+        sd = synth_state_dict(int(name.split(":", 1)[1]), encoder=name.startswith("synthetic-full:"))
+    else:
+        sd = read_component(name)[1]
+    if sd is None:
+        raise FileNotFoundError(f"OpenSoraVAE_V1_2(from_pretrained={name!r}): not a local checkpoint directory (model.safetensors) and "
+                                "not 'synthetic[-full]:<seed>' — hub ids cannot be fetched on this box")
+    return OpenSoraVAE(sd, device=device, micro_frame_size=micro_frame_size, micro_batch_size=micro_batch_size)
+
+
 class AutoencoderKLDecoder(OpenSoraVAE):
     """Per-frame decode with a diffusers ``AutoencoderKL`` (SD / SDXL VAE geometry, state-dict keys ``decoder.*``,
     ``post_quant_conv.*``) — what LattePipeline.decode_latents does with ``enable_vae_temporal_decoder=False``
