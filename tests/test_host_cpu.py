@@ -215,6 +215,81 @@ def test_dsp_two_ranks_gloo(T, S):
         assert status == "ok", f"rank {rank}: {status}"
 
 
+def _ref_comm_worker(rank, world, port, ret):
+    """Runs the REFERENCE's comm.py functions (imported from /root/reference through oracle/ref_loader.py) and this build's
+    videosys_amd.comm on the same tensors over the same gloo group.  gloo has no list all-to-all, so ``dist.all_to_all`` — the one
+    collective the reference's ``_all_to_all_func`` issues — is served by all_to_all_single here; the reference's own
+    tensor_split / contiguous / cat / pad / narrow logic runs unchanged."""
+    try:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+
+        def list_all_to_all(outs, ins, group=None):
+            send = torch.stack(ins)
+            recv = torch.empty_like(send)
+            dist.all_to_all_single(recv, send, group=group)
+            for o, r in zip(outs, recv.unbind(0)):
+                o.copy_(r)
+
+        dist.all_to_all = list_all_to_all
+        from oracle import ref_loader
+
+        R = ref_loader.load_reference_modules()["comm"]
+        from videosys_amd import comm as M
+
+        g = torch.Generator().manual_seed(7)
+        grp = dist.group.WORLD
+        with torch.no_grad():
+            for shape, sdim, gdim in (((2, 5, 12, 8), 1, 2), ((2, 4, 7, 8), 2, 1), ((3, 6, 10), 1, 2), ((2, 19, 6, 4), 1, 2)):
+                x = torch.randn(*shape, generator=g)
+                n_s, n_g = x.shape[sdim], x.shape[gdim]
+                pad_s, pad_g = (world - n_s % world) % world, (world - n_g % world) % world
+                # at rest: sharded along gdim (padded); the switch scatters sdim and gathers gdim
+                a = R.split_sequence(x, grp, dim=gdim, grad_scale="down", pad=pad_g)
+                b = M.split_sequence(x, grp, dim=gdim, grad_scale="down", pad=pad_g)
+                assert torch.equal(a, b), ("split_sequence", shape)
+                a2 = R.all_to_all_with_pad(a, grp, scatter_dim=sdim, gather_dim=gdim, scatter_pad=pad_s, gather_pad=pad_g)
+                b2 = M.all_to_all_with_pad(b, grp, scatter_dim=sdim, gather_dim=gdim, scatter_pad=pad_s, gather_pad=pad_g)
+                assert a2.shape == b2.shape and torch.equal(a2, b2), ("all_to_all_with_pad", shape)
+                a3 = R.all_to_all_with_pad(a2, grp, scatter_dim=gdim, gather_dim=sdim, scatter_pad=pad_g, gather_pad=pad_s)
+                b3 = M.all_to_all_with_pad(b2, grp, scatter_dim=gdim, gather_dim=sdim, scatter_pad=pad_g, gather_pad=pad_s)
+                assert torch.equal(a3, b3) and torch.equal(b3, b), ("switch back", shape)
+                if not pad_s:
+                    assert torch.equal(R.all_to_all_comm(a, grp, sdim, gdim), M.all_to_all_comm(b, grp, sdim, gdim)), ("all_to_all_comm", shape)
+                # pad value other than zero, pad registry
+                assert torch.equal(R.split_sequence(x, grp, gdim, 1.0, pad_g, -3), M.split_sequence(x, grp, gdim, 1.0, pad_g, -3))
+                R.set_pad("temporal", n_s, grp), M.set_pad("temporal", n_s, grp)
+                assert R.get_pad("temporal") == M.get_pad("temporal") == pad_s
+            f = torch.randn(2 * 5, 3, 4, generator=g)
+            R.set_pad("temporal", 5, grp), M.set_pad("temporal", 5, grp)
+            assert torch.equal(R.split_from_second_dim(f, 2, grp), M.split_from_second_dim(f, 2, grp))
+        ret.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+
+        ret.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_comm_operators_equal_the_reference_functions_over_gloo():
+    """SURVEY §8a row a13 at the function level: split_sequence / all_to_all_with_pad / all_to_all_comm / split_from_second_dim /
+    set_pad of videosys_amd.comm against the reference's comm.py itself, two real processes, bit-equal."""
+    if not os.path.isdir("/root/reference/videosys"):
+        pytest.skip("reference tree not present on this box")
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ref_comm_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [ret.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, status in res:
+        assert status == "ok", f"rank {rank}: {status}"
+
+
 @pytest.mark.parametrize("T,S", [(19, 16), (38, 24)])
 def test_dsp_eight_ranks_gloo(T, S):
     """The BASELINE degree (P = 8) with the frame counts of configs 2 and 4: T = 19 -> 3 padded frames per rank, ranks 6 / 7
