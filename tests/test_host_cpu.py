@@ -1087,7 +1087,7 @@ def test_local_checkpoint_directories_are_read_like_from_pretrained(tmp_path, mo
                      patch_size=2, in_channels=16, out_channels=16, text_embed_dim=4096, time_embed_dim=512, device=None, **kw):
             self.config = SimpleNamespace(num_attention_heads=num_attention_heads, num_layers=num_layers, patch_size=patch_size,
                                           use_rotary_positional_embeddings=use_rotary_positional_embeddings,
-                                          attention_head_dim=attention_head_dim)
+                                          attention_head_dim=attention_head_dim, text_embed_dim=text_embed_dim)
             self.parallel_manager = SimpleNamespace(dp_rank=0)
 
         def load_state_dict(self, sd):
@@ -1119,7 +1119,7 @@ def test_local_checkpoint_directories_are_read_like_from_pretrained(tmp_path, mo
     class FakeLatte:
         def __init__(self, num_layers=28, caption_channels=4096, video_length=16, device=None, **unused):
             seen["latte"] = (num_layers, caption_channels, sorted(unused))
-            self.config = SimpleNamespace(num_layers=num_layers)
+            self.config = SimpleNamespace(num_layers=num_layers, caption_channels=caption_channels)
             self.parallel_manager = SimpleNamespace(dp_rank=0)
 
         def load_state_dict(self, sd):
@@ -1131,3 +1131,82 @@ def test_local_checkpoint_directories_are_read_like_from_pretrained(tmp_path, mo
     monkeypatch.setattr(VS, "AutoencoderKLTemporalDecoder", lambda sd, device=None: ("svd", sorted(sd)))
     lp = PL.LattePipeline(PL.LatteConfig(model_path=str(lroot)), device="cpu")
     assert seen["latte"] == (3, 64, []) and seen["latte_sd"] == ["w"] and lp.vae_decoder == ("svd", ["d"])
+
+
+def test_pipeline_constructors_take_the_reference_components(tmp_path, monkeypatch):
+    """The constructors keep the reference's parameter names and order (pipeline_open_sora.py:194-204, pipeline_latte.py:192-202,
+    pipeline_cogvideox.py:124-134); ready-made components are adopted: a torch module holding reference weights is read through
+    state_dict() / config, this build's own objects and schedulers are used as they are, a local ``text_encoder/`` + ``tokenizer``
+    pair becomes the T5 callable.  Device models are recorders (host logic only)."""
+    import ast
+    import inspect
+    import json
+    from types import SimpleNamespace
+
+    from safetensors.torch import save_file
+
+    from videosys_amd import pipeline_cogvideox as PC, pipeline_latte as PL, pipeline_open_sora as PO
+    import videosys_amd.t5 as T5
+
+    ref_root = "/root/reference/videosys/pipelines"
+    if os.path.isdir(ref_root):
+        for path, cls, ours in (("open_sora/pipeline_open_sora.py", "OpenSoraPipeline", PO.OpenSoraPipeline),
+                                ("latte/pipeline_latte.py", "LattePipeline", PL.LattePipeline),
+                                ("cogvideox/pipeline_cogvideox.py", "CogVideoXPipeline", PC.CogVideoXPipeline)):
+            node = next(n for n in ast.parse(open(os.path.join(ref_root, path)).read()).body if isinstance(n, ast.ClassDef) and n.name == cls)
+            init = next(it for it in node.body if isinstance(it, ast.FunctionDef) and it.name == "__init__")
+            want = [a.arg for a in init.args.args]
+            have = [k for k, v in inspect.signature(ours.__init__).parameters.items() if v.kind == v.POSITIONAL_OR_KEYWORD]
+            assert have == want, (cls, have, want)
+
+    seen = {}
+
+    class FakeT5:
+        def __init__(self, d_model=4096, d_kv=64, d_ff=10240, num_layers=24, num_heads=64, vocab_size=32128, device=None, **kw):
+            self.config = SimpleNamespace(d_model=d_model, num_layers=num_layers, vocab_size=vocab_size)
+
+        def load_state_dict(self, sd):
+            seen["t5_sd"] = sorted(sd)
+
+    monkeypatch.setattr(T5, "T5Encoder", FakeT5)
+
+    class FakeCog:
+        def __init__(self, num_attention_heads=30, attention_head_dim=64, num_layers=30, use_rotary_positional_embeddings=False,
+                     patch_size=2, in_channels=16, out_channels=16, text_embed_dim=4096, time_embed_dim=512, device=None, **kw):
+            self.config = SimpleNamespace(num_layers=num_layers, text_embed_dim=text_embed_dim, num_attention_heads=num_attention_heads)
+            self.parallel_manager = SimpleNamespace(dp_rank=0)
+
+        def load_state_dict(self, sd):
+            seen["cog_sd"] = sorted(sd)
+
+    monkeypatch.setattr(PC, "CogVideoXTransformer3DModel", FakeCog)
+
+    class RefModule:   # stands for a torch module of the reference: state_dict() + .config
+        config = SimpleNamespace(num_layers=42, num_attention_heads=48, use_rotary_positional_embeddings=True, _name_or_path="x")
+
+        def state_dict(self):
+            return {"blocks.0.w": torch.ones(1)}
+
+    root = tmp_path / "ckpt"
+    (root / "text_encoder").mkdir(parents=True)
+    (root / "text_encoder" / "config.json").write_text(json.dumps(dict(d_model=256, d_kv=64, d_ff=512, num_layers=2, num_heads=4,
+                                                                        vocab_size=100, model_type="t5")))
+    save_file({"shared.weight": torch.zeros(100, 256)}, str(root / "text_encoder" / "model.safetensors"))
+    tok = lambda *a, **k: None
+    sched = SimpleNamespace(timesteps=[1], init_noise_sigma=1.0)
+    vae = lambda z: z
+    pipe = PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path=str(root)), tok, None, vae, RefModule(), sched, device="cpu")
+    assert pipe.transformer.config.num_layers == 42 and seen["cog_sd"] == ["blocks.0.w"]          # the module's geometry and weights
+    assert pipe.scheduler is sched and pipe.vae is vae and pipe.vae_decoder is vae
+    te = pipe.text_encoder                                                                       # <model_path>/text_encoder + tokenizer
+    assert type(te).__name__ == "T5TextEncoder" and te.tokenizer is tok and pipe.tokenizer is tok and seen["t5_sd"] == ["shared.weight"]
+    assert te.max_length == 226 and te.use_attention_mask is False and te.encoder.config.d_model == 256
+    with pytest.raises(NotImplementedError):
+        PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path=str(root)), tok, None, vae, RefModule(), sched, device="cpu", dtype=torch.float32)
+    with pytest.raises(ValueError):   # a text-encoder MODULE needs its tokenizer
+        PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), None, RefModule(), vae, RefModule(), sched, device="cpu")
+    # own objects pass through; fp16 request accepted (same width, computed in bf16)
+    own = FakeCog(num_layers=30)
+    pipe2 = PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), transformer=own, text_encoder=lambda p: p,
+                                 device="cpu", dtype=torch.float16)
+    assert pipe2.transformer is own and pipe2.text_encoder("x") == "x" and pipe2.vae is None

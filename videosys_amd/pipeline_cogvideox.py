@@ -11,6 +11,7 @@ SNR, "trailing" spacing, v-prediction, eta = 0) whose per-step CFG combine + upd
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, List, Optional
 
 import numpy as np
@@ -20,7 +21,7 @@ from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, randn_t
 from . import ops, pab
 from .cogvideox import CogVideoXTransformer3DModel, synth_state_dict
 from .pab import PABConfig
-from .pipeline import VideoSysPipeline, VideoSysPipelineOutput
+from .pipeline import VideoSysPipeline, VideoSysPipelineOutput, build_text_encoder, is_foreign_module, module_state
 
 
 class CogVideoXPABConfig(PABConfig):
@@ -135,42 +136,65 @@ class CogVideoXPipeline(VideoSysPipeline):
     vae_scale_factor_spatial = 8
     vae_scale_factor_temporal = 4
 
-    def __init__(self, config: CogVideoXConfig, device=None, text_encoder: Optional[Callable] = None,
-                 vae_decoder: Optional[Callable] = None):
+    def __init__(self, config: CogVideoXConfig, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None,
+                 device=None, dtype: torch.dtype = torch.bfloat16, *, vae_decoder: Optional[Callable] = None):
+        """pipeline_cogvideox.py:124-187, same parameter order.  Components left at None are read from ``config.model_path`` when
+        that is a LOCAL checkpoint directory in the published layout (``transformer/``, ``scheduler/``, ``vae/``, ``text_encoder/`` +
+        ``tokenizer/``); a hub id selects the published geometry with seeded synthetic weights and no text encoder / VAE
+        (generate() then takes ``prompt_embeds`` and returns latents).  A component may be this build's object, or a torch module
+        holding the reference's weights (pipeline.module_state); ``text_encoder="synthetic:<seed>"`` builds an offline stand-in.
+        ``dtype``: see VideoSysPipeline._check_dtype (the reference switches the 2b model to fp16).  ``vae_decoder`` = ``vae``."""
         self._config = config
-        if device is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("CogVideoXPipeline needs a HIP device (videosys_amd has no CPU execution path)")
-            device = torch.device("cuda", torch.cuda.current_device())
-        self._device = torch.device(device)
+        self._dtype = self._check_dtype(dtype)
+        self._device = self._resolve_device(device, "CogVideoXPipeline")
         name = config.model_path
         base = name.split("@", 1)[0] if isinstance(name, str) else ""
-        # <model_path>/transformer/{config.json, *.safetensors}, <model_path>/scheduler/scheduler_config.json when model_path is a
-        # local checkpoint directory (pipeline_cogvideox.py:150-160 from_pretrained); else the published geometry of the hub id +
-        # seeded weights
-        file_cfg, sd = read_component(name, "transformer")
-        tcfg = dict(_GEOMETRY.get(base, {}))
-        tcfg.update(ctor_kwargs(CogVideoXTransformer3DModel.__init__, file_cfg))
-        tcfg.update(config.transformer_config or {})
-        self.transformer = CogVideoXTransformer3DModel(**tcfg, device=self._device)
-        if sd is None:
-            seed = int(name.rsplit(":", 1)[1]) if isinstance(name, str) and ":" in name and name.rsplit(":", 1)[1].isdigit() else 777
-            c = self.transformer.config
-            sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.text_embed_dim, c.in_channels,
-                                  c.out_channels, c.time_embed_dim, c.patch_size, seed=seed)
-        self.transformer.load_state_dict(sd)
+        if transformer is None or is_foreign_module(transformer, CogVideoXTransformer3DModel):
+            # <model_path>/transformer/{config.json, *.safetensors} (:141-144 from_pretrained); else the published geometry of the
+            # hub id + seeded weights
+            file_cfg, sd = module_state(transformer) if transformer is not None else read_component(name, "transformer")
+            tcfg = dict(_GEOMETRY.get(base, {}))
+            tcfg.update(ctor_kwargs(CogVideoXTransformer3DModel.__init__, file_cfg))
+            tcfg.update(config.transformer_config or {})
+            transformer = CogVideoXTransformer3DModel(**tcfg, device=self._device)
+            if sd is None:
+                seed = int(name.rsplit(":", 1)[1]) if isinstance(name, str) and ":" in name and name.rsplit(":", 1)[1].isdigit() else 777
+                c = transformer.config
+                sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.text_embed_dim, c.in_channels,
+                                      c.out_channels, c.time_embed_dim, c.patch_size, seed=seed)
+            transformer.load_state_dict(sd)
+        self.transformer = transformer
         is_5b = base.endswith("5b") or self.transformer.config.num_layers == 42
-        sched_cfg = ctor_kwargs(CogVideoXDDIMScheduler.__init__, read_component(name, "scheduler")[0])
-        sched_cfg.setdefault("snr_shift_scale", 1.0 if is_5b else 3.0)
-        self.scheduler = CogVideoXDDIMScheduler(**sched_cfg)
-        if vae_decoder is None:
-            vae_decoder = self._load_vae(config, base, is_5b)
-        self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
+        if scheduler is None:   # <model_path>/scheduler/scheduler_config.json (:155-158)
+            sched_cfg = ctor_kwargs(CogVideoXDDIMScheduler.__init__, read_component(name, "scheduler")[0])
+            sched_cfg.setdefault("snr_shift_scale", 1.0 if is_5b else 3.0)
+            scheduler = CogVideoXDDIMScheduler(**sched_cfg)
+        self.scheduler = scheduler
+        vae = vae if vae is not None else vae_decoder
+        if vae is None:
+            vae = self._load_vae(config, base, is_5b)
+        elif is_foreign_module(vae):
+            from .vae_cogvideox import CogVideoXVAE
+
+            cfg, sd = module_state(vae)
+            vae = CogVideoXVAE(sd, device=self._device, scaling_factor=cfg.get("scaling_factor", 0.7 if is_5b else 1.15258426),
+                               use_tiling=config.vae_tiling)
+        if text_encoder is None and isinstance(name, str) and os.path.isdir(os.path.join(name, "text_encoder")):
+            text_encoder = os.path.join(name, "text_encoder")   # (:149-153) T5EncoderModel + T5Tokenizer of the checkpoint
+        # the reference hands the encoder no attention mask (:244): the padding is attended
+        self.text_encoder = build_text_encoder(text_encoder, tokenizer, device=self._device,
+                                               caption_channels=self.transformer.config.text_embed_dim, max_length=226,
+                                               use_attention_mask=False,
+                                               tokenizer_path=os.path.join(name, "tokenizer") if isinstance(name, str) else None)
+        self.vae_decoder = vae
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
         self._set_parallel()
         # cpu_offload: each stage's weights live in pinned host memory and are resident only while the stage runs
         self._init_stages(config.cpu_offload, self._device, text_encoder=getattr(self.text_encoder, "encoder", None),
                           transformer=self.transformer, vae=self.vae_decoder)
+
+    vae = property(lambda self: self.vae_decoder)                                      # register_modules names (:161-163)
+    tokenizer = property(lambda self: getattr(self.text_encoder, "tokenizer", None))
 
     def _load_vae(self, config, base, is_5b=False):
         """pipeline_cogvideox.py:146-147,170-172: AutoencoderKLCogVideoX from ``<model_path>/vae`` (local config.json + safetensors)

@@ -10,6 +10,7 @@ CFG combine + update is one HIP kernel (vsys_cfg_linear_step).
 from __future__ import annotations
 
 import math
+import os
 from typing import Callable, List, Optional
 
 import torch
@@ -18,7 +19,7 @@ from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, randn_t
 from . import ops, pab
 from .latte import LatteT2V, synth_state_dict
 from .pab import PABConfig
-from .pipeline import VideoSysPipeline, VideoSysPipelineOutput
+from .pipeline import VideoSysPipeline, VideoSysPipelineOutput, build_text_encoder, is_foreign_module, module_state
 
 _MLP = {k: {"block": [0, 1, 2, 3, 4], "skip_count": 2} for k in (720, 640, 560, 480, 400)}
 
@@ -96,37 +97,64 @@ class DDIMScheduler:
 class LattePipeline(VideoSysPipeline):
     vae_scale_factor = 8   # 2 ** (len(vae.config.block_out_channels) - 1) (pipeline_latte.py:239)
 
-    def __init__(self, config: LatteConfig, device=None, text_encoder: Optional[Callable] = None,
-                 vae_decoder: Optional[Callable] = None):
+    def __init__(self, config: LatteConfig, tokenizer=None, text_encoder=None, vae=None, transformer=None, scheduler=None,
+                 device=None, dtype: torch.dtype = torch.bfloat16, *, vae_decoder: Optional[Callable] = None):
+        """pipeline_latte.py:192-254, same parameter order.  Components left at None are read from ``config.model_path`` when that
+        is a LOCAL checkpoint directory in the published layout (``transformer/``, ``vae_temporal_decoder/`` or ``vae/``,
+        ``text_encoder/`` + ``tokenizer/``), else seeded synthetic weights for the transformer and no text encoder / VAE
+        (generate() then takes ``prompt_embeds`` and returns latents).  A component may be this build's object, or a torch module
+        holding the reference's weights (pipeline.module_state); ``text_encoder="synthetic:<seed>"`` builds an offline stand-in.
+        ``dtype``: see VideoSysPipeline._check_dtype (the reference's default here is fp16).  ``vae_decoder`` = ``vae``."""
         self._config = config
-        if device is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("LattePipeline needs a HIP device (videosys_amd has no CPU execution path)")
-            device = torch.device("cuda", torch.cuda.current_device())
-        self._device = torch.device(device)
+        self._dtype = self._check_dtype(dtype)
+        self._device = self._resolve_device(device, "LattePipeline")
         name = config.model_path
-        # <model_path>/transformer/{config.json, *.safetensors} of a local checkpoint directory (pipeline_latte.py:208-210
-        # LatteT2V.from_pretrained(model_path, subfolder="transformer", video_length=16)); else seeded weights
-        file_cfg, sd = read_component(name, "transformer")
-        tcfg = ctor_kwargs(LatteT2V.__init__, file_cfg)
-        tcfg.update(config.transformer_config or {})
-        self.transformer = LatteT2V(**tcfg, device=self._device)
-        if sd is None:
-            seed = int(name.split(":", 1)[1]) if isinstance(name, str) and name.startswith("synthetic:") else 4321
-            c = self.transformer.config
-            sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.caption_channels, c.in_channels,
-                                  c.out_channels, c.patch_size, seed=seed)
-        self.transformer.load_state_dict(sd)
-        self.scheduler = DDIMScheduler(beta_start=config.beta_start, beta_end=config.beta_end,
-                                       beta_schedule=config.beta_schedule, variance_type=config.variance_type)
-        if vae_decoder is None:
-            vae_decoder = self._load_vae(config)
-        self.text_encoder, self.vae_decoder = text_encoder, vae_decoder
+        if transformer is None or is_foreign_module(transformer, LatteT2V):
+            # <model_path>/transformer/{config.json, *.safetensors} (:208-210 LatteT2V.from_pretrained(model_path,
+            # subfolder="transformer", video_length=16)); else seeded weights
+            file_cfg, sd = module_state(transformer) if transformer is not None else read_component(name, "transformer")
+            tcfg = ctor_kwargs(LatteT2V.__init__, file_cfg)
+            tcfg.update(config.transformer_config or {})
+            transformer = LatteT2V(**tcfg, device=self._device)
+            if sd is None:
+                seed = int(name.split(":", 1)[1]) if isinstance(name, str) and name.startswith("synthetic:") else 4321
+                c = transformer.config
+                sd = synth_state_dict(c.num_layers, c.num_attention_heads, c.attention_head_dim, c.caption_channels, c.in_channels,
+                                      c.out_channels, c.patch_size, seed=seed)
+            transformer.load_state_dict(sd)
+        self.transformer = transformer
+        self.scheduler = scheduler if scheduler is not None else DDIMScheduler(
+            beta_start=config.beta_start, beta_end=config.beta_end, beta_schedule=config.beta_schedule, variance_type=config.variance_type)
+        vae = vae if vae is not None else vae_decoder
+        if vae is None:
+            vae = self._load_vae(config)
+        elif is_foreign_module(vae):
+            vae = self._vae_from_state(config, *module_state(vae))
+        if text_encoder is None and isinstance(name, str) and os.path.isdir(os.path.join(name, "text_encoder")):
+            text_encoder = os.path.join(name, "text_encoder")   # (:219-223) T5EncoderModel + T5Tokenizer of the checkpoint
+        self.text_encoder = build_text_encoder(text_encoder, tokenizer, device=self._device,
+                                               caption_channels=self.transformer.config.caption_channels, max_length=120,
+                                               tokenizer_path=os.path.join(name, "tokenizer") if isinstance(name, str) else None)
+        self.vae_decoder = vae
         pab.set_pab_manager(config.pab_config if config.enable_pab else None)
         self._set_parallel()
         # cpu_offload: each stage's weights live in pinned host memory and are resident only while the stage runs
         self._init_stages(config.cpu_offload, self._device, text_encoder=getattr(self.text_encoder, "encoder", None),
                           transformer=self.transformer, vae=self.vae_decoder)
+
+    vae = property(lambda self: self.vae_decoder)                                      # register_modules names (:238-240)
+    tokenizer = property(lambda self: getattr(self.text_encoder, "tokenizer", None))
+
+    def _vae_from_state(self, config, cfg, sd):
+        """The decoder object for a VAE state dict (pipeline_latte.py:211-217: the SVD temporal decoder when
+        ``enable_vae_temporal_decoder``, else the plain AutoencoderKL)."""
+        if config.enable_vae_temporal_decoder:
+            from .vae_svd_temporal import AutoencoderKLTemporalDecoder
+
+            return AutoencoderKLTemporalDecoder(sd, device=self._device)
+        from .vae_open_sora import AutoencoderKLDecoder
+
+        return AutoencoderKLDecoder(sd, device=self._device, scaling_factor=cfg.get("scaling_factor", 0.18215))
 
     def _load_vae(self, config):
         """pipeline_latte.py:211-217: ``enable_vae_temporal_decoder=True`` (the reference default) -> the SVD

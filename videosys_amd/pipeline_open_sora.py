@@ -21,8 +21,9 @@ import torch
 from . import pab
 from .pab import PABConfig
 from .rflow import RFLOW
-from .stdit3 import STDiT3
-from .pipeline import VideoSysPipeline, VideoSysPipelineOutput  # noqa: F401 (re-exported)
+from .stdit3 import STDiT3, STDiT3Config
+from .pipeline import (VideoSysPipeline, VideoSysPipelineOutput, build_text_encoder, is_foreign_module,  # noqa: F401 (re-exported)
+                       module_state)
 
 
 class OpenSoraPABConfig(PABConfig):
@@ -114,26 +115,41 @@ def get_latent_size(num_frames: int, height: int, width: int):
 class OpenSoraPipeline(VideoSysPipeline):
     """The per-rank pipeline object the engine instantiates (engine.py:68-72) and whose ``generate`` it calls."""
 
-    def __init__(self, config: OpenSoraConfig, device=None, text_encoder: Optional[Callable] = None,
-                 vae_decoder: Optional[Callable] = None):
+    def __init__(self, config: OpenSoraConfig, text_encoder=None, tokenizer=None, vae=None, transformer=None, scheduler=None,
+                 device=None, dtype: torch.dtype = torch.bfloat16, *, vae_decoder: Optional[Callable] = None):
+        """pipeline_open_sora.py:194-250, same parameter order.  Components left at None are loaded as the reference loads them
+        (``config.text_encoder`` / ``config.vae`` / ``config.transformer``: LOCAL checkpoint directories or ``"synthetic:<seed>"``);
+        a component may be this build's object or a torch module holding the reference's weights (pipeline.module_state).
+        ``dtype``: see VideoSysPipeline._check_dtype.  ``vae_decoder`` = ``vae``."""
         self._config = config
-        if device is None:
-            if not torch.cuda.is_available():
-                raise RuntimeError("OpenSoraPipeline needs a HIP device (videosys_amd has no CPU execution path)")
-            device = torch.device("cuda", torch.cuda.current_device())
-        self._device = torch.device(device)
-        name = config.transformer   # a local checkpoint directory or "synthetic:<seed>"; a hub id cannot be fetched: seeded weights
-        local = isinstance(name, str) and (name.startswith("synthetic:") or bool(glob.glob(os.path.join(name, "*.safetensors"))))
-        self.transformer = STDiT3.from_pretrained(name if local else "synthetic:1234", device=self._device,
-                                                  **(config.transformer_config or {}))
-        self.scheduler = RFLOW(num_sampling_steps=config.num_sampling_steps, cfg_scale=config.cfg_scale,
-                               use_timestep_transform=True)
-        if text_encoder is None:
-            text_encoder = self._load_text_encoder(config.text_encoder)
-        self.text_encoder = text_encoder
-        if vae_decoder is None:
-            vae_decoder = self._load_vae(config.vae)
-        self.vae_decoder = vae_decoder
+        self._dtype = self._check_dtype(dtype)
+        self._device = self._resolve_device(device, "OpenSoraPipeline")
+        if transformer is None:
+            name = config.transformer   # a local checkpoint directory or "synthetic:<seed>"; a hub id cannot be fetched: seeded weights
+            local = isinstance(name, str) and (name.startswith("synthetic:") or bool(glob.glob(os.path.join(name, "*.safetensors"))))
+            transformer = STDiT3.from_pretrained(name if local else "synthetic:1234", device=self._device,
+                                                 **(config.transformer_config or {}))
+        elif is_foreign_module(transformer, STDiT3):   # e.g. the reference's own STDiT3 module: geometry + weights are taken over
+            cfg, sd = module_state(transformer)
+            known = set(STDiT3Config().__dict__)
+            cfg = {k: v for k, v in cfg.items() if k in known}
+            cfg.update(config.transformer_config or {})
+            transformer = STDiT3(STDiT3Config(**cfg), device=self._device)
+            transformer.load_state_dict({k: v for k, v in sd.items() if "pos_embed" not in k and "inv_freq" not in k})
+        self.transformer = transformer
+        self.scheduler = scheduler if scheduler is not None else RFLOW(
+            num_sampling_steps=config.num_sampling_steps, cfg_scale=config.cfg_scale, use_timestep_transform=True)
+        self.text_encoder = build_text_encoder(text_encoder if text_encoder is not None else config.text_encoder, tokenizer,
+                                               device=self._device, caption_channels=self.transformer.config.caption_channels,
+                                               max_length=self.transformer.config.model_max_length)
+        vae = vae if vae is not None else vae_decoder
+        if vae is None:
+            vae = self._load_vae(config.vae)
+        elif is_foreign_module(vae):
+            from .vae_open_sora import OpenSoraVAE
+
+            vae = OpenSoraVAE(module_state(vae)[1], device=self._device, micro_batch_size=config.tiling_size)
+        self.vae_decoder = vae
         if config.enable_pab:
             pab.set_pab_manager(config.pab_config)
         else:
@@ -144,45 +160,13 @@ class OpenSoraPipeline(VideoSysPipeline):
         self._init_stages(config.cpu_offload, self._device, text_encoder=getattr(self.text_encoder, "encoder", None),
                           transformer=self.transformer, vae=self.vae_decoder)
 
+    vae = property(lambda self: self.vae_decoder)                                      # register_modules names (:233-235)
+    tokenizer = property(lambda self: getattr(self.text_encoder, "tokenizer", None))
+
     def _after_onload(self, name):
         if name == "transformer":   # attribute paths the sampler reads alias entries of the weight table
             self.transformer.x_embedder.proj.weight = self.transformer.w["x_embedder.proj.weight"]
             self.transformer.y_embedder.y_embedding = self.transformer.w["y_embedder.y_embedding"]
-
-    def _load_text_encoder(self, name):
-        """pipeline_open_sora.py:211-214: T5EncoderModel + AutoTokenizer from ``config.text_encoder`` — here a LOCAL directory
-        holding the HF checkpoint (config.json, *.safetensors, tokenizer files); a hub id cannot be fetched, so the pipeline then
-        expects ``prompt_embeds``."""
-        import json
-
-        if isinstance(name, str) and name.startswith("synthetic:"):
-            # offline stand-in: random T5 v1.1 weights of the geometry the transformer's caption projection expects (XXL for the
-            # real 4096-wide model) + a byte tokenizer — lets generate(prompt) run end to end without any checkpoint
-            from .t5 import ByteTokenizer, T5Encoder, T5TextEncoder
-
-            d = self.transformer.config.caption_channels
-            geo = dict(d_model=4096, d_ff=10240, num_layers=24, num_heads=64) if d == 4096 else \
-                dict(d_model=d, d_ff=2 * d, num_layers=2, num_heads=max(d // 64, 2))
-            enc = T5Encoder(device=self._device, **geo).init_random_(int(name.split(":", 1)[1]))
-            return T5TextEncoder(enc, ByteTokenizer(enc.config.vocab_size), max_length=self.transformer.config.model_max_length)
-        if not (isinstance(name, str) and os.path.isdir(name) and os.path.exists(os.path.join(name, "config.json"))):
-            return None
-        from safetensors.torch import load_file
-        from transformers import AutoTokenizer
-
-        from .t5 import T5Encoder, T5TextEncoder
-
-        with open(os.path.join(name, "config.json")) as fh:
-            c = json.load(fh)
-        enc = T5Encoder(d_model=c["d_model"], d_kv=c["d_kv"], d_ff=c["d_ff"], num_layers=c["num_layers"], num_heads=c["num_heads"],
-                        vocab_size=c["vocab_size"], relative_attention_num_buckets=c.get("relative_attention_num_buckets", 32),
-                        relative_attention_max_distance=c.get("relative_attention_max_distance", 128),
-                        layer_norm_epsilon=c.get("layer_norm_epsilon", 1e-6), device=self._device)
-        sd = {}
-        for f in sorted(glob.glob(os.path.join(name, "*.safetensors"))):
-            sd.update(load_file(f))
-        enc.load_state_dict(sd)
-        return T5TextEncoder(enc, AutoTokenizer.from_pretrained(name), max_length=300)
 
     def _load_vae(self, name):
         """OpenSoraVAE_V1_2 (autoencoder_kl_open_sora.py:738-761): a local checkpoint directory (model.safetensors with the
