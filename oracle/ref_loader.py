@@ -99,6 +99,10 @@ def install_stubs():
         raise RuntimeError(f"reference tree not found at {REFERENCE_ROOT}")
     import transformers  # noqa: F401  (must be imported before the fake package is installed)
 
+    # the repo ships an alias package of the same name whose submodule aliases point at videosys_amd (videosys/__init__.py): if a
+    # test imported it earlier in this process, drop every entry so that "videosys.*" below can only come from the reference tree
+    for k in [k for k in sys.modules if k == "videosys" or k.startswith("videosys.")]:
+        del sys.modules[k]
     pkg = types.ModuleType("videosys")
     pkg.__path__ = [os.path.join(REFERENCE_ROOT, "videosys")]
     sys.modules["videosys"] = pkg
@@ -145,7 +149,10 @@ def load_reference_modules():
         "pab_mgr": "videosys.core.pab.pab_mgr",
         "comm": "videosys.core.distributed.comm",
     }
-    return {k: importlib.import_module(v) for k, v in names.items()}
+    mods = {k: importlib.import_module(v) for k, v in names.items()}
+    for k, m in mods.items():   # the checker must be the reference's file, never this repo's module of the same dotted name
+        assert os.path.abspath(m.__file__).startswith(os.path.abspath(REFERENCE_ROOT) + os.sep), (k, m.__file__)
+    return mods
 
 
 def build_reference_stdit3(cfg_kwargs: dict, state_dict=None, dtype=torch.float32):
