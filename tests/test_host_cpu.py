@@ -1210,3 +1210,47 @@ def test_pipeline_constructors_take_the_reference_components(tmp_path, monkeypat
     pipe2 = PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), transformer=own, text_encoder=lambda p: p,
                                  device="cpu", dtype=torch.float16)
     assert pipe2.transformer is own and pipe2.text_encoder("x") == "x" and pipe2.vae is None
+
+
+def test_save_video_writes_a_playable_file_without_an_encoder_package(tmp_path):
+    """utils.save_video (utils/utils.py:84-92): with imageio absent the frames land in a Motion-JPEG AVI; the container is parsed
+    back here (RIFF sizes, stream header, index) and every frame decoded."""
+    import io
+    import struct
+
+    import numpy as np
+    from PIL import Image
+
+    from videosys_amd.utils import save_video
+
+    try:
+        import imageio  # noqa: F401
+        pytest.skip("imageio present: the reference's own writer runs")
+    except ImportError:
+        pass
+    T, H, W = 6, 48, 80
+    yy, xx = np.mgrid[0:H, 0:W]
+    v = np.stack([np.stack([(xx * 3 + t * 10) % 256, (yy * 5) % 256, np.full_like(xx, t * 40)], -1) for t in range(T)]).astype(np.uint8)
+    path = save_video(torch.from_numpy(v), str(tmp_path / "clips" / "sunset.mp4"), fps=8)
+    assert path.endswith("sunset.avi") and os.path.isfile(path)
+    d = open(path, "rb").read()
+    assert d[:4] == b"RIFF" and d[8:12] == b"AVI " and struct.unpack("<I", d[4:8])[0] == len(d) - 8
+    h = d.index(b"avih")
+    usec, _, _, flags, total, _, streams, _, w, hgt = struct.unpack("<10I", d[h + 8:h + 48])
+    assert (usec, total, streams, w, hgt) == (125000, T, 1, W, H) and flags & 0x10
+    sh = d.index(b"strh")
+    assert d[sh + 8:sh + 16] == b"vidsMJPG"
+    scale, rate = struct.unpack("<II", d[sh + 28:sh + 36])
+    assert rate / scale == 8
+    movi = d.index(b"movi")
+    idx = d.index(b"idx1", movi)
+    assert struct.unpack("<I", d[idx + 4:idx + 8])[0] == 16 * T
+    for n in range(T):
+        tag, fl, off, size = struct.unpack("<4sIII", d[idx + 8 + 16 * n:idx + 24 + 16 * n])
+        at = movi + off
+        assert tag == b"00dc" and fl == 0x10 and d[at:at + 4] == b"00dc" and struct.unpack("<I", d[at + 4:at + 8])[0] == size
+        img = np.asarray(Image.open(io.BytesIO(d[at + 8:at + 8 + size])).convert("RGB"))
+        assert img.shape == (H, W, 3) and np.abs(img.astype(int) - v[n].astype(int)).mean() < 4.0
+    # float frames [T, 3, H, W] in [0, 1] (Latte's single-image branch) and an explicit .avi name
+    p2 = save_video(torch.from_numpy(v[:1]).permute(0, 3, 1, 2).float() / 255, str(tmp_path / "img.avi"), fps=8)
+    assert p2.endswith("img.avi") and open(p2, "rb").read(4) == b"RIFF"

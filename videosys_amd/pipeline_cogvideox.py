@@ -401,4 +401,4 @@ class CogVideoXPipeline(VideoSysPipeline):
     def save_video(self, video, output_path):
         from .utils import save_video
 
-        save_video(video, output_path)
+        return save_video(video, output_path, fps=8)   # the reference's frame rate for this pipeline

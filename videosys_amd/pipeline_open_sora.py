@@ -350,4 +350,4 @@ class OpenSoraPipeline(VideoSysPipeline):
     def save_video(self, video, output_path):
         from .utils import save_video
 
-        save_video(video, output_path)
+        return save_video(video, output_path, fps=24)   # the reference's frame rate for this pipeline

@@ -1,4 +1,5 @@
 """videosys/utils/utils.py mirror: set_seed (:19-34), batch_func (:37-52), save_video."""
+import logging
 import random
 
 import numpy as np
@@ -162,12 +163,71 @@ def batch_func(func, *args):
     return tuple(func(a) if isinstance(a, torch.Tensor) and a.shape[0] > 0 else a for a in args)
 
 
+def write_mjpeg_avi(frames, path, fps=24, quality=90):
+    """uint8 frames [T, H, W, 3] -> a Motion-JPEG AVI file (RIFF 'AVI ': one 'vids' / 'MJPG' stream, every frame a JPEG key frame,
+    'idx1' index) with nothing but the standard library and PIL for the JPEG compression.  Plays in ffmpeg / VLC / browsers'
+    ``<video>`` fallbacks; used when no video encoder package is installed."""
+    import io
+    import struct
+
+    from PIL import Image
+
+    frames = np.ascontiguousarray(frames)
+    if frames.ndim != 4 or frames.shape[-1] != 3 or frames.dtype != np.uint8:
+        raise ValueError(f"expected uint8 frames [T, H, W, 3], got {frames.dtype} {tuple(frames.shape)}")
+    T, H, W, _ = frames.shape
+    jpegs = []
+    for f in frames:
+        buf = io.BytesIO()
+        Image.fromarray(f, "RGB").save(buf, format="JPEG", quality=quality)
+        jpegs.append(buf.getvalue())
+    chunk = lambda tag, data: tag + struct.pack("<I", len(data)) + data + (b"\0" if len(data) & 1 else b"")
+    lst = lambda tag, data: b"LIST" + struct.pack("<I", len(data) + 4) + tag + data
+    biggest = max((len(j) for j in jpegs), default=0)
+    fps_num, fps_den = (int(round(fps * 1000)), 1000) if fps != int(fps) else (int(fps), 1)
+    avih = struct.pack("<14I", int(round(1e6 * fps_den / fps_num)), biggest * fps_num // fps_den, 0, 0x10, T, 0, 1, biggest, W, H, 0, 0, 0, 0)
+    strh = b"vidsMJPG" + struct.pack("<IHHIIIIIIII4H", 0, 0, 0, 0, fps_den, fps_num, 0, T, biggest, 0xFFFFFFFF, 0, 0, 0, W, H)
+    strf = struct.pack("<IiiHH4sIiiII", 40, W, H, 1, 24, b"MJPG", W * H * 3, 0, 0, 0, 0)
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi, index, off = b"", b"", 4                      # index offsets count from the 'movi' fourcc
+    for j in jpegs:
+        index += b"00dc" + struct.pack("<III", 0x10, off, len(j))
+        c = chunk(b"00dc", j)
+        movi += c
+        off += len(c)
+    body = b"AVI " + hdrl + lst(b"movi", movi) + chunk(b"idx1", index)
+    with open(path, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+    return path
+
+
 def save_video(video, output_path, fps=24):
-    """uint8 [T,H,W,C] -> file.  imageio is not installed in this image: frames go to an .npy next to the name."""
+    """utils/utils.py:84-92: uint8 frames [T, H, W, C] -> ``output_path``; rank 0 only in a process group.  The reference hands the
+    frames to ``imageio.mimwrite`` (third-party, needs an ffmpeg plugin for .mp4); when imageio is installed that is what runs.
+    Without it there is no H.264 encoder to produce an .mp4: the frames are written as a Motion-JPEG AVI next to the requested name
+    (``sunset.mp4`` -> ``sunset.avi``, write_mjpeg_avi) and the path actually written is returned."""
     import os
 
+    if dist.is_initialized() and dist.get_rank() != 0:
+        return None
     os.makedirs(os.path.dirname(output_path) or ".", exist_ok=True)
-    np.save(os.path.splitext(output_path)[0] + ".npy", video.cpu().numpy())
+    frames = video.detach().cpu().numpy() if torch.is_tensor(video) else np.asarray(video)
+    try:
+        import imageio
+    except ImportError:
+        imageio = None
+    if imageio is not None:
+        imageio.mimwrite(output_path, frames, fps=fps)
+        return output_path
+    if frames.dtype != np.uint8:   # float frames in [0, 1] (Latte's single-image output)
+        frames = (np.clip(frames, 0, 1) * 255).round().astype(np.uint8)
+    if frames.ndim == 4 and frames.shape[1] == 3 and frames.shape[-1] != 3:
+        frames = frames.transpose(0, 2, 3, 1)          # [T, 3, H, W] -> [T, H, W, 3]
+    alt = output_path if output_path.lower().endswith(".avi") else os.path.splitext(output_path)[0] + ".avi"
+    if alt != output_path:
+        logging.getLogger(__name__).warning("no video encoder package (imageio) in this environment: writing Motion-JPEG %s "
+                                            "instead of %s", alt, output_path)
+    return write_mjpeg_avi(frames, alt, fps=fps)
 
 
 class HostOffload:
