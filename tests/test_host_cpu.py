@@ -646,6 +646,59 @@ print("ok")
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-1500:]
 
 
+def test_reference_example_scripts_run_against_this_build():
+    """The reference's own examples/inference/{open_sora,latte,cogvideox}/sample.py and its pipeline tests, executed unchanged with
+    this repo in front on sys.path: every config they build is accepted and every ``engine.generate(...)`` call binds to the
+    pipeline's ``generate`` signature.  The engine is replaced by a recorder (no GPU here); the same call shapes run on the device in
+    tests/test_gpu_pipeline.py.  Subprocess: see the alias test above."""
+    import subprocess
+    import sys
+
+    if not os.path.isdir("/root/reference/examples/inference"):
+        pytest.skip("reference tree not present on this box")
+    code = r"""
+import inspect, os, runpy, sys, types
+import videosys
+
+calls = []
+
+class Engine:
+    def __init__(self, config):
+        assert hasattr(config, "pipeline_cls") and isinstance(config.num_gpus, int)
+        self.config = config
+    def generate(self, *a, **k):
+        sig = inspect.signature(self.config.pipeline_cls.generate)
+        bound = sig.bind(None, *a, **k)           # TypeError if the reference's call does not fit
+        calls.append((self.config.pipeline_cls.__name__, sorted(bound.arguments)))
+        return types.SimpleNamespace(video=["frames"])
+    def save_video(self, video, path):
+        assert video == "frames" and path.endswith(".mp4")
+
+videosys.VideoSysEngine = Engine
+import torch
+torch.cuda.empty_cache = lambda: None
+ran = 0
+for fam in ("open_sora", "latte", "cogvideox"):
+    for path in (f"/root/reference/examples/inference/{fam}/sample.py", f"/root/reference/tests/pipelines/{fam}/test_{fam}.py"):
+        ns = runpy.run_path(path, run_name="not_main")
+        for name, fn in ns.items():
+            if callable(fn) and getattr(fn, "__module__", None) is None or name.startswith(("run_", "test_")):
+                if not name.startswith(("run_", "test_")):
+                    continue
+                import itertools
+                marks = [m for m in getattr(fn, "pytestmark", []) if m.name == "parametrize"]   # the tests' own parameter grids
+                names = [m.args[0] for m in marks]
+                for combo in itertools.product(*[m.args[1] for m in marks]):
+                    fn(**dict(zip(names, combo)))
+                    ran += 1
+assert ran >= 18 and len(calls) >= ran, (ran, len(calls))
+assert {c[0] for c in calls} == {"OpenSoraPipeline", "LattePipeline", "CogVideoXPipeline"}
+print("ok", ran, len(calls))
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-400:], r.stderr[-1500:])
+
+
 def test_torch_custom_ops_are_registered():
     """``torch.ops.videosys_amd.*`` (north_star: "through PyTorch-ROCm custom ops"): every op of videosys_amd/torch_ops.py is
     registered with an out-variant schema that names the tensors it mutates; on CPU tensors it raises (no fallback)."""
