@@ -1304,6 +1304,16 @@ def test_save_video_writes_a_playable_file_without_an_encoder_package(tmp_path):
         assert tag == b"00dc" and fl == 0x10 and d[at:at + 4] == b"00dc" and struct.unpack("<I", d[at + 4:at + 8])[0] == size
         img = np.asarray(Image.open(io.BytesIO(d[at + 8:at + 8 + size])).convert("RGB"))
         assert img.shape == (H, W, 3) and np.abs(img.astype(int) - v[n].astype(int)).mean() < 4.0
+    # and back: the reader used for video references (open_sora_condition.read_from_path on .avi clips)
+    from videosys_amd.open_sora_condition import read_from_path
+    from videosys_amd.utils import read_mjpeg_avi
+
+    back = read_mjpeg_avi(path)
+    assert len(back) == T and back[0].size == (W, H) and np.abs(np.asarray(back[2]).astype(int) - v[2].astype(int)).mean() < 4.0
+    clip = read_from_path(path, (24, 40))
+    assert tuple(clip.shape) == (3, T, 24, 40) and -1.0 <= float(clip.min()) and float(clip.max()) <= 1.0
+    with pytest.raises(NotImplementedError):
+        read_from_path(str(tmp_path / "other.mp4"), (24, 40))
     # float frames [T, 3, H, W] in [0, 1] (Latte's single-image branch) and an explicit .avi name
     p2 = save_video(torch.from_numpy(v[:1]).permute(0, 3, 1, 2).float() / 255, str(tmp_path / "img.avi"), fps=8)
     assert p2.endswith("img.avi") and open(p2, "rb").read(4) == b"RIFF"

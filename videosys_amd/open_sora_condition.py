@@ -138,23 +138,34 @@ def _resize_crop_to_fill(img, size):
 
 
 def read_from_path(path: str, image_size, transform_name: str = "resize_crop") -> torch.Tensor:
-    """An image file -> [3, 1, H, W] in [-1, 1] (data_process.py:770-788 with the "resize_crop" transform: cover + centre crop,
-    ToTensor, Normalize(0.5, 0.5)).  Video files need a decoder (torchvision.io / av in the reference) that this image does not
-    have: hand the frames over as a tensor instead (``refs=[tensor]``)."""
+    """An image file -> [3, 1, H, W], a video file -> [3, T, H, W], in [-1, 1] (data_process.py:761-788 with the "resize_crop"
+    transform: cover + centre crop, ToTensor, Normalize(0.5, 0.5)).  Images are read with PIL.  The reference decodes videos with
+    torchvision.io / av, which this image does not have: Motion-JPEG AVI files (what ``save_video`` writes here, utils.read_mjpeg_avi)
+    are decoded, any other video must be handed over as a tensor (``refs=[tensor]``).  (The reference's video branch applies
+    ``resize_crop_to_fill`` — a PIL function, data_process.py:742-758 — to the tensor clip and cannot run as written; the per-frame
+    cover + crop it intends is what is done here.)"""
     ext = os.path.splitext(path)[-1].lower()
-    if ext in VID_EXTENSIONS:
-        raise NotImplementedError(f"{path}: no video decoder in this environment; pass the reference clip as a [3, T, H, W] "
-                                  "tensor in [-1, 1] (refs=[tensor]) or as latents")
-    assert ext in IMG_EXTENSIONS, f"Unsupported file format: {ext}"
+    assert ext in VID_EXTENSIONS or ext in IMG_EXTENSIONS, f"Unsupported file format: {ext}"
     assert transform_name == "resize_crop", transform_name
     import numpy as np
     from PIL import Image
 
-    with open(path, "rb") as fh:
-        img = Image.open(fh).convert("RGB")
-    img = _resize_crop_to_fill(img, tuple(image_size))
-    x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
-    return x.sub_(0.5).div_(0.5).unsqueeze(1)
+    if ext in VID_EXTENSIONS:
+        from .utils import read_mjpeg_avi
+
+        try:
+            frames = read_mjpeg_avi(path) if ext == ".avi" else None
+        except ValueError:
+            frames = None
+        if not frames:
+            raise NotImplementedError(f"{path}: no decoder for this video in this environment (Motion-JPEG .avi files are read); pass "
+                                      "the reference clip as a [3, T, H, W] tensor in [-1, 1] (refs=[tensor]) or as latents")
+    else:
+        with open(path, "rb") as fh:
+            frames = [Image.open(fh).convert("RGB")]
+    arr = np.stack([np.asarray(_resize_crop_to_fill(f, tuple(image_size)), dtype=np.uint8) for f in frames])     # [T, H, W, 3]
+    x = torch.from_numpy(arr.copy()).permute(3, 0, 1, 2).float().div_(255.0)
+    return x.sub_(0.5).div_(0.5)
 
 
 def collect_references_batch(reference_paths: Sequence, vae_encode, image_size) -> List[list]:

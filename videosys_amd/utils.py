@@ -201,6 +201,38 @@ def write_mjpeg_avi(frames, path, fps=24, quality=90):
     return path
 
 
+def read_mjpeg_avi(path):
+    """The frames of a Motion-JPEG AVI (what write_mjpeg_avi produces; also ffmpeg's ``-c:v mjpeg``) as PIL RGB images, with the
+    standard library + PIL only.  Any other codec / container: ValueError."""
+    import io
+    import struct
+
+    from PIL import Image
+
+    with open(path, "rb") as fh:
+        d = fh.read()
+    if d[:4] != b"RIFF" or d[8:12] != b"AVI ":
+        raise ValueError(f"{path}: not a RIFF AVI file")
+    sh = d.find(b"strh")
+    if sh < 0 or d[sh + 8:sh + 12] != b"vids" or d[sh + 12:sh + 16].upper() not in (b"MJPG", b"JPEG"):
+        raise ValueError(f"{path}: the video stream is not Motion-JPEG (handler {d[sh + 12:sh + 16]!r})")
+    pos = d.find(b"movi")
+    if pos < 0:
+        raise ValueError(f"{path}: no 'movi' list")
+    end = pos - 4 + struct.unpack("<I", d[pos - 4:pos])[0]
+    pos += 4
+    frames = []
+    while pos + 8 <= min(end, len(d)):
+        tag, size = d[pos:pos + 4], struct.unpack("<I", d[pos + 4:pos + 8])[0]
+        if tag == b"LIST":                     # 'rec ' groups: step inside
+            pos += 12
+            continue
+        if tag[2:] in (b"dc", b"db") and size:
+            frames.append(Image.open(io.BytesIO(d[pos + 8:pos + 8 + size])).convert("RGB"))
+        pos += 8 + size + (size & 1)
+    return frames
+
+
 def save_video(video, output_path, fps=24):
     """utils/utils.py:84-92: uint8 frames [T, H, W, C] -> ``output_path``; rank 0 only in a process group.  The reference hands the
     frames to ``imageio.mimwrite`` (third-party, needs an ffmpeg plugin for .mp4); when imageio is installed that is what runs.
