@@ -1277,8 +1277,9 @@ def test_save_video_writes_a_playable_file_without_an_encoder_package(tmp_path):
     from videosys_amd.utils import save_video
 
     try:
-        import imageio  # noqa: F401
-        pytest.skip("imageio present: the reference's own writer runs")
+        import imageio
+        if hasattr(imageio, "mimwrite"):   # (oracle/ref_loader.py parks an empty stub of this name in the test process)
+            pytest.skip("imageio present: the reference's own writer runs")
     except ImportError:
         pass
     T, H, W = 6, 48, 80

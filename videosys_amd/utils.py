@@ -248,7 +248,7 @@ def save_video(video, output_path, fps=24):
         import imageio
     except ImportError:
         imageio = None
-    if imageio is not None:
+    if imageio is not None and hasattr(imageio, "mimwrite"):
         imageio.mimwrite(output_path, frames, fps=fps)
         return output_path
     if frames.dtype != np.uint8:   # float frames in [0, 1] (Latte's single-image output)
