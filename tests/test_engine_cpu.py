@@ -14,7 +14,7 @@ def _engine(**kw):
     return VideoSysEngine(FakeConfig(**kw), backend="gloo")
 
 
-def test_engine_two_ranks_results_and_error_isolation():
+def test_engine_two_ranks_results_and_error_isolation(capfd):
     eng = _engine(num_gpus=2)
     try:
         assert eng.generate(10) == 21.0              # (10 + 0) + (10 + 1) over the group: both ranks ran the call
@@ -25,6 +25,16 @@ def test_engine_two_ranks_results_and_error_isolation():
             eng.generate(1, mode="raise", who=0)     # driver-side failure: the worker's result of that call is still collected
         assert eng.generate(3) == 7.0
         assert eng.save_video(None, "x.mp4") == "x.mp4"
+        # what a worker prints is led by its process name and pid on every line (mp_utils.py:154-178); the driver's is not
+        assert eng.generate(4, mode="talk") == 9.0
+        import time as _t
+
+        _t.sleep(0.3)
+        out = capfd.readouterr().out
+        lines = [ln for ln in out.splitlines() if "says" in ln or "two lines" in ln]
+        assert "rank 0 says" in lines and "two lines" in lines
+        tagged = [ln for ln in lines if "VideoSysWorkerProcess-1 pid=" in ln]
+        assert len(tagged) == 2 and tagged[0].endswith("rank 1 says") and tagged[1].endswith("two lines")
     finally:
         eng.shutdown()
 

@@ -39,8 +39,38 @@ def get_open_port() -> int:
         return s.getsockname()[1]
 
 
+class _PrefixedStream:
+    """A worker's stdout / stderr with every line led by ``(VideoSysWorkerProcess-<rank> pid=<pid>)`` (mp_utils.py:154-178,190-194):
+    the output of N ranks lands in one terminal and stays attributable.  Everything else is the wrapped stream's."""
+
+    CYAN, RESET = "\033[1;36m", "\033[0;0m"
+
+    def __init__(self, stream, worker_name: str, pid: int):
+        self._stream, self._at_line_start = stream, True
+        self._prefix = f"{self.CYAN}({worker_name} pid={pid}){self.RESET} "
+
+    def write(self, s: str):
+        if not s:
+            return 0
+        out = []
+        for piece in s.splitlines(keepends=True):
+            if self._at_line_start:
+                out.append(self._prefix)
+            out.append(piece)
+            self._at_line_start = piece.endswith("\n")
+        self._stream.write("".join(out))
+        return len(s)
+
+    def __getattr__(self, name):
+        return getattr(self._stream, name)
+
+
 def _worker_main(rank, world_size, init_method, config, task_q, result_q, backend):
     """Worker process event loop (mp_utils.py:181-216): build the pipeline, then serve (task id, method, args, kwargs) tuples."""
+    import sys
+
+    name = mp.current_process().name
+    sys.stdout, sys.stderr = _PrefixedStream(sys.stdout, name, os.getpid()), _PrefixedStream(sys.stderr, name, os.getpid())
     try:
         try:
             from . import dsp
