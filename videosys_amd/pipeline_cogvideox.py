@@ -132,6 +132,10 @@ def get_3d_rotary_pos_embed(embed_dim, crops_coords, grid_size, temporal_size, t
     return freqs.cos().contiguous(), freqs.sin().contiguous()
 
 
+class _CustomTimestepsUnsupported(ValueError, NotImplementedError):
+    """ValueError as the reference raises it; also a NotImplementedError for callers of earlier versions of this package."""
+
+
 class CogVideoXPipeline(VideoSysPipeline):
     vae_scale_factor_spatial = 8
     vae_scale_factor_temporal = 4
@@ -331,9 +335,10 @@ class CogVideoXPipeline(VideoSysPipeline):
         """pipeline_cogvideox.py:498-755 for text-to-video (CFG batch [negative | prompt], eta = 0).  The reference's other
         keywords keep their meaning where the path has them: ``generator`` draws the start latents, ``callback_on_step_end(self,
         i, t, {...})`` sees the tensors named in ``callback_on_step_end_tensor_inputs`` and may hand back new ones (:725-734), ``return_dict=False`` returns a tuple; ``timesteps`` (a
-        custom schedule), ``eta`` != 0 and ``num_videos_per_prompt`` != 1 (the reference overrides it to 1, :603) are refused."""
-        if timesteps is not None:
-            raise NotImplementedError("custom timestep schedules: the CogVideoX DDIM schedule is set from num_inference_steps")
+        custom schedule) and ``eta`` != 0 are refused; ``num_videos_per_prompt`` is overridden to 1 exactly as the reference does (:603)."""
+        if timesteps is not None:   # the reference's retrieve_timesteps (:47-88) raises ValueError for this scheduler too
+            raise _CustomTimestepsUnsupported("The current scheduler class CogVideoXDDIMScheduler's `set_timesteps` does not support "
+                                              "custom timestep schedules: the schedule is set from num_inference_steps")
         if eta != 0.0:
             raise NotImplementedError("the scheduler step is DDIM with eta = 0 (what the reference pipeline runs)")
         self.check_inputs(prompt, height, width, negative_prompt, callback_on_step_end_tensor_inputs, prompt_embeds,
