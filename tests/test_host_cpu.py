@@ -1246,7 +1246,7 @@ def test_pipeline_constructors_take_the_reference_components(tmp_path, monkeypat
                                                                         vocab_size=100, model_type="t5")))
     save_file({"shared.weight": torch.zeros(100, 256)}, str(root / "text_encoder" / "model.safetensors"))
     tok = lambda *a, **k: None
-    sched = SimpleNamespace(timesteps=[1], init_noise_sigma=1.0)
+    sched = PC.CogVideoXDDIMScheduler(snr_shift_scale=2.0)
     vae = lambda z: z
     pipe = PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path=str(root)), tok, None, vae, RefModule(), sched, device="cpu")
     assert pipe.transformer.config.num_layers == 42 and seen["cog_sd"] == ["blocks.0.w"]          # the module's geometry and weights
@@ -1258,6 +1258,9 @@ def test_pipeline_constructors_take_the_reference_components(tmp_path, monkeypat
         PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path=str(root)), tok, None, vae, RefModule(), sched, device="cpu", dtype=torch.float32)
     with pytest.raises(ValueError):   # a text-encoder MODULE needs its tokenizer
         PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), None, RefModule(), vae, RefModule(), sched, device="cpu")
+    with pytest.raises(TypeError):    # a foreign scheduler (e.g. the DPM one) has no fused-step coefficients
+        PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), transformer=FakeCog(), scheduler=SimpleNamespace(step=print),
+                             device="cpu")
     # own objects pass through; fp16 request accepted (same width, computed in bf16)
     own = FakeCog(num_layers=30)
     pipe2 = PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), transformer=own, text_encoder=lambda p: p,

@@ -42,6 +42,14 @@ class VideoSysPipeline(StagedOffloadMixin):
             raise NotImplementedError(f"dtype {dtype}: videosys_amd computes in bf16 (fp32 accumulation and islands)")
         return torch.bfloat16
 
+    @staticmethod
+    def _check_scheduler(scheduler, needs: str, what: str):
+        """A scheduler handed to the constructor must be this build's mirror of the reference class: the step itself is a fused
+        kernel driven by the scheduler's per-step coefficients, a foreign ``step()`` cannot be called on HBM buffers."""
+        if not callable(getattr(scheduler, needs, None)):
+            raise TypeError(f"scheduler: expected {what} (it has no `{needs}`): got {type(scheduler).__name__}")
+        return scheduler
+
     def generate(self, *args, **kwargs):   # pipeline.py:21-23 (abstract there)
         raise NotImplementedError(f"{type(self).__name__} does not define generate()")
 

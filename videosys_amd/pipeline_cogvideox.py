@@ -173,7 +173,7 @@ class CogVideoXPipeline(VideoSysPipeline):
             sched_cfg = ctor_kwargs(CogVideoXDDIMScheduler.__init__, read_component(name, "scheduler")[0])
             sched_cfg.setdefault("snr_shift_scale", 1.0 if is_5b else 3.0)
             scheduler = CogVideoXDDIMScheduler(**sched_cfg)
-        self.scheduler = scheduler
+        self.scheduler = self._check_scheduler(scheduler, "coeffs", "videosys_amd.pipeline_cogvideox.CogVideoXDDIMScheduler")
         vae = vae if vae is not None else vae_decoder
         if vae is None:
             vae = self._load_vae(config, base, is_5b)

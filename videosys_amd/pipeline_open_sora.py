@@ -137,7 +137,7 @@ class OpenSoraPipeline(VideoSysPipeline):
             transformer = STDiT3(STDiT3Config(**cfg), device=self._device)
             transformer.load_state_dict({k: v for k, v in sd.items() if "pos_embed" not in k and "inv_freq" not in k})
         self.transformer = transformer
-        self.scheduler = scheduler if scheduler is not None else RFLOW(
+        self.scheduler = self._check_scheduler(scheduler, "sample", "videosys_amd.rflow.RFLOW") if scheduler is not None else RFLOW(
             num_sampling_steps=config.num_sampling_steps, cfg_scale=config.cfg_scale, use_timestep_transform=True)
         self.text_encoder = build_text_encoder(text_encoder if text_encoder is not None else config.text_encoder, tokenizer,
                                                device=self._device, caption_channels=self.transformer.config.caption_channels,
