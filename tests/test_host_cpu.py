@@ -1258,6 +1258,13 @@ def test_pipeline_constructors_take_the_reference_components(tmp_path, monkeypat
         PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path=str(root)), tok, None, vae, RefModule(), sched, device="cpu", dtype=torch.float32)
     with pytest.raises(ValueError):   # a text-encoder MODULE needs its tokenizer
         PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), None, RefModule(), vae, RefModule(), sched, device="cpu")
+    # a REAL transformers.T5EncoderModel handed over with its tokenizer: geometry from its config, weights from its state dict
+    from transformers import T5Config, T5EncoderModel
+
+    hf = T5EncoderModel(T5Config(d_model=128, d_kv=64, d_ff=256, num_layers=1, num_heads=2, vocab_size=64, feed_forward_proj="gated-gelu"))
+    pipe3 = PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), tok, hf, transformer=FakeCog(), device="cpu")
+    assert pipe3.text_encoder.encoder.config.d_model == 128 and pipe3.text_encoder.encoder.config.num_layers == 1
+    assert "shared.weight" in seen["t5_sd"] and "encoder.block.0.layer.0.SelfAttention.q.weight" in seen["t5_sd"]
     with pytest.raises(TypeError):    # a foreign scheduler (e.g. the DPM one) has no fused-step coefficients
         PC.CogVideoXPipeline(PC.CogVideoXConfig(model_path="THUDM/CogVideoX-2b"), transformer=FakeCog(), scheduler=SimpleNamespace(step=print),
                              device="cpu")
