@@ -487,3 +487,28 @@ def test_generate_conditioning_and_loop_host_flow():
         vae.has_encoder = False
         with pytest.raises(RuntimeError):
             pipe.generate(refs=[img], ms="0", **kw)
+
+
+def test_pipeline_adopts_the_reference_transformer_module():
+    """OpenSoraPipeline(config, transformer=<the reference's own STDiT3 module>): geometry from its config, weights from its
+    state_dict() (INTEGRATION.md "Handing over components") — the live reference class, imported through oracle/ref_loader.py."""
+    from oracle import ref_loader
+
+    if not ref_loader.reference_available():
+        pytest.skip("reference tree not present on this box")
+    from videosys_amd import OpenSoraConfig, OpenSoraPipeline
+    from videosys_amd.stdit3 import STDiT3
+
+    cfg = dict(CFG)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in O.synth_state_dict(**cfg, seed=3).items()}
+    ref = ref_loader.build_reference_stdit3(cfg, sd)
+    with fake_ops():
+        pipe = OpenSoraPipeline(OpenSoraConfig(num_sampling_steps=2), transformer=ref, device="cpu")
+        m = pipe.transformer
+        assert isinstance(m, STDiT3) and m.config.depth == cfg["depth"] and m.config.hidden_size == cfg["hidden_size"]
+        assert m.config.caption_channels == cfg["caption_channels"] and m.config.model_max_length == cfg["model_max_length"]
+        for k in ("spatial_blocks.1.attn.qkv.weight", "temporal_blocks.0.mlp.fc2.bias", "final_layer.linear.weight", "y_embedder.y_embedding"):
+            assert torch.equal(m.w[k].float(), ref.state_dict()[k].to(torch.bfloat16).float()), k
+        assert torch.equal(m.rope_freqs, ref.state_dict()["rope.freqs"].float())
+        own = STDiT3.from_pretrained("synthetic:3", device="cpu", **cfg)                # this build's own object: used as it is
+        assert OpenSoraPipeline(OpenSoraConfig(), transformer=own, device="cpu").transformer is own
