@@ -80,6 +80,10 @@ def initialize(rank=0, world_size=1, init_method=None, backend: Optional[str] = 
         dist.init_process_group(backend=backend, init_method=init_method, world_size=world_size, rank=rank)
         if torch.cuda.is_available():
             torch.cuda.set_device(rank % torch.cuda.device_count())
+        if not logging.getLogger().handlers:   # (:115 init_logger()) INFO lines on rank 0, silence on the others — unless the
+            from .utils import init_logger     # application configured logging itself, which is then left alone
+
+            init_logger()
 
 
 class ParallelManager:
