@@ -1328,3 +1328,14 @@ def test_save_video_writes_a_playable_file_without_an_encoder_package(tmp_path):
     # float frames [T, 3, H, W] in [0, 1] (Latte's single-image branch) and an explicit .avi name
     p2 = save_video(torch.from_numpy(v[:1]).permute(0, 3, 1, 2).float() / 255, str(tmp_path / "img.avi"), fps=8)
     assert p2.endswith("img.avi") and open(p2, "rb").read(4) == b"RIFF"
+
+
+def test_progress_wrap_is_a_bar_on_request_only():
+    """utils.progress_wrap (scheduling_rflow_open_sora.py:219): tqdm when asked (rank 0 of a group, or no group), the plain
+    iterable otherwise; same items either way."""
+    from videosys_amd.utils import progress_wrap
+
+    items = list(enumerate([5, 6, 7]))
+    assert progress_wrap(items, False) is items
+    bar = progress_wrap(items, True, disable=True)
+    assert type(bar).__name__.startswith("tqdm") and list(bar) == items

@@ -17,7 +17,7 @@ from typing import Callable, List, Optional
 import numpy as np
 import torch
 
-from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, randn_tensor as _randn, read_component
+from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, progress_wrap, randn_tensor as _randn, read_component
 from . import ops, pab
 from .cogvideox import CogVideoXTransformer3DModel, synth_state_dict
 from .pab import PABConfig
@@ -327,7 +327,7 @@ class CogVideoXPipeline(VideoSysPipeline):
     @torch.no_grad()
     def generate(self, prompt=None, negative_prompt=None, height: int = 480, width: int = 720, num_frames: int = 49,
                  num_inference_steps: int = 50, guidance_scale: float = 6, use_dynamic_cfg: bool = False, seed: int = -1,
-                 verbose: bool = False, *, prompt_embeds: Optional[torch.Tensor] = None,
+                 verbose: bool = True, *, prompt_embeds: Optional[torch.Tensor] = None,
                  negative_prompt_embeds: Optional[torch.Tensor] = None, latents: Optional[torch.Tensor] = None,
                  output_type: str = "auto", timesteps=None, num_videos_per_prompt: int = 1, eta: float = 0.0,
                  generator: Optional[torch.Generator] = None, return_dict: bool = True, callback_on_step_end=None,
@@ -368,7 +368,8 @@ class CogVideoXPipeline(VideoSysPipeline):
         self._num_timesteps = len(self.scheduler.timesteps)
         rope = self._prepare_rotary_positional_embeddings(height, width, z.shape[1]) if c.use_rotary_positional_embeddings else None
         zf = z.view(B, 1, -1)  # the step kernel sees [Bz, Cin = 1, thw]: CogVideoX predicts all 16 channels (no sigma half)
-        for step_i, t in enumerate(self.scheduler.timesteps):
+        # (:678,737) the reference runs diffusers' progress bar on every call; ``verbose=False`` (an extension) turns it off
+        for step_i, t in progress_wrap(list(enumerate(self.scheduler.timesteps)), verbose):
             if self._interrupt:   # (:682-683) a callback may set pipe._interrupt: the remaining steps are skipped
                 continue
             out = self.transformer(z, emb, torch.full((nb,), t, dtype=torch.int64), image_rotary_emb=rope,

@@ -15,7 +15,7 @@ from typing import Callable, List, Optional
 
 import torch
 
-from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, randn_tensor as _randn, read_component
+from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, progress_wrap, randn_tensor as _randn, read_component
 from . import ops, pab
 from .latte import LatteT2V, synth_state_dict
 from .pab import PABConfig
@@ -291,7 +291,7 @@ class LattePipeline(VideoSysPipeline):
 
     @torch.no_grad()
     def generate(self, prompt=None, negative_prompt: str = "", num_inference_steps: int = 50, guidance_scale: float = 7.5,
-                 seed: int = -1, verbose: bool = False, *, prompt_embeds: Optional[torch.Tensor] = None,
+                 seed: int = -1, verbose: bool = True, *, prompt_embeds: Optional[torch.Tensor] = None,
                  negative_prompt_embeds: Optional[torch.Tensor] = None, prompt_mask: Optional[torch.Tensor] = None,
                  negative_mask: Optional[torch.Tensor] = None, latents: Optional[torch.Tensor] = None,
                  video_length: int = 16, height: int = 512, width: int = 512, output_type: str = "auto",
@@ -341,7 +341,7 @@ class LattePipeline(VideoSysPipeline):
         z = self.prepare_latents(B, cin, video_length, height, width, torch.float32, self._device, generator,
                                  None if latents is None else latents.float()).contiguous().clone()
         all_ts = torch.tensor(ts)
-        for step_i, t in enumerate(ts):
+        for step_i, t in progress_wrap(list(enumerate(ts)), verbose):   # (:834-835) tqdm on rank 0
             tt = torch.full((nb,), t, dtype=torch.int64)
             out = self.transformer(z, timestep=tt, all_timesteps=all_ts, encoder_hidden_states=emb,
                                    encoder_attention_mask=mask, added_cond_kwargs={"resolution": None, "aspect_ratio": None},

@@ -8,6 +8,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
+from .utils import progress_wrap
 
 
 def timestep_transform(t, model_kwargs, base_resolution=512 * 512, base_num_frames=1, scale=1.0, num_timesteps=1):
@@ -73,7 +74,7 @@ class RFLOW:
                 raise ValueError(f"mask must be [B, T] = [{B}, {z.shape[2]}], got {tuple(cond.shape)}")
             noise_added = cond == 1
             frames = lambda m: m.to(z.device)[:, None, :, None, None]
-        for i, t in enumerate(timesteps):
+        for i, t in progress_wrap(list(enumerate(timesteps)), progress):   # (:219,224) tqdm on rank 0
             if mask is not None:
                 x0 = z.clone()
                 upper = (cond * self.num_timesteps) >= t.unsqueeze(1)            # frames that are being denoised at this step

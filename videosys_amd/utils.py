@@ -78,6 +78,18 @@ def init_logger(logging_dir: str = None, master_only: bool = True):
     return logging.getLogger()
 
 
+def progress_wrap(iterable, enabled: bool = True, **tqdm_kwargs):
+    """The denoise loops' progress bar: tqdm on rank 0 when asked for (scheduling_rflow_open_sora.py:219,
+    pipeline_latte.py:834), the plain iterable otherwise (other ranks, ``verbose=False``, tqdm not installed)."""
+    if not enabled or (dist.is_initialized() and dist.get_rank() != 0):
+        return iterable
+    try:
+        from tqdm import tqdm
+    except ImportError:
+        return iterable
+    return tqdm(iterable, **tqdm_kwargs)
+
+
 def randn_tensor(shape, generator=None, dtype=None):
     """Start noise the way the pipelines draw it (diffusers' ``randn_tensor``, third-party: drawn on the generator's device, then
     moved by the caller): fp32 from ``generator`` — a torch.Generator, or a list of them, one per sample — else from torch's
