@@ -25,6 +25,8 @@ from .stdit3 import STDiT3, STDiT3Config
 from .pipeline import (VideoSysPipeline, VideoSysPipelineOutput, build_text_encoder, is_foreign_module,  # noqa: F401 (re-exported)
                        module_state)
 
+os.environ.setdefault("TOKENIZERS_PARALLELISM", "true")   # pipeline_open_sora.py:24 (kept if the application set it)
+
 
 class OpenSoraPABConfig(PABConfig):
     """pipeline_open_sora.py:32-69 — identical defaults, incl. mlp_broadcast=True with the three default windows (in the
