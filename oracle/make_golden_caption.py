@@ -51,10 +51,13 @@ CASES = [
 ]
 
 
-def main():
+def reference_cleaners(fix_text=lambda t: t, soup_text=lambda s: s):
+    """The reference's own caption functions, compiled from its files: -> (open_sora, latte) namespaces with ``_clean_caption(c)``
+    and ``text_preprocessing`` / ``_text_preprocessing``.  ``fix_text`` / ``soup_text`` stand in for ftfy.fix_text and
+    BeautifulSoup(s, features="html.parser").text (identity by default, see the module docstring)."""
     src = open(PATH).read()
-    ns = {"re": re, "html": html, "ul": ul, "ftfy": SimpleNamespace(fix_text=lambda t: t),
-          "BeautifulSoup": lambda s, features=None: SimpleNamespace(text=s)}
+    ns = {"re": re, "html": html, "ul": ul, "ftfy": SimpleNamespace(fix_text=fix_text),
+          "BeautifulSoup": lambda s, features=None: SimpleNamespace(text=soup_text(s))}
     funcs = {}
     for node in ast.parse(src).body:
         if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) == "BAD_PUNCT_REGEX":
@@ -68,6 +71,7 @@ def main():
     me = SimpleNamespace()
     me._basic_clean = funcs["_basic_clean"]
     me._clean_caption = lambda c: funcs["_clean_caption"](me, c)
+    me.text_preprocessing = lambda c, use=True: funcs["text_preprocessing"](me, c, use)
     # LattePipeline: the diffusers IFPipeline copy (pipeline_latte.py:185-189 bad_punct_regex, :519-650)
     lpath = "/root/reference/videosys/pipelines/latte/pipeline_latte.py"
     lns = dict(ns)
@@ -81,13 +85,19 @@ def main():
                 if isinstance(item, ast.FunctionDef) and item.name in ("_clean_caption", "_text_preprocessing"):
                     exec(compile(ast.Module([item], []), lpath, "exec"), lns)
     lat._clean_caption = lambda c: lns["_clean_caption"](lat, c)
+    lat._text_preprocessing = lambda c, clean_caption=False: lns["_text_preprocessing"](lat, c, clean_caption=clean_caption)
+    return me, lat
+
+
+def main():
+    me, lat = reference_cleaners()
     out = []
     for c in CASES:
         assert "<" not in c.replace("<person>", "") and "&" not in c
-        out.append({"in": c, "once": me._clean_caption(c), "twice": funcs["text_preprocessing"](me, c),
-                    "plain": funcs["text_preprocessing"](me, c, False),
-                    "latte_twice": lns["_text_preprocessing"](lat, c, clean_caption=True)[0],
-                    "latte_plain": lns["_text_preprocessing"](lat, c, clean_caption=False)[0]})
+        out.append({"in": c, "once": me._clean_caption(c), "twice": me.text_preprocessing(c),
+                    "plain": me.text_preprocessing(c, False),
+                    "latte_twice": lat._text_preprocessing(c, clean_caption=True)[0],
+                    "latte_plain": lat._text_preprocessing(c, clean_caption=False)[0]})
     with open(os.path.join(ROOT, "tests", "golden", "clean_caption_cases.json"), "w") as fh:
         json.dump(out, fh, ensure_ascii=False, indent=1)
     for o in out[:6]:

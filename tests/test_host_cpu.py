@@ -1339,3 +1339,54 @@ def test_progress_wrap_is_a_bar_on_request_only():
     assert progress_wrap(items, False) is items
     bar = progress_wrap(items, True, disable=True)
     assert type(bar).__name__.startswith("tqdm") and list(bar) == items
+
+
+def test_caption_cleaner_equals_the_reference_on_generated_text():
+    """Property test (hypothesis): caption.clean_caption / text_preprocessing against the reference's own functions compiled from
+    its files (oracle/make_golden_caption.reference_cleaners), Open-Sora and Latte variants, on text assembled from the token
+    classes the rules target (urls, html, entities, ids, sizes, CJK, dashes, quotes, shipping spam ...).  The two third-party steps
+    are the same stand-ins on both sides (NFC for ftfy.fix_text, the standard library's html.parser for BeautifulSoup(...).text),
+    so what is compared is the rule sequence."""
+    if not os.path.isdir("/root/reference/videosys/pipelines"):
+        pytest.skip("reference tree not present on this box")
+    import unicodedata
+
+    from hypothesis import given, settings, strategies as st
+
+    from oracle.make_golden_caption import reference_cleaners
+    from videosys_amd import caption as C
+
+    soup = C._html_text
+    try:
+        import bs4  # noqa: F401
+        pytest.skip("bs4 present: the product uses it, the stand-in comparison does not apply")
+    except ImportError:
+        pass
+    try:
+        import ftfy  # noqa: F401
+        pytest.skip("ftfy present: the product uses it, the stand-in comparison does not apply")
+    except ImportError:
+        pass
+    ref_os, ref_latte = reference_cleaners(fix_text=lambda t: unicodedata.normalize("NFC", t), soup_text=soup)
+    pieces = st.sampled_from([
+        "a cat", "Sunset", "over the sea", " ", "  ", ",", ".", "..", "...", ":", " : ", ";", "!", "?", "-", "_", "--", "—", "–", "\\n", "\n",
+        "https://example.com/a/b", "www.test.org", "http://x.co", "foo.com/page", "mail@host.ru", "@user_1", "#12", "#123456", "1234567",
+        "192.168.0.1", "12:30 ", "IMG_001.jpg", "clip.mp4", "a.png", "jpg image", "png images", "<b>bold</b>", "<person>", "<br/>", "&amp;",
+        "&quot;", "&lt;tag&gt;", "&#39;", "&amp", "湖边", "日落", "ｶﾀｶﾅ", "㈱", "“q”", "‘s’", "`tick`", "«g»", "\"", "'", "''", "\"\"", "(x)", "[y]",
+        "{z}", "|", "/", "\\", "*", "~", "®", "™", "©", "free shipping", "worldwide free shipping", "download free", "free download",
+        "click for more", "click on here", "page 12", "jc6640", "abc123def", "6640vc231", "j2d1a2a", "1920x1080", "3.5x2", "12×8", "10х10",
+        "a%20b", "a+b", "é", "é", "ﬁ", "Ａ", "word.Word", "x,y", "a/b", "this-is-my-cute-cat", "this_is_my_cute_cat", ".hidden", "'lead",
+        "trail:", "trail-", "+", "A1B2C3", "v2", "4k", "8K UHD", "№5", "½", "·", "•", "º", "¿que?", "¡hola!", "§2",
+    ])
+    text = st.lists(pieces, min_size=1, max_size=12).map("".join)
+
+    @settings(max_examples=400, deadline=None, derandomize=True)
+    @given(text)
+    def check(s):
+        assert C.clean_caption(s) == ref_os._clean_caption(s), ("open-sora once", s)
+        assert C.text_preprocessing(s) == ref_os.text_preprocessing(s), ("open-sora twice", s)
+        assert C.text_preprocessing(s, False) == ref_os.text_preprocessing(s, False), ("open-sora plain", s)
+        assert C.clean_caption(s, mid_strip=False) == ref_latte._clean_caption(s), ("latte once", s)
+        assert C.text_preprocessing(s, True, mid_strip=False) == ref_latte._text_preprocessing(s, clean_caption=True)[0], ("latte twice", s)
+
+    check()
