@@ -1390,3 +1390,67 @@ def test_caption_cleaner_equals_the_reference_on_generated_text():
         assert C.text_preprocessing(s, True, mid_strip=False) == ref_latte._text_preprocessing(s, clean_caption=True)[0], ("latte twice", s)
 
     check()
+
+
+def test_mask_strategy_helpers_equal_the_reference_on_generated_cases():
+    """Property test (hypothesis): parse_mask_strategy / find_nearest_point / apply_mask_strategy / append_generated /
+    dframe_to_frame of open_sora_condition.py against the reference's own functions compiled from pipeline_open_sora.py:795-875,
+    over generated strategies (all six fields, negative starts, several groups, several loops, alignment on / off)."""
+    path = "/root/reference/videosys/pipelines/open_sora/pipeline_open_sora.py"
+    if not os.path.isfile(path):
+        pytest.skip("reference tree not present on this box")
+    import ast
+
+    from hypothesis import given, settings, strategies as st
+
+    from videosys_amd import open_sora_condition as K
+
+    want = {"MASK_DEFAULT", "parse_mask_strategy", "find_nearest_point", "apply_mask_strategy", "append_generated", "dframe_to_frame"}
+    ns = {"torch": torch}
+    for node in ast.parse(open(path).read()).body:
+        name = getattr(node, "name", None) or (node.targets[0].id if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Name) else None)
+        if name in want:
+            exec(compile(ast.Module([node], []), path, "exec"), ns)
+
+    group = st.tuples(st.integers(0, 2), st.integers(0, 1), st.integers(-6, 6), st.integers(-6, 12), st.integers(0, 8),
+                      st.sampled_from([0.0, 0.3, 0.5, 1.0]), st.integers(1, 6))
+    to_str = lambda gs: ";".join(",".join(str(v) for v in g[:g[6]]) for g in gs)
+
+    @settings(max_examples=300, deadline=None, derandomize=True)
+    @given(st.lists(group, min_size=0, max_size=3), st.integers(0, 2), st.sampled_from([None, 5]), st.integers(5, 15), st.integers(1, 12),
+           st.integers(0, 10 ** 6))
+    def check(groups, loop_i, align, Tz, Tref, seed):
+        ms = to_str(groups)
+        assert K.parse_mask_strategy(ms) == ns["parse_mask_strategy"](ms)
+        g = torch.Generator().manual_seed(seed)
+        z = torch.randn(1, 4, Tz, 2, 2, generator=g)
+        refs = [[torch.randn(4, Tref, 2, 2, generator=g), torch.randn(4, Tref + 2, 2, 2, generator=g)]]
+        za, zb = z.clone(), z.clone()
+        try:
+            want_masks = ns["apply_mask_strategy"](za, refs, [ms], loop_i, align=align)
+        except Exception as e:     # e.g. a start beyond the clip: whatever the reference raises, this build raises too
+            with pytest.raises(type(e)):
+                K.apply_mask_strategy(zb, refs, [ms], loop_i, align=align)
+            return
+        got = K.apply_mask_strategy(zb, refs, [ms], loop_i, align=align)
+        assert torch.equal(za, zb) and torch.equal(got, want_masks), ms
+
+    check()
+    for v in range(0, 40):
+        for p in (1, 3, 5):
+            for m in (5, 15, 38):
+                assert K.find_nearest_point(v, p, m) == ns["find_nearest_point"](v, p, m)
+    for n in (0, 5, 10, 35):
+        assert K.dframe_to_frame(n) == ns["dframe_to_frame"](n)
+    with pytest.raises(AssertionError):
+        K.dframe_to_frame(7)
+
+    class Vae:
+        def encode(self, v):
+            return v[:, :4, :3] * 2
+
+    vid = torch.arange(2 * 4 * 6 * 2 * 2, dtype=torch.float32).view(2, 4, 6, 2, 2)
+    # (an entry without references is [] in the reference's flow — its `refs is None` branch dies on len(None) two lines later)
+    ra, ma = ns["append_generated"](Vae(), vid, [[], [torch.zeros(4, 1, 2, 2)]], [None, "0"], 1, 5, 0.0)
+    rb, mb = K.append_generated(Vae().encode, vid, [[], [torch.zeros(4, 1, 2, 2)]], [None, "0"], 1, 5, 0.0)
+    assert ma == mb and len(ra) == len(rb) and all(len(x) == len(y) and all(torch.equal(p, q) for p, q in zip(x, y)) for x, y in zip(ra, rb))
