@@ -101,6 +101,11 @@ def test_config_surface_and_latent_size():
     assert get_latent_size(64, 512, 512) == (19, 64, 64)
     assert get_latent_size(128, 720, 1280) == (38, 90, 160)
     assert get_latent_size(1, 512, 512) == (1, 64, 64)
+    # every frame count against the reference's arithmetic (autoencoder_kl_open_sora.py:424-439, 706-717: 17-frame micro batches,
+    # each padded up to a multiple of the temporal factor 4, then divided by it; spatial / 8)
+    for nf in range(1, 300):
+        want = (nf // 17) * ((17 + 3) // 4) + ((nf % 17 + 3) // 4 if nf % 17 else 0)
+        assert get_latent_size(nf, 360, 640) == (want, 45, 80), nf
 
 
 def test_host_tables_match_oracle():
