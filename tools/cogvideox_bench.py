@@ -40,7 +40,7 @@ def main():
     pos = (torch.randn(1, 226, 4096, generator=g) * 0.1).to(torch.bfloat16).float()
     neg = (torch.randn(1, 226, 4096, generator=g) * 0.1).to(torch.bfloat16).float()
     kw = dict(prompt_embeds=pos, negative_prompt_embeds=neg, height=480, width=720, num_frames=49, guidance_scale=6.0,
-              use_dynamic_cfg=True, seed=0, output_type="latent")
+              use_dynamic_cfg=True, seed=0, output_type="latent", verbose=False)
     pipe.generate(num_inference_steps=2, **kw)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -40,7 +40,7 @@ def main():
     pipe = LattePipeline(LatteConfig(model_path="synthetic:4321", transformer_config=cfg, enable_pab=a.pab,
                                      pab_config=LattePABConfig()), device="cuda:0")
     kw = dict(prompt_embeds=pos, negative_prompt_embeds=neg, prompt_mask=pmask, negative_mask=nmask, latents=lat,
-              guidance_scale=7.5, output_type="latent")
+              guidance_scale=7.5, output_type="latent", verbose=False)
     pipe.generate(num_inference_steps=2, **kw)  # warm-up
     torch.cuda.synchronize()
     t0 = time.perf_counter()
