@@ -6,7 +6,8 @@ For every kernel symbol of the gfx950 code object: the innermost loop that holds
 branch and its target), its instructions by class, and the figures a kernel writer reads off them: VALU issues per MFMA (MFMA
 32x32x16 bf16 occupies the matrix pipe for 8 passes = 32 cycles of a SIMD; what has to issue beside it has to fit those gaps,
 MI355X_MICROARCH.md "one wave per SIMD" row), LDS and memory instructions per MFMA, waits and barriers per iteration.  The counts are
-per LOOP ITERATION of one wave as the compiler scheduled it; they say nothing about stalls — PMC (profiles/*pmc*) does."""
+per LOOP ITERATION of one wave as the compiler scheduled it; they say nothing about stalls — PMC (profiles/*pmc*) does —
+and they include the COLD blocks the compiler places inside a loop's address range (rare out-of-line branches): upper bounds on what executes."""
 import argparse
 import collections
 import os
@@ -137,7 +138,8 @@ def main():
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     out = open(a.out, "w") if a.out else sys.stdout
-    print(f"# tools/isa_mix.py {a.object}: per-wave instruction mix of the hot loop of each kernel (static; gfx950 code object)", file=out)
+    print(f"# tools/isa_mix.py {a.object}: per-wave instruction mix of the hot loop of each kernel (static; gfx950 code object).\n"
+          "# Counts cover every instruction between the loop head and its backward branch, cold out-of-line blocks included: upper bounds.", file=out)
     for name, ins in kernels(device_disassembly(a.object)).items():
         if a.kernel and a.kernel not in name and a.kernel not in demangle(name):
             continue
