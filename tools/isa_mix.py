@@ -113,21 +113,25 @@ def report(name, ins, out):
     print(f"\n== {demangle(name)}", file=out)
     print(f"   {len(ins)} instructions, {total_mfma} MFMA in the whole kernel", file=out)
     if loop is None:
-        print("   (no loop with MFMAs)", file=out)
-        return
-    s, e = loop
+        print("   (no loop with MFMAs: a VALU kernel — the mix below is the WHOLE kernel, straight-line code and cold blocks included)", file=out)
+        s, e = 0, len(ins) - 1
+    else:
+        s, e = loop
     body = ins[s:e + 1]
     cnt = collections.Counter(classify(op) for _, op, _ in body)
     ops = collections.Counter(op for _, op, _ in body)
     mfma = cnt["mfma"]
     valu = sum(v for k, v in cnt.items() if k in VALU)
-    print(f"   hot loop: {len(body)} instructions at +0x{body[0][0] - ins[0][0]:x} .. +0x{body[-1][0] - ins[0][0]:x}", file=out)
+    print(f"   {'hot loop' if loop is not None else 'kernel'}: {len(body)} instructions at +0x{body[0][0] - ins[0][0]:x} .. +0x{body[-1][0] - ins[0][0]:x}", file=out)
     for cname, _ in CLASSES:
         if cnt[cname]:
             top = ", ".join(f"{o} x{n}" for o, n in ops.most_common() if classify(o) == cname)[:150]
             print(f"   {cname:28s} {cnt[cname]:5d}   {top}", file=out)
-    print(f"   VALU issues per MFMA        {valu / mfma:5.2f}   (a 32x32x16 bf16 MFMA holds the matrix pipe 8 passes; ~5 fillers fit a gap)", file=out)
-    print(f"   LDS reads per MFMA          {cnt['LDS read'] / mfma:5.2f}", file=out)
+    if mfma:
+        print(f"   VALU issues per MFMA        {valu / mfma:5.2f}   (a 32x32x16 bf16 MFMA holds the matrix pipe 8 passes; ~5 fillers fit a gap)", file=out)
+        print(f"   LDS reads per MFMA          {cnt['LDS read'] / mfma:5.2f}", file=out)
+    else:
+        print(f"   VALU issues                 {valu:5d}", file=out)
     print(f"   waits + barriers per iter   {cnt['wait'] + cnt['barrier']:5d}", file=out)
 
 
