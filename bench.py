@@ -168,10 +168,32 @@ def main():
             ev.append((s, e, 2.0 * x.shape[0] * w.shape[0] * x.shape[1], k.get("epilogue", 0)))
             return r
 
+        # the AdaLN-folded forms of the same GEMMs (qkv / fc1 with LayerNorm + modulation in the epilogue: "epilogue" 3 / 4;
+        # cross-proj / fc2 that also emit the row statistics: 5)
+        real_gemm_ln, real_gemm_stats = ops.gemm_ln, ops.gemm_stats
+
+        def timed_gemm_ln(x, wp, cs, cv, stats, **k):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = real_gemm_ln(x, wp, cs, cv, stats, **k)
+            e.record()
+            ev.append((s, e, 2.0 * x.shape[0] * wp.shape[0] * x.shape[1], 4 if k.get("gelu") else 3))
+            return r
+
+        def timed_gemm_stats(x, w, bias, stats, **k):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = real_gemm_stats(x, w, bias, stats, **k)
+            e.record()
+            ev.append((s, e, 2.0 * x.shape[0] * w.shape[0] * x.shape[1], 5))
+            return r
+
     barrier()
     nrep = min(args.steps, 3)
     if rank == 0:
-        ops.gemm = timed_gemm  # every rank replays the steps (DSP collectives); only rank 0 is instrumented
+        ops.gemm, ops.gemm_ln, ops.gemm_stats = timed_gemm, timed_gemm_ln, timed_gemm_stats  # every rank replays the steps (DSP collectives); only rank 0 is instrumented
     was_prog = model.use_programs
     model.use_programs = False   # the instrumented replay issues every launch from Python (a recorded launch program would bypass
     try:                         # the event brackets); the TIMED region above ran the product default
@@ -181,7 +203,7 @@ def main():
     finally:
         model.use_programs = was_prog
         if rank == 0:
-            ops.gemm = real_gemm
+            ops.gemm, ops.gemm_ln, ops.gemm_stats = real_gemm, real_gemm_ln, real_gemm_stats
     if rank == 0:
         # drop the once-per-prompt kv_linear launches (none after warm-up) and aggregate
         tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in ev)

@@ -72,6 +72,38 @@ int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const
                    int64_t M, int64_t N, int64_t K, int epilogue, const void* gate, int64_t gate_sample_stride,
                    int64_t rows_per_sample, const void* res, int64_t ldr, void* aux, int64_t ldaux, void* stream);
 
+/* AdaLN folded into the qkv / fc1 GEMMs: x_m = t2i_modulate(norm(x), shift, scale) followed by the Linear
+ * (open_sora_transformer_3d.py:196-197 + attentions.py:59; :260-261 + timm Mlp fc1 :130-132,267) without ever writing x_m:
+ *   out[m][n] = rstd_m (sum_k x[m][k] W'[n][k] - mu_m cs[n]) + cv[n]   (+ GELU-tanh for VSYS_EPI_BIAS_GELU)
+ * with W' = bf16(W (1 + scale)), cs[n] = sum_k W'[n][k], cv[n] = shift . W[n] + bias[n] (fp32 [N] each, from
+ * vsys_adaln_prescale) and the LayerNorm statistics of row m (eps as nn.LayerNorm, :116-117) combined from K / 96 partial
+ * (mean, M2) pairs over 96-column blocks: float2 stats[b * stats_ld + m] (written by vsys_gemm_bf16_stats or vsys_ln_row_stats).
+ * x is the RAW residual stream [M, K]; K % 96 == 0, K <= 1152; epilogue = VSYS_EPI_BIAS or VSYS_EPI_BIAS_GELU; otherwise as
+ * vsys_gemm_bf16. */
+int vsys_gemm_bf16_ln(const void* x, int64_t ldx, const void* wp, int64_t ldw, const void* cs, const void* cv, void* out, int64_t ldo,
+                      int64_t M, int64_t N, int64_t K, int epilogue, const void* stats, int64_t stats_ld, float eps, void* stream);
+
+/* vsys_gemm_bf16 with VSYS_EPI_GATE_RES (out = res + gate (x W^T + b): attentions.py:107 / :183 / timm Mlp fc2 + the residual adds
+ * of open_sora_transformer_3d.py:228,240,284) that ALSO emits the LayerNorm partials of the rows it stores — what the next block's
+ * norm1 / norm2 (open_sora_transformer_3d.py:116-117,196,260) would compute from them: float2 stats[b * stats_ld + m] = (mean, M2)
+ * of out[m][96 b .. 96 b + 95].  No aux output; N % 192 == 0. */
+int vsys_gemm_bf16_stats(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo, int64_t M,
+                         int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride, int64_t rows_per_sample, const void* res,
+                         int64_t ldr, void* stats, int64_t stats_ld, void* stream);
+
+/* The step-level half of the AdaLN fold: for every site of a step (one qkv or fc1 Linear of one block) W' = bf16(W (1 + scale)),
+ * cs, cv as defined at vsys_gemm_bf16_ln, all sites in ONE launch.  shift / scale are the sample-0 rows of the step's modulation
+ * table (t2i_modulate operands, open_sora_transformer_3d.py:177-179; valid when every sample of the batch shares the timestep, as
+ * the CFG pair of scheduling_rflow_open_sora.py:239-244 does).  ``sites``: DEVICE array of nsites x 10 int64: W, bias, W', cs, cv
+ * (addresses), shift_off, scale_off (element offsets into ``mod``), N, K, first block of the site; 4 weight rows per block,
+ * nblocks = sum ceil(N / 4). */
+int vsys_adaln_prescale(const void* sites, int64_t nsites, int64_t nblocks, const void* mod, void* stream);
+
+/* LayerNorm partials (format of vsys_gemm_bf16_ln) of a [rows, C] bf16 tensor no GEMM epilogue produced: the patch embedding
+ * in front of block 0 and the x += cached-output steps of PAB (open_sora_transformer_3d.py:116-117,192-193).  C % 96 == 0,
+ * C <= 1536. */
+int vsys_ln_row_stats(const void* x, int64_t rows, int64_t C, void* stats, int64_t stats_ld, void* stream);
+
 /* Small / odd-shaped nn.Linear (any M, N; K % 8 == 0): act_in is applied to x (SiLU of t_block,
  * open_sora_transformer_3d.py:396-399), act_out to the result (TimestepEmbedder/SizeEmbedder mlp, embeddings.py:114-118;
  * OpenSoraCaptionEmbedder y_proj, embeddings.py:197-203). */
@@ -363,7 +395,11 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
 #define VSYS_OP_PATCH_EMBED_SHARD   20
 #define VSYS_OP_FINAL_LAYER_TOKENS  21
 #define VSYS_OP_UNPATCHIFY_TOKENS   22
-#define VSYS_OP_COUNT              23
+#define VSYS_OP_GEMM_BF16_LN        23
+#define VSYS_OP_GEMM_BF16_STATS     24
+#define VSYS_OP_ADALN_PRESCALE      25
+#define VSYS_OP_LN_ROW_STATS        26
+#define VSYS_OP_COUNT              27
 
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */

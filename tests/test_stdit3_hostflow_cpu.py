@@ -21,6 +21,7 @@ class FakeOps:
 
     def __init__(self):
         self.calls = {}
+        self.stats_valid = False
 
     def _n(self, name):
         self.calls[name] = self.calls.get(name, 0) + 1
@@ -34,7 +35,42 @@ class FakeOps:
         assert bias is None or bias.shape == (N,)
         if epilogue == 2 and gate is not None:
             assert rows_per_sample > 0 and gate.shape == (N,)
+        if epilogue == 2:
+            self.stats_valid = False   # x was rewritten without statistics
         return out if out is not None else _zeros((M, N))
+
+    LN_BLOCK = 96
+
+    def ln_stats_buffer(self, rows, C, device):
+        assert C % 96 == 0
+        return torch.zeros(C // 96, rows, 2)
+
+    def gemm_ln(self, x, wp, cs, cv, stats, *, gelu=False, eps=1e-6, out=None):
+        self._n("gemm_ln")
+        M, K = x.shape
+        N = wp.shape[0]
+        assert wp.shape == (N, K) and cs.shape == cv.shape == (N,) and stats.shape == (K // 96, M, 2)
+        assert self.stats_valid, "gemm_ln reads statistics nobody wrote for the current x"
+        assert out is None or tuple(out.shape) == (M, N)
+        return out if out is not None else _zeros((M, N))
+
+    def gemm_stats(self, x, w, bias, stats, *, gate=None, gate_stride=0, rows_per_sample=0, res=None, out=None):
+        self._n("gemm_stats")
+        M, N = x.shape[0], w.shape[0]
+        assert x.shape[1] == w.shape[1] and stats.shape == (N // 96, M, 2) and tuple(out.shape) == (M, N)
+        self.stats_valid = True
+        return out
+
+    def adaln_prescale(self, sites, nblocks, mod):
+        self._n("adaln_prescale")
+        assert sites.dtype == torch.int64 and sites.shape[1] == 10 and int(sites[-1, 9]) + -(-int(sites[-1, 7]) // 4) == nblocks
+        assert int(sites[:, 6].max()) + int(sites[0, 8]) <= mod.numel()
+
+    def ln_row_stats(self, x, stats):
+        self._n("ln_row_stats")
+        assert stats.shape == (x.shape[1] // 96, x.shape[0], 2)
+        self.stats_valid = True
+        return stats
 
     def linear_small(self, x, w, bias=None, act_in=0, act_out=0, out=None):
         self._n("linear_small")
@@ -85,6 +121,7 @@ class FakeOps:
     def add_rows(self, x, y):
         self._n("add_rows")
         assert x.numel() == y.numel()
+        self.stats_valid = False
         return x
 
     def alloc_kv_buffers(self, batch, heads, kv_len, device):
@@ -118,7 +155,7 @@ def fake_ops():
     from videosys_amd import ops
 
     f = FakeOps()
-    names = [n for n in dir(f) if not n.startswith("_") and n != "calls"]
+    names = [n for n in dir(f) if not n.startswith("_") and n not in ("calls", "stats_valid")]
     saved = {n: getattr(ops, n) for n in names}
     for n in names:
         setattr(ops, n, getattr(f, n))
@@ -157,11 +194,15 @@ def test_step_launch_counts_and_program_replay():
         t = torch.tensor([500.0, 500.0])
         out = m(x, t, y, **kw)
         assert out.shape == (2, 8, 5, 8, 8)
-        # per block: 2 AdaLN, 6 token GEMMs, 2 attention calls (self + cross), K/V prep for spatial blocks only
+        # per block (AdaLN fold, the default when the batch shares one timestep): no AdaLN pass; qkv and fc1 are folded GEMMs,
+        # cross-proj and fc2 emit the statistics the next folded GEMM reads, attention proj and cross q are plain; one pre-scale
+        # launch per step; one stand-alone statistics pass in front of block 0 (x comes from the patch embedding there)
         nblk = 2 * CFG["depth"]
-        assert f.calls["adaln_modulate"] == 2 * nblk and f.calls["attn_temporal"] == CFG["depth"]
+        assert "adaln_modulate" not in f.calls and f.calls["attn_temporal"] == CFG["depth"]
+        assert f.calls["gemm_ln"] == 2 * nblk and f.calls["gemm_stats"] == 2 * nblk and f.calls["adaln_prescale"] == 1
+        assert f.calls["ln_row_stats"] == 1
         assert f.calls["flash_attn"] == nblk + CFG["depth"]
-        gemms_text = f.calls["gemm"] - 6 * nblk     # the once-per-prompt kv_linear projections (GEMM or small linear by shape)
+        gemms_text = f.calls["gemm"] - 2 * nblk     # the once-per-prompt kv_linear projections (GEMM or small linear by shape)
         assert gemms_text in (0, nblk)
         before = dict(f.calls)
         assert m.program_stats == dict(recorded=1, replayed=0, eager=0)
@@ -174,6 +215,19 @@ def test_step_launch_counts_and_program_replay():
         assert m.program_stats["eager"] == 1
         m.reset_text_cache()
         assert not m._programs
+        # two samples at different timesteps have different modulations: the fold is off for that call (own program key),
+        # and VSYS_ADALN_FOLD=0 (model.adaln_fold) keeps the separate LayerNorm-modulate pass everywhere
+        m.use_programs = True
+        g0 = dict(f.calls)
+        m(x, torch.tensor([500.0, 400.0]), y, **kw)
+        assert f.calls["adaln_modulate"] == 2 * nblk and f.calls["gemm_ln"] == g0["gemm_ln"]
+        m.adaln_fold = False
+        g1, rep = dict(f.calls), m.program_stats["replayed"]
+        m(x, t, y, **kw)                            # the unfused step at this geometry was recorded by the call above: replayed
+        assert f.calls == g1 and m.program_stats["replayed"] == rep + 1
+        m.use_programs = False
+        m(x, t, y, **kw)
+        assert f.calls["adaln_modulate"] == 4 * nblk and f.calls["gemm_ln"] == g0["gemm_ln"]
 
 
 def test_pab_patterns_get_their_own_programs_and_mlp_steps_run_eagerly():

@@ -70,6 +70,49 @@ int vsys_gemm_bf16(const void* x, int64_t ldx, const void* w, int64_t ldw, const
   return launch_gemm(p, epilogue, S(stream));
 }
 
+int vsys_gemm_bf16_ln(const void* x, int64_t ldx, const void* wp, int64_t ldw, const void* cs, const void* cv, void* out, int64_t ldo,
+                      int64_t M, int64_t N, int64_t K, int epilogue, const void* stats, int64_t stats_ld, float eps, void* stream) {
+  if (!x || !wp || !cs || !cv || !out || !stats) return VSYS_ERR_ARG;
+  if (!fits_int(M) || !fits_int(N) || !fits_int(K)) return VSYS_ERR_SHAPE;
+  if (epilogue != VSYS_EPI_BIAS && epilogue != VSYS_EPI_BIAS_GELU) return VSYS_ERR_ARG;
+  if (K % LN_BLOCK != 0 || K / LN_BLOCK > 12) return VSYS_ERR_SHAPE;
+  GemmParams p;
+  p.A = B16(x); p.lda = ldx; p.W = B16(wp); p.ldw = ldw; p.bias = nullptr; p.out = B16(out); p.ldo = ldo;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.gate = nullptr; p.gate_stride = 0; p.res = nullptr; p.ldr = 0; p.aux = nullptr; p.ldaux = 0; p.rows_per_sample = 0;
+  p.seg_split = 0; p.gate_alt = 0; p.ks = 0; p.out32 = nullptr; p.slab = 0; p.ldo32 = 0;
+  p.cs = reinterpret_cast<const float*>(cs); p.cv = reinterpret_cast<const float*>(cv);
+  p.ln_stats = reinterpret_cast<const float2*>(stats); p.ln_ld = stats_ld; p.ln_nb = (int)(K / LN_BLOCK); p.ln_eps = eps;
+  return launch_gemm(p, epilogue == VSYS_EPI_BIAS ? EPI_LN_BIAS : EPI_LN_GELU, S(stream));
+}
+
+int vsys_gemm_bf16_stats(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo, int64_t M,
+                         int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride, int64_t rows_per_sample, const void* res,
+                         int64_t ldr, void* stats, int64_t stats_ld, void* stream) {
+  if (!x || !w || !out || !stats) return VSYS_ERR_ARG;
+  if (!fits_int(M) || !fits_int(N) || !fits_int(K) || !fits_int(rows_per_sample)) return VSYS_ERR_SHAPE;
+  GemmParams p;
+  p.A = B16(x); p.lda = ldx; p.W = B16(w); p.ldw = ldw; p.bias = B16(bias); p.out = B16(out); p.ldo = ldo;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.gate = B16(gate); p.gate_stride = gate_sample_stride; p.res = B16(res); p.ldr = ldr; p.aux = nullptr; p.ldaux = 0;
+  p.rows_per_sample = (int)rows_per_sample;
+  p.seg_split = 0; p.gate_alt = 0; p.ks = 0; p.out32 = nullptr; p.slab = 0; p.ldo32 = 0;
+  p.stats_out = reinterpret_cast<float2*>(stats); p.stats_ld = stats_ld;
+  return launch_gemm(p, EPI_GATE_RES_STATS, S(stream));
+}
+
+int vsys_adaln_prescale(const void* sites, int64_t nsites, int64_t nblocks, const void* mod, void* stream) {
+  if (!sites || !mod) return VSYS_ERR_ARG;
+  if (!fits_int(nsites)) return VSYS_ERR_SHAPE;
+  return launch_adaln_prescale(reinterpret_cast<const int64_t*>(sites), (int)nsites, nblocks, B16(mod), S(stream));
+}
+
+int vsys_ln_row_stats(const void* x, int64_t rows, int64_t C, void* stats, int64_t stats_ld, void* stream) {
+  if (!x || !stats) return VSYS_ERR_ARG;
+  if (!fits_int(C)) return VSYS_ERR_SHAPE;
+  return launch_ln_row_stats(B16(x), rows, (int)C, reinterpret_cast<float2*>(stats), stats_ld, S(stream));
+}
+
 int vsys_gemm_bf16_gate2(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
                          int64_t M, int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride,
                          int64_t rows_per_sample, int64_t seg_split, int64_t gate_alt, const void* res, int64_t ldr,

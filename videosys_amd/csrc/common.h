@@ -53,6 +53,42 @@ __device__ __forceinline__ float gelu_tanh(float x) {
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
+// ---- AdaLN fold: LayerNorm statistics as per-96-column partials (mean_b, M2_b) at st[b * ld + row] (vsys_internal.h GemmParams).
+// (mu, rstd) of one row from its nb <= 12 partials.  Chan's combination around the first block's mean: no E[x^2] - mu^2 form
+// anywhere, so a row mean that is many sigma away from zero costs nothing.
+__device__ __forceinline__ void ln_combine(const float2* __restrict__ st, int64_t ld, int nb, int64_t row, float eps, float& mu,
+                                           float& rstd) {
+  float2 v[12];
+#pragma unroll
+  for (int b = 0; b < 12; ++b) v[b] = b < nb ? st[b * ld + row] : make_float2(0.f, 0.f);
+  float sd = 0.f, sdd = 0.f, m2 = v[0].y;
+#pragma unroll
+  for (int b = 1; b < 12; ++b) {
+    if (b < nb) {
+      const float d = v[b].x - v[0].x;
+      sd += d;
+      sdd += d * d;
+      m2 += v[b].y;
+    }
+  }
+  const float inv = 1.0f / (float)nb;
+  mu = v[0].x + sd * inv;
+  m2 += 96.0f * (sdd - sd * sd * inv);
+  rstd = rsqrtf(fmaxf(m2, 0.f) / (96.0f * (float)nb) + eps);
+}
+// running (sum, sum of squares) of values taken relative to a pivot close to them -> (mean, M2) of n values
+struct LnAcc {
+  float p, s1, s2;
+  __device__ __forceinline__ void init(float pivot) { p = pivot; s1 = 0.f; s2 = 0.f; }
+  __device__ __forceinline__ void add(float x) { const float d = x - p; s1 += d; s2 = fmaf(d, d, s2); }
+  __device__ __forceinline__ float2 finish(float n) const { return make_float2(p + s1 / n, fmaxf(s2 - s1 * s1 / n, 0.f)); }
+};
+// two equal-sized (n each) partials -> one
+__device__ __forceinline__ float2 ln_merge_equal(float2 a, float2 b, float n) {
+  const float d = b.x - a.x;
+  return make_float2(a.x + 0.5f * d, a.y + b.y + d * d * (0.5f * n));
+}
+
 // XCD-aware bijective remap of a 1-D block id: block b runs on XCD b%8; give each XCD a contiguous
 // chunk of logical tile ids so neighbouring tiles (sharing an operand panel) hit the same L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {

@@ -296,18 +296,62 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) bb[j][g] = make_uint2(0, 0);
-  if (p.bias != nullptr) {
+  if (p.bias != nullptr && EPI != EPI_LN_BIAS && EPI != EPI_LN_GELU) {
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bb[j][g] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * hi);
   }
   const bool full = row0 + BM <= p.M;
+  constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_GELU;
 #pragma unroll
   for (int ih = 0; ih < 2; ++ih) {
     const int wrow0 = row0 + wm * 128 + ih * 64;
+    if constexpr (LN) {
+      // AdaLN folded into the GEMM: the operand rows were the RAW residual stream and W = bf16(W0 (1 + scale)); the LayerNorm of
+      // row m and the shift enter here:  out = rstd_m (acc - mu_m cs[n]) + cv[n]  (vsys_internal.h GemmParams).
+      float mu[2], rs[2];
 #pragma unroll
-    for (int i2 = 0; i2 < 2; ++i2) {
+      for (int i2 = 0; i2 < 2; ++i2) {
+        int grow = wrow0 + i2 * 32 + l31;
+        grow = grow < p.M ? grow : p.M - 1;
+        ln_combine(p.ln_stats, p.ln_ld, p.ln_nb, grow, p.ln_eps, mu[i2], rs[i2]);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float4 c_s[4], c_v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          c_s[g] = *reinterpret_cast<const float4*>(p.cs + ncol0 + j * 32 + 8 * g + 4 * hi);
+          c_v[g] = *reinterpret_cast<const float4*>(p.cv + ncol0 + j * 32 + 8 * g + 4 * hi);
+        }
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int i = ih * 2 + i2;
+          const int m_local = i2 * 32 + l31;
+          const float nmu = -mu[i2], r_ = rs[i2];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int n_local = j * 32 + 8 * g + 4 * hi;
+            float v[4];
+            v[0] = fmaf(r_, fmaf(nmu, c_s[g].x, acc[i][j][4 * g + 0]), c_v[g].x);
+            v[1] = fmaf(r_, fmaf(nmu, c_s[g].y, acc[i][j][4 * g + 1]), c_v[g].y);
+            v[2] = fmaf(r_, fmaf(nmu, c_s[g].z, acc[i][j][4 * g + 2]), c_v[g].z);
+            v[3] = fmaf(r_, fmaf(nmu, c_s[g].w, acc[i][j][4 * g + 3]), c_v[g].w);
+            if (EPI == EPI_LN_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+            }
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2) = o;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i2 = 0; i2 < (LN ? 0 : 2); ++i2) {
       const int i = ih * 2 + i2;
       const int m_local = i2 * 32 + l31;
       const bf16_t* gate_row = nullptr;
@@ -424,8 +468,12 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
   }
   switch (epi) {
+    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_LN_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;

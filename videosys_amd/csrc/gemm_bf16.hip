@@ -454,8 +454,10 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   // Residual rows for the store phase below are fetched NOW (12 x 16 B per lane, rows clamped instead of branched) so
   // their HBM latency hides under the accumulator -> LDS transposition; a load-wait-store chain per 16 bytes would
   // serialise 12 HBM round trips per wave (CDNA4 vmcnt also counts the stores).
+  constexpr bool GATED = EPI == EPI_GATE_RES || EPI == EPI_GATE_RES_STATS;
+  constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_GELU;
   uint4 rres[12];
-  if (EPI == EPI_GATE_RES) {
+  if (GATED) {
 #pragma unroll
     for (int it = 0; it < 12; ++it) rres[it] = make_uint4(0, 0, 0, 0);
     if (p.res != nullptr) {
@@ -471,23 +473,78 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   }
   char* st = smem + wave * OUT_WAVE_BYTES;
   const int ncol0 = col0 + wn * 96;
+  if constexpr (EPI == EPI_GATE_RES_STATS) {
+    // The residual rows go INTO the wave's image first (coalesced 16-byte units), so that the accumulator pass below sees
+    // x_new = res + gate (acc + bias) in the layout where a lane owns one token row: it rounds x_new as the store phase of the
+    // plain epilogue does, takes the LayerNorm partial of its 48 columns on the way, and the store phase becomes a copy.
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+      const int q = lane + 64 * it;
+      const int m_local = q / 12, c = q - m_local * 12;
+      *reinterpret_cast<uint4*>(st + m_local * OUT_ROW_BYTES + c * 16) = rres[it];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if constexpr (LN) {
+    // AdaLN folded into the GEMM (vsys_internal.h GemmParams): out = rstd_m (acc - mu_m cs[n]) + cv[n]
+    float mu[2], rs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int grow = row0 + wm * 64 + i * 32 + l31;
+      grow = grow < p.M ? grow : p.M - 1;
+      ln_combine(p.ln_stats, p.ln_ld, p.ln_nb, grow, p.ln_eps, mu[i], rs[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      float4 c_s[4], c_v[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        c_s[g] = *reinterpret_cast<const float4*>(p.cs + ncol0 + j * 32 + 8 * g + 4 * hi);
+        c_v[g] = *reinterpret_cast<const float4*>(p.cv + ncol0 + j * 32 + 8 * g + 4 * hi);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m_local = i * 32 + l31;
+        const float nmu = -mu[i], r_ = rs[i];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int n_local = j * 32 + 8 * g + 4 * hi;
+          float v[4];
+          v[0] = fmaf(r_, fmaf(nmu, c_s[g].x, acc[i][j][4 * g + 0]), c_v[g].x);
+          v[1] = fmaf(r_, fmaf(nmu, c_s[g].y, acc[i][j][4 * g + 1]), c_v[g].y);
+          v[2] = fmaf(r_, fmaf(nmu, c_s[g].z, acc[i][j][4 * g + 2]), c_v[g].z);
+          v[3] = fmaf(r_, fmaf(nmu, c_s[g].w, acc[i][j][4 * g + 3]), c_v[g].w);
+          if (EPI == EPI_LN_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2) = o;
+        }
+      }
+    }
+  }
   // bias for this lane's 12 column groups (4 consecutive columns each), loaded back-to-back under one uniform branch
   uint2 bb[3][4];
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) bb[j][g] = make_uint2(0, 0);
-  if (p.bias != nullptr) {
+  if (p.bias != nullptr && !LN) {
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bb[j][g] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * hi);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < (LN ? 0 : 2); ++i) {
     const int m_local = i * 32 + l31;
     uint2 gg[3][4];
-    if (EPI == EPI_GATE_RES) {
+    LnAcc lacc;
+    if (GATED) {
 #pragma unroll
       for (int j = 0; j < 3; ++j)
 #pragma unroll
@@ -517,14 +574,30 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
         }
-        if (EPI == EPI_GATE_RES) {
+        if (GATED) {
           v[0] *= bflo(gg[j][g].x); v[1] *= bfhi(gg[j][g].x); v[2] *= bflo(gg[j][g].y); v[3] *= bfhi(gg[j][g].y);
         }
         uint2 o;
         o.x = pack2bf(v[0], v[1]);
         o.y = pack2bf(v[2], v[3]);
+        if constexpr (EPI == EPI_GATE_RES_STATS) {
+          // + residual (same two roundings as the plain epilogue: bf16(u), then bf16(u + res)), statistics of what is stored
+          const uint2 rr = *reinterpret_cast<const uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2);
+          o.x = pack2bf(bflo(o.x) + bflo(rr.x), bfhi(o.x) + bfhi(rr.x));
+          o.y = pack2bf(bflo(o.y) + bflo(rr.y), bfhi(o.y) + bfhi(rr.y));
+          if (j == 0 && g == 0) lacc.init(bflo(o.x));
+          lacc.add(bflo(o.x)); lacc.add(bfhi(o.x)); lacc.add(bflo(o.y)); lacc.add(bfhi(o.y));
+        }
         *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2) = o;
       }
+    }
+    if constexpr (EPI == EPI_GATE_RES_STATS) {
+      // the other 48 columns of this row's 96-column block live in lane l31 + 32
+      const float2 mine = lacc.finish(48.f);
+      const float2 other = make_float2(__shfl_xor(mine.x, 32, 64), __shfl_xor(mine.y, 32, 64));
+      const float2 blk = ln_merge_equal(mine, other, 48.f);
+      const int grow = row0 + wm * 64 + m_local;
+      if (hi == 0 && grow < p.M) p.stats_out[(int64_t)(ncol0 / LN_BLOCK) * p.stats_ld + grow] = blk;
     }
   }
   __syncthreads();
@@ -654,7 +727,7 @@ int set_gemm_variant(int v) {
 template <int PIPE, int BM_, int RASTER = 1, int PROD = 0>
 static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   using G = Geo<BM_>;
-  if (PROD && epi == EPI_GATE_RES) return launch_gemm_t<PIPE, BM_, RASTER, 0>(p, epi, stream);  // 208 VGPRs: no third wave
+  if (PROD && epi != EPI_BIAS && epi != EPI_BIAS_GELU) return launch_gemm_t<PIPE, BM_, RASTER, 0>(p, epi, stream);  // 208 VGPRs: no third wave
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
   const int grid = nbm * nbn;
   const size_t lds = (PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE;
@@ -663,12 +736,20 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (!PROD) {
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
   }
   constexpr int NTH = G::NT + PROD * 256;
   switch (epi) {
     case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>), dim3(grid), dim3(NTH), lds, stream, p); break;
     case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>), dim3(grid), dim3(NTH), lds, stream, p); break;
     case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_GATE_RES_STATS: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_LN_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -678,7 +759,20 @@ int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.M <= 0) return 0;
   if (p.N % BN != 0 || p.K % BK != 0 || p.N <= 0 || p.K <= 0) return VSYS_ERR_SHAPE;
   if ((p.lda % 8) || (p.ldw % 8) || (p.ldo % 8) || (p.res && (p.ldr % 8)) || (p.aux && (p.ldaux % 8))) return VSYS_ERR_ALIGN;
-  if (epi == EPI_GATE_RES && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;
+  if ((epi == EPI_GATE_RES || epi == EPI_GATE_RES_STATS) && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;
+  const bool ln = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
+  if (ln && (!p.cs || !p.cv || !p.ln_stats || p.ln_nb < 1 || p.ln_nb > 12 || p.ln_nb * LN_BLOCK != p.K || p.ln_ld < p.M)) return VSYS_ERR_SHAPE;
+  if (epi == EPI_GATE_RES_STATS && (!p.stats_out || p.stats_ld < p.M || p.aux)) return VSYS_ERR_ARG;
+  // the statistics-emitting epilogue lives in gemm_kernel only (lab / forced variants of other kernel families fall back to it)
+  if (epi == EPI_GATE_RES_STATS) {
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+    return launch_gemm_t<8, 256>(p, epi, stream);
+  }
+  if (ln) {   // same shape dispatch as the store-only epilogues below
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+    if (p.K <= 1536 && p.N >= 2304 && g_gemm_variant_a.load(std::memory_order_relaxed) != 8) return launch_gemm2(p, epi, 0, stream);
+    return launch_gemm_t<8, 256>(p, epi, stream);
+  }
   // tile-relative operand offsets are 32-bit (buffer addressing)
   if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 384 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
   const int g_gemm_variant = g_gemm_variant_a.load(std::memory_order_relaxed);

@@ -31,6 +31,10 @@ constexpr OpInfo kOps[VSYS_OP_COUNT] = {
     {16, 0},  // PATCH_EMBED_SHARD
     {11, 1},  // FINAL_LAYER_TOKENS
     {13, 0},  // UNPATCHIFY_TOKENS
+    {14, 1},  // GEMM_BF16_LN
+    {17, 0},  // GEMM_BF16_STATS
+    {4, 0},   // ADALN_PRESCALE
+    {5, 0},   // LN_ROW_STATS
 };
 }  // namespace
 
@@ -113,6 +117,15 @@ int vsys_program_run(const vsys_cmd* cmds, int64_t n, void* const* streams, int6
         case VSYS_OP_UNPATCHIFY_TOKENS:
           rc = vsys_unpatchify_tokens(CP(0), P(1), I(2), I(3), I(4), I(5), I(6), I(7), I(8), I(9), I(10), I(11), I(12), st);
           break;
+        case VSYS_OP_GEMM_BF16_LN:
+          rc = vsys_gemm_bf16_ln(CP(0), I(1), CP(2), I(3), CP(4), CP(5), P(6), I(7), I(8), I(9), I(10), N32(11), CP(12), I(13), c.f[0], st);
+          break;
+        case VSYS_OP_GEMM_BF16_STATS:
+          rc = vsys_gemm_bf16_stats(CP(0), I(1), CP(2), I(3), CP(4), P(5), I(6), I(7), I(8), I(9), CP(10), I(11), I(12), CP(13), I(14),
+                                    P(15), I(16), st);
+          break;
+        case VSYS_OP_ADALN_PRESCALE: rc = vsys_adaln_prescale(CP(0), I(1), I(2), CP(3), st); break;
+        case VSYS_OP_LN_ROW_STATS: rc = vsys_ln_row_stats(CP(0), I(1), I(2), P(3), I(4), st); break;
         default: rc = VSYS_ERR_ARG;
       }
 #undef I

@@ -36,7 +36,12 @@ inline int cu_count_this_device() {
 }
 
 enum { EPI_BIAS = VSYS_EPI_BIAS, EPI_BIAS_GELU = VSYS_EPI_BIAS_GELU, EPI_GATE_RES = VSYS_EPI_GATE_RES,
+       // AdaLN folded into the GEMM (vsys_gemm_bf16_ln): W is the pre-scaled weight, the epilogue applies the row statistics
+       EPI_LN_BIAS = 3, EPI_LN_GELU = 4,
+       // EPI_GATE_RES that also emits the LayerNorm partials of the rows it stores (vsys_gemm_bf16_stats); no aux
+       EPI_GATE_RES_STATS = 5,
        EPI_F32_SLICES = 100 /* internal (gemm2_bf16.hip): fp32 K-slice partials, see launch_gemm2_slices */ };
+constexpr int LN_BLOCK = 96;   // columns per LayerNorm partial (= the column width of a GEMM wave tile)
 enum { ACT_NONE = VSYS_ACT_NONE, ACT_SILU = VSYS_ACT_SILU, ACT_GELU_TANH = VSYS_ACT_GELU_TANH };
 
 struct GemmParams {
@@ -55,6 +60,13 @@ struct GemmParams {
   // EPI_F32_SLICES only (launch_gemm2_slices): K slice length, fp32 output [slices][N][M] (element (m, n) of slice s at
   // out32[s * slab + n * ldo32 + m]: "A" is the weight here, so this is activation-row-major)
   int ks; float* out32; int64_t slab, ldo32;
+  // AdaLN fold.  Row statistics travel as per-96-column partials (mean_b, M2_b) at stats[b * ld + row], b = column / 96:
+  //   EPI_GATE_RES_STATS writes them for x_new = res + gate (acc + bias) (what it stores to out);
+  //   EPI_LN_BIAS / EPI_LN_GELU combine the ln_nb partials of a row into (mu, rstd) and compute
+  //   out = rstd (acc - mu cs[n]) + cv[n]  with W = bf16(W0 (1 + scale)), cs[n] = sum_k W[n][k], cv[n] = shift . W0[n] + bias[n].
+  const float* cs = nullptr; const float* cv = nullptr;
+  const float2* ln_stats = nullptr; int64_t ln_ld = 0; int ln_nb = 0; float ln_eps = 0.f;
+  float2* stats_out = nullptr; int64_t stats_ld = 0;
 };
 
 // implicit-GEMM convolution / 128-column GEMM (conv_bf16.hip).  A points at the row that tap (0,0,0) reads for output row 0.
@@ -127,6 +139,9 @@ int launch_linear_small(const bf16_t* x, int64_t ldx, const bf16_t* w, int64_t l
                         int64_t ldo, int M, int N, int K, int act_in, int act_out, hipStream_t stream);
 int launch_adaln_modulate(const bf16_t* x, const bf16_t* shift, const bf16_t* scale, bf16_t* y, int64_t rows, int C,
                           int64_t rows_per_sample, int64_t mod_stride, float eps, hipStream_t stream);
+// AdaLN fold (adaln_fold.hip): pre-scaled weights + column sums of every site of a step; row statistics of a tensor
+int launch_adaln_prescale(const int64_t* sites, int nsites, int64_t nblocks, const bf16_t* mod, hipStream_t stream);
+int launch_ln_row_stats(const bf16_t* x, int64_t rows, int C, float2* stats, int64_t ld, hipStream_t stream);
 int launch_mod_table(const bf16_t* table, const bf16_t* t_mlp, bf16_t* out, int nblk, int B, int C6, hipStream_t stream);
 int launch_timestep_embedding(const float* t, bf16_t* out, int B, int dim, hipStream_t stream);
 int launch_patch_embed(const float* x, int Bz, const bf16_t* w, const bf16_t* bias, const bf16_t* pos, bf16_t* out, int B,

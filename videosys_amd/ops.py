@@ -72,6 +72,65 @@ def gemm(x, w, bias=None, *, epilogue=EPI_BIAS, gate=None, gate_stride=0, rows_p
     return out
 
 
+LN_BLOCK = 96   # columns per LayerNorm partial of the AdaLN fold (include/videosys_amd.h, vsys_gemm_bf16_ln)
+
+
+def ln_stats_buffer(rows, C, device):
+    """fp32 [C / 96, rows, 2]: (mean, M2) of every 96-column block of every row (the statistics format of the AdaLN fold)."""
+    assert C % LN_BLOCK == 0
+    return torch.empty(C // LN_BLOCK, rows, 2, dtype=torch.float32, device=device)
+
+
+def gemm_ln(x, wp, cs, cv, stats, *, gelu=False, eps=1e-6, out=None):
+    """out = [gelu](Linear(t2i_modulate(LayerNorm(x), shift, scale))) with the modulation folded into wp / cs / cv
+    (adaln_prescale) and the LayerNorm statistics of x's rows taken from ``stats`` (gemm_stats / ln_row_stats)."""
+    _chk(x, wp, cs, cv, stats, out)
+    _bf16(x, wp, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and wp.stride(1) == 1 and cs.dtype == torch.float32 and cv.dtype == torch.float32
+    M, K = x.shape
+    N = wp.shape[0]
+    assert wp.shape[1] == K and stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[0] == K // LN_BLOCK
+    assert stats.shape[1] >= M and stats.shape[2] == 2
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _call("vsys_gemm_bf16_ln", _p(x), x.stride(0), _p(wp), wp.stride(0), _p(cs), _p(cv), _p(out), out.stride(0), M, N, K,
+          EPI_BIAS_GELU if gelu else EPI_BIAS, _p(stats), stats.shape[1], float(eps))
+    return out
+
+
+def gemm_stats(x, w, bias, stats, *, gate=None, gate_stride=0, rows_per_sample=0, res=None, out=None):
+    """gemm(..., epilogue=EPI_GATE_RES) that also writes the LayerNorm partials of the rows it stores into ``stats``."""
+    _chk(x, w, bias, gate, res, out, stats)
+    _bf16(x, w, bias, gate, res, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[0] == N // LN_BLOCK and stats.shape[1] >= M
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _call("vsys_gemm_bf16_stats", _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(gate),
+          gate_stride, rows_per_sample, _p(res), res.stride(0) if res is not None else 0, _p(stats), stats.shape[1])
+    return out
+
+
+def adaln_prescale(sites, nblocks, mod):
+    """sites: int64 device tensor [nsites, 10] (include/videosys_amd.h, vsys_adaln_prescale); mod: the step's modulation table."""
+    _chk(sites, mod)
+    _bf16(mod)
+    assert sites.dtype == torch.int64 and sites.is_contiguous() and sites.shape[1] == 10 and mod.is_contiguous()
+    _call("vsys_adaln_prescale", _p(sites), sites.shape[0], nblocks, _p(mod))
+
+
+def ln_row_stats(x, stats):
+    _chk(x, stats)
+    _bf16(x)
+    assert x.is_contiguous() and x.dim() == 2 and stats.dtype == torch.float32 and stats.is_contiguous()
+    rows, C = x.shape
+    assert stats.shape[0] == C // LN_BLOCK and stats.shape[1] >= rows
+    _call("vsys_ln_row_stats", _p(x), rows, C, _p(stats), stats.shape[1])
+    return stats
+
+
 def linear_small(x, w, bias=None, act_in=ACT_NONE, act_out=ACT_NONE, out=None):
     _chk(x, w, bias, out)
     _bf16(x, w, bias, out)

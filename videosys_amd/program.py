@@ -42,6 +42,7 @@ OPCODES = {
     "vsys_attn_prep_kv": 11, "vsys_flash_attn_d72": 12, "vsys_attn_temporal_d72": 13, "vsys_add_bcast_rows": 14,
     "vsys_gemm_bf16_gate2": 15, "vsys_ln_modulate": 16, "vsys_gate_add_rows": 17, "vsys_attn_prep_kv64": 18,
     "vsys_flash_attn_d64": 19, "vsys_patch_embed_shard": 20, "vsys_final_layer_tokens": 21, "vsys_unpatchify_tokens": 22,
+    "vsys_gemm_bf16_ln": 23, "vsys_gemm_bf16_stats": 24, "vsys_adaln_prescale": 25, "vsys_ln_row_stats": 26,
 }
 
 _tls = threading.local()

@@ -149,6 +149,11 @@ class STDiT3:
         # through vsys_program_run afterwards; VSYS_PROGRAMS=0 issues every launch from Python every step
         self.pab_elide_unused = os.environ.get("VSYS_PAB_ELIDE", "1") != "0"   # see _pab_plan: slabs nobody will read are not written
         self.use_programs = os.environ.get("VSYS_PROGRAMS", "1") != "0"
+        # AdaLN folded into the qkv / fc1 GEMMs (csrc/adaln_fold.hip): pre-scaled weights per step, row statistics from the
+        # producing epilogue; VSYS_ADALN_FOLD=0 keeps the separate LayerNorm-modulate pass everywhere
+        self.adaln_fold = os.environ.get("VSYS_ADALN_FOLD", "1") != "0"
+        self._fold = None          # per-B site table + the W' / cs / cv buffers (built on first use)
+        self._stats_fresh = False  # "the statistics buffer describes the current x" (within one step)
         self._programs = {}
         self.program_stats = dict(recorded=0, replayed=0, eager=0)
         # attribute paths the reference's callers read (scheduling_rflow_open_sora.py:221, pipeline_open_sora.py:295)
@@ -181,6 +186,7 @@ class STDiT3:
         self._text_cache = None
         self._rope_cache = {}
         self._programs = {}
+        self._fold = None
         return self
 
     def expected_keys(self):
@@ -354,6 +360,45 @@ class STDiT3:
                                 y_lens=y_lens, kp=kps, vt=vts, Lk=Lk, lens_key=lens_key)
         return self._text_cache
 
+    # ------------------------------------------------------------------ AdaLN fold
+    def _fold_ok(self, ts_host, fkey, x_mask):
+        """The fold needs ONE modulation per site: no sequence parallelism around the GEMMs it touches, no per-frame conditioning
+        mask, and every sample of the batch at the same timestep / fps (the CFG pair of a sampling step is)."""
+        C = self.hidden_size
+        return (self.adaln_fold and self._sp is None and x_mask is None and C % ops.LN_BLOCK == 0 and C // ops.LN_BLOCK <= 12
+                and bool((ts_host == ts_host[0]).all()) and len(set(fkey[:-1])) == 1)
+
+    def _fold_tables(self, B):
+        """Site table of vsys_adaln_prescale for a modulation table laid out [2*depth, B, 6C] (sample-0 rows) and the per-site
+        W' / cs / cv buffers (allocated once: 2 x the qkv + fc1 weight bytes)."""
+        f = self._fold
+        if f is not None and f["B"] == B:
+            return f
+        w, C, dev = self.w, self.hidden_size, self.device
+        bufs = f["bufs"] if f is not None else {}
+        rows, blk = [], 0
+        for i in range(2 * self.depth):
+            p = self.block_prefix(i)
+            for name, s_sh, s_sc in ((p + ".attn.qkv", 0, C), (p + ".mlp.fc1", 3 * C, 4 * C)):
+                W, b = w[name + ".weight"], w[name + ".bias"]
+                N, K = W.shape
+                if name not in bufs:
+                    bufs[name] = (torch.empty_like(W), torch.empty(N, dtype=torch.float32, device=dev),
+                                  torch.empty(N, dtype=torch.float32, device=dev))
+                Wp, cs, cv = bufs[name]
+                base = i * B * 6 * C
+                rows.append([W.data_ptr(), b.data_ptr(), Wp.data_ptr(), cs.data_ptr(), cv.data_ptr(), base + s_sh, base + s_sc,
+                             N, K, blk])
+                blk += -(-N // 4)
+        self._fold = dict(B=B, bufs=bufs, sites=torch.tensor(rows, dtype=torch.int64).to(dev), nblocks=blk)
+        return self._fold
+
+    def _ln_stats(self, N):
+        key = ("ln_stats", N)
+        if key not in self._ws:
+            self._ws[key] = ops.ln_stats_buffer(N, self.hidden_size, self.device)
+        return self._ws[key]
+
     def reset_text_cache(self):
         """Forget the per-prompt text projections (and their references to the prompt tensors) and the recorded steps."""
         self._text_cache = None
@@ -400,16 +445,17 @@ class STDiT3:
             self._fps_cache[fkey] = self._embed_vec(f, "fps_embedder")
         self._rope(T)
         static = (txt, pos, self._fps_cache[fkey])
+        fold = self._fold_ok(ts_host, fkey, x_mask)
 
         mlp_action = plan is not None and any(d[2] or d[3] for d in plan)   # stores / replays host-side dict entries: eager
         # (a conditioning mask changes from step to step and selects rows with torch ops: the step is issued eagerly)
         if not (self.use_programs and self._hidden_tap is None and not mlp_action and x_mask is None):
             self.program_stats["eager"] += 1
             xz = x.to(device=dev, dtype=torch.float32).contiguous()
-            out = self._forward_device(xz, ts_host.to(dev), static, plan, timestep_int, valid_depth, cp, x_mask)
+            out = self._forward_device(xz, ts_host.to(dev), static, plan, timestep_int, valid_depth, cp, x_mask, fold=fold)
         else:
             sp = self._sp
-            key = (B, Tx, Hx, Wx, float(height[0]), float(width[0]), fkey, valid_depth, cp,
+            key = (B, Tx, Hx, Wx, float(height[0]), float(width[0]), fkey, valid_depth, cp, fold,
                    None if plan is None else tuple(d[:2] + d[5:7] for d in plan),
                    None if sp is None else (sp.P, sp.rank, self._scatter, self._switch, self._overlap))
             ent = self._programs.get(key)
@@ -426,7 +472,7 @@ class STDiT3:
                 xin.copy_(x)
                 tin.copy_(ts_host)
                 with program.Recorder() as rec:
-                    out = self._forward_device(xin, tin, static, plan, timestep_int, valid_depth, cp)
+                    out = self._forward_device(xin, tin, static, plan, timestep_int, valid_depth, cp, fold=fold)
                 prog = rec.finish()
                 if prog is not None:
                     self._programs[key] = (prog, xin, tin, out)
@@ -478,7 +524,7 @@ class STDiT3:
                          kept(kind, st.attn_count), kept("cross", st.cross_count)))
         return plan
 
-    def _forward_device(self, xz, ts, static, plan, timestep_int, valid_depth, cp, x_mask=None):
+    def _forward_device(self, xz, ts, static, plan, timestep_int, valid_depth, cp, x_mask=None, fold=False):
         """Everything of a step that runs on the device, from resident inputs: xz fp32 [B, C_in, T, H, W], ts fp32 [B];
         x_mask bool [B, T] on the device or None."""
         w, C = self.w, self.hidden_size
@@ -504,6 +550,11 @@ class STDiT3:
             t0_mlp = ops.linear_small(t0, w["t_block.1.weight"], w["t_block.1.bias"], act_in=ops.ACT_SILU)
             t_mlp = torch.where(x_mask[:, :, None], t_mlp[:, None, :], t0_mlp[:, None, :]).reshape(B * T, -1).contiguous()
         mod = ops.mod_table(w["_all_tables"], t_mlp)  # [2*depth, B, 6C]  (x_mask: [2*depth, B*T, 6C])
+        ftab = None
+        if fold:   # W' = bf16(W (1 + scale)), cs, cv of all 2 x 2 x depth sites of this step: one launch
+            ftab = self._fold_tables(B)
+            ops.adaln_prescale(ftab["sites"], ftab["nblocks"], mod)
+        self._stats_fresh = False
 
         # ---- x embed (+ pos).  Sequence parallel: split_sequence(x, dim=2) (:598-603) keeps tokens rank*Sl .. of every frame, so
         # only those are embedded (the reference embeds the whole frame on every rank and slices)
@@ -520,7 +571,7 @@ class STDiT3:
         for d in range(valid_depth):
             for i in (2 * d, 2 * d + 1):
                 xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, None if plan is None else plan[i], timestep_int,
-                                   rps=S if x_mask is not None else T * S)
+                                   rps=S if x_mask is not None else T * S, ftab=ftab)
             if self._hidden_tap is not None:
                 self._hidden_tap(d, xcur)
 
@@ -554,7 +605,7 @@ class STDiT3:
 
     __call__ = forward
 
-    def _block(self, i, x, mod_i, txt, B, T, S, S_full, decisions, timestep_int, rps=None):
+    def _block(self, i, x, mod_i, txt, B, T, S, S_full, decisions, timestep_int, rps=None, ftab=None):
         """STDiT3Block.forward (open_sora_transformer_3d.py:162-286). x: [B*T*S, C] (S = local shard), updated in place.
         ``decisions`` = this block's entry of _pab_plan (None: PAB off).  ``rps``: rows that share one modulation row of ``mod_i``
         — a sample's T*S rows, or one frame's S rows when a conditioning mask picks the modulation per frame."""
@@ -576,23 +627,41 @@ class STDiT3:
         broadcast_attn, broadcast_cross, broadcast_mlp, broadcast_next, skip_range, keep_attn, keep_cross = \
             decisions or (False, False, False, False, None, False, False)
         sp = self._sp
+        # AdaLN fold (ftab: this step's pre-scaled weights): the qkv / fc1 GEMMs read x itself and apply LayerNorm + modulation
+        # in their epilogues; the row statistics come from the epilogue that last wrote x (gemm_stats) or, when x was last
+        # written by something else (patch embedding, proj, a PAB broadcast), from one ln_row_stats pass.
+        fold = ftab is not None
+        stats = self._ln_stats(N) if fold else None
+
+        def folded(site, gelu, out):
+            if not self._stats_fresh:
+                ops.ln_row_stats(x, stats)
+                self._stats_fresh = True
+            Wp, cs, cv = ftab["bufs"][site]
+            return ops.gemm_ln(x, Wp, cs, cv, stats, gelu=gelu, out=out)
 
         # ---------------- self attention
         if broadcast_attn:
             ops.add_rows(x, st.last_attn)
+            self._stats_fresh = False
         else:
-            xm = ops.adaln_modulate(x, shift_msa, scale_msa, rps, C6, out=_buf("xm", (N, C)))
+            if fold:
+                qkv = folded(p + ".attn.qkv", False, _buf("qkv", (N, 3 * C)))
+            else:
+                xm = ops.adaln_modulate(x, shift_msa, scale_msa, rps, C6, out=_buf("xm", (N, C)))
             aux = None
             if use_pab and keep_attn:
                 st.last_attn = slab(st.last_attn)
                 aux = st.last_attn
             if temporal:
-                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
+                if not fold:
+                    qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
                 ao = _buf("attn_out", (N, C))
                 cos, sin = self._rope(T)
                 ops.attn_temporal(qkv, C, w[p + ".attn.q_norm.weight"], w[p + ".attn.k_norm.weight"], cos, sin, ao, B, T, S, H)
             elif sp is None:
-                qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
+                if not fold:
+                    qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
                 kp, vt = self._kv_spatial(B * T, S)
                 ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * T, H, S)
                 ao = _buf("attn_out", (N, C))
@@ -601,10 +670,12 @@ class STDiT3:
                 ao = self._spatial_attn_sharded(p, xm, B, T, S, S_full)
             ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
                      gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
+            self._stats_fresh = False
 
         # ---------------- cross attention (no norm, no modulation, no gate)
         if broadcast_cross:
             ops.add_rows(x, st.last_cross)
+            self._stats_fresh = False
         else:
             q = ops.gemm(x, w[p + ".cross_attn.q_linear.weight"], w[p + ".cross_attn.q_linear.bias"], out=_buf("xm", (N, C)))
             ao = _buf("attn_out", (N, C))
@@ -613,8 +684,13 @@ class STDiT3:
             if use_pab and keep_cross:
                 st.last_cross = slab(st.last_cross)
                 aux = st.last_cross
-            ops.gemm(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], epilogue=ops.EPI_GATE_RES,
-                     res=x, aux=aux, out=x)
+            if fold and aux is None and not broadcast_mlp:   # the MLP's norm2 reads this x next: emit its statistics here
+                ops.gemm_stats(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], stats, res=x, out=x)
+                self._stats_fresh = True
+            else:
+                ops.gemm(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], epilogue=ops.EPI_GATE_RES,
+                         res=x, aux=aux, out=x)
+                self._stats_fresh = False
 
         # ---------------- MLP (+ PAB MLP broadcast, open_sora_transformer_3d.py:232-280 / pab_mgr.py:93-174: inside a configured
         # window the block replays gate_mlp * mlp(...) of the window's first timestep).  ``all_timesteps`` reaches the blocks
@@ -622,16 +698,26 @@ class STDiT3:
         if broadcast_mlp:
             slab = pab.get_mlp_output(skip_range, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal)
             ops.add_rows(x, slab)
+            self._stats_fresh = False
             if timestep_int == skip_range[-1]:   # the window closed (the store dropped the entry): the slab is free again,
                 self._ws.setdefault("mlp_slab_pool", []).append(slab)   # in stream order behind the add above
             return x
-        xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, rps, C6, out=_buf("xm", (N, C)))
         hdim = w[p + ".mlp.fc1.weight"].shape[0]
-        hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
-                        out=_buf("mlp_h", (N, hdim)))
+        if fold:
+            hbuf = folded(p + ".mlp.fc1", True, _buf("mlp_h", (N, hdim)))
+        else:
+            xm = ops.adaln_modulate(x, shift_mlp, scale_mlp, rps, C6, out=_buf("xm", (N, C)))
+            hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
+                            out=_buf("mlp_h", (N, hdim)))
         aux = self._mlp_slab(x) if broadcast_next else None   # the post-gate output, written by the fc2 epilogue
-        ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
-                 gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
+        if fold and aux is None:   # the next block's norm1 reads this x: emit its statistics here
+            ops.gemm_stats(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], stats, gate=gate_mlp, gate_stride=C6,
+                           rows_per_sample=rps, res=x, out=x)
+            self._stats_fresh = True
+        else:
+            ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
+                     gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
+            self._stats_fresh = False
         if broadcast_next:
             pab.save_mlp_output(timestep=timestep_int, block_idx=st.block_idx, ff_output=aux, is_temporal=temporal)
         return x
