@@ -52,7 +52,7 @@ int vsys_device_count(void);
  * leaves the selection unchanged.  (Ablation / cycle-stamp variants whose output is NOT valid, and the measured-but-not-shipped
  * ping-pong / persistent / stream-K GEMMs 60 / 70 / 80, exist only in -DVSYS_LAB builds together with
  * include/videosys_amd_lab.h; the shipped library contains no such code, and no launch path of it allocates or synchronises.)
- * gemm:  0 = shape dispatch (default); 8 = schedule 8 for every shape (three A slots + two W slots, counted waits); 3 / 6 =
+ * gemm:  2GGPP = tile raster only (see vsys_gemm_raster_probe); 0 = shape dispatch (default); 8 = schedule 8 for every shape (three A slots + two W slots, counted waits); 3 / 6 =
  *        two-stage LDS-DMA schedules; 9 = schedule 8, plain row-major tile order; 20 = 4-wave workgroups, two per CU; 28 =
  *        schedule 8 + producer waves; 30 = 256 x 384 tile; 103 = 128-row tiles.
  * flash: 0 = default (two workgroups per CU; resident K/V for few keys; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
@@ -62,6 +62,11 @@ int vsys_device_count(void);
  * No reference counterpart (measurement tooling). */
 int vsys_tune_gemm_variant(int variant);
 int vsys_tune_flash_variant(int variant);
+/* Host-only: where the GEMM kernels' tile raster (column groups of gw tiles inside panel chunks of ph panels inside the 8 per-XCD
+ * panel groups; vsys_tune_gemm_variant(20000 + 100 gw + ph) selects it for measurements, 20600 = the default) sends logical tile
+ * ``tile`` of an nbm x nbn grid: *bm, *bn.  Lets a CPU test check that every raster is a bijection.  No reference counterpart
+ * (measurement tooling). */
+int vsys_gemm_raster_probe(int64_t tile, int64_t nbm, int64_t nbn, int64_t gw, int64_t ph, int64_t* bm, int64_t* bn);
 
 /* nn.Linear on token rows with fused epilogue (bf16 in/out, fp32 MFMA accumulate).
  * Replaces: attentions.py:59 (qkv), :107 (proj) + open_sora_transformer_3d.py:219,228 (gate, residual);

@@ -19,6 +19,7 @@ SIGNATURES = {
     "vsys_device_count": [],
     "vsys_tune_gemm_variant": [_int],
     "vsys_tune_flash_variant": [_int],
+    "vsys_gemm_raster_probe": [_i64, _i64, _i64, _i64, _i64, _ptr, _ptr],
     "vsys_gemm_bf16": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _i64, _ptr, _i64,
                        _ptr, _i64, _ptr],
     "vsys_gemm_bf16_ln": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _f32, _ptr],

@@ -1,4 +1,5 @@
 // extern "C" entry points declared in include/videosys_amd.h: argument validation + launch, nothing else.
+#include "common.h"
 #include "vsys_internal.h"
 
 using namespace vsys;
@@ -34,6 +35,15 @@ int vsys_device_count(void) {
 int vsys_tune_gemm_variant(int variant) { return set_gemm_variant(variant); }
 
 int vsys_tune_flash_variant(int variant) { return set_flash_variant(variant); }
+
+int vsys_gemm_raster_probe(int64_t tile, int64_t nbm, int64_t nbn, int64_t gw, int64_t ph, int64_t* bm, int64_t* bn) {
+  if (!bm || !bn || tile < 0 || nbm <= 0 || nbn <= 0 || tile >= nbm * nbn || !fits_int(nbm * nbn)) return VSYS_ERR_ARG;
+  int m = 0, n = 0;
+  gemm_raster((int)tile, (int)nbm, (int)nbn, (int)gw, (int)ph, m, n);
+  *bm = m;
+  *bn = n;
+  return 0;
+}
 
 #ifdef VSYS_LAB   // include/videosys_amd_lab.h
 int vsys_gemm_streamk_plan(int ntiles, int nt, int grid, int32_t* segs, int cap_rows, int* nseg_max) {

@@ -99,4 +99,45 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
   return base + idx;
 }
 
+// Tile raster of the GEMM kernels (gemm_bf16.hip, gemm2_bf16.hip).  The row panels are split into 8 contiguous groups, one per
+// XCD chunk of xcd_remap; inside a group the order is  for panel-chunk (ph panels; 0 = all of the group's):  for column group
+// (gw column tiles):  for panel:  for column.  The tiles an XCD runs at once are then a compact (panels x gw) rectangle whose W
+// slab stays in the XCD's 4 MiB L2 while its panels sweep by.  gw >= nbn or gw <= 0: plain row-major.
+__host__ __device__ __forceinline__ void gemm_raster(int tile, int nbm, int nbn, int gw, int ph, int& bm, int& bn) {
+  if (gw <= 0 || gw >= nbn) {
+    bm = tile / nbn;
+    bn = tile - bm * nbn;
+    return;
+  }
+  const int q = nbm / 8, r = nbm - q * 8;
+  const int big = r * (q + 1) * nbn;
+  int off, np, p0;
+  if (tile < big) {
+    const int xg = tile / ((q + 1) * nbn);
+    off = tile - xg * (q + 1) * nbn; np = q + 1; p0 = xg * (q + 1);
+  } else {
+    const int t2 = tile - big;
+    const int xg = t2 / (q * nbn);
+    off = t2 - xg * q * nbn; np = q; p0 = r * (q + 1) + xg * q;
+  }
+  int pc0 = 0, npc = np;   // panel chunk: panels [pc0, pc0 + npc) of the group
+  if (ph > 0 && ph < np) {
+    const int per = ph * nbn;
+    int c = off / per;
+    const int nch = (np + ph - 1) / ph;
+    c = c < nch - 1 ? c : nch - 1;
+    pc0 = c * ph;
+    npc = c < nch - 1 ? ph : np - pc0;
+    off -= c * per;
+  }
+  const int ng = (nbn + gw - 1) / gw;
+  int g = off / (npc * gw);
+  g = g < ng - 1 ? g : ng - 1;
+  const int off2 = off - g * npc * gw;
+  const int width = g < ng - 1 ? gw : nbn - (ng - 1) * gw;
+  const int pm = off2 / width;
+  bm = p0 + pc0 + pm;
+  bn = g * gw + (off2 - pm * width);
+}
+
 }  // namespace vsys

@@ -69,32 +69,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     tile -= kslice * ntile;
   }
   int bm, bn;
-  if (nbn > 6) {
-    const int nbm = (p.M + BM - 1) / BM;
-    const int q = nbm / 8, r = nbm - q * 8;
-    const int big = r * (q + 1) * nbn;
-    int off, np, p0;
-    if (tile < big) {
-      const int xg = tile / ((q + 1) * nbn);
-      off = tile - xg * (q + 1) * nbn; np = q + 1; p0 = xg * (q + 1);
-    } else {
-      const int t2 = tile - big;
-      const int xg = t2 / (q * nbn);
-      off = t2 - xg * q * nbn; np = q; p0 = r * (q + 1) + xg * q;
-    }
-    constexpr int GW = 6;
-    const int ng = (nbn + GW - 1) / GW;
-    int g = off / (np * GW);
-    g = g < ng - 1 ? g : ng - 1;
-    const int off2 = off - g * np * GW;
-    const int width = g < ng - 1 ? GW : nbn - (ng - 1) * GW;
-    const int pm = off2 / width;
-    bm = p0 + pm;
-    bn = g * GW + (off2 - pm * width);
-  } else {
-    bm = tile / nbn;
-    bn = tile - bm * nbn;
-  }
+  gemm_raster(tile, (p.M + BM - 1) / BM, nbn, p.raster_gw, p.raster_ph, bm, bn);
   const int row0 = bm * BM, col0 = bn * BN;
 
   // ---- LDS-DMA assignment: a piece = 1 KiB = 16 rows x 64 B; lane l -> row (l>>2), physical chunk l&3, which holds

@@ -79,32 +79,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   // operand with the two-tile lead, is re-read once per column group from L2 / MALL.  With plain row-major order every
   // wave of tiles re-reads all of W (8-10.6 MB > L2) from the fabric: 586 MB fetched for 98 MB of operands at qkv shape.
   int bm, bn;
-  if (RASTER && nbn > 6) {
-    const int nbm = (p.M + BM_ - 1) / BM_;
-    const int q = nbm / 8, r = nbm - q * 8;
-    const int big = r * (q + 1) * nbn;
-    int off, np, p0;
-    if (tile < big) {
-      const int xg = tile / ((q + 1) * nbn);
-      off = tile - xg * (q + 1) * nbn; np = q + 1; p0 = xg * (q + 1);
-    } else {
-      const int t2 = tile - big;
-      const int xg = t2 / (q * nbn);
-      off = t2 - xg * q * nbn; np = q; p0 = r * (q + 1) + xg * q;
-    }
-    constexpr int GW = 6;
-    const int ng = (nbn + GW - 1) / GW;
-    int g = off / (np * GW);
-    g = g < ng - 1 ? g : ng - 1;
-    const int off2 = off - g * np * GW;
-    const int width = g < ng - 1 ? GW : nbn - (ng - 1) * GW;
-    const int pm = off2 / width;
-    bm = p0 + pm;
-    bn = g * GW + (off2 - pm * width);
-  } else {
-    bm = tile / nbn;
-    bn = tile - bm * nbn;
-  }
+  gemm_raster(tile, (p.M + BM_ - 1) / BM_, nbn, RASTER ? p.raster_gw : 0, p.raster_ph, bm, bn);
   const int row0 = bm * BM_, col0 = bn * BN;
 
   // ---- LDS-DMA staging assignment.  global_load_lds writes lane l of a wave to  M0_base + 16*l  (lane-linear), so each
@@ -709,9 +684,16 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const bf16_t* __restr
 // geometry).  0 = the shipped default.
 // (process-wide A/B selector of the measurement tools and the schedule-equivalence tests; read once per launch)
 static std::atomic<int> g_gemm_variant_a{0};
+// tile raster of the measurement tools: ids 2GGPP of vsys_tune_gemm_variant set column-group width GG and panel-chunk height PP
+// for every later launch (20600 = the default); any raster computes the same tiles, so the bits do not depend on it
+static std::atomic<int> g_gemm_raster_a{600};
 // 0 = shape dispatch (default).  The shipped library only accepts ids whose kernels produce VALID output (they differ in
 // schedule / geometry only and are bit-identical); ablation and stamp variants exist in -DVSYS_LAB builds (VSYS_LAB=1 build()).
 int set_gemm_variant(int v) {
+  if (v >= 20000 && v < 30000) {
+    g_gemm_raster_a.store(v - 20000, std::memory_order_relaxed);
+    return 0;
+  }
   switch (v) {
     case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 103: break;
 #ifdef VSYS_LAB
@@ -755,8 +737,14 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
-int launch_gemm(const GemmParams& p, int epi, hipStream_t stream) {
-  if (p.M <= 0) return 0;
+int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
+  if (p_.M <= 0) return 0;
+  GemmParams p = p_;
+  {
+    const int ras = g_gemm_raster_a.load(std::memory_order_relaxed);
+    p.raster_gw = ras / 100;
+    p.raster_ph = ras % 100;
+  }
   if (p.N % BN != 0 || p.K % BK != 0 || p.N <= 0 || p.K <= 0) return VSYS_ERR_SHAPE;
   if ((p.lda % 8) || (p.ldw % 8) || (p.ldo % 8) || (p.res && (p.ldr % 8)) || (p.aux && (p.ldaux % 8))) return VSYS_ERR_ALIGN;
   if ((epi == EPI_GATE_RES || epi == EPI_GATE_RES_STATS) && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;

@@ -67,6 +67,8 @@ struct GemmParams {
   const float* cs = nullptr; const float* cv = nullptr;
   const float2* ln_stats = nullptr; int64_t ln_ld = 0; int ln_nb = 0; float ln_eps = 0.f;
   float2* stats_out = nullptr; int64_t stats_ld = 0;
+  // tile raster (common.h gemm_raster), filled in by launch_gemm: column-group width / panel-chunk height; 6 / 0 = the default
+  int raster_gw = 6, raster_ph = 0;
 };
 
 // implicit-GEMM convolution / 128-column GEMM (conv_bf16.hip).  A points at the row that tap (0,0,0) reads for output row 0.
