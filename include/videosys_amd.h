@@ -105,8 +105,8 @@ int vsys_gemm_bf16_stats(const void* x, int64_t ldx, const void* w, int64_t ldw,
 int vsys_adaln_prescale(const void* sites, int64_t nsites, int64_t nblocks, const void* mod, void* stream);
 
 /* LayerNorm partials (format of vsys_gemm_bf16_ln) of a [rows, C] bf16 tensor no GEMM epilogue produced: the patch embedding
- * in front of block 0 and the x += cached-output steps of PAB (open_sora_transformer_3d.py:116-117,192-193).  C % 96 == 0,
- * C <= 1536. */
+ * in front of block 0 and the x += cached-output steps of PAB (open_sora_transformer_3d.py:116-117,192-193).  Same accumulation
+ * order as the epilogue of vsys_gemm_bf16_stats: the same rows give the same partial bits from either.  C % 96 == 0, C <= 1536. */
 int vsys_ln_row_stats(const void* x, int64_t rows, int64_t C, void* stats, int64_t stats_ld, void* stream);
 
 /* Small / odd-shaped nn.Linear (any M, N; K % 8 == 0): act_in is applied to x (SiLU of t_block,

@@ -1459,3 +1459,29 @@ def test_mask_strategy_helpers_equal_the_reference_on_generated_cases():
     ra, ma = ns["append_generated"](Vae(), vid, [[], [torch.zeros(4, 1, 2, 2)]], [None, "0"], 1, 5, 0.0)
     rb, mb = K.append_generated(Vae().encode, vid, [[], [torch.zeros(4, 1, 2, 2)]], [None, "0"], 1, 5, 0.0)
     assert ma == mb and len(ra) == len(rb) and all(len(x) == len(y) and all(torch.equal(p, q) for p, q in zip(x, y)) for x, y in zip(ra, rb))
+
+
+def test_gemm_tile_raster_is_a_bijection_for_every_setting():
+    """csrc/common.h gemm_raster (through the host probe vsys_gemm_raster_probe): whatever column-group width / panel-chunk height
+    the measurement tools select, every tile of the grid is visited exactly once — so the raster can never change a result."""
+    import ctypes
+
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    bm, bn = ctypes.c_int64(), ctypes.c_int64()
+    for nbm, nbn in ((152, 18), (152, 24), (152, 6), (19, 18), (7, 24), (1, 9), (3, 3), (37, 12)):
+        for gw, ph in ((6, 0), (12, 0), (4, 0), (3, 0), (6, 6), (8, 4), (9, 2), (6, 1), (0, 0), (24, 3), (5, 7)):
+            seen = set()
+            for t in range(nbm * nbn):
+                assert lib.vsys_gemm_raster_probe(t, nbm, nbn, gw, ph, ctypes.byref(bm), ctypes.byref(bn)) == 0
+                assert 0 <= bm.value < nbm and 0 <= bn.value < nbn
+                seen.add((bm.value, bn.value))
+            assert len(seen) == nbm * nbn, (nbm, nbn, gw, ph)
+    assert lib.vsys_gemm_raster_probe(152 * 18, 152, 18, 6, 0, ctypes.byref(bm), ctypes.byref(bn)) != 0
+    # the default raster keeps the 32 tiles an XCD runs first inside 6 column tiles (one W slab)
+    cols = set()
+    for t in range(32):
+        lib.vsys_gemm_raster_probe(t, 152, 18, 6, 0, ctypes.byref(bm), ctypes.byref(bn))
+        cols.add(bn.value)
+    assert cols == set(range(6))

@@ -20,8 +20,18 @@ class FakeOps:
     shape / dtype the real kernel produces.  ``calls`` counts launches by name."""
 
     def __init__(self):
+        import threading
+
         self.calls = {}
-        self.stats_valid = False
+        self._tl = threading.local()   # "the statistics buffer describes the current x", per thread (= per in-process rank)
+
+    @property
+    def stats_valid(self):
+        return getattr(self._tl, "v", False)
+
+    @stats_valid.setter
+    def stats_valid(self, v):
+        self._tl.v = v
 
     def _n(self, name):
         self.calls[name] = self.calls.get(name, 0) + 1

@@ -72,31 +72,33 @@ __global__ __launch_bounds__(256) void adaln_prescale_kernel(const int64_t* __re
   }
 }
 
-// one wave per row, C = 96 nb <= 1536: lane l holds elements 24 l .. 24 l + 23 (three 16-byte units), so the four lanes of a quad
-// hold one 96-column block
+// Two rows per wave; lane (b, hi) = (q >> 1, q & 1), q = lane & 31 < 2 nb, accumulates the SAME 48 columns of block b in the SAME
+// order as a lane of the EPI_GATE_RES_STATS epilogue (columns 96 b + 32 j + 8 g + 4 hi + 0..3 for j = 0..2, g = 0..3, pivot = the
+// first of them) and the pair is merged the same way: a tensor gets the same partial bits from either producer, so a step that
+// takes its statistics from this pass (x last written by a plain epilogue or a PAB broadcast) equals the step that got them from
+// the GEMM epilogue bit for bit.  C = 96 nb, nb <= 16.
 __global__ __launch_bounds__(256) void ln_row_stats_kernel(const bf16_t* __restrict__ x, int64_t rows, int C, float2* __restrict__ stats,
                                                            int64_t ld) {
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int e0 = 24 * lane;
-  const bool act = e0 < C;
-  float v[24];
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+  const int q = lane & 31, b = q >> 1, hi = q & 1;
+  const bool act = row < rows && b * LN_BLOCK < C;
+  const bf16_t* xr = x + (act ? row : 0) * C + (act ? b : 0) * LN_BLOCK + 4 * hi;
+  uint2 u[12];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const uint4 u = act ? *reinterpret_cast<const uint4*>(x + row * C + e0 + 8 * i) : make_uint4(0, 0, 0, 0);
-    unpack8(u, v + 8 * i);
-  }
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) u[4 * j + g] = *reinterpret_cast<const uint2*>(xr + 32 * j + 8 * g);
   LnAcc a;
-  a.init(v[0]);
+  a.init(bflo(u[0].x));
 #pragma unroll
-  for (int e = 0; e < 24; ++e) a.add(v[e]);
-  float2 m = a.finish(24.f);
-  float2 o = make_float2(__shfl_xor(m.x, 1, 64), __shfl_xor(m.y, 1, 64));
-  m = (lane & 1) ? ln_merge_equal(o, m, 24.f) : ln_merge_equal(m, o, 24.f);   // both lanes of a pair compute the same bits
-  o = make_float2(__shfl_xor(m.x, 2, 64), __shfl_xor(m.y, 2, 64));
-  m = (lane & 2) ? ln_merge_equal(o, m, 48.f) : ln_merge_equal(m, o, 48.f);
-  if (act && (lane & 3) == 0) stats[(int64_t)(lane >> 2) * ld + row] = m;
+  for (int k = 0; k < 12; ++k) {
+    a.add(bflo(u[k].x)); a.add(bfhi(u[k].x)); a.add(bflo(u[k].y)); a.add(bfhi(u[k].y));
+  }
+  const float2 mine = a.finish(48.f);
+  const float2 other = make_float2(__shfl_xor(mine.x, 1, 64), __shfl_xor(mine.y, 1, 64));
+  const float2 blk = ln_merge_equal(mine, other, 48.f);   // (as the epilogue: evaluated by the hi = 0 lane, mine = its own half)
+  if (act && hi == 0) stats[(int64_t)b * ld + row] = blk;
 }
 
 }  // namespace
@@ -110,8 +112,8 @@ int launch_adaln_prescale(const int64_t* sites, int nsites, int64_t nblocks, con
 
 int launch_ln_row_stats(const bf16_t* x, int64_t rows, int C, float2* stats, int64_t ld, hipStream_t stream) {
   if (rows <= 0) return 0;
-  if (C % LN_BLOCK != 0 || C > 64 * 24 || ld < rows) return VSYS_ERR_SHAPE;
-  hipLaunchKernelGGL(ln_row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, C, stats, ld);
+  if (C % LN_BLOCK != 0 || C > 16 * LN_BLOCK || ld < rows) return VSYS_ERR_SHAPE;
+  hipLaunchKernelGGL(ln_row_stats_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, stream, x, rows, C, stats, ld);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

@@ -76,6 +76,32 @@ __device__ __forceinline__ void ln_combine(const float2* __restrict__ st, int64_
   m2 += 96.0f * (sdd - sd * sd * inv);
   rstd = rsqrtf(fmaxf(m2, 0.f) / (96.0f * (float)nb) + eps);
 }
+// Cooperative staging of what an EPI_LN_* epilogue needs for one output tile into LDS, so that the epilogue itself reads no
+// global memory (a dependent global round trip per row pair / column block is ~1 us each under load and nothing covers it at
+// one or two workgroups per CU): rows [row0, row0 + nrows) -> float2 (mu, rstd) at lds[r], columns [col0, col0 + ncols) ->
+// float2 (cs, cv) at lds[nrows + c].  Every thread of the workgroup calls it; the caller orders the writes against the reads
+// (lgkmcnt(0) + barrier).
+__device__ __forceinline__ void ln_stage_tile(float2* __restrict__ lds, const float2* __restrict__ st, int64_t ld, int nb, float eps,
+                                              int M, int row0, int nrows, const float* __restrict__ cs, const float* __restrict__ cv,
+                                              int col0, int ncols, int tid, int nthreads) {
+  // one row and one column per thread (nrows, ncols <= nthreads at every call site); the column loads are issued in front of
+  // the row partials so that ONE round trip covers both
+  const int c = nthreads - 1 - tid;
+  float c_s = 0.f, c_v = 0.f;
+  if (c < ncols) {
+    c_s = cs[col0 + c];
+    c_v = cv[col0 + c];
+  }
+  if (tid < nrows) {
+    int grow = row0 + tid;
+    grow = grow < M ? grow : M - 1;
+    float mu, rstd;
+    ln_combine(st, ld, nb, grow, eps, mu, rstd);
+    lds[tid] = make_float2(mu, rstd);
+  }
+  if (c < ncols) lds[nrows + c] = make_float2(c_s, c_v);
+}
+
 // running (sum, sum of squares) of values taken relative to a pivot close to them -> (mean, M2) of n values
 struct LnAcc {
   float p, s1, s2;

@@ -41,6 +41,8 @@ struct G2 {
   static constexpr int NWSLOT = WLEAD + 1;
   static constexpr int STAGING = W_BASE + NWSLOT * W_SLOT;
   static constexpr int LDS_BYTES = STAGING > NW * OUT_WAVE_BYTES ? STAGING : NW * OUT_WAVE_BYTES;  // 73728 or 106496
+  // EPI_LN_*: (mu, rstd) of the tile's 256 rows + (cs, cv) of its columns behind the staging area (common.h ln_stage_tile)
+  static constexpr int LN_BYTES = (BM + BN) * 8;
 };
 
 // STAMP = 1 (lab, variant 31): s_memtime stamps around the four phases of every stage (fragment reads landed / MFMA block issued /
@@ -116,6 +118,8 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_GELU;
+  float2* ln_lds = reinterpret_cast<float2*>(smem + G::LDS_BYTES);
   // (slices: the last one may be shorter — K need not divide evenly)
   const int nt = (EPI == EPI_F32_SLICES ? (p.ks < p.K - kslice * p.ks ? p.ks : p.K - kslice * p.ks) : p.K) / BK;
 #pragma unroll
@@ -128,6 +132,17 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     if constexpr (WLEAD == 2) {
 #pragma unroll
       for (int i = 0; i < 3; ++i) dma_w(i, 1, 1);
+    }
+  }
+  // behind the first LDS-DMA pieces: the partials' round trip runs beside the operand fetch the loop start waits for anyway (hipcc
+  // waits vmcnt(0) for these ordinary loads, i.e. for the pieces issued so far as well: stage 1 lands ~0.2 us after stage 0)
+  if constexpr (LN) {
+    __builtin_amdgcn_sched_barrier(0);
+    ln_stage_tile(ln_lds, p.ln_stats, p.ln_ld, p.ln_nb, p.ln_eps, p.M, row0, BM, p.cs, p.cv, col0, BN, tid, G::NT);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (nt > 1) {
+    if constexpr (WLEAD == 2) {
       asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // stage 1 (2 A + 3 W pieces) may still be in flight
     } else if constexpr (NA == 4) {
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -137,6 +152,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
+  if constexpr (LN) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's part of the (mu, rstd) / (cs, cv) image
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
@@ -278,7 +294,6 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
       for (int g = 0; g < 4; ++g) bb[j][g] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * hi);
   }
   const bool full = row0 + BM <= p.M;
-  constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_GELU;
 #pragma unroll
   for (int ih = 0; ih < 2; ++ih) {
     const int wrow0 = row0 + wm * 128 + ih * 64;
@@ -288,17 +303,19 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
       float mu[2], rs[2];
 #pragma unroll
       for (int i2 = 0; i2 < 2; ++i2) {
-        int grow = wrow0 + i2 * 32 + l31;
-        grow = grow < p.M ? grow : p.M - 1;
-        ln_combine(p.ln_stats, p.ln_ld, p.ln_nb, grow, p.ln_eps, mu[i2], rs[i2]);
+        const float2 ms = ln_lds[wm * 128 + ih * 64 + i2 * 32 + l31];   // staged before the K loop
+        mu[i2] = ms.x;
+        rs[i2] = ms.y;
       }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         float4 c_s[4], c_v[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          c_s[g] = *reinterpret_cast<const float4*>(p.cs + ncol0 + j * 32 + 8 * g + 4 * hi);
-          c_v[g] = *reinterpret_cast<const float4*>(p.cv + ncol0 + j * 32 + 8 * g + 4 * hi);
+        for (int g = 0; g < 4; ++g) {   // (cs, cv) pairs of four consecutive columns
+          const float4* cp = reinterpret_cast<const float4*>(ln_lds + BM + wn * 96 + j * 32 + 8 * g + 4 * hi);
+          const float4 a = cp[0], b = cp[1];
+          c_s[g] = make_float4(a.x, a.z, b.x, b.z);
+          c_v[g] = make_float4(a.y, a.w, b.y, b.w);
         }
 #pragma unroll
         for (int i2 = 0; i2 < 2; ++i2) {
@@ -443,12 +460,12 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
   }
   switch (epi) {
-    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
-    case EPI_LN_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
+    case EPI_LN_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
     case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;

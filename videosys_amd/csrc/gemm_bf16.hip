@@ -168,10 +168,25 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
     }
   };
 
+  // EPI_LN_*: (mu, rstd) of the tile's rows + (cs, cv) of its columns in LDS (common.h ln_stage_tile).  256-row tiles have the
+  // room behind the staging slots and fill it here, in front of the LDS-DMA stream; 128-row tiles (two workgroups per CU, no
+  // room) fill the part of the staging area the epilogue images leave free, after the K loop.
+  constexpr bool LNE = EPI == EPI_LN_BIAS || EPI == EPI_LN_GELU;
+  constexpr int LN_OFF = BM_ == 256 ? (BASE == 8 ? 3 * A_BYTES + 2 * B_BYTES : 2 * STAGE_BYTES) : G::NW * OUT_WAVE_BYTES;
+  static_assert(BM_ == 256 || LN_OFF + (BM_ + BN) * 8 <= 2 * STAGE_BYTES, "no room for the LayerNorm image");
+  float2* ln_lds = reinterpret_cast<float2*>(smem + LN_OFF);
+  auto ln_prologue = [&]() {   // called right behind the first tile's LDS-DMA pieces: its global round trip runs beside them
+    if constexpr (LNE && BM_ == 256) {
+      ln_stage_tile(ln_lds, p.ln_stats, p.ln_ld, p.ln_nb, p.ln_eps, p.M, row0, BM_, p.cs, p.cv, col0, BN, tid, G::NT);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (ordered for the other waves by the first tile barrier below)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
   const int nt = p.K / BK;
   const int last = nt - 1;
   if constexpr (BASE != 8) {
     GEMM_DMA_RANGE(0, NP, 0, 0);
+    ln_prologue();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
@@ -299,6 +314,9 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
       if (nt > 1) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) dma_a(i, 1, 1);
+      }
+      ln_prologue();
+      if (nt > 1) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -463,20 +481,26 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   }
   if constexpr (LN) {
     // AdaLN folded into the GEMM (vsys_internal.h GemmParams): out = rstd_m (acc - mu_m cs[n]) + cv[n]
+    if constexpr (BM_ != 256) {
+      ln_stage_tile(ln_lds, p.ln_stats, p.ln_ld, p.ln_nb, p.ln_eps, p.M, row0, BM_, p.cs, p.cv, col0, BN, tid, G::NT);
+      __syncthreads();
+    }
     float mu[2], rs[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int grow = row0 + wm * 64 + i * 32 + l31;
-      grow = grow < p.M ? grow : p.M - 1;
-      ln_combine(p.ln_stats, p.ln_ld, p.ln_nb, grow, p.ln_eps, mu[i], rs[i]);
+      const float2 ms = ln_lds[wm * 64 + i * 32 + l31];
+      mu[i] = ms.x;
+      rs[i] = ms.y;
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       float4 c_s[4], c_v[4];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        c_s[g] = *reinterpret_cast<const float4*>(p.cs + ncol0 + j * 32 + 8 * g + 4 * hi);
-        c_v[g] = *reinterpret_cast<const float4*>(p.cv + ncol0 + j * 32 + 8 * g + 4 * hi);
+      for (int g = 0; g < 4; ++g) {   // (cs, cv) pairs of four consecutive columns
+        const float4* cp = reinterpret_cast<const float4*>(ln_lds + BM_ + wn * 96 + j * 32 + 8 * g + 4 * hi);
+        const float4 a = cp[0], b = cp[1];
+        c_s[g] = make_float4(a.x, a.z, b.x, b.z);
+        c_v[g] = make_float4(a.y, a.w, b.y, b.w);
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -712,9 +736,11 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   if (PROD && epi != EPI_BIAS && epi != EPI_BIAS_GELU) return launch_gemm_t<PIPE, BM_, RASTER, 0>(p, epi, stream);  // 208 VGPRs: no third wave
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
   const int grid = nbm * nbn;
-  const size_t lds = (PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE;
+  const bool lnl = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
+  const size_t lds = ((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (lnl && BM_ == 256 ? (BM_ + BN) * 8 : 0);
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
   if (first_use_on_this_device(attr_seen)) {
+    const int lds = (int)(((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (BM_ == 256 ? (BM_ + BN) * 8 : 0));
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

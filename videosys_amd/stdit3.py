@@ -152,6 +152,8 @@ class STDiT3:
         # AdaLN folded into the qkv / fc1 GEMMs (csrc/adaln_fold.hip): pre-scaled weights per step, row statistics from the
         # producing epilogue; VSYS_ADALN_FOLD=0 keeps the separate LayerNorm-modulate pass everywhere
         self.adaln_fold = os.environ.get("VSYS_ADALN_FOLD", "1") != "0"
+        self.fold_spatial_qkv = True   # test hook: False = the spatial qkv site keeps the separate AdaLN pass on one GPU too (what a
+        #                                sequence-parallel rank whose modulated activations travel computes, bit for bit)
         self._fold = None          # per-B site table + the W' / cs / cv buffers (built on first use)
         self._stats_fresh = False  # "the statistics buffer describes the current x" (within one step)
         self._programs = {}
@@ -362,10 +364,11 @@ class STDiT3:
 
     # ------------------------------------------------------------------ AdaLN fold
     def _fold_ok(self, ts_host, fkey, x_mask):
-        """The fold needs ONE modulation per site: no sequence parallelism around the GEMMs it touches, no per-frame conditioning
-        mask, and every sample of the batch at the same timestep / fps (the CFG pair of a sampling step is)."""
+        """The fold needs ONE modulation per site: no per-frame conditioning mask, and every sample of the batch at the same
+        timestep / fps (the CFG pair of a sampling step is).  Under sequence parallelism every site at rest folds; the spatial
+        qkv site folds when the q|k|v travel (the GEMM then runs at rest), not when the modulated activations do."""
         C = self.hidden_size
-        return (self.adaln_fold and self._sp is None and x_mask is None and C % ops.LN_BLOCK == 0 and C // ops.LN_BLOCK <= 12
+        return (self.adaln_fold and x_mask is None and C % ops.LN_BLOCK == 0 and C // ops.LN_BLOCK <= 12
                 and bool((ts_host == ts_host[0]).all()) and len(set(fkey[:-1])) == 1)
 
     def _fold_tables(self, B):
@@ -423,6 +426,8 @@ class STDiT3:
         B, _, Tx, Hx, Wx = x.shape
         T, Hp, Wp = self.get_dynamic_size(x)
         dev = self.device
+        if x_mask is not None and not x_mask.is_cuda and bool(x_mask.to(torch.bool).all()):
+            x_mask = None        # an all-True mask IS the plain step (every frame takes the timestep's modulation)
         if x_mask is not None:   # [B, T] bool: False = conditioning frame (sees the timestep-0 modulation, :181-184,578-582)
             if tuple(x_mask.shape) != (B, T):
                 raise ValueError(f"x_mask must be [B, T] = [{B}, {T}], got {tuple(x_mask.shape)}")
@@ -455,7 +460,7 @@ class STDiT3:
             out = self._forward_device(xz, ts_host.to(dev), static, plan, timestep_int, valid_depth, cp, x_mask, fold=fold)
         else:
             sp = self._sp
-            key = (B, Tx, Hx, Wx, float(height[0]), float(width[0]), fkey, valid_depth, cp, fold,
+            key = (B, Tx, Hx, Wx, float(height[0]), float(width[0]), fkey, valid_depth, cp, fold, self.fold_spatial_qkv,
                    None if plan is None else tuple(d[:2] + d[5:7] for d in plan),
                    None if sp is None else (sp.P, sp.rank, self._scatter, self._switch, self._overlap))
             ent = self._programs.get(key)
@@ -640,34 +645,45 @@ class STDiT3:
             Wp, cs, cv = ftab["bufs"][site]
             return ops.gemm_ln(x, Wp, cs, cv, stats, gelu=gelu, out=out)
 
+        # which form the qkv site of this block takes (see _fold_ok)
+        sp_order = None
+        if sp is not None and not temporal:
+            flat = T == 1 or self._scatter == "flat"
+            sp_order = self._switch_order(*((1, B * T) if flat else (B, T)), S_full)
+        fold_attn = fold and (temporal or (sp is None and self.fold_spatial_qkv) or sp_order == "qkv")
+
         # ---------------- self attention
         if broadcast_attn:
             ops.add_rows(x, st.last_attn)
             self._stats_fresh = False
         else:
-            if fold:
+            xm = None
+            if fold_attn and sp_order is None:
                 qkv = folded(p + ".attn.qkv", False, _buf("qkv", (N, 3 * C)))
-            else:
+            elif not fold_attn:
                 xm = ops.adaln_modulate(x, shift_msa, scale_msa, rps, C6, out=_buf("xm", (N, C)))
             aux = None
             if use_pab and keep_attn:
                 st.last_attn = slab(st.last_attn)
                 aux = st.last_attn
             if temporal:
-                if not fold:
+                if not fold_attn:
                     qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
                 ao = _buf("attn_out", (N, C))
                 cos, sin = self._rope(T)
                 ops.attn_temporal(qkv, C, w[p + ".attn.q_norm.weight"], w[p + ".attn.k_norm.weight"], cos, sin, ao, B, T, S, H)
             elif sp is None:
-                if not fold:
+                if not fold_attn:
                     qkv = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=_buf("qkv", (N, 3 * C)))
                 kp, vt = self._kv_spatial(B * T, S)
                 ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * T, H, S)
                 ao = _buf("attn_out", (N, C))
                 ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * T, H, S, S)
             else:
-                ao = self._spatial_attn_sharded(p, xm, B, T, S, S_full)
+                qkv_rest = None
+                if fold_attn:   # (order "qkv") the folded GEMM at rest produces what travels
+                    qkv_rest = folded(p + ".attn.qkv", False, self._buf("qkv_rest", (N, 3 * C)))
+                ao = self._spatial_attn_sharded(p, xm, B, T, S, S_full, qkv_rest=qkv_rest)
             ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
                      gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
             self._stats_fresh = False
@@ -722,7 +738,7 @@ class STDiT3:
             pab.save_mlp_output(timestep=timestep_int, block_idx=st.block_idx, ff_output=aux, is_temporal=temporal)
         return x
 
-    def _spatial_attn_sharded(self, p, xm, B, T, S, S_full):
+    def _spatial_attn_sharded(self, p, xm, B, T, S, S_full, qkv_rest=None):
         """The DSP section of a spatial block (dynamic_switch, open_sora_transformer_3d.py:208-216,288-315): modulated activations
         [B,T,S/P,C] -> all-to-all -> T-shard [.., S, C] -> qkv GEMM -> spatial attention -> all-to-all -> [B,T,S/P,C].
 
@@ -747,7 +763,8 @@ class STDiT3:
         wide = 3 * C if order == "qkv" else C
         src = xm
         if order == "qkv":   # qkv GEMM at rest on the un-padded S-shard; the 3C-wide q|k|v travels
-            src = ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"], out=self._buf("qkv_rest", (B * T * S, 3 * C)))
+            src = qkv_rest if qkv_rest is not None else ops.gemm(xm, w[p + ".attn.qkv.weight"], w[p + ".attn.qkv.bias"],
+                                                                 out=self._buf("qkv_rest", (B * T * S, 3 * C)))
         src4 = src.view(Bv, Tv, S, wide)
         back = self._buf("attn_back", (Bv, Tv, S, C))
 
