@@ -55,7 +55,8 @@ int vsys_device_count(void);
  * gemm:  2GGPP = tile raster only (see vsys_gemm_raster_probe); 0 = shape dispatch (default); 8 = schedule 8 for every shape (three A slots + two W slots, counted waits); 3 / 6 =
  *        two-stage LDS-DMA schedules; 9 = schedule 8, plain row-major tile order; 20 = 4-wave workgroups, two per CU; 28 =
  *        schedule 8 + producer waves; 30 = 256 x 384 tile; 103 = 128-row tiles.
- * flash: 0 = default (two workgroups per CU; resident K/V for few keys; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
+ * flash: 14 / 15 = the 64-query-rows-per-wave kernel with the hand-allocated tile loop wherever it applies (>= 256 keys and rows) /
+ *        never (default: for >= 512 keys);  0 = default (two workgroups per CU; resident K/V for few keys; temporal attention on the matrix pipe for T <= 32); 3 = three workgroups per CU;
  *        4 = VALU temporal kernel (v2) for T <= 40; 8 / 10 = the resident-K/V kernel (all KV tiles of a
  *        (batch, head) staged once per workgroup; default for <= 320 keys and many query rows) whenever the keys fit / never;
  *        9 = online-softmax temporal kernel for every T; 12 = the head-dim-64 kernel on a two-stage K/V ring (shipped: three).

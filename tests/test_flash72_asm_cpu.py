@@ -1,0 +1,67 @@
+"""CPU (-m "not gpu"): the hand-allocated instruction stream of flash_attn_d72_w64 (csrc/attention_w64.hip).
+
+  * the committed csrc/flash72_w64_asm.inc is what csrc/gen/flash72_gen.py generates (the build does not run the generator);
+  * tools/gcn_emu.py executes that text for all four waves of a workgroup — LDS-DMA pieces and ds_read results landing as LATE and
+    as EARLY as the counters allow, both stepping orders of the waves — around the numpy restatement of the kernel's C++ prologue /
+    epilogue (tools/flash72_emu_case.py), against float64 attention on the same bf16 inputs: even / odd tile counts, a ragged last
+    tile, inputs that force the deferred-rescale branch; tolerance 2^-8 of max|ref| (P is rounded to bf16);
+  * no software-visible hazard in any executed path (MFMA result -> use, VALU -> MFMA operand, VALU -> permlane, transcendental -> use,
+    M0 -> LDS-DMA, MFMA C read -> overwrite), and every MFMA gap of the steady-state loop carries at most 5 other instructions."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "videosys_amd", "csrc", "gen"))
+
+
+def test_committed_include_is_what_the_generator_emits(tmp_path):
+    import flash72_gen as G
+
+    out = str(tmp_path / "f.inc")
+    G.write_inc(out)
+    with open(out) as a, open(os.path.join(ROOT, "videosys_amd", "csrc", "flash72_w64_asm.inc")) as b:
+        assert a.read() == b.read(), "regenerate: python videosys_amd/csrc/gen/flash72_gen.py"
+
+
+def test_steady_state_gaps_hold_at_most_five_fillers():
+    import flash72_gen as G
+
+    lines = G.generate()
+    top, tail = lines.index("TOP_%=:"), lines.index("TAIL0_%=:")
+    loop = [ln for ln in lines[top:tail] if not ln.endswith(":")]
+    gaps, cur, seen = [], 0, False
+    for ln in loop:
+        if ln.startswith("v_mfma"):
+            if seen:
+                gaps.append(cur)
+            cur, seen = 0, True
+        else:
+            cur += 1
+    n_mfma = sum(1 for ln in loop if ln.startswith("v_mfma"))
+    assert n_mfma == 88                      # two tiles of 44 per trip of the unrolled loop
+    # phase boundaries (wait + barrier, loop control, the branch to the rare rescale block) are the only longer gaps
+    assert sorted(gaps)[-5] <= 5 and max(gaps) <= 12, sorted(gaps)[-8:]
+    assert sum(gaps) / len(gaps) <= 4.6
+
+
+@pytest.mark.parametrize("kv_len,spike,qscale,late_vm,late_ds,order", [
+    (256, False, 1.0, True, True, None),            # 4 tiles: no trip of the main loop
+    (320, True, 3.0, False, False, [3, 2, 1, 0]),   # odd tile count, rescale branch taken repeatedly
+    (300, True, 1.0, True, False, None),            # ragged last tile (the text length of the cross attention)
+    (448, False, 1.0, False, True, [3, 2, 1, 0]),
+    (384, False, 6.0, True, True, [3, 2, 1, 0]),    # large logits: the branch fires on most tiles
+])
+def test_emulated_workgroup_matches_numpy_attention(kv_len, spike, qscale, late_vm, late_ds, order):
+    import flash72_emu_case as C
+
+    with np.errstate(all="ignore"):
+        err, viol, stats = C.run(kv_len, spike=spike, qscale=qscale, late_vm=late_vm, late_ds=late_ds, order=order)
+    assert not viol, viol[:5]
+    assert err <= 2.0**-8, err
+    if spike or qscale > 1.0:
+        assert stats["counts"].get("v_accvgpr_read_b32", 0) >= 96, "the rescale branch was never taken"
+    assert stats["barriers"] == 2 + (kv_len + 63) // 64 - 1

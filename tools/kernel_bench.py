@@ -105,6 +105,8 @@ def main():
             res[f"vendor_linear_{name}"] = [(ms, 2.0 * N * n * k / (ms * 1e-3) / 1e12)]
     if args.only == "gemm":
         return report(res)
+    if args.only == "flash":
+        res.clear()
 
     # attention: spatial (38 frames x 1024), cross (2 x 19456 q, 300 keys), temporal
     qkv = rnd(N, 3 * C)

@@ -926,13 +926,14 @@ __global__ __launch_bounds__(256) void attn_temporal_d72_v2_kernel(const bf16_t*
 // launch.  Every id the SHIPPED build accepts selects a valid kernel for the same contract.
 static std::atomic<int> g_flash_variant_a{0};
 static unsigned long long* g_flash_dbg = nullptr;
+// 14 / 15 = the 64-rows-per-wave kernel (attention_w64.hip) wherever it applies / never;
 // 0 = shipped default (resident-K/V kernel for <= 320 keys and many query rows), 3 = three workgroups per CU, 4 / 9 = force the VALU (v2) /
 // online-softmax temporal kernels, 8 = resident-K/V kernel whenever the keys fit, 10 = never, 12 = the d64 kernel (CogVideoX) on its
 // two-stage K/V ring instead of the shipped three-stage one: all valid.  1 (K/V tiles not
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 8: case 9: case 10: case 12: break;
+    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: break;
 #ifdef VSYS_LAB
     case 1: case 2: break;
 #endif
@@ -990,6 +991,10 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
       return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
     }
   }
+  // long key sequences: 64 query rows per wave, one wave per SIMD, hand-allocated instruction stream (attention_w64.hip)
+  static const bool w64_default = [] { const char* e = getenv("VSYS_FLASH_W64"); return !(e && e[0] == '0'); }();
+  if ((g_flash_variant == 14 || (g_flash_variant == 0 && w64_default && kv_len >= 512)) && flash_w64_supports(q_len, kv_len, kv_pad))
+    return launch_flash_attn_d72_w64(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps, stream);
   // three workgroups per CU pay for long, unmasked key sequences (spatial attention: 0.241 vs 0.251 ms); with a masked last tile
   // the 168-register variant spills in the peeled tile (cross shape 0.156 vs 0.099 ms)
   static const bool wps3_ok = [] { const char* e = getenv("VSYS_FLASH_WPS3"); return !(e && e[0] == '0'); }();

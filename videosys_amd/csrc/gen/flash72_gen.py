@@ -1,0 +1,423 @@
+#!/usr/bin/env python
+"""Generator of the hand-allocated gfx950 instruction stream of flash_attn_d72_w64 (csrc/attention_w64.hip).
+
+    python videosys_amd/csrc/gen/flash72_gen.py            -> videosys_amd/csrc/flash72_w64_asm.inc  (committed; build() does not run this)
+
+One wave = 64 query rows (two 32-row blocks A, B) of one (batch, head), ONE wave per SIMD (512 registers), 4 waves per workgroup.
+Replaces the tile loop of flash_attn_d72_kernel (attention.hip; reference: modules/attentions.py:80-120 SDPA of OpenSoraAttention)
+with the same arithmetic: S^T = K Q^T - m on v_mfma_f32_32x32x16_bf16 (running max as the C operand), deferred rescale
+(threshold 8 in the exp2 domain), P = exp2(S) rounded to bf16, O^T += Vt P^T with the row sum in the ones rows of Vt.
+
+Register file (fixed, listed as clobbers of the asm statement):
+  a[0:47] O_A   a[48:95] O_B   a[96:115] Q_A   a[116:135] Q_B   a[136:175] K fragments   a[176:223] Vt fragments
+  v[0:63] S buffer 0 (A | B)   v[64:127] S buffer 1   v[128:143] P_A   v[144:159] P_B   v[160:175] -m_A splat   v[176:191] -m_B splat
+  v[192:209] temporaries
+Software pipeline per 64-key tile i (two phases, one s_barrier):
+  X_i  20 MFMA  S(i+1) = K(i+1) Q^T - m      beside   P(i) = exp2(S(i)) (A, and keys 0..31 of B), Vt(i) fragment reads
+  Y_i  24 MFMA  O += Vt(i) P(i)^T            beside   exp2 of B's keys 32..63, row max of S(i+1), K(i+2) fragment reads, LDS-DMA of tile i+4
+with every non-MFMA instruction PLACED in a gap behind an MFMA (<= 5 per gap where the counts allow: MI355X_MICROARCH.md "one wave
+per SIMD" row).  K/V tiles travel HBM -> LDS by LDS-DMA into a ring of 4 stages, two tiles ahead of their first reader.
+tools/gcn_emu.py executes the text this file emits (all four waves, LDS-DMA / ds_read completion as late and as early as the
+counters allow) and checks the software-visible hazards; tests/test_flash72_asm_cpu.py runs it against numpy attention."""
+import os
+import sys
+
+K_TILE, STAGE, NSTAGE = 9216, 21504, 4
+O = {"A": 0, "B": 48}
+Q = {"A": 96, "B": 116}
+KF, VF = 136, 176
+SBUF = [{"A": 0, "B": 32}, {"A": 64, "B": 96}]
+P = {"A": 128, "B": 144}
+NM = {"A": 160, "B": 176}
+MX = {"A": 192, "B": 193}
+TT = {"A": 194, "B": 195}
+KADDR = 196
+VADDR = [197, 198, 199, 200]
+DL = {"A": 201, "B": 202}
+AL = {"A": 203, "B": 204}
+TMP = [205, 206, 207, 208]
+NEGBIG = 209
+NV = 210        # v0..v209 are the asm's
+NA = 224        # a0..a223
+# scalar registers of the asm (clobbered): s40..s63
+S_CNT, S_ST, S_ST2, S_T, S_KA, S_KB, S_VC, S_VD, S_E, S_DST, S_WRAP, S_T2 = range(40, 52)
+NS_LO, NS_HI = 40, 52
+
+
+def v(i, n=1):
+    return f"v{i}" if n == 1 else f"v[{i}:{i + n - 1}]"
+
+
+def a(i, n=1):
+    return f"a{i}" if n == 1 else f"a[{i}:{i + n - 1}]"
+
+
+def s(i):
+    return f"s{i}"
+
+
+def kf(kt, cc):
+    return KF + kt * 20 + cc * 4
+
+
+def vf(kt, cc, dt):
+    return VF + ((kt * 2 + cc) * 3 + dt) * 4
+
+
+def sreg(buf, blk, kt, r=0):
+    return SBUF[buf][blk] + kt * 16 + r
+
+
+def preg(blk, kt, cc):
+    return P[blk] + (kt * 2 + cc) * 4
+
+
+class Emit:
+    def __init__(self):
+        self.lines = []
+        self.uid = 0
+
+    def __call__(self, text):
+        self.lines.append(text)
+
+    def label(self, name):
+        self.lines.append(name + ":")
+
+
+def schedule(e, mfmas, fillers, cap=5, front=False):
+    """Emit MFMAs in order; behind MFMA g up to ``cap`` fillers whose ``after`` index is <= g (fillers keep their order).
+    fillers: list of (text, after) — ``after`` = the index of the last MFMA that must have ISSUED before it."""
+    q = list(fillers)
+    n = len(mfmas)
+    for g, m in enumerate(mfmas):
+        e(m)
+        left = n - g
+        # even spreading: what is left over what is left, but never above cap and always respecting ``after``
+        want = (cap if front else min(cap, -(-len(q) // left))) if q else 0
+        k = 0
+        while q and k < want and q[0][1] <= g:
+            e(q.pop(0)[0])
+            k += 1
+    for t, _ in q:
+        e(t)
+
+
+def qk_mfmas(nxt):
+    out = []
+    for c in range(5):
+        for blk in ("A", "B"):
+            for kt in range(2):
+                d = v(sreg(nxt, blk, kt), 16)
+                src_c = v(NM[blk], 16) if c == 0 else d
+                out.append(f"v_mfma_f32_32x32x16_bf16 {d}, {a(kf(kt, c), 4)}, {a(Q[blk] + 4 * c, 4)}, {src_c}")
+    # order inside a chunk: A.kt0, A.kt1, B.kt0, B.kt1
+    return out
+
+
+def pv_mfmas():
+    out = []
+    for kt in range(2):
+        for blk in ("A", "B"):
+            for cc in range(2):
+                for dt in range(3):
+                    d = a(O[blk] + 16 * dt, 16)
+                    out.append((f"v_mfma_f32_32x32x16_bf16 {d}, {a(vf(kt, cc, dt), 4)}, {v(preg(blk, kt, cc), 4)}, {d}", blk, kt))
+    return out   # order: A.kt0 (6), B.kt0 (6), A.kt1 (6), B.kt1 (6)
+
+
+def p_unit(cur, blk, kt, cc):
+    """8 exps in place + 4 converts: S[8cc .. 8cc+7] of (blk, kt) -> P fragment (blk, kt, cc)"""
+    base = sreg(cur, blk, kt, 8 * cc)
+    out = [f"v_exp_f32_e32 {v(base + r)}, {v(base + r)}" for r in range(8)]
+    out += [f"v_cvt_pk_bf16_f32 {v(preg(blk, kt, cc) + w)}, {v(base + 2 * w)}, {v(base + 2 * w + 1)}" for w in range(4)]
+    return out
+
+
+def v_reads():
+    out = []
+    for kt in range(2):
+        for cc in range(2):
+            for dt in range(3):
+                out.append(f"ds_read_b128 {a(vf(kt, cc, dt), 4)}, {v(VADDR[kt * 2 + cc])} offset:{dt * 4096}")
+    return out
+
+
+def k_reads():
+    return [f"ds_read_b128 {a(kf(kt, cc), 4)}, {v(KADDR)} offset:{kt * 4608 + cc * 32}" for kt in range(2) for cc in range(5)]
+
+
+def max_chain(buf, blk):
+    r0 = SBUF[buf][blk]
+    out = [f"v_max3_f32 {v(MX[blk])}, {v(r0)}, {v(r0 + 1)}, {v(r0 + 2)}"]
+    for i in range(3, 32, 2):
+        b = v(r0 + i + 1) if i + 1 < 32 else v(r0 + i)
+        out.append(f"v_max3_f32 {v(MX[blk])}, {v(MX[blk])}, {v(r0 + i)}, {b}")
+    return out   # 16 instructions: 3 + 15 * 2 = 33 >= 32 values
+
+
+def mask_ops(buf):
+    """keys 64 (ntiles - 1) + 32 kt + 16 hi + r >= kv_len of the LAST tile -> -1e30 (lim = kv_len - 64 (ntiles - 1) - 16 hi)"""
+    out = []
+    for blk in ("A", "B"):
+        for kt in range(2):
+            for r in range(16):
+                reg = v(sreg(buf, blk, kt, r))
+                out.append(f"v_cmp_lt_i32_e32 vcc, {kt * 32 + r}, %[lim]")
+                out.append(f"v_cndmask_b32_e32 {reg}, {v(NEGBIG)}, {reg}, vcc")
+    return out
+
+
+def dma_tile_static(e, stage_expr_k, t):
+    """prologue: the five pieces of tile t (this wave's) into stage t; soff registers are advanced afterwards"""
+    raise NotImplementedError
+
+
+def dma_ops():
+    """the wave's five LDS-DMA pieces of the next tile into the stage at s[S_ST] (+ soff advance); (text, after) tuples spread by
+    the caller.  An independent instruction sits between every M0 write and the load that reads it."""
+    return [
+        f"s_add_i32 {s(S_DST)}, {s(S_ST)}, %[wl]",
+        f"s_mov_b32 m0, {s(S_DST)}",
+        f"s_add_i32 {s(S_T2)}, {s(S_DST)}, 4096",
+        f"buffer_load_dwordx4 %[kvo], %[rk], {s(S_KA)} offen lds",
+        f"s_mov_b32 m0, {s(S_T2)}",
+        f"s_add_i32 {s(S_KA)}, {s(S_KA)}, {K_TILE}",
+        f"buffer_load_dwordx4 %[kvo], %[rk], {s(S_KB)} offen lds",
+        f"s_add_i32 m0, {s(S_DST)}, {K_TILE}",
+        f"s_add_i32 {s(S_KB)}, {s(S_KB)}, {K_TILE}",
+        f"buffer_load_dwordx4 %[vvo], %[rv], {s(S_VC)} offen lds",
+        f"s_add_i32 m0, {s(S_DST)}, {K_TILE + 4096}",
+        f"s_add_i32 {s(S_VC)}, {s(S_VC)}, 128",
+        f"buffer_load_dwordx4 %[vvo], %[rv], {s(S_VD)} offen lds",
+        f"s_add_i32 m0, {s(S_ST)}, %[l4]",
+        f"s_add_i32 {s(S_VD)}, {s(S_VD)}, 128",
+        f"buffer_load_dwordx4 %[v4o], %[r4], {s(S_E)} offen lds",
+        f"s_add_i32 {s(S_E)}, {s(S_E)}, %[st4]",
+    ]
+
+
+def stage_advance():
+    """s[S_ST] = stage of tile i -> tile i + 1;  s[S_ST2] = stage of tile (i + 1) + 2"""
+    return [
+        f"s_add_u32 {s(S_ST)}, {s(S_ST)}, {STAGE}",
+        f"s_cmp_eq_u32 {s(S_ST)}, {s(S_WRAP)}",
+        f"s_cselect_b32 {s(S_ST)}, %[lb], {s(S_ST)}",
+        f"s_add_u32 {s(S_ST2)}, {s(S_ST)}, {2 * STAGE}",
+        f"s_sub_u32 {s(S_T)}, {s(S_ST2)}, {NSTAGE * STAGE}",
+        f"s_cmp_ge_u32 {s(S_ST2)}, {s(S_WRAP)}",
+        f"s_cselect_b32 {s(S_ST2)}, {s(S_T)}, {s(S_ST2)}",
+    ]
+
+
+def rescale_block(e, tag, buf):
+    """out of line: raise the running max of both blocks by delta = max(mx, 0), rescale O, shift S(next) and -m"""
+    e.label(f"RESC_{tag}_%=")
+    e("s_nop 15")   # the last PV MFMA's result -> v_accvgpr_read
+    for blk in ("A", "B"):
+        e(f"v_max_f32_e32 {v(DL[blk])}, 0, {v(MX[blk])}")
+    for blk in ("A", "B"):
+        e(f"v_exp_f32_e64 {v(AL[blk])}, -{v(DL[blk])}")
+    for blk in ("A", "B"):
+        for i in range(16):
+            e(f"v_sub_f32_e32 {v(NM[blk] + i)}, {v(NM[blk] + i)}, {v(DL[blk])}")
+        for r in range(32):
+            e(f"v_sub_f32_e32 {v(SBUF[buf][blk] + r)}, {v(SBUF[buf][blk] + r)}, {v(DL[blk])}")
+    for blk in ("A", "B"):
+        for r0 in range(0, 48, 4):
+            for j in range(4):
+                e(f"v_accvgpr_read_b32 {v(TMP[j])}, {a(O[blk] + r0 + j)}")
+            for j in range(4):
+                e(f"v_mul_f32_e32 {v(TMP[j])}, {v(TMP[j])}, {v(AL[blk])}")
+            for j in range(4):
+                e(f"v_accvgpr_write_b32 {a(O[blk] + r0 + j)}, {v(TMP[j])}")
+    e("s_nop 7")
+    e(f"s_branch BACK_{tag}_%=")
+
+
+def body(e, tag, p, masked, resc):
+    """iteration i with S(i) in buffer p: X_i, barrier, Y_i.  ``resc`` collects the out-of-line rescale blocks to emit later."""
+    cur, nxt = p, 1 - p
+    # ---- X
+    e("s_waitcnt lgkmcnt(0)")        # K(i+1) fragments (read during Y_{i-1})
+    fill = [(f"v_add_u32_e32 {v(VADDR[k])}, {s(S_ST)}, %[vfa{k}]", 0) for k in range(4)]
+    units = [("A", 0, 0), ("A", 0, 1), ("A", 1, 0), ("A", 1, 1), ("B", 0, 0), ("B", 0, 1)]
+    vr = v_reads()
+    for u, (blk, kt, cc) in enumerate(units):
+        pu = p_unit(cur, blk, kt, cc)
+        fill += [(t, 0) for t in pu[:6]]
+        fill.append((vr[2 * u], 0))
+        fill += [(t, 0) for t in pu[6:]]
+        fill.append((vr[2 * u + 1], 0))
+    schedule(e, qk_mfmas(nxt), fill)
+    e("s_waitcnt vmcnt(5) lgkmcnt(0)")   # Vt(i) fragments are in; this wave's pieces of tile i+2 have landed
+    e("s_barrier")                       # ... and everybody else's; every wave is done reading stage(i)
+    # ---- Y
+    pv = pv_mfmas()
+    fill = [(f"v_add_u32_e32 {v(KADDR)}, {s(S_ST2)}, %[kfa]", 0)]
+    kr = k_reads()
+    pb = p_unit(cur, "B", 1, 0) + p_unit(cur, "B", 1, 1)
+    # keys 32..63 of block B: exp + convert, with the K(i+2) fragment reads in between
+    for j, t in enumerate(pb):
+        fill.append((t, 0))
+        if j % 3 == 2 and kr:
+            fill.append((kr.pop(0), 0))
+    fill += [(t, 0) for t in kr]
+    dma = dma_ops()
+    fill += [(t, 0) for t in dma]
+    if masked:
+        fill += [(t, 0) for t in mask_ops(nxt)]
+    ca, cb = max_chain(nxt, "A"), max_chain(nxt, "B")
+    fill += [(t, 0) for t in ca]
+    fill.append((f"v_mov_b32_e32 {v(TT['A'])}, {v(MX['A'])}", 0))
+    fill += [(t, 0) for t in cb]
+    fill.append((f"v_permlane32_swap_b32_e32 {v(MX['A'])}, {v(TT['A'])}", 0))
+    fill.append((f"v_mov_b32_e32 {v(TT['B'])}, {v(MX['B'])}", 0))
+    fill.append((f"v_max_f32_e32 {v(MX['A'])}, {v(MX['A'])}, {v(TT['A'])}", 0))
+    adv = stage_advance()
+    fill.append((adv[0], 0))
+    fill.append((f"v_permlane32_swap_b32_e32 {v(MX['B'])}, {v(TT['B'])}", 0))
+    fill += [(t, 0) for t in adv[1:3]]
+    fill.append((f"v_max_f32_e32 {v(MX['B'])}, {v(MX['B'])}, {v(TT['B'])}", 0))
+    fill += [(t, 0) for t in adv[3:]]
+    fill.append((f"v_max_f32_e32 {v(TMP[0])}, {v(MX['A'])}, {v(MX['B'])}", 0))
+    fill.append((f"v_cmp_lt_f32_e32 vcc, 8.0, {v(TMP[0])}", 0))
+    schedule(e, [m for m, _, _ in pv], fill, cap=6 if masked else 5)
+    e(f"s_cbranch_vccnz RESC_{tag}_%=")
+    e.label(f"BACK_{tag}_%=")
+    resc.append((tag, nxt))
+
+
+def final(e, p):
+    """last tile: P = exp2(S), O += Vt P^T, nothing for a next tile"""
+    cur = p
+    for k in range(4):
+        e(f"v_add_u32_e32 {v(VADDR[k])}, {s(S_ST)}, %[vfa{k}]")
+    vr = v_reads()
+    for t in vr:
+        e(t)
+    units = [("A", 0, 0), ("A", 0, 1), ("B", 0, 0), ("B", 0, 1), ("A", 1, 0), ("A", 1, 1), ("B", 1, 0), ("B", 1, 1)]
+    pre = []
+    for blk, kt, cc in units[:4]:
+        pre += p_unit(cur, blk, kt, cc)
+    for t in pre:
+        e(t)
+    e("s_waitcnt lgkmcnt(0)")
+    fill = []
+    for blk, kt, cc in units[4:]:
+        fill += [(t, 0) for t in p_unit(cur, blk, kt, cc)]
+    schedule(e, [m for m, _, _ in pv_mfmas()], fill, cap=5, front=True)   # P of keys 32..63 is needed from the 13th MFMA on
+
+
+def prologue(e):
+    e(f"v_mov_b32_e32 {v(NEGBIG)}, 0xf149f2ca")
+    for i in range(96):
+        e(f"v_accvgpr_write_b32 {a(i)}, 0")
+    for blk in ("A", "B"):
+        for i in range(16):
+            e(f"v_mov_b32_e32 {v(NM[blk] + i)}, 0")
+    # DMA soff registers of tile 0
+    e(f"s_mov_b32 {s(S_KA)}, %[wl]")
+    e(f"s_add_i32 {s(S_KB)}, %[wl], 4096")
+    e(f"s_mov_b32 {s(S_VC)}, %[sv0]")
+    e(f"s_mov_b32 {s(S_VD)}, %[sv1]")
+    e(f"s_mov_b32 {s(S_E)}, %[s4]")
+    e(f"s_add_u32 {s(S_WRAP)}, %[lb], {NSTAGE * STAGE}")
+    e(f"s_mov_b32 {s(S_ST)}, %[lb]")
+    for t in range(4):    # tiles 0..3 into stages 0..3
+        for ln in dma_ops():
+            e(ln)
+        e(f"s_add_u32 {s(S_ST)}, {s(S_ST)}, {STAGE}")
+    e(f"s_mov_b32 {s(S_ST)}, %[lb]")
+    e(f"s_add_u32 {s(S_ST2)}, %[lb], {2 * STAGE}")
+    e(f"s_sub_u32 {s(S_CNT)}, %[nt], 2")
+    # tile 0: K fragments, S(0) = K(0) Q^T (-m = 0), adopt its row max
+    e("s_waitcnt vmcnt(15)")
+    e("s_barrier")
+    e(f"v_add_u32_e32 {v(KADDR)}, {s(S_ST)}, %[kfa]")
+    for t in k_reads():
+        e(t)
+    e("s_waitcnt lgkmcnt(0)")
+    for m in qk_mfmas(0):
+        e(m)
+    e("s_waitcnt vmcnt(10)")
+    e("s_barrier")
+    e(f"v_add_u32_e32 {v(KADDR)}, {s(S_ST)}, %[kfa]")
+    e(f"v_add_u32_e32 {v(KADDR)}, {STAGE}, {v(KADDR)}")
+    for t in k_reads():
+        e(t)
+    e("s_nop 7")
+    for t in max_chain(0, "A"):
+        e(t)
+    e(f"v_mov_b32_e32 {v(TT['A'])}, {v(MX['A'])}")
+    for t in max_chain(0, "B"):
+        e(t)
+    e(f"v_permlane32_swap_b32_e32 {v(MX['A'])}, {v(TT['A'])}")
+    e(f"v_mov_b32_e32 {v(TT['B'])}, {v(MX['B'])}")
+    e(f"v_max_f32_e32 {v(MX['A'])}, {v(MX['A'])}, {v(TT['A'])}")
+    e("s_nop 1")
+    e(f"v_permlane32_swap_b32_e32 {v(MX['B'])}, {v(TT['B'])}")
+    e(f"v_max_f32_e32 {v(MX['B'])}, {v(MX['B'])}, {v(TT['B'])}")
+    for blk in ("A", "B"):
+        for r in range(32):
+            e(f"v_sub_f32_e32 {v(SBUF[0][blk] + r)}, {v(SBUF[0][blk] + r)}, {v(MX[blk])}")
+        for i in range(16):
+            e(f"v_sub_f32_e32 {v(NM[blk] + i)}, 0, {v(MX[blk])}")
+
+
+def generate():
+    e = Emit()
+    resc = []
+    prologue(e)
+    e.label("TOP_%=")
+    e(f"s_cmp_eq_u32 {s(S_CNT)}, 0")
+    e("s_cbranch_scc1 TAIL0_%=")
+    e(f"s_sub_u32 {s(S_CNT)}, {s(S_CNT)}, 1")
+    body(e, "r0", 0, False, resc)
+    e(f"s_cmp_eq_u32 {s(S_CNT)}, 0")
+    e("s_cbranch_scc1 TAIL1_%=")
+    e(f"s_sub_u32 {s(S_CNT)}, {s(S_CNT)}, 1")
+    body(e, "r1", 1, False, resc)
+    e("s_branch TOP_%=")
+    e.label("TAIL0_%=")
+    body(e, "m0", 0, True, resc)
+    final(e, 1)
+    e("s_branch END_%=")
+    e.label("TAIL1_%=")
+    body(e, "m1", 1, True, resc)
+    final(e, 0)
+    e("s_branch END_%=")
+    for tag, buf in resc:
+        rescale_block(e, tag, buf)
+    e.label("END_%=")
+    e("s_waitcnt vmcnt(0)")
+    e("s_nop 15")    # the last PV MFMAs -> the v_accvgpr_read of the epilogue (a separate asm statement)
+    return e.lines
+
+
+OPERANDS = ["rk", "rv", "r4", "wl", "sv0", "sv1", "s4", "st4", "l4", "lb", "nt", "lim", "kvo", "vvo", "v4o", "kfa", "vfa0", "vfa1",
+            "vfa2", "vfa3"]
+
+
+def clobbers():
+    return [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in range(NS_LO, NS_HI)] + ["vcc", "memory"]
+
+
+def write_inc(path):
+    lines = generate()
+    with open(path, "w") as f:
+        f.write("// GENERATED by csrc/gen/flash72_gen.py — do not edit (tests/test_flash72_asm_cpu.py regenerates and compares).\n")
+        f.write("// The tile loop of flash_attn_d72_w64_kernel as ONE asm statement; register map and schedule: see the generator.\n")
+        f.write("#define FLASH72_W64_ASM \\\n")
+        for ln in lines:
+            f.write('  "' + ln + '\\n\\t" \\\n')
+        f.write('  ""\n')
+        f.write("#define FLASH72_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers()) + "\n")
+    return lines
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(here), "flash72_w64_asm.inc")
+    lines = write_inc(out)
+    n_mfma = sum(1 for ln in lines if ln.startswith("v_mfma"))
+    print(f"{out}: {len(lines)} lines, {n_mfma} MFMA")
