@@ -30,7 +30,7 @@ def test_committed_include_is_what_the_generator_emits(tmp_path):
 def test_steady_state_gaps_hold_at_most_five_fillers():
     import flash72_gen as G
 
-    lines = G.generate()
+    lines = G.generate(1)       # the shipped placement variant (attention.hip W64_DEFAULT_VAR)
     top, tail = lines.index("TOP_%=:"), lines.index("TAIL0_%=:")
     loop = [ln for ln in lines[top:tail] if not ln.endswith(":")]
     gaps, cur, seen = [], 0, False
@@ -44,7 +44,7 @@ def test_steady_state_gaps_hold_at_most_five_fillers():
     n_mfma = sum(1 for ln in loop if ln.startswith("v_mfma"))
     assert n_mfma == 88                      # two tiles of 44 per trip of the unrolled loop
     # phase boundaries (wait + barrier, loop control, the branch to the rare rescale block) are the only longer gaps
-    assert sorted(gaps)[-5] <= 5 and max(gaps) <= 12, sorted(gaps)[-8:]
+    assert sorted(gaps)[-9] <= 5 and max(gaps) <= 12, sorted(gaps)[-12:]
     assert sum(gaps) / len(gaps) <= 4.6
 
 
@@ -55,11 +55,12 @@ def test_steady_state_gaps_hold_at_most_five_fillers():
     (448, False, 1.0, False, True, [3, 2, 1, 0]),
     (384, False, 6.0, True, True, [3, 2, 1, 0]),    # large logits: the branch fires on most tiles
 ])
-def test_emulated_workgroup_matches_numpy_attention(kv_len, spike, qscale, late_vm, late_ds, order):
+@pytest.mark.parametrize("variant", [0, 1, 3])
+def test_emulated_workgroup_matches_numpy_attention(kv_len, spike, qscale, late_vm, late_ds, order, variant):
     import flash72_emu_case as C
 
     with np.errstate(all="ignore"):
-        err, viol, stats = C.run(kv_len, spike=spike, qscale=qscale, late_vm=late_vm, late_ds=late_ds, order=order)
+        err, viol, stats = C.run(kv_len, spike=spike, qscale=qscale, late_vm=late_vm, late_ds=late_ds, order=order, variant=variant)
     assert not viol, viol[:5]
     assert err <= 2.0**-8, err
     if spike or qscale > 1.0:

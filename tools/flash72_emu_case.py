@@ -49,10 +49,10 @@ def to_bytes_bf16(x):
     return E.bf16_round(x).astype(np.uint16).view(np.uint8).reshape(-1)
 
 
-def run(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qscale=1.0, lb=0):
+def run(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qscale=1.0, lb=0, variant=1):
     q, k, vt, kv_pad = make_case(kv_len, seed, spike, qscale)
     ntiles = (kv_len + 63) // 64
-    lines = G.generate()
+    lines = G.generate(variant)
     kbytes = to_bytes_bf16(k)
     vbytes = to_bytes_bf16(vt)
     rs_k, rs_v = E.Rsrc(kbytes, kv_pad * HD * 2), E.Rsrc(vbytes, 96 * kv_pad * 2)

@@ -61,6 +61,8 @@ def main():
     mod = rnd(2, 6 * C, scale=0.3)
     shapes = [("qkv", 3 * C, C, ops.EPI_BIAS), ("proj", C, C, ops.EPI_GATE_RES), ("fc1", 4 * C, C, ops.EPI_BIAS_GELU),
               ("fc2", C, 4 * C, ops.EPI_GATE_RES), ("crossq", C, C, ops.EPI_BIAS)]
+    if args.only == "flash":
+        shapes = []
     bufs = {}
     for name, n, k, epi in shapes:
         bufs[name] = (rnd(n, k, scale=1 / math.sqrt(k)), rnd(n, scale=0.1), torch.empty(N, n, dtype=torch.bfloat16, device=dev))
@@ -124,7 +126,7 @@ def main():
     kv = rnd(600, 2 * C)
     kpc, vtc = ops.alloc_kv_buffers(2, H, 300, dev)
     ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kpc, vtc, 2, H, 300)
-    for rd in range(args.rounds):
+    for rd in range(0 if os.environ.get("VSYS_KB_SPATIAL_ONLY") else args.rounds):
         for fv in [int(v) for v in args.flash_variants.split(',')]:
             assert lib.vsys_tune_flash_variant(fv) == 0
             ms = timeit(lambda: ops.flash_attn(x, None, kpc, vtc, ao, 2, H, 19456, 300), args.reps)
@@ -141,6 +143,8 @@ def main():
         ops.flash_attn(x, None, kpc, vtc, o2, 2, H, 19456, 300)
         print(f"  check flash variant {fv} == default: spatial {bool(torch.equal(o1, ref_s))}, cross {bool(torch.equal(o2, ref_c))}")
     lib.vsys_tune_flash_variant(0)
+    if args.only == "flash":
+        return report(res)
     freqs = 1.0 / (10000 ** (torch.arange(0, 72, 2).float() / 72))
     ang = torch.einsum("p,f->pf", torch.arange(19).float(), freqs).repeat_interleave(2, -1)
     cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)

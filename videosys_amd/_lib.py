@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvideosys_amd.so")
+# (VSYS_LIB: another build of the same library, e.g. the -DVSYS_LAB flavour the measurement tools load; never a fallback)
+LIB_PATH = os.environ.get("VSYS_LIB") or os.path.join(_HERE, "libvideosys_amd.so")
 
 _i64, _f32, _ptr, _int = ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
 

@@ -46,6 +46,8 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, unsigned bytes) {
   return r;
 }
 
+// VAR: placement variant of the LDS-DMA pieces inside the tile loop (flash72_gen.py body()); same arithmetic, same bits
+template <int VAR>
 __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Params p) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -157,12 +159,29 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
 #undef QW
 
   // ---- the tile loop
+#define W64_LOOP(TEXT_)                                                                                                          \
+  asm volatile(TEXT_                                                                                                             \
+               :                                                                                                                 \
+               : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [r4] "s"(rsrc_4), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [s4] "s"(s4), \
+                 [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff), \
+                 [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)       \
+               : FLASH72_W64_CLOBBERS)
+  if constexpr (VAR == 0) W64_LOOP(FLASH72_W64_ASM_V0);
+  else if constexpr (VAR == 1) W64_LOOP(FLASH72_W64_ASM_V1);
+  else if constexpr (VAR == 3) W64_LOOP(FLASH72_W64_ASM_V3);
+#ifdef VSYS_LAB
+  else if constexpr (VAR == 8) W64_LOOP(FLASH72_W64_ASM_V8);
+  else if constexpr (VAR == 9) W64_LOOP(FLASH72_W64_ASM_V9);
+#endif
+#undef W64_LOOP
+#if 0
   asm volatile(FLASH72_W64_ASM
                :
                : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [r4] "s"(rsrc_4), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [s4] "s"(s4),
                  [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff),
                  [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)
                : FLASH72_W64_CLOBBERS);
+#endif
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi; 16-byte stores through
   // v_permlane32_swap (as flash_attn_d72_kernel::store_o)
@@ -217,8 +236,18 @@ bool flash_w64_supports(int q_len, int kv_len, int kv_pad) {
   return kv_len >= 256 && q_len >= 256;   // >= 4 tiles of 64 keys, at least one full 256-row workgroup
 }
 
+template <int VAR>
+static int launch_w64_t(const FlashW64Params& p, unsigned nblk, size_t lds, hipStream_t stream) {
+  static std::atomic<unsigned long long> attr_seen{0};
+  if (first_use_on_this_device(attr_seen))
+    (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(flash_attn_d72_w64_kernel<VAR>, dim3(nblk), dim3(256), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
 int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
-                              int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, hipStream_t stream) {
+                              int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, int var,
+                              hipStream_t stream) {
   FlashW64Params p;
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
@@ -226,11 +255,16 @@ int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
   if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = (size_t)W64_STAGES * KV_STAGE;
-  static std::atomic<unsigned long long> attr_seen{0};
-  if (first_use_on_this_device(attr_seen))
-    (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(flash_attn_d72_w64_kernel, dim3((unsigned)nblk), dim3(256), lds, stream, p);
-  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  switch (var) {
+    case 0: return launch_w64_t<0>(p, (unsigned)nblk, lds, stream);
+    case 1: return launch_w64_t<1>(p, (unsigned)nblk, lds, stream);
+    case 3: return launch_w64_t<3>(p, (unsigned)nblk, lds, stream);
+#ifdef VSYS_LAB
+    case 8: return launch_w64_t<8>(p, (unsigned)nblk, lds, stream);
+    case 9: return launch_w64_t<9>(p, (unsigned)nblk, lds, stream);
+#endif
+    default: return VSYS_ERR_ARG;
+  }
 }
 
 }  // namespace vsys
