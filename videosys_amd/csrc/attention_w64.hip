@@ -32,6 +32,7 @@ struct FlashW64Params {
   bf16_t* out; int64_t out_stride;
   int heads, q_len, kv_len, kv_pad, nqb;
   float eps;
+  unsigned long long* dbg;   // lab variant 7: per wave 8 s_memtime stamps
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (VAR == 7) stamp[0] = __builtin_amdgcn_s_memtime();
   const int tile_id = xcd_remap(blockIdx.x, gridDim.x);   // the q-blocks of one (batch, head) are consecutive on one XCD
   const int bh = tile_id / p.nqb, qb = tile_id - bh * p.nqb;
   const int b = bh / p.heads, h = bh - b * p.heads;
@@ -170,6 +173,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
   else if constexpr (VAR == 1) W64_LOOP(FLASH72_W64_ASM_V1);
   else if constexpr (VAR == 3) W64_LOOP(FLASH72_W64_ASM_V3);
 #ifdef VSYS_LAB
+  else if constexpr (VAR == 7) {
+    asm volatile(FLASH72_W64_ASM_V7
+                 : [t0] "=s"(stamp[1]), [t1] "=s"(stamp[2]), [t2] "=s"(stamp[3])
+                 : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [r4] "s"(rsrc_4), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [s4] "s"(s4),
+                   [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff),
+                   [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)
+                 : FLASH72_W64_CLOBBERS);
+    stamp[4] = __builtin_amdgcn_s_memtime();
+  }
   else if constexpr (VAR == 8) W64_LOOP(FLASH72_W64_ASM_V8);
   else if constexpr (VAR == 9) W64_LOOP(FLASH72_W64_ASM_V9);
 #endif
@@ -225,6 +237,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
       }
     }
   }
+  if constexpr (VAR == 7) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left
+    stamp[5] = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && p.dbg != nullptr) {
+      unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) d[i] = stamp[i];
+    }
+  }
 #endif
 }
 
@@ -251,6 +272,7 @@ int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q
   FlashW64Params p;
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
+  p.dbg = reinterpret_cast<unsigned long long*>(get_lab_debug_buffer());
   p.nqb = (q_len + 255) / 256;
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
   if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
@@ -260,6 +282,7 @@ int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q
     case 1: return launch_w64_t<1>(p, (unsigned)nblk, lds, stream);
     case 3: return launch_w64_t<3>(p, (unsigned)nblk, lds, stream);
 #ifdef VSYS_LAB
+    case 7: return launch_w64_t<7>(p, (unsigned)nblk, lds, stream);
     case 8: return launch_w64_t<8>(p, (unsigned)nblk, lds, stream);
     case 9: return launch_w64_t<9>(p, (unsigned)nblk, lds, stream);
 #endif

@@ -41,7 +41,7 @@ NV = 210        # v0..v209 are the asm's
 NA = 224        # a0..a223
 # scalar registers of the asm (clobbered): s40..s63
 S_CNT, S_ST, S_ST2, S_T, S_KA, S_KB, S_VC, S_VD, S_E, S_DST, S_WRAP, S_T2 = range(40, 52)
-NS_LO, NS_HI = 40, 52
+NS_LO, NS_HI = 40, 58
 
 
 def v(i, n=1):
@@ -399,7 +399,13 @@ def prologue(e):
 def generate(variant=0):
     e = Emit()
     resc = []
+    stamps = variant == 7      # lab: s_memtime at the start of the statement, at the loop head and at the end (variant 1 otherwise)
+    if stamps:
+        variant = 1
+        e("s_memtime s[52:53]")
     prologue(e)
+    if stamps:
+        e("s_memtime s[54:55]")
     e.label("TOP_%=")
     e(f"s_cmp_eq_u32 {s(S_CNT)}, 0")
     e("s_cbranch_scc1 TAIL0_%=")
@@ -423,6 +429,12 @@ def generate(variant=0):
     e.label("END_%=")
     e("s_waitcnt vmcnt(0)")
     e("s_nop 15")    # the last PV MFMAs -> the v_accvgpr_read of the epilogue (a separate asm statement)
+    if stamps:
+        e("s_memtime s[56:57]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 %[t0], s[52:53]")
+        e("s_mov_b64 %[t1], s[54:55]")
+        e("s_mov_b64 %[t2], s[56:57]")
     return e.lines
 
 
@@ -434,7 +446,7 @@ def clobbers():
     return [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in range(NS_LO, NS_HI)] + ["vcc", "memory"]
 
 
-VARIANTS = (0, 1, 3, 8, 9)   # 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
+VARIANTS = (0, 1, 3, 7, 8, 9)   # 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
 
 
 def write_inc(path):
