@@ -86,11 +86,11 @@ def test_w64_flash_kernel_owns_its_accumulator_registers(tmp_path):
     import subprocess
 
     u = _usage("attention_w64.hip")
-    hits = {k: v for k, v in u.items() if "flash_attn_d72_w64_kernel" in k}
-    assert len(hits) == 1
-    res = next(iter(hits.values()))
-    assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) == 0, res
-    assert res.get("VGPRs", 0) <= 256 and res.get("AGPRs", 0) == 224, res
+    hits = {k: v for k, v in u.items() if "flash_attn_d72_w64" in k}
+    assert len(hits) >= 4      # the three placement variants + the persistent form
+    for name, res in hits.items():
+        assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) == 0, (name, res)
+        assert res.get("VGPRs", 0) <= 256 and res.get("AGPRs", 0) == 224, (name, res)
     out = str(tmp_path / "w64.s")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
                     os.path.join(CSRC, "attention_w64.hip")], check=True, capture_output=True)

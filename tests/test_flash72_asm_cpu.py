@@ -66,3 +66,21 @@ def test_emulated_workgroup_matches_numpy_attention(kv_len, spike, qscale, late_
     if spike or qscale > 1.0:
         assert stats["counts"].get("v_accvgpr_read_b32", 0) >= 96, "the rescale branch was never taken"
     assert stats["barriers"] == 2 + (kv_len + 63) // 64 - 1
+
+
+@pytest.mark.parametrize("kv_len,nitems,late_vm,late_ds,order", [
+    (256, 3, True, True, None),               # 4 tiles per item: the descriptor switch precedes the first tile
+    (512, 3, False, False, [3, 2, 1, 0]),
+    (1024, 2, True, False, None),             # the config-2 spatial length
+    (256, 4, False, True, [3, 2, 1, 0]),
+])
+def test_emulated_persistent_walk_matches_numpy_attention(kv_len, nitems, late_vm, late_ds, order):
+    """The persistent form (FLASH72_W64P_ASM): consecutive items on one workgroup state — tiles 0..3 and the Q rows of item k+1 are
+    fetched by the tail of item k, K / Vt change between items, the output stores of item k are still in flight when item k+1
+    starts, the last item's tail issues zero-length pieces."""
+    import flash72_emu_case as C
+
+    with np.errstate(all="ignore"):
+        errs, viol, stats = C.run_persist(kv_len, nitems=nitems, late_vm=late_vm, late_ds=late_ds, order=order, spike=True, qscale=2.0)
+    assert not viol, viol[:5]
+    assert max(errs) <= 2.0**-8, errs

@@ -500,6 +500,47 @@ def test_flash_w64_matches_default_and_torch(ops, q_len, kv_len, heads, batch, n
             check(base[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"32-row flash b{bi} h{h}")
 
 
+@pytest.mark.parametrize("q_len,kv_len,heads,batch,norm,qscale", [
+    (1024, 1024, 16, 10, True, 1.0),    # 640 items on 256 workgroups: every workgroup walks 2-3 items, K / Vt change inside a walk
+    (700, 512, 16, 12, False, 1.0),     # 576 items, ragged last query block of every (batch, head)
+    (512, 256, 8, 40, True, 1.0),       # 4 tiles per item: the descriptor switch happens before the first tile of every item
+    (1024, 1024, 2, 2, False, 2.5),     # fewer items than CUs; the deferred-rescale branch fires
+])
+def test_flash_w64_persistent_matches_one_item_kernel(ops, q_len, kv_len, heads, batch, norm, qscale):
+    """flash variant 16 (the persistent form of the w64 kernel: one workgroup per CU walks (batch, head, query block) items, the tail
+    of an item's tile loop prefetches the next item's tiles and Q rows) against variant 14 (one item per workgroup, same instruction
+    stream per tile): the same bits, whatever the walk; and torch fp32 SDPA on sampled (batch, head) pairs."""
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    C = heads * 72
+    g = torch.Generator().manual_seed(q_len + kv_len + heads)
+    q = (torch.randn(batch * q_len, C, generator=g) * qscale).to(torch.bfloat16).to(dev())
+    k = (torch.randn(batch * kv_len, C, generator=g) * qscale).to(torch.bfloat16).to(dev())
+    v = torch.randn(batch * kv_len, C, generator=g).to(torch.bfloat16).to(dev())
+    qw = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16).to(dev()) if norm else None
+    kw_ = (1 + 0.1 * torch.randn(72, generator=g)).to(torch.bfloat16).to(dev()) if norm else None
+    try:
+        assert lib.vsys_tune_flash_variant(14) == 0
+        base = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        assert lib.vsys_tune_flash_variant(16) == 0
+        res = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        res2 = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        torch.cuda.synchronize()
+    finally:
+        lib.vsys_tune_flash_variant(0)
+    assert torch.equal(res, res2), "two launches of the persistent kernel differ (a race)"
+    assert torch.equal(res, base), f"persistent form differs from the one-item kernel: max {float((res.float() - base.float()).abs().max()):.3e}"
+    for bi, h in ((0, 0), (batch - 1, heads - 1), (batch // 2, heads // 2)):
+        qq = q[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72]
+        kk = k[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72]
+        vv = v[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72].float()
+        if norm:
+            qq, kk = O.rms_norm(qq, qw.float()), O.rms_norm(kk, kw_.float())
+        ref = O.sdpa(qq.float()[None], kk.float()[None], vv[None])[0]
+        check(res[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"persistent w64 flash b{bi} h{h}")
+
+
 def test_attn_config2_sizes_vs_torch(ops):
     """Config-2 geometry for one CFG sample slice: spatial (frames x 1024 tokens, 16 heads) vs torch fp32 SDPA on the
     GPU for sampled (frame, head) pairs, plus the softmax-of-constant-V property on everything."""

@@ -55,7 +55,7 @@ def run(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qsc
     lines = G.generate(variant)
     kbytes = to_bytes_bf16(k)
     vbytes = to_bytes_bf16(vt)
-    rs_k, rs_v = E.Rsrc(kbytes, kv_pad * HD * 2), E.Rsrc(vbytes, 96 * kv_pad * 2)
+    KID, VID = (0x1000, 1), (0x2000, 2)
     lane = np.arange(64)
     l31, hi = lane & 31, lane >> 5
     binds = []
@@ -74,7 +74,10 @@ def run(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qsc
     for w, wave in enumerate(wg.waves):
         s4k = w == 0
         s4j = 8 if w == 1 else 9
-        wg.rsrc[4], wg.rsrc[8] = rs_k, rs_v
+        wg.bufs[KID], wg.bufs[VID] = kbytes, vbytes
+        r4 = KID if s4k else VID
+        wave.s.update({4: KID[0], 5: KID[1], 6: kv_pad * HD * 2, 7: 0x20000, 8: VID[0], 9: VID[1], 10: 96 * kv_pad * 2, 11: 0x20000,
+                       12: r4[0], 13: r4[1], 14: kv_pad * HD * 2 if s4k else 96 * kv_pad * 2, 15: 0x20000})
         wave.s.update({16: w * 1024, 17: w * 8 * kv_pad * 2, 18: (w + 4) * 8 * kv_pad * 2, 19: 8 * 1024 if s4k else s4j * 8 * kv_pad * 2,
                        20: K_TILE if s4k else 128, 21: 8 * 1024 if s4k else K_TILE + s4j * 1024, 22: lb, 23: ntiles})
         k_voff = lane * 16
@@ -96,25 +99,7 @@ def run(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qsc
                     lo = np.where(d < HD, E.bf16_round(q[rows, np.minimum(d, HD - 1)]), 0)
                     hi_ = np.where(d + 1 < HD, E.bf16_round(q[rows, np.minimum(d + 1, HD - 1)]), 0)
                     wave.a[96 + 20 * blk + 4 * c + j] = (lo | (hi_ << 16)).astype(np.uint32)
-    # slot-4 descriptor differs per wave: the emulator keys descriptors by their first SGPR, so step waves with their own table
-    viol = []
-    wg_r4 = {0: rs_k, 1: rs_v, 2: rs_v, 3: rs_v}
-
-    class RsrcView(dict):
-        pass
-
-    # run with a per-wave view of s[12:15]
-    orig_run = E.Wave.run_until_barrier
-
-    def run_wave(self):
-        self.wg.rsrc[12] = wg_r4[self.wid]
-        return orig_run(self)
-
-    E.Wave.run_until_barrier = run_wave
-    try:
-        viol = wg.run(order=order)
-    finally:
-        E.Wave.run_until_barrier = orig_run
+    viol = wg.run(order=order)
     # epilogue: O^T[d][q] / l
     out = np.zeros((256, HD), dtype=np.float32)
     for w, wave in enumerate(wg.waves):
@@ -141,3 +126,119 @@ if __name__ == "__main__":
         print("  ", x)
     c = stats["counts"]
     print({k: c[k] for k in sorted(c) if c[k] > 20})
+
+
+def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None, qscale=1.0, spike=False, switch_kv_at=2):
+    """``nitems`` consecutive work items of one workgroup in the PERSISTENT form (FLASH72_W64P_ASM): items < switch_kv_at share one
+    (batch, head)'s K / Vt, the others use a second one; every item has its own 256 query rows.  Between the statements the numpy
+    code does what the C++ of flash_attn_d72_w64p_kernel does: Q(k) from the wave's LDS image into a[96:135], O read-out, output
+    stores (as operations in flight: the next statement's opening wait has to cover them)."""
+    assert kv_len % 256 == 0
+    ntiles = kv_len // 64
+    kv_pad = kv_len
+    cases = [make_case(kv_len, seed + 17 * j, spike and j == 1, qscale) for j in range(nitems)]
+    kvsets = [cases[0], cases[-1]]                      # two (batch, head)s
+    kv_of = [0 if j < switch_kv_at else 1 for j in range(nitems)]
+    lines = G.generate(1, persist=True)
+    lane = np.arange(64)
+    l31, hi = lane & 31, lane >> 5
+    binds = []
+    for w in range(4):
+        binds.append({"kb": "s[4:5]", "vb": "s[6:7]", "kbn": "s[8:9]", "vbn": "s[10:11]", "rqn": "s[12:15]", "wl": "s16", "kvp2": "s17",
+                      "hn": "s18", "s4": "s19", "st4": "s20", "l4": "s21", "lb": "s22", "nt": "s23", "qlds": "s24", "lim": "v210",
+                      "kvo": "v211", "vvo": "v212", "v4o": "v213", "kfa": "v214", "vfa0": "v215", "vfa1": "v216", "vfa2": "v217",
+                      "vfa3": "v218", "qvo": "v219"})
+    wg = E.Workgroup(lines, binds, late_vm=late_vm, late_ds=late_ds)
+    wg.lds[:] = 0xAB
+    lb, QBASE = 0, 4 * STAGE
+    for st in range(4):
+        o = lb + st * STAGE + K_TILE + 80 * VROW
+        wg.lds[o:o + 16 * VROW] = 0
+    ids = {}
+    for j, (q, k, vt, _) in enumerate(kvsets):
+        ids[("k", j)], ids[("v", j)] = (0x1000 + j, 1), (0x2000 + j, 2)
+        wg.bufs[ids[("k", j)]], wg.bufs[ids[("v", j)]] = to_bytes_bf16(k), to_bytes_bf16(vt)
+    for j in range(nitems):
+        ids[("q", j)] = (0x3000 + j, 3)
+        wg.bufs[ids[("q", j)]] = to_bytes_bf16(cases[j][0])
+
+    def dma_piece(wave, buf, nrec, goff, lds_addr):
+        data = np.zeros((64, 16), dtype=np.uint8)
+        for l in range(64):
+            if 0 <= goff[l] and goff[l] + 16 <= nrec:
+                data[l] = buf[goff[l]:goff[l] + 16]
+        addr = lds_addr + 16 * lane.astype(np.int64)
+        if late_vm:
+            wave.pend_vm.append((addr, data))
+        else:
+            wg.lds_write(addr, data)
+            wave.pend_vm.append((addr, None))
+
+    # ---- kernel entry (C++): Q(0) and tiles 0..3 of item 0 by LDS-DMA
+    for w, wave in enumerate(wg.waves):
+        s4k, s4j = w == 0, (8 if w == 1 else 9)
+        k_voff = lane * 16
+        v_voff0 = (lane >> 3) * kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4)
+        v_voff = v_voff0 ^ ((w & 1) << 6)
+        voff_4 = k_voff if s4k else (v_voff0 ^ ((s4j & 1) << 6))
+        kbuf, vbuf = wg.bufs[ids[("k", 0)]], wg.bufs[ids[("v", 0)]]
+        qbuf = wg.bufs[ids[("q", 0)]]
+        for p in range(9):
+            dma_piece(wave, qbuf, 256 * 144, (64 * w + lane) * 144 + 16 * p, QBASE + w * 9216 + p * 1024)
+        for t in range(4):
+            st = lb + t * STAGE
+            dma_piece(wave, kbuf, kv_pad * 144, k_voff + t * K_TILE + w * 1024, st + w * 1024)
+            dma_piece(wave, kbuf, kv_pad * 144, k_voff + t * K_TILE + (w + 4) * 1024, st + (w + 4) * 1024)
+            dma_piece(wave, vbuf, 96 * kv_pad * 2, v_voff + w * 8 * kv_pad * 2 + t * 128, st + K_TILE + w * 1024)
+            dma_piece(wave, vbuf, 96 * kv_pad * 2, v_voff + (w + 4) * 8 * kv_pad * 2 + t * 128, st + K_TILE + (w + 4) * 1024)
+            if s4k:
+                dma_piece(wave, kbuf, kv_pad * 144, voff_4 + 8 * 1024 + t * K_TILE, st + 8 * 1024)
+            else:
+                dma_piece(wave, vbuf, 96 * kv_pad * 2, voff_4 + s4j * 8 * kv_pad * 2 + t * 128, st + K_TILE + s4j * 1024)
+        krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3)
+        v_roff = K_TILE + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4)
+        for reg, val in ((210, 64 - 16 * hi), (211, k_voff), (212, v_voff), (213, voff_4), (214, krow * KROW + 16 * hi),
+                         (215, v_roff ^ 0), (216, v_roff ^ 16), (217, v_roff ^ 64), (218, v_roff ^ 80), (219, (64 * w + lane) * 144)):
+            wave.v[reg] = np.asarray(val).astype(np.int64).astype(np.uint32)
+        wave.s.update({16: w * 1024, 17: kv_pad * 2, 19: 8 * 1024 if s4k else s4j * 8 * kv_pad * 2, 20: K_TILE if s4k else 128,
+                       21: 8 * 1024 if s4k else K_TILE + s4j * 1024, 22: lb, 23: ntiles, 24: QBASE + w * 9216})
+    errs, viol = [], []
+    for j in range(nitems):
+        has_next = j + 1 < nitems
+        for w, wave in enumerate(wg.waves):
+            wave.wait_vm(0)          # C++: s_waitcnt vmcnt(0) — this wave's Q image has landed
+            kid, vid = ids[("k", kv_of[j])], ids[("v", kv_of[j])]
+            nk, nv = (ids[("k", kv_of[j + 1])], ids[("v", kv_of[j + 1])]) if has_next else ((0, 0), (0, 0))
+            nq = ids[("q", j + 1)] if has_next else (0, 0)
+            wave.s.update({4: kid[0], 5: kid[1], 6: vid[0], 7: vid[1], 8: nk[0], 9: nk[1], 10: nv[0], 11: nv[1],
+                           12: nq[0], 13: nq[1], 14: 256 * 144, 15: 0x20000, 18: 1 if has_next else 0})
+            # Q(j) from the LDS image [chunk][row] -> a[96:135]
+            for blk in range(2):
+                for c in range(5):
+                    ch = 2 * c + hi                       # 16-byte chunk of the row (chunk 9 = d 72..79 does not exist: zero)
+                    addr = QBASE + w * 9216 + np.minimum(ch, 8) * 1024 + (32 * blk + l31) * 16
+                    data = wg.lds_read16(addr.astype(np.int64)).view(np.uint32).reshape(64, 4)
+                    data = np.where((ch < 9)[:, None], data, 0)
+                    for k4 in range(4):
+                        wave.a[96 + 20 * blk + 4 * c + k4] = data[:, k4]
+        wg.bufs[(0, 0)] = np.zeros(16, dtype=np.uint8)
+        wg.load(lines)
+        viol += wg.run(order=order)
+        q, _, _, _ = cases[j]
+        _, k, vt, _ = kvsets[kv_of[j]]
+        out = np.zeros((256, HD), dtype=np.float32)
+        for w, wave in enumerate(wg.waves):
+            for blk in range(2):
+                base = 48 * blk
+                l_ = E.f32(wave.a[base + 32 + 4])
+                for dt in range(3):
+                    for r in range(16):
+                        d = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * hi
+                        val = E.f32(wave.a[base + 16 * dt + r]) / l_
+                        ok = d < HD
+                        out[(64 * w + 32 * blk + l31)[ok], d[ok]] = val[ok]
+            for _ in range(10):                            # the output stores of the epilogue: operations in flight
+                wave.pend_vm.append((None, None))
+        ref = reference(q, k, vt, kv_len)
+        errs.append(float(np.abs(out - ref).max() / np.abs(ref).max()))
+    return errs, viol, {"barriers": wg.waves[0].nbarrier, "counts": wg.waves[0].count}

@@ -202,8 +202,9 @@ class Wave:
         prog = self.wg.prog
         while True:
             if self.pc >= len(prog):
-                self.wait_vm(0)
-                self.wait_lgkm(0)
+                if getattr(self, "drain_at_end", True):
+                    self.wait_vm(0)
+                    self.wait_lgkm(0)
                 self.done = True
                 return "done"
             text, op, args = prog[self.pc]
@@ -243,6 +244,19 @@ class Wave:
                 self.m0_t = self.t
             else:
                 self.s[parse_reg(A[0])[1]] = val
+            return
+        if op in ("s_mul_i32", "s_lshr_b32", "s_lshl_b32"):
+            x, y = self.ssrc(A[1]), self.ssrc(A[2])
+            val = {"s_mul_i32": x * y, "s_lshr_b32": x >> (y & 31), "s_lshl_b32": x << (y & 31)}[op] & 0xFFFFFFFF
+            self.s[parse_reg(A[0])[1]] = val
+            return
+        if op in ("s_mov_b64", "s_cselect_b64"):
+            _, d0, n = parse_reg(A[0])
+            assert n == 2
+            src = A[1] if (op == "s_mov_b64" or self.scc) else A[2]
+            _, s0, n2 = parse_reg(src)
+            assert n2 == 2
+            self.s[d0], self.s[d0 + 1] = self.s[s0], self.s[s0 + 1]
             return
         if op in ("s_cmp_eq_u32", "s_cmp_ge_u32", "s_cmp_lt_u32"):
             x, y = self.ssrc(A[0]), self.ssrc(A[1])
@@ -360,13 +374,15 @@ class Wave:
             assert n == 4
             if self.t - self.m0_t - 1 < 1:
                 self.viol("LDS-DMA issued right behind the M0 write (need 1 wait state)")
-            rsrc = wg.rsrc[rs]
+            # descriptor = 4 SGPRs: words 0..1 name a buffer of the table (a fake address), word 2 = num_records
+            buf = wg.bufs[(int(self.s[rs]), int(self.s[rs + 1]))]
+            nrec = int(self.s[rs + 2])
             soff = self.ssrc(A[2])
             goff = v[vo].astype(np.int64) + soff
             data = np.zeros((64, 16), dtype=np.uint8)
             for l in range(64):
-                if 0 <= goff[l] and goff[l] + 16 <= rsrc.n:
-                    data[l] = rsrc.data[goff[l]:goff[l] + 16]
+                if 0 <= goff[l] and goff[l] + 16 <= nrec:
+                    data[l] = buf[goff[l]:goff[l] + 16]
             addr = self.m0 + 16 * np.arange(64, dtype=np.int64)   # (gfx950: M0 carries the full LDS byte address; the GEMM kernels of this repo DMA beyond 64 KiB)
             if wg.late_vm:
                 self.pend_vm.append((addr, data))
@@ -426,7 +442,7 @@ class Workgroup:
     def __init__(self, lines, binds, nwaves=4, lds_bytes=160 * 1024, late_vm=True, late_ds=True):
         self.late_vm, self.late_ds = late_vm, late_ds
         self.lds = np.zeros(lds_bytes, dtype=np.uint8)
-        self.rsrc = {}
+        self.bufs = {}                  # (address word 0, word 1) -> uint8 array (buffer descriptors name them)
         self.labels = {}
         self.prog = []
         for ln in lines:
@@ -459,7 +475,7 @@ class Workgroup:
         return out
 
     def lds_write(self, addr, data):
-        if data is None:
+        if data is None or addr is None:
             return
         for l in range(64):
             self.lds[addr[l]:addr[l] + 16] = data[l]
@@ -469,6 +485,22 @@ class Workgroup:
         for l in range(64):
             out[l] = self.lds[addr[l]:addr[l] + 16]
         return out
+
+    def load(self, lines):
+        """another asm statement on the same workgroup state (registers, LDS, operations in flight carry over)"""
+        self.labels = {}
+        self.raw = []
+        for ln in lines:
+            ln = ln.strip()
+            if not ln or ln.startswith(";"):
+                continue
+            ln = ln.replace("_%=", "")
+            if ln.endswith(":"):
+                self.labels[ln[:-1]] = len(self.raw)
+                continue
+            self.raw.append(ln)
+        for w in self.waves:
+            w.pc, w.done, w.drain_at_end = 0, False, False
 
     def run(self, order=None, max_rounds=100000):
         order = order or list(range(len(self.waves)))

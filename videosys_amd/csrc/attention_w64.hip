@@ -249,6 +249,227 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Persistent form: gridDim.x workgroups (one per CU) walk the (batch, head, 256-row query block) items in contiguous ranges.
+// What an item pays at its seams in the one-item-per-workgroup kernel above (stamps, profiles/r04_flash_w64_stamps_nonpersistent.json:
+// 11k cycles of Q fetch + norm, 4.3k of LDS-DMA issue + landing + pipeline fill, 3.5k of output stores against 27k in the tile loop,
+// none of it covered at one workgroup per CU) is taken out of the seam where it can be: the tail of an item's tile loop already
+// fetches the NEXT item's first four K / Vt tiles and its Q rows (LDS-DMA into a wave-private [chunk][row] image), so an item
+// starts with everything on chip.  Whole tiles only (kv_len % 256 == 0: the ring position of tile 0 is then the same for every item).
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int W64P_QIMG = 64 * KROW;   // 9216 bytes per wave: 9 chunks x 64 rows x 16 B
+
+__device__ __forceinline__ unsigned long long uniform_addr(const void* ptr) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi_ = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);
+  return ((unsigned long long)hi_ << 32) | lo;
+}
+
+__global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Params p, int total_items) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wgp = xcd_remap(blockIdx.x, gridDim.x);    // consecutive item ranges on one XCD: the query blocks of a (batch, head) share L2
+  const int i0 = (int)((int64_t)wgp * total_items / (int)gridDim.x), i1 = (int)((int64_t)(wgp + 1) * total_items / (int)gridDim.x);
+  if (i0 >= i1) return;
+
+  const unsigned kbytes = (unsigned)(p.kv_pad * HD * 2), vbytes = (unsigned)(HD_ROWS * p.kv_pad * 2);
+  const bool s4k = wave_u == 0;
+  const int s4j = wave_u == 1 ? 8 : 9;
+  const int k_voff = lane * 16;
+  const int v_voff0 = (lane >> 3) * p.kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4);
+  const int v_voff = v_voff0 ^ ((wave_u & 1) << 6);
+  const int voff_4 = s4k ? k_voff : (v_voff0 ^ ((s4j & 1) << 6));
+  const int wl = wave_u * 1024, kvp2 = p.kv_pad * 2;
+  const int s4 = s4k ? 8 * 1024 : s4j * 8 * p.kv_pad * 2, st4 = s4k ? K_TILE_BYTES : 128;
+  const int l4 = s4k ? 8 * 1024 : K_TILE_BYTES + s4j * 1024;
+  const int lb = (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  const int qlds = lb + W64_STAGES * KV_STAGE + wave_u * W64P_QIMG;
+  const int ntiles = p.kv_len >> 6;
+  for (int u = tid; u < W64_STAGES * 128; u += 256)
+    *reinterpret_cast<uint4*>(smem + (u >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (u & 127) * 16) = make_uint4(0, 0, 0, 0);
+  const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
+  const int kfa = krow * KROW + 16 * hi;
+  const int v_roff = K_TILE_BYTES + l31 * VROW + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4);
+  const int vfa0 = v_roff ^ (0 << 4), vfa1 = v_roff ^ (1 << 4), vfa2 = v_roff ^ (4 << 4), vfa3 = v_roff ^ (5 << 4);
+
+  // what an item needs from the outside: K / Vt of its (batch, head), its Q rows (descriptor over the batch's rows of head h + the
+  // lane's row offset), its output rows
+  auto item_bh = [&](int it) { return it / p.nqb; };
+  auto q_rsrc = [&](int it) {
+    const int bh = item_bh(it), b = bh / p.heads, h = bh - b * p.heads;
+    return make_rsrc(p.q + (int64_t)b * p.q_len * p.q_stride + h * HD, (unsigned)((int64_t)p.q_len * p.q_stride * 2));
+  };
+  auto q_voff = [&](int it) {   // this lane's row of the wave's 64 (clamped at the end of the sequence)
+    const int qb = it - item_bh(it) * p.nqb;
+    int r = qb * 256 + wave * 64 + lane;
+    r = r < p.q_len ? r : p.q_len - 1;
+    return r * (int)p.q_stride * 2;
+  };
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+  // ---- entry: Q rows and the first four tiles of the first item
+  {
+    const int bh = item_bh(i0);
+    const bf16_t* kbase = p.kp + (int64_t)bh * p.kv_pad * HD;
+    const bf16_t* vbase = p.vt + (int64_t)bh * HD_ROWS * p.kv_pad;
+    const auto rk = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)kbytes, 0x00020000);
+    const auto rv = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)vbytes, 0x00020000);
+    const int bq = bh / p.heads, hq = bh - bq * p.heads;
+    const auto rq = __builtin_amdgcn_make_buffer_rsrc((void*)(p.q + (int64_t)bq * p.q_len * p.q_stride + hq * HD), 0,
+                                                      (int)((int64_t)p.q_len * p.q_stride * 2), 0x00020000);
+    const int qv = q_voff(i0);
+#pragma unroll
+    for (int pc = 0; pc < 9; ++pc)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rq, (lds_ptr_t)(smem + W64_STAGES * KV_STAGE + wave_u * W64P_QIMG + pc * 1024), 16, qv, pc * 16, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      char* st = smem + t * KV_STAGE;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(st + wl), 16, k_voff, t * K_TILE_BYTES + wl, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(st + wl + 4096), 16, k_voff, t * K_TILE_BYTES + wl + 4096, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(st + K_TILE_BYTES + wl), 16, v_voff, wave_u * 8 * kvp2 + t * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(st + K_TILE_BYTES + wl + 4096), 16, v_voff, (wave_u + 4) * 8 * kvp2 + t * 128, 0, 0);
+      if (s4k) __builtin_amdgcn_raw_ptr_buffer_load_lds(rk, (lds_ptr_t)(st + l4), 16, voff_4, s4 + t * st4, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(st + l4), 16, voff_4, s4 + t * st4, 0, 0);
+    }
+  }
+
+  for (int it = i0; it < i1; ++it) {
+    const int bh = item_bh(it), qb = it - bh * p.nqb;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int q0 = qb * 256 + wave_u * 64;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q image has landed (nobody else touches it)
+    // ---- Q fragments from the image [chunk][row]: lane holds Q[row][16c + 8hi .. +8] = chunk 2c + hi of row 32 blk + l31
+    unsigned qw[2][20];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      const char* qimg = smem + W64_STAGES * KV_STAGE + wave_u * W64P_QIMG + (32 * blk + l31) * 16;
+      uint4 qraw[5];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const int ch = 2 * c + hi;
+        qraw[c] = ch < 9 ? *reinterpret_cast<const uint4*>(qimg + ch * 1024) : make_uint4(0, 0, 0, 0);
+      }
+      float x[5][8];
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        unpack8(qraw[c], x[c]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
+      }
+      if (p.q_norm_w != nullptr) {
+        ss += __shfl_xor(ss, 32, 64);
+        const float rstd = rsqrtf(ss / (float)HD + p.eps);
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          const int d0 = 16 * c + 8 * hi;
+          if (d0 < HD) {
+            float w[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.q_norm_w + d0), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[c][e] = bf2f(f2bf(x[c][e] * rstd)) * w[e];
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const uint4 pk = pack8(x[c]);
+        qw[blk][4 * c + 0] = pk.x; qw[blk][4 * c + 1] = pk.y; qw[blk][4 * c + 2] = pk.z; qw[blk][4 * c + 3] = pk.w;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image reads are done before the tile loop overwrites it with the next item's rows
+#define QW(b_, i_) "v"(qw[b_][i_])
+    asm volatile(
+        "v_accvgpr_write_b32 a96, %0\n\tv_accvgpr_write_b32 a97, %1\n\tv_accvgpr_write_b32 a98, %2\n\tv_accvgpr_write_b32 a99, %3\n\t"
+        "v_accvgpr_write_b32 a100, %4\n\tv_accvgpr_write_b32 a101, %5\n\tv_accvgpr_write_b32 a102, %6\n\tv_accvgpr_write_b32 a103, %7\n\t"
+        "v_accvgpr_write_b32 a104, %8\n\tv_accvgpr_write_b32 a105, %9\n\tv_accvgpr_write_b32 a106, %10\n\tv_accvgpr_write_b32 a107, %11\n\t"
+        "v_accvgpr_write_b32 a108, %12\n\tv_accvgpr_write_b32 a109, %13\n\tv_accvgpr_write_b32 a110, %14\n\tv_accvgpr_write_b32 a111, %15\n\t"
+        "v_accvgpr_write_b32 a112, %16\n\tv_accvgpr_write_b32 a113, %17\n\tv_accvgpr_write_b32 a114, %18\n\tv_accvgpr_write_b32 a115, %19\n\t"
+        :
+        : QW(0, 0), QW(0, 1), QW(0, 2), QW(0, 3), QW(0, 4), QW(0, 5), QW(0, 6), QW(0, 7), QW(0, 8), QW(0, 9), QW(0, 10), QW(0, 11),
+          QW(0, 12), QW(0, 13), QW(0, 14), QW(0, 15), QW(0, 16), QW(0, 17), QW(0, 18), QW(0, 19)
+        : "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111",
+          "a112", "a113", "a114", "a115");
+    asm volatile(
+        "v_accvgpr_write_b32 a116, %0\n\tv_accvgpr_write_b32 a117, %1\n\tv_accvgpr_write_b32 a118, %2\n\tv_accvgpr_write_b32 a119, %3\n\t"
+        "v_accvgpr_write_b32 a120, %4\n\tv_accvgpr_write_b32 a121, %5\n\tv_accvgpr_write_b32 a122, %6\n\tv_accvgpr_write_b32 a123, %7\n\t"
+        "v_accvgpr_write_b32 a124, %8\n\tv_accvgpr_write_b32 a125, %9\n\tv_accvgpr_write_b32 a126, %10\n\tv_accvgpr_write_b32 a127, %11\n\t"
+        "v_accvgpr_write_b32 a128, %12\n\tv_accvgpr_write_b32 a129, %13\n\tv_accvgpr_write_b32 a130, %14\n\tv_accvgpr_write_b32 a131, %15\n\t"
+        "v_accvgpr_write_b32 a132, %16\n\tv_accvgpr_write_b32 a133, %17\n\tv_accvgpr_write_b32 a134, %18\n\tv_accvgpr_write_b32 a135, %19\n\t"
+        "s_nop 1\n\t"
+        :
+        : QW(1, 0), QW(1, 1), QW(1, 2), QW(1, 3), QW(1, 4), QW(1, 5), QW(1, 6), QW(1, 7), QW(1, 8), QW(1, 9), QW(1, 10), QW(1, 11),
+          QW(1, 12), QW(1, 13), QW(1, 14), QW(1, 15), QW(1, 16), QW(1, 17), QW(1, 18), QW(1, 19)
+        : "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131",
+          "a132", "a133", "a134", "a135");
+#undef QW
+
+    // ---- this item's K / Vt, and what the tail of the loop prefetches for the next one
+    const bool has_next = it + 1 < i1;
+    const int nit = has_next ? it + 1 : it;
+    const int nbh = item_bh(nit);
+    const unsigned long long kb = uniform_addr(p.kp + (int64_t)bh * p.kv_pad * HD), vb = uniform_addr(p.vt + (int64_t)bh * HD_ROWS * p.kv_pad);
+    const unsigned long long kbn = uniform_addr(p.kp + (int64_t)nbh * p.kv_pad * HD), vbn = uniform_addr(p.vt + (int64_t)nbh * HD_ROWS * p.kv_pad);
+    const u32x4 rqn = q_rsrc(nit);
+    const int qvo = q_voff(nit);
+    const int hn = __builtin_amdgcn_readfirstlane(has_next ? 1 : 0);
+    asm volatile(FLASH72_W64P_ASM
+                 :
+                 : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
+                   [s4] "s"(s4), [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [qlds] "s"(qlds), [kvo] "v"(k_voff),
+                   [vvo] "v"(v_voff), [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2),
+                   [vfa3] "v"(vfa3), [qvo] "v"(qvo)
+                 : FLASH72_W64_CLOBBERS);
+
+    // ---- epilogue (as the one-item kernel)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      float o[3][16];
+#define RDO(dt_, r_, reg_) asm volatile("v_accvgpr_read_b32 %0, " reg_ : "=v"(o[dt_][r_]))
+      if (blk == 0) {
+        RDO(0, 0, "a0"); RDO(0, 1, "a1"); RDO(0, 2, "a2"); RDO(0, 3, "a3"); RDO(0, 4, "a4"); RDO(0, 5, "a5"); RDO(0, 6, "a6"); RDO(0, 7, "a7");
+        RDO(0, 8, "a8"); RDO(0, 9, "a9"); RDO(0, 10, "a10"); RDO(0, 11, "a11"); RDO(0, 12, "a12"); RDO(0, 13, "a13"); RDO(0, 14, "a14"); RDO(0, 15, "a15");
+        RDO(1, 0, "a16"); RDO(1, 1, "a17"); RDO(1, 2, "a18"); RDO(1, 3, "a19"); RDO(1, 4, "a20"); RDO(1, 5, "a21"); RDO(1, 6, "a22"); RDO(1, 7, "a23");
+        RDO(1, 8, "a24"); RDO(1, 9, "a25"); RDO(1, 10, "a26"); RDO(1, 11, "a27"); RDO(1, 12, "a28"); RDO(1, 13, "a29"); RDO(1, 14, "a30"); RDO(1, 15, "a31");
+        RDO(2, 0, "a32"); RDO(2, 1, "a33"); RDO(2, 2, "a34"); RDO(2, 3, "a35"); RDO(2, 4, "a36"); RDO(2, 5, "a37"); RDO(2, 6, "a38"); RDO(2, 7, "a39");
+        RDO(2, 8, "a40"); RDO(2, 9, "a41"); RDO(2, 10, "a42"); RDO(2, 11, "a43"); RDO(2, 12, "a44"); RDO(2, 13, "a45"); RDO(2, 14, "a46"); RDO(2, 15, "a47");
+      } else {
+        RDO(0, 0, "a48"); RDO(0, 1, "a49"); RDO(0, 2, "a50"); RDO(0, 3, "a51"); RDO(0, 4, "a52"); RDO(0, 5, "a53"); RDO(0, 6, "a54"); RDO(0, 7, "a55");
+        RDO(0, 8, "a56"); RDO(0, 9, "a57"); RDO(0, 10, "a58"); RDO(0, 11, "a59"); RDO(0, 12, "a60"); RDO(0, 13, "a61"); RDO(0, 14, "a62"); RDO(0, 15, "a63");
+        RDO(1, 0, "a64"); RDO(1, 1, "a65"); RDO(1, 2, "a66"); RDO(1, 3, "a67"); RDO(1, 4, "a68"); RDO(1, 5, "a69"); RDO(1, 6, "a70"); RDO(1, 7, "a71");
+        RDO(1, 8, "a72"); RDO(1, 9, "a73"); RDO(1, 10, "a74"); RDO(1, 11, "a75"); RDO(1, 12, "a76"); RDO(1, 13, "a77"); RDO(1, 14, "a78"); RDO(1, 15, "a79");
+        RDO(2, 0, "a80"); RDO(2, 1, "a81"); RDO(2, 2, "a82"); RDO(2, 3, "a83"); RDO(2, 4, "a84"); RDO(2, 5, "a85"); RDO(2, 6, "a86"); RDO(2, 7, "a87");
+        RDO(2, 8, "a88"); RDO(2, 9, "a89"); RDO(2, 10, "a90"); RDO(2, 11, "a91"); RDO(2, 12, "a92"); RDO(2, 13, "a93"); RDO(2, 14, "a94"); RDO(2, 15, "a95");
+      }
+#undef RDO
+      const float inv = 1.0f / o[2][4];
+      const int qs = q0 + 32 * blk + l31;
+      bf16_t* orow = p.out + ((int64_t)b * p.q_len + (qs < p.q_len ? qs : p.q_len - 1)) * p.out_stride + h * HD + 8 * hi;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt) {
+        uint2 w[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          w[g].x = pack2bf(o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv);
+          w[g].y = pack2bf(o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const auto sx = __builtin_amdgcn_permlane32_swap(w[2 * k].x, w[2 * k + 1].x, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(w[2 * k].y, w[2 * k + 1].y, false, false);
+          const int d0 = dt * 32 + 16 * k;
+          if (qs < p.q_len && d0 + 8 * hi + 8 <= HD) *reinterpret_cast<uint4*>(orow + d0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (zero-length pieces of the last item's tail: nothing may be in flight when the LDS is released)
+#endif
+}
+
 }  // namespace
 
 // true when the w64 kernel takes the problem (launch_flash_attn_d72 falls back to flash_attn_d72_kernel otherwise)
@@ -263,6 +484,30 @@ static int launch_w64_t(const FlashW64Params& p, unsigned nblk, size_t lds, hipS
   if (first_use_on_this_device(attr_seen))
     (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(flash_attn_d72_w64_kernel<VAR>, dim3(nblk), dim3(256), lds, stream, p);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+// persistent form: whole 256-key groups only, 32-bit Q row offsets
+bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride) {
+  return kv_len >= 256 && kv_len % 256 == 0 && kv_pad == kv_len && q_len >= 256 && (int64_t)q_len * q_stride * 2 < 0x7fffffff;
+}
+
+int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
+                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, hipStream_t stream) {
+  FlashW64Params p;
+  p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
+  p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
+  p.dbg = nullptr;
+  p.nqb = (q_len + 255) / 256;
+  const int64_t total = (int64_t)p.nqb * batch * heads;
+  if (total > 0x7fffffff) return VSYS_ERR_SHAPE;
+  const int ncu = cu_count_this_device();
+  const unsigned grid = (unsigned)(total < ncu ? total : ncu);
+  const size_t lds = (size_t)W64_STAGES * KV_STAGE + 4 * W64P_QIMG;
+  static std::atomic<unsigned long long> attr_seen{0};
+  if (first_use_on_this_device(attr_seen))
+    (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(flash_attn_d72_w64p_kernel, dim3(grid), dim3(256), lds, stream, p, (int)total);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

@@ -41,7 +41,7 @@ NV = 210        # v0..v209 are the asm's
 NA = 224        # a0..a223
 # scalar registers of the asm (clobbered): s40..s63
 S_CNT, S_ST, S_ST2, S_T, S_KA, S_KB, S_VC, S_VD, S_E, S_DST, S_WRAP, S_T2 = range(40, 52)
-NS_LO, NS_HI = 40, 58
+NS_LO, NS_HI = 40, 82
 
 
 def v(i, n=1):
@@ -72,13 +72,23 @@ def preg(blk, kt, cc):
     return P[blk] + (kt * 2 + cc) * 4
 
 
+PERSIST = False   # set by generate(): the persistent (workgroup walks several work items) form of the statement
+S_QP, S_QM, S_QO = 52, 53, 54
+DK, DV, D4 = 60, 64, 68           # LDS-DMA descriptors of the tiles being fetched (persistent form: a copy the tail re-points to the
+S_KNR, S_VNR = 72, 73             # next item's K / Vt), byte sizes of one (batch, head)'s Kp / Vt
+
+
+def sq(i):
+    return f"s[{i}:{i + 3}]"
+
+
 class Emit:
     def __init__(self):
         self.lines = []
         self.uid = 0
 
     def __call__(self, text):
-        self.lines.append(text)
+        self.lines.extend(text.split("\n"))
 
     def label(self, name):
         self.lines.append(name + ":")
@@ -192,25 +202,71 @@ def dma_tile_static(e, stage_expr_k, t):
 def dma_ops():
     """the wave's five LDS-DMA pieces of the next tile into the stage at s[S_ST] (+ soff advance); (text, after) tuples spread by
     the caller.  An independent instruction sits between every M0 write and the load that reads it."""
+    rk, rv, r4 = (sq(DK), sq(DV), sq(D4)) if PERSIST else ("%[rk]", "%[rv]", "%[r4]")
     return [
         f"s_add_i32 {s(S_DST)}, {s(S_ST)}, %[wl]",
         f"s_mov_b32 m0, {s(S_DST)}",
         f"s_add_i32 {s(S_T2)}, {s(S_DST)}, 4096",
-        f"buffer_load_dwordx4 %[kvo], %[rk], {s(S_KA)} offen lds",
+        f"buffer_load_dwordx4 %[kvo], {rk}, {s(S_KA)} offen lds",
         f"s_mov_b32 m0, {s(S_T2)}",
         f"s_add_i32 {s(S_KA)}, {s(S_KA)}, {K_TILE}",
-        f"buffer_load_dwordx4 %[kvo], %[rk], {s(S_KB)} offen lds",
+        f"buffer_load_dwordx4 %[kvo], {rk}, {s(S_KB)} offen lds",
         f"s_add_i32 m0, {s(S_DST)}, {K_TILE}",
         f"s_add_i32 {s(S_KB)}, {s(S_KB)}, {K_TILE}",
-        f"buffer_load_dwordx4 %[vvo], %[rv], {s(S_VC)} offen lds",
+        f"buffer_load_dwordx4 %[vvo], {rv}, {s(S_VC)} offen lds",
         f"s_add_i32 m0, {s(S_DST)}, {K_TILE + 4096}",
         f"s_add_i32 {s(S_VC)}, {s(S_VC)}, 128",
-        f"buffer_load_dwordx4 %[vvo], %[rv], {s(S_VD)} offen lds",
+        f"buffer_load_dwordx4 %[vvo], {rv}, {s(S_VD)} offen lds",
         f"s_add_i32 m0, {s(S_ST)}, %[l4]",
         f"s_add_i32 {s(S_VD)}, {s(S_VD)}, 128",
-        f"buffer_load_dwordx4 %[v4o], %[r4], {s(S_E)} offen lds",
+        f"buffer_load_dwordx4 %[v4o], {r4}, {s(S_E)} offen lds",
         f"s_add_i32 {s(S_E)}, {s(S_E)}, %[st4]",
     ]
+
+
+def soff_reset(tile):
+    """the five LDS-DMA source offsets of this wave for tile ``tile`` of a (batch, head) (persistent form: from wl, kvp2, s4, st4)"""
+    out = [f"s_add_u32 {s(S_KA)}, %[wl], {tile * K_TILE}",
+           f"s_add_u32 {s(S_KB)}, {s(S_KA)}, 4096",
+           f"s_lshr_b32 {s(S_T)}, %[wl], 7",                       # 8 w
+           f"s_mul_i32 {s(S_VC)}, {s(S_T)}, %[kvp2]",               # Vt piece w: row 8 w
+           f"s_lshl_b32 {s(S_T)}, %[kvp2], 5",
+           f"s_add_u32 {s(S_VD)}, {s(S_VC)}, {s(S_T)}",             # Vt piece w + 4: 32 rows further
+           f"s_mov_b32 {s(S_E)}, %[s4]"]
+    if tile:
+        out += [f"s_add_u32 {s(S_VC)}, {s(S_VC)}, {tile * 128}", f"s_add_u32 {s(S_VD)}, {s(S_VD)}, {tile * 128}",
+                f"s_mul_i32 {s(S_T)}, %[st4], {tile}", f"s_add_u32 {s(S_E)}, {s(S_E)}, {s(S_T)}"]
+    return out
+
+
+def q_prefetch_hook(e_uid):
+    """three of the nine LDS-DMA pieces of the NEXT item's Q rows (this wave's 64 rows, image [chunk][row]) while any are left;
+    contiguous (a branch may not jump over MFMAs), issued in front of the tile pieces of the same phase"""
+    lines = [f"s_cmp_eq_u32 {s(S_QP)}, 0", f"s_cbranch_scc1 QSKIP_{e_uid}_%="]
+    for _ in range(3):
+        lines += [f"s_mov_b32 m0, {s(S_QM)}", f"s_add_u32 {s(S_QM)}, {s(S_QM)}, 1024",
+                  f"buffer_load_dwordx4 %[qvo], %[rqn], {s(S_QO)} offen lds", f"s_add_u32 {s(S_QO)}, {s(S_QO)}, 16"]
+    lines += [f"s_sub_u32 {s(S_QP)}, {s(S_QP)}, 3", f"QSKIP_{e_uid}_%=:"]
+    return "\n".join(lines)
+
+
+def switch_block(e, tag):
+    """out of line, once per item (four tiles before its end): from here on the LDS-DMA stream fetches the NEXT item's tiles 0..3"""
+    e.label(f"SWITCH_{tag}_%=")
+    e("s_cmp_eq_u32 %[hn], 0")
+    e(f"s_cbranch_scc1 NONEXT_{tag}_%=")
+    e(f"s_mov_b64 s[{DK}:{DK + 1}], %[kbn]")
+    e(f"s_mov_b64 s[{DV}:{DV + 1}], %[vbn]")
+    e("s_cmp_eq_u32 %[wl], 0")
+    e(f"s_cselect_b64 s[{D4}:{D4 + 1}], %[kbn], %[vbn]")
+    e(f"s_branch SOFF_{tag}_%=")
+    e.label(f"NONEXT_{tag}_%=")       # no next item: zero-length descriptors, the pieces return zeros (same count of operations)
+    for d in (DK, DV, D4):
+        e(f"s_mov_b32 {s(d + 2)}, 0")
+    e.label(f"SOFF_{tag}_%=")
+    for ln in soff_reset(0):
+        e(ln)
+    e(f"s_branch BACKSW_{tag}_%=")
 
 
 def stage_advance():
@@ -306,6 +362,9 @@ def body(e, tag, p, masked, resc, variant=0):
     if masked:
         streams.append((mask_ops(nxt), 2, 10))
     streams.append((chains, 5, 17))
+    if PERSIST:
+        assert variant == 1
+        streams.append(([q_prefetch_hook(tag)], 6, 6))
     if variant == 0:
         streams.append((dma, 5, 9))
     elif variant == 1:
@@ -332,13 +391,86 @@ def final(e, p):
     for t in pre:
         e(t)
     e("s_waitcnt lgkmcnt(0)")
+    if PERSIST:
+        e("s_barrier")   # every wave has its Vt(n-1) fragments: the stage may now receive the next item's tile 3
     fill = []
     for blk, kt, cc in units[4:]:
         fill += [(t, 0) for t in p_unit(cur, blk, kt, cc)]
+    if PERSIST:   # the next item's tile 3 (stage of the tile being consumed is NOT touched: it goes to stage(i) + ... see prologue)
+        fill += [(t, 0) for t in dma_ops()]
     schedule(e, [m for m, _, _ in pv_mfmas()], fill, cap=5, front=True)   # P of keys 32..63 is needed from the 13th MFMA on
 
 
+def prologue_persist(e):
+    """start of an item in the persistent form: tiles 0..3 are already in flight (issued by the previous item's tail or by the
+    kernel's entry code), and so may be the previous item's output stores — one full drain, then the ring is at tile 0"""
+    e("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    e("s_barrier")
+    e(f"v_mov_b32_e32 {v(NEGBIG)}, 0xf149f2ca")
+    for i in range(96):
+        e(f"v_accvgpr_write_b32 {a(i)}, 0")
+    for blk in ("A", "B"):
+        for i in range(16):
+            e(f"v_mov_b32_e32 {v(NM[blk] + i)}, 0")
+    # descriptors of the tiles this item still has to fetch (4 .. n-1): its own K / Vt
+    e(f"s_mul_i32 {s(S_KNR)}, %[kvp2], 72")
+    e(f"s_mul_i32 {s(S_VNR)}, %[kvp2], 96")
+    e(f"s_mov_b64 s[{DK}:{DK + 1}], %[kb]")
+    e(f"s_mov_b32 {s(DK + 2)}, {s(S_KNR)}")
+    e(f"s_mov_b32 {s(DK + 3)}, 0x20000")
+    e(f"s_mov_b64 s[{DV}:{DV + 1}], %[vb]")
+    e(f"s_mov_b32 {s(DV + 2)}, {s(S_VNR)}")
+    e(f"s_mov_b32 {s(DV + 3)}, 0x20000")
+    e("s_cmp_eq_u32 %[wl], 0")
+    e(f"s_cselect_b64 s[{D4}:{D4 + 1}], %[kb], %[vb]")
+    e(f"s_cselect_b32 {s(D4 + 2)}, {s(S_KNR)}, {s(S_VNR)}")
+    e(f"s_mov_b32 {s(D4 + 3)}, 0x20000")
+    for ln in soff_reset(4):
+        e(ln)
+    e(f"s_mul_i32 {s(S_QP)}, %[hn], 9")
+    e(f"s_mov_b32 {s(S_QM)}, %[qlds]")
+    e(f"s_mov_b32 {s(S_QO)}, 0")
+    e(f"s_add_u32 {s(S_WRAP)}, %[lb], {NSTAGE * STAGE}")
+    e(f"s_mov_b32 {s(S_ST)}, %[lb]")
+    e(f"s_add_u32 {s(S_ST2)}, %[lb], {2 * STAGE}")
+    e(f"s_sub_u32 {s(S_CNT)}, %[nt], 2")
+    e(f"v_add_u32_e32 {v(KADDR)}, {s(S_ST)}, %[kfa]")
+    for t in k_reads():
+        e(t)
+    e("s_waitcnt lgkmcnt(0)")
+    for m in qk_mfmas(0):
+        e(m)
+    e(f"v_add_u32_e32 {v(KADDR)}, {STAGE}, {v(KADDR)}")
+    for t in k_reads():
+        e(t)
+    adopt(e)
+
+
+def adopt(e):
+    e("s_nop 7")
+    for t in max_chain(0, "A"):
+        e(t)
+    e(f"v_mov_b32_e32 {v(TT['A'])}, {v(MX['A'])}")
+    for t in max_chain(0, "B"):
+        e(t)
+    e(f"v_permlane32_swap_b32_e32 {v(MX['A'])}, {v(TT['A'])}")
+    e(f"v_mov_b32_e32 {v(TT['B'])}, {v(MX['B'])}")
+    e(f"v_max_f32_e32 {v(MX['A'])}, {v(MX['A'])}, {v(TT['A'])}")
+    e("s_nop 1")
+    e(f"v_permlane32_swap_b32_e32 {v(MX['B'])}, {v(TT['B'])}")
+    e(f"v_max_f32_e32 {v(MX['B'])}, {v(MX['B'])}, {v(TT['B'])}")
+    for blk in ("A", "B"):
+        for r in range(32):
+            e(f"v_sub_f32_e32 {v(SBUF[0][blk] + r)}, {v(SBUF[0][blk] + r)}, {v(MX[blk])}")
+        for i in range(16):
+            e(f"v_sub_f32_e32 {v(NM[blk] + i)}, 0, {v(MX[blk])}")
+    for k in range(4):
+        e(f"v_add_u32_e32 {v(VADDR[k])}, {s(S_ST)}, %[vfa{k}]")
+
+
 def prologue(e):
+    if PERSIST:
+        return prologue_persist(e)
     e(f"v_mov_b32_e32 {v(NEGBIG)}, 0xf149f2ca")
     for i in range(96):
         e(f"v_accvgpr_write_b32 {a(i)}, 0")
@@ -375,66 +507,69 @@ def prologue(e):
     e(f"v_add_u32_e32 {v(KADDR)}, {STAGE}, {v(KADDR)}")
     for t in k_reads():
         e(t)
-    e("s_nop 7")
-    for t in max_chain(0, "A"):
-        e(t)
-    e(f"v_mov_b32_e32 {v(TT['A'])}, {v(MX['A'])}")
-    for t in max_chain(0, "B"):
-        e(t)
-    e(f"v_permlane32_swap_b32_e32 {v(MX['A'])}, {v(TT['A'])}")
-    e(f"v_mov_b32_e32 {v(TT['B'])}, {v(MX['B'])}")
-    e(f"v_max_f32_e32 {v(MX['A'])}, {v(MX['A'])}, {v(TT['A'])}")
-    e("s_nop 1")
-    e(f"v_permlane32_swap_b32_e32 {v(MX['B'])}, {v(TT['B'])}")
-    e(f"v_max_f32_e32 {v(MX['B'])}, {v(MX['B'])}, {v(TT['B'])}")
-    for blk in ("A", "B"):
-        for r in range(32):
-            e(f"v_sub_f32_e32 {v(SBUF[0][blk] + r)}, {v(SBUF[0][blk] + r)}, {v(MX[blk])}")
-        for i in range(16):
-            e(f"v_sub_f32_e32 {v(NM[blk] + i)}, 0, {v(MX[blk])}")
-    for k in range(4):
-        e(f"v_add_u32_e32 {v(VADDR[k])}, {s(S_ST)}, %[vfa{k}]")
+    adopt(e)
 
 
-def generate(variant=0):
+def generate(variant=0, persist=False):
+    global PERSIST
+    PERSIST = persist
+    try:
+        return _generate(variant)
+    finally:
+        PERSIST = False
+
+
+def _generate(variant):
     e = Emit()
     resc = []
     stamps = variant == 7      # lab: s_memtime at the start of the statement, at the loop head and at the end (variant 1 otherwise)
     if stamps:
         variant = 1
-        e("s_memtime s[52:53]")
+        e("s_memtime s[76:77]")
     prologue(e)
     if stamps:
-        e("s_memtime s[54:55]")
+        e("s_memtime s[78:79]")
+    def switch_check(tag):
+        if PERSIST:   # four tiles before the end of the item the LDS-DMA stream turns to the next item
+            e(f"s_cmp_eq_u32 {s(S_CNT)}, 2")
+            e(f"s_cbranch_scc1 SWITCH_{tag}_%=")
+            e.label(f"BACKSW_{tag}_%=")
+
     e.label("TOP_%=")
     e(f"s_cmp_eq_u32 {s(S_CNT)}, 0")
     e("s_cbranch_scc1 TAIL0_%=")
+    switch_check("a")
     e(f"s_sub_u32 {s(S_CNT)}, {s(S_CNT)}, 1")
     body(e, "r0", 0, False, resc, variant)
     e(f"s_cmp_eq_u32 {s(S_CNT)}, 0")
     e("s_cbranch_scc1 TAIL1_%=")
+    switch_check("b")
     e(f"s_sub_u32 {s(S_CNT)}, {s(S_CNT)}, 1")
     body(e, "r1", 1, False, resc, variant)
     e("s_branch TOP_%=")
     e.label("TAIL0_%=")
-    body(e, "m0", 0, True, resc, variant)
+    body(e, "m0", 0, not PERSIST, resc, variant)   # (persistent form: whole tiles only, nothing to mask)
     final(e, 1)
     e("s_branch END_%=")
     e.label("TAIL1_%=")
-    body(e, "m1", 1, True, resc, variant)
+    body(e, "m1", 1, not PERSIST, resc, variant)
     final(e, 0)
     e("s_branch END_%=")
     for tag, buf in resc:
         rescale_block(e, tag, buf)
+    if PERSIST:
+        switch_block(e, "a")
+        switch_block(e, "b")
     e.label("END_%=")
-    e("s_waitcnt vmcnt(0)")
+    if not PERSIST:
+        e("s_waitcnt vmcnt(0)")
     e("s_nop 15")    # the last PV MFMAs -> the v_accvgpr_read of the epilogue (a separate asm statement)
     if stamps:
-        e("s_memtime s[56:57]")
+        e("s_memtime s[80:81]")
         e("s_waitcnt lgkmcnt(0)")
-        e("s_mov_b64 %[t0], s[52:53]")
-        e("s_mov_b64 %[t1], s[54:55]")
-        e("s_mov_b64 %[t2], s[56:57]")
+        e("s_mov_b64 %[t0], s[76:77]")
+        e("s_mov_b64 %[t1], s[78:79]")
+        e("s_mov_b64 %[t2], s[80:81]")
     return e.lines
 
 
@@ -443,7 +578,8 @@ OPERANDS = ["rk", "rv", "r4", "wl", "sv0", "sv1", "s4", "st4", "l4", "lb", "nt",
 
 
 def clobbers():
-    return [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in range(NS_LO, NS_HI)] + ["vcc", "memory"]
+    sregs = list(range(40, 55)) + list(range(60, 74)) + list(range(76, 82))   # (76..81: the stamp variant's s_memtime pairs)
+    return [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in sregs] + ["vcc", "memory"]
 
 
 VARIANTS = (0, 1, 3, 7, 8, 9)   # 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
@@ -460,6 +596,12 @@ def write_inc(path):
             for ln in lines:
                 f.write('  "' + ln + '\\n\\t" \\\n')
             f.write('  ""\n')
+        f.write("// FLASH72_W64P_ASM: the persistent form (a workgroup walks several (batch, head, query block) items: no LDS-DMA issue at the\n")
+        f.write("// start of an item, the tail fetches the next item's first four tiles and its Q rows), placement variant 1.\n")
+        f.write("#define FLASH72_W64P_ASM \\\n")
+        for ln in generate(1, persist=True):
+            f.write('  "' + ln + '\\n\\t" \\\n')
+        f.write('  ""\n')
         f.write("#define FLASH72_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers()) + "\n")
     return generate(0)
 
