@@ -44,6 +44,25 @@ def main():
     out["per_tile_cycles"] = round(out["tile loop (16 tiles)"]["mean_cycles"] / 16, 1)
     out["kernel_span_cycles"] = float(d[..., 5].max() - d[..., 0].min())
     print(json.dumps(out, indent=1))
+    # ---- the persistent form (lab variant 146): per wave sums over the items it walked
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    dbg2 = torch.zeros(ncu * 4 * 8, dtype=torch.int64, device=dev)
+    lib.vsys_lab_flash_debug_buffer(dbg2.data_ptr())
+    assert lib.vsys_tune_flash_variant(146) == 0
+    ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024)
+    torch.cuda.synchronize()
+    dbg2.zero_()
+    ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024)
+    torch.cuda.synchronize()
+    lib.vsys_tune_flash_variant(0)
+    e = dbg2.view(ncu, 4, 8).cpu().double()
+    n = e[..., 6].clamp_min(1)
+    names = ["wait for the Q image", "Q fragments (LDS reads, norm, accumulator writes, descriptors)",
+             "opening wait + barrier of the statement", "O / -m init, K(0), S(0), adopt", "tile loop", "O read-out, normalise, stores issued"]
+    out2 = {nm: round(float((e[..., i] / n).mean()), 1) for i, nm in enumerate(names)}
+    out2["cycles per item"] = round(sum(out2.values()), 1)
+    out2["items per wave (min, max)"] = [float(e[..., 6].min()), float(e[..., 6].max())]
+    print(json.dumps({"persistent form, mean cycles per item": out2}, indent=1))
 
 
 if __name__ == "__main__":

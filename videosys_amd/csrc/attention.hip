@@ -935,7 +935,7 @@ int set_flash_variant(int v) {
   switch (v) {
     case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 140: case 141: case 143: break;
 #ifdef VSYS_LAB
-    case 1: case 2: case 147: case 148: case 149: break;
+    case 1: case 2: case 146: case 147: case 148: case 149: break;
 #endif
     default: return VSYS_ERR_ARG;
   }
@@ -994,8 +994,9 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   // long key sequences: 64 query rows per wave, one wave per SIMD, hand-allocated instruction stream (attention_w64.hip)
   static const bool w64_default = [] { const char* e = getenv("VSYS_FLASH_W64"); return !(e && e[0] == '0'); }();
   // 16 = the persistent form of the w64 kernel (one workgroup per CU walks the query blocks; whole 256-key groups)
-  if (g_flash_variant == 16 && flash_w64p_supports(q_len, kv_len, kv_pad, q_stride))
-    return launch_flash_attn_d72_w64p(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps, stream);
+  if ((g_flash_variant == 16 || g_flash_variant == 146) && flash_w64p_supports(q_len, kv_len, kv_pad, q_stride))
+    return launch_flash_attn_d72_w64p(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
+                                      g_flash_variant == 146, stream);
   constexpr int W64_DEFAULT_VAR = 1;   // 140 / 141 / 143 select placement variant 0 / 1 / 3 (lab builds: 148 / 149 = ablations 8 / 9)
   if ((g_flash_variant == 14 || g_flash_variant >= 140 || (g_flash_variant == 0 && w64_default && kv_len >= 512)) &&
       flash_w64_supports(q_len, kv_len, kv_pad))

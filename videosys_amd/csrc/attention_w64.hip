@@ -265,6 +265,8 @@ __device__ __forceinline__ unsigned long long uniform_addr(const void* ptr) {
   return ((unsigned long long)hi_ << 32) | lo;
 }
 
+// STAMP (lab): per wave the s_memtime cycles of an item's phases, summed over the items it walked, into p.dbg[wave][8]
+template <bool STAMP>
 __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Params p, int total_items) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,11 +338,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
     }
   }
 
+  unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
   for (int it = i0; it < i1; ++it) {
     const int bh = item_bh(it), qb = it - bh * p.nqb;
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int q0 = qb * 256 + wave_u * 64;
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+    if constexpr (STAMP) t0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's Q image has landed (nobody else touches it)
+    if constexpr (STAMP) t1 = __builtin_amdgcn_s_memtime();
     // ---- Q fragments from the image [chunk][row]: lane holds Q[row][16c + 8hi .. +8] = chunk 2c + hi of row 32 blk + l31
     unsigned qw[2][20];
 #pragma unroll
@@ -416,6 +422,19 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
     const u32x4 rqn = q_rsrc(nit);
     const int qvo = q_voff(nit);
     const int hn = __builtin_amdgcn_readfirstlane(has_next ? 1 : 0);
+    if constexpr (STAMP) {
+      t2 = __builtin_amdgcn_s_memtime();
+#ifdef VSYS_LAB
+      asm volatile(FLASH72_W64P_ASM_STAMP
+                   : [t0] "=s"(ta), [t1] "=s"(tb)
+                   : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
+                     [s4] "s"(s4), [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [qlds] "s"(qlds), [kvo] "v"(k_voff),
+                     [vvo] "v"(v_voff), [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2),
+                     [vfa3] "v"(vfa3), [qvo] "v"(qvo)
+                   : FLASH72_W64_CLOBBERS);
+#endif
+      t3 = __builtin_amdgcn_s_memtime();
+    } else
     asm volatile(FLASH72_W64P_ASM
                  :
                  : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
@@ -465,6 +484,23 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
         }
       }
     }
+    if constexpr (STAMP) {
+      t4 = __builtin_amdgcn_s_memtime();
+      acc[0] += t1 - t0;   // wait for the Q image (and whatever else is in flight)
+      acc[1] += t2 - t1;   // Q fragments: LDS reads, RMS norm, accumulator-file writes, next item's descriptors
+      acc[2] += ta - t2;   // the statement's opening wait + barrier (output stores of the previous item, tiles 0..3)
+      acc[3] += tb - ta;   // O / -m init, descriptors, K(0), S(0), adopt
+      acc[4] += t3 - tb;   // tile loop
+      acc[5] += t4 - t3;   // O read-out, normalise, stores issued
+      acc[6] += 1;
+    }
+  }
+  if constexpr (STAMP) {
+    if (lane == 0 && p.dbg != nullptr) {
+      unsigned long long* d = p.dbg + ((size_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) d[i] = acc[i];
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (zero-length pieces of the last item's tail: nothing may be in flight when the LDS is released)
 #endif
@@ -493,7 +529,8 @@ bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride) {
 }
 
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
-                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, hipStream_t stream) {
+                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, bool stamp,
+                               hipStream_t stream) {
   FlashW64Params p;
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
@@ -505,9 +542,21 @@ int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* 
   const unsigned grid = (unsigned)(total < ncu ? total : ncu);
   const size_t lds = (size_t)W64_STAGES * KV_STAGE + 4 * W64P_QIMG;
   static std::atomic<unsigned long long> attr_seen{0};
-  if (first_use_on_this_device(attr_seen))
-    (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(flash_attn_d72_w64p_kernel, dim3(grid), dim3(256), lds, stream, p, (int)total);
+  if (first_use_on_this_device(attr_seen)) {
+    (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#ifdef VSYS_LAB
+    (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+#endif
+  }
+#ifdef VSYS_LAB
+  if (stamp) {
+    p.dbg = reinterpret_cast<unsigned long long*>(get_lab_debug_buffer());
+    hipLaunchKernelGGL(flash_attn_d72_w64p_kernel<true>, dim3(grid), dim3(256), lds, stream, p, (int)total);
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
+#endif
+  (void)stamp;
+  hipLaunchKernelGGL(flash_attn_d72_w64p_kernel<false>, dim3(grid), dim3(256), lds, stream, p, (int)total);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

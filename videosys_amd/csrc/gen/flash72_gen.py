@@ -72,6 +72,7 @@ def preg(blk, kt, cc):
     return P[blk] + (kt * 2 + cc) * 4
 
 
+PSTAMP = False    # lab: s_memtime behind the opening wait + barrier and at the loop head of the persistent form
 PERSIST = False   # set by generate(): the persistent (workgroup walks several work items) form of the statement
 S_QP, S_QM, S_QO = 52, 53, 54
 DK, DV, D4 = 60, 64, 68           # LDS-DMA descriptors of the tiles being fetched (persistent form: a copy the tail re-points to the
@@ -406,6 +407,8 @@ def prologue_persist(e):
     kernel's entry code), and so may be the previous item's output stores — one full drain, then the ring is at tile 0"""
     e("s_waitcnt vmcnt(0) lgkmcnt(0)")
     e("s_barrier")
+    if PSTAMP:
+        e("s_memtime s[76:77]")
     e(f"v_mov_b32_e32 {v(NEGBIG)}, 0xf149f2ca")
     for i in range(96):
         e(f"v_accvgpr_write_b32 {a(i)}, 0")
@@ -510,13 +513,13 @@ def prologue(e):
     adopt(e)
 
 
-def generate(variant=0, persist=False):
-    global PERSIST
-    PERSIST = persist
+def generate(variant=0, persist=False, pstamp=False):
+    global PERSIST, PSTAMP
+    PERSIST, PSTAMP = persist, pstamp
     try:
         return _generate(variant)
     finally:
-        PERSIST = False
+        PERSIST = PSTAMP = False
 
 
 def _generate(variant):
@@ -527,8 +530,9 @@ def _generate(variant):
         variant = 1
         e("s_memtime s[76:77]")
     prologue(e)
-    if stamps:
+    if stamps or PSTAMP:
         e("s_memtime s[78:79]")
+
     def switch_check(tag):
         if PERSIST:   # four tiles before the end of the item the LDS-DMA stream turns to the next item
             e(f"s_cmp_eq_u32 {s(S_CNT)}, 2")
@@ -564,6 +568,10 @@ def _generate(variant):
     if not PERSIST:
         e("s_waitcnt vmcnt(0)")
     e("s_nop 15")    # the last PV MFMAs -> the v_accvgpr_read of the epilogue (a separate asm statement)
+    if PSTAMP:
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 %[t0], s[76:77]")
+        e("s_mov_b64 %[t1], s[78:79]")
     if stamps:
         e("s_memtime s[80:81]")
         e("s_waitcnt lgkmcnt(0)")
@@ -600,6 +608,10 @@ def write_inc(path):
         f.write("// start of an item, the tail fetches the next item's first four tiles and its Q rows), placement variant 1.\n")
         f.write("#define FLASH72_W64P_ASM \\\n")
         for ln in generate(1, persist=True):
+            f.write('  "' + ln + '\\n\\t" \\\n')
+        f.write('  ""\n')
+        f.write("#define FLASH72_W64P_ASM_STAMP \\\n")
+        for ln in generate(1, persist=True, pstamp=True):
             f.write('  "' + ln + '\\n\\t" \\\n')
         f.write('  ""\n')
         f.write("#define FLASH72_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers()) + "\n")

@@ -182,7 +182,8 @@ int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q
                               hipStream_t stream);   // var: LDS-DMA placement variant 0 / 1 / 3 (lab builds: 8, 9 ablations)
 bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride);   // persistent form of the w64 kernel
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
-                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, hipStream_t stream);
+                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, bool stamp,
+                               hipStream_t stream);   // stamp: lab builds only (cycle accounting into the lab debug buffer)
 int launch_attn_prep_kv64(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* ln_w,
                           const bf16_t* ln_b, const float* rope_cos, const float* rope_sin, int rope_start, int rope_len,
                           bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps, hipStream_t stream);
