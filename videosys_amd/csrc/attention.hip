@@ -992,13 +992,18 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
     }
   }
   // long key sequences: 64 query rows per wave, one wave per SIMD, hand-allocated instruction stream (attention_w64.hip)
-  static const bool w64_default = [] { const char* e = getenv("VSYS_FLASH_W64"); return !(e && e[0] == '0'); }();
+  // (opt-in, VSYS_FLASH_W64=1 or variant 16: in situ it ties the 32-row kernel — 104.9 vs 104.6 ms per step, profiles/r04_flash_w64p_insitu.txt)
+  static const bool w64_default = [] { const char* e = getenv("VSYS_FLASH_W64"); return e && e[0] == '1'; }();
   // 16 = the persistent form of the w64 kernel (one workgroup per CU walks the query blocks; whole 256-key groups)
-  if ((g_flash_variant == 16 || g_flash_variant == 146) && flash_w64p_supports(q_len, kv_len, kv_pad, q_stride))
+  // It is the default where every workgroup walks at least four items (the seams of an item are what the walk amortises); the
+  // one-item-per-workgroup form below is selectable only (it loses to the 32-row kernel: profiles/r04_flash_w64_placement_kbench.txt).
+  const bool w64p_default = g_flash_variant == 0 && w64_default && kv_len >= 512 &&
+                            (int64_t)batch * heads * ((q_len + 255) / 256) >= 4ll * cu_count_this_device();
+  if ((g_flash_variant == 16 || g_flash_variant == 146 || w64p_default) && flash_w64p_supports(q_len, kv_len, kv_pad, q_stride))
     return launch_flash_attn_d72_w64p(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
                                       g_flash_variant == 146, stream);
   constexpr int W64_DEFAULT_VAR = 1;   // 140 / 141 / 143 select placement variant 0 / 1 / 3 (lab builds: 148 / 149 = ablations 8 / 9)
-  if ((g_flash_variant == 14 || g_flash_variant >= 140 || (g_flash_variant == 0 && w64_default && kv_len >= 512)) &&
+  if ((g_flash_variant == 14 || g_flash_variant >= 140) &&
       flash_w64_supports(q_len, kv_len, kv_pad))
     return launch_flash_attn_d72_w64(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
                                      g_flash_variant >= 140 ? g_flash_variant - 140 : W64_DEFAULT_VAR, stream);

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------
-// Persistent form: gridDim.x workgroups (one per CU) walk the (batch, head, 256-row query block) items in contiguous ranges.
+// Persistent form: gridDim.x workgroups (one per CU) walk the (batch, head, 256-row query block) items with stride gridDim.x.
 // What an item pays at its seams in the one-item-per-workgroup kernel above (stamps, profiles/r04_flash_w64_stamps_nonpersistent.json:
 // 11k cycles of Q fetch + norm, 4.3k of LDS-DMA issue + landing + pipeline fill, 3.5k of output stores against 27k in the tile loop,
 // none of it covered at one workgroup per CU) is taken out of the seam where it can be: the tail of an item's tile loop already
@@ -273,8 +273,12 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int wgp = xcd_remap(blockIdx.x, gridDim.x);    // consecutive item ranges on one XCD: the query blocks of a (batch, head) share L2
-  const int i0 = (int)((int64_t)wgp * total_items / (int)gridDim.x), i1 = (int)((int64_t)(wgp + 1) * total_items / (int)gridDim.x);
+  // Round j of the walk is items j G .. j G + G - 1, workgroup wgp takes item j G + wgp: the workgroups of one XCD (consecutive wgp) are
+  // then on consecutive query blocks of the same one or two (batch, head) at any moment and share their K / Vt in that XCD's L2.
+  // (Contiguous item RANGES per workgroup put every workgroup on its own head: 180 MB of K / Vt in flight, every tile from the
+  // fabric, tile loop 34.0k cycles per item instead of 27.1k — profiles/r04_flash_w64p_stamps_ranges.json.)
+  const int wgp = xcd_remap(blockIdx.x, gridDim.x), istep = (int)gridDim.x;
+  const int i0 = wgp, i1 = total_items;
   if (i0 >= i1) return;
 
   const unsigned kbytes = (unsigned)(p.kv_pad * HD * 2), vbytes = (unsigned)(HD_ROWS * p.kv_pad * 2);
@@ -338,8 +342,16 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
     }
   }
 
+  // the RMS-norm weights of this lane's five column chunks, held packed across the items (registers above the statement's clobbers):
+  // read per item they were five global round trips behind the item's opening vmcnt(0)
+  uint4 qnw[5];
+#pragma unroll
+  for (int c = 0; c < 5; ++c) {
+    const int d0 = 16 * c + 8 * hi;
+    qnw[c] = (p.q_norm_w != nullptr && d0 < HD) ? *reinterpret_cast<const uint4*>(p.q_norm_w + d0) : make_uint4(0, 0, 0, 0);
+  }
   unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
-  for (int it = i0; it < i1; ++it) {
+  for (int it = i0; it < i1; it += istep) {
     const int bh = item_bh(it), qb = it - bh * p.nqb;
     const int b = bh / p.heads, h = bh - b * p.heads;
     const int q0 = qb * 256 + wave_u * 64;
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
           const int d0 = 16 * c + 8 * hi;
           if (d0 < HD) {
             float w[8];
-            unpack8(*reinterpret_cast<const uint4*>(p.q_norm_w + d0), w);
+            unpack8(qnw[c], w);
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[c][e] = bf2f(f2bf(x[c][e] * rstd)) * w[e];
           }
@@ -414,8 +426,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
 #undef QW
 
     // ---- this item's K / Vt, and what the tail of the loop prefetches for the next one
-    const bool has_next = it + 1 < i1;
-    const int nit = has_next ? it + 1 : it;
+    const bool has_next = it + istep < i1;
+    const int nit = has_next ? it + istep : it;
     const int nbh = item_bh(nit);
     const unsigned long long kb = uniform_addr(p.kp + (int64_t)bh * p.kv_pad * HD), vb = uniform_addr(p.vt + (int64_t)bh * HD_ROWS * p.kv_pad);
     const unsigned long long kbn = uniform_addr(p.kp + (int64_t)nbh * p.kv_pad * HD), vbn = uniform_addr(p.vt + (int64_t)nbh * HD_ROWS * p.kv_pad);

@@ -240,14 +240,16 @@ def soff_reset(tile):
     return out
 
 
-def q_prefetch_hook(e_uid):
-    """three of the nine LDS-DMA pieces of the NEXT item's Q rows (this wave's 64 rows, image [chunk][row]) while any are left;
-    contiguous (a branch may not jump over MFMAs), issued in front of the tile pieces of the same phase"""
+def q_prefetch_hook(e_uid, npieces):
+    """``npieces`` of the nine LDS-DMA pieces of the NEXT item's Q rows (this wave's 64 rows, image [chunk][row]); contiguous (a
+    branch may not jump over MFMAs).  Issued in the LAST two tiles of an item, behind their tile pieces: counted waits are in issue
+    order, so a Q piece (a cold HBM fetch) in front of a tile piece makes the next tile's wait sit out its whole latency; behind the
+    last tile pieces of the item nothing waits on it before the next item's opening vmcnt(0)."""
     lines = [f"s_cmp_eq_u32 {s(S_QP)}, 0", f"s_cbranch_scc1 QSKIP_{e_uid}_%="]
-    for _ in range(3):
+    for _ in range(npieces):
         lines += [f"s_mov_b32 m0, {s(S_QM)}", f"s_add_u32 {s(S_QM)}, {s(S_QM)}, 1024",
                   f"buffer_load_dwordx4 %[qvo], %[rqn], {s(S_QO)} offen lds", f"s_add_u32 {s(S_QO)}, {s(S_QO)}, 16"]
-    lines += [f"s_sub_u32 {s(S_QP)}, {s(S_QP)}, 3", f"QSKIP_{e_uid}_%=:"]
+    lines += [f"QSKIP_{e_uid}_%=:"]
     return "\n".join(lines)
 
 
@@ -365,13 +367,14 @@ def body(e, tag, p, masked, resc, variant=0):
     streams.append((chains, 5, 17))
     if PERSIST:
         assert variant == 1
-        streams.append(([q_prefetch_hook(tag)], 6, 6))
     if variant == 0:
         streams.append((dma, 5, 9))
     elif variant == 1:
         streams.append((flat(dma_groups), 9, 21))
     elif variant == 3:
         streams.append((flat(dma_groups[2:]), 9, 20))
+    if PERSIST and tag.startswith("m"):       # (the tail body of an item = its second-to-last tile)
+        streams.append(([q_prefetch_hook(tag, 5)], 22, 22))
     streams.append((tail, 18, 23))
     place(e, pv, [st for st in streams if st[0]])
     e(f"s_cbranch_vccnz RESC_{tag}_%=")
@@ -397,8 +400,9 @@ def final(e, p):
     fill = []
     for blk, kt, cc in units[4:]:
         fill += [(t, 0) for t in p_unit(cur, blk, kt, cc)]
-    if PERSIST:   # the next item's tile 3 (stage of the tile being consumed is NOT touched: it goes to stage(i) + ... see prologue)
+    if PERSIST:   # the next item's tile 3 into the stage of the tile being consumed (every wave has its Vt fragments: barrier above)
         fill += [(t, 0) for t in dma_ops()]
+        fill.append((q_prefetch_hook(f"f{p}", 4), 0))
     schedule(e, [m for m, _, _ in pv_mfmas()], fill, cap=5, front=True)   # P of keys 32..63 is needed from the 13th MFMA on
 
 
