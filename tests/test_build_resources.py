@@ -81,7 +81,7 @@ def test_conv_and_producer_gemm_resources():
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
 def test_w64_flash_kernel_owns_its_accumulator_registers(tmp_path):
     """attention_w64.hip keeps O, Q and the K / Vt fragments in a[0:223] across several asm statements: the compiler-generated
-    code around them must not touch the accumulator file (no v_accvgpr_* / a-register operand outside ;;#ASMSTART .. ;;#ASMEND), must
+    code around them must not touch those (no a-register operand below a224 outside ;;#ASMSTART .. ;;#ASMEND), must
     not spill, and the kernel must fit one wave per SIMD (<= 512 registers)."""
     import subprocess
 
@@ -90,7 +90,7 @@ def test_w64_flash_kernel_owns_its_accumulator_registers(tmp_path):
     assert len(hits) >= 4      # the three placement variants + the persistent form
     for name, res in hits.items():
         assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) == 0, (name, res)
-        assert res.get("VGPRs", 0) <= 256 and res.get("AGPRs", 0) == 224, (name, res)
+        assert res.get("VGPRs", 0) <= 256 and 224 <= res.get("AGPRs", 0) <= 256, (name, res)
     out = str(tmp_path / "w64.s")
     subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
                     os.path.join(CSRC, "attention_w64.hip")], check=True, capture_output=True)
@@ -102,6 +102,8 @@ def test_w64_flash_kernel_owns_its_accumulator_registers(tmp_path):
             inside = False
         elif not inside and not ln.lstrip().startswith((".", ";")):
             code = ln.split(";")[0]
-            if "v_accvgpr" in code or re.search(r"\ba\d+\b|\ba\[\d", code) or "scratch_" in code:
+            # (a224 and up are the compiler's: the persistent form parks loop-invariant values there)
+            regs = [int(m) for m in re.findall(r"\ba\[?(\d+)", code)]
+            if any(r < 224 for r in regs) or ("v_accvgpr" in code and not regs) or "scratch_" in code:
                 bad.append(ln.strip())
     assert not bad, bad[:5]
