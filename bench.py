@@ -123,6 +123,9 @@ def main():
     kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([float(height)] * 2),
               width=torch.tensor([float(width)] * 2))
 
+    if args.pab:   # the sampler hands its schedule to the model (rflow.py:65, scheduling_rflow_open_sora.py sample()): slabs nobody reads are not kept
+        kw["all_timesteps"] = [int(t.to(torch.bfloat16)[0]) for t in timesteps]
+
     def one_step(i):
         t = timesteps[i % STEPS_PER_VIDEO]
         out = model(torch.cat([z, z], 0), torch.cat([t, t], 0), yy, **kw)
@@ -190,9 +193,21 @@ def main():
             ev.append((s, e, 2.0 * x.shape[0] * w.shape[0] * x.shape[1], 5))
             return r
 
+        real_gemm_gra = ops.gemm_gate_res_add   # (--pab) gate + residual GEMMs that carry the broadcasts behind them: "epilogue" 6
+
+        def timed_gemm_gra(x, w, bias, **k):
+            s = torch.cuda.Event(enable_timing=True)
+            e = torch.cuda.Event(enable_timing=True)
+            s.record()
+            r = real_gemm_gra(x, w, bias, **k)
+            e.record()
+            ev.append((s, e, 2.0 * x.shape[0] * w.shape[0] * x.shape[1], 6))
+            return r
+
     barrier()
     nrep = min(args.steps, 3)
     if rank == 0:
+        ops.gemm_gate_res_add = timed_gemm_gra
         ops.gemm, ops.gemm_ln, ops.gemm_stats = timed_gemm, timed_gemm_ln, timed_gemm_stats  # every rank replays the steps (DSP collectives); only rank 0 is instrumented
     was_prog = model.use_programs
     model.use_programs = False   # the instrumented replay issues every launch from Python (a recorded launch program would bypass
@@ -204,6 +219,7 @@ def main():
         model.use_programs = was_prog
         if rank == 0:
             ops.gemm, ops.gemm_ln, ops.gemm_stats = real_gemm, real_gemm_ln, real_gemm_stats
+            ops.gemm_gate_res_add = real_gemm_gra
     if rank == 0:
         # drop the once-per-prompt kv_linear launches (none after warm-up) and aggregate
         tot_ms = sum(s.elapsed_time(e) for s, e, _, _ in ev)

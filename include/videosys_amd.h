@@ -97,6 +97,17 @@ int vsys_gemm_bf16_stats(const void* x, int64_t ldx, const void* w, int64_t ldw,
                          int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride, int64_t rows_per_sample, const void* res,
                          int64_t ldr, void* stats, int64_t stats_ld, void* stream);
 
+/* vsys_gemm_bf16 with VSYS_EPI_GATE_RES whose store phase also takes the `x = x + cached_output` passes that FOLLOW it in program
+ * order when the next sub-blocks of the residual stream are PAB broadcasts (open_sora_transformer_3d.py:186-190,219-225,
+ * /root/reference/videosys/core/pab/pab_mgr.py:54-91):  out = bf16(bf16(bf16(res + u) + add1) + add2),  u = bf16(gate (x W^T + b)) —
+ * the roundings of the separate torch adds.  res is required; add1 / add2 ([M, N], leading dimension ldr) and aux (the PAB slab
+ * copy of u, leading dimension ldr) may be NULL; stats (format of vsys_gemm_bf16_stats, may be NULL) receives the LayerNorm
+ * partials of the rows stored. */
+int vsys_gemm_bf16_gate_res_add(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                                int64_t M, int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride, int64_t rows_per_sample,
+                                const void* res, int64_t ldr, void* aux, const void* add1, const void* add2, void* stats,
+                                int64_t stats_ld, void* stream);
+
 /* The step-level half of the AdaLN fold: for every site of a step (one qkv or fc1 Linear of one block) W' = bf16(W (1 + scale)),
  * cs, cv as defined at vsys_gemm_bf16_ln, all sites in ONE launch.  shift / scale are the sample-0 rows of the step's modulation
  * table (t2i_modulate operands, open_sora_transformer_3d.py:177-179; valid when every sample of the batch shares the timestep, as
@@ -405,7 +416,8 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
 #define VSYS_OP_GEMM_BF16_STATS     24
 #define VSYS_OP_ADALN_PRESCALE      25
 #define VSYS_OP_LN_ROW_STATS        26
-#define VSYS_OP_COUNT              27
+#define VSYS_OP_GEMM_BF16_GATE_RES_ADD 27
+#define VSYS_OP_COUNT              28
 
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */

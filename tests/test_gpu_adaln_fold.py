@@ -210,3 +210,95 @@ def test_stdit3_fold_on_off_agree_and_record(ops):
         cos = torch.nn.functional.cosine_similarity(o.flatten(), ref.flatten(), dim=0).item()
         assert err <= 3e-2 * scale and cos >= 0.999, f"{name}: max|err| {err:.3e} / {scale:.3f}, cosine {cos:.6f}"
     assert (out_f - out_u).abs().max().item() <= 1.5e-2 * scale
+
+
+@pytest.mark.parametrize("M,N,K,rps", [(1100, 576, 1152, 400), (2048, 1152, 1152, 1024), (300, 1152, 4608, 300), (25856, 1152, 1152, 12928)])
+def test_gemm_gate_res_add_same_bits_as_separate_passes(ops, M, N, K, rps):
+    """PAB broadcasts folded into the store phase of the GEMM in front of them (vsys_gemm_bf16_gate_res_add): the stored rows, the
+    slab copy and the LayerNorm partials are the bits the separate launches give — gate + residual GEMM (with its slab copy), one
+    `x += cached` pass per broadcast, one row-statistics pass.  Shapes as the statistics test (128-row and 8-wave geometry, ragged
+    last tile)."""
+    g = torch.Generator().manual_seed(M + 1)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev())
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev())
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(dev())
+    gate = torch.randn(-(-M // rps), N, generator=g).to(torch.bfloat16).to(dev())
+    res = _rows(M, N, g, offset=4.0).to(dev())
+    a1, a2 = _rows(M, N, g, offset=-1.0).to(dev()), _rows(M, N, g, offset=0.5).to(dev())
+    for use_gate, nadd, use_aux, use_stats in ((True, 2, True, True), (False, 1, False, True), (True, 1, True, False),
+                                               (False, 2, False, False), (True, 0, True, True)):
+        kw = dict(gate=gate[0] if use_gate else None, gate_stride=N if use_gate else 0, rows_per_sample=rps if use_gate else 0)
+        adds = (a1, a2)[:nadd]
+        r0, r1 = res.clone(), res.clone()
+        aux0 = torch.full_like(res, float("nan")) if use_aux else None
+        aux1 = torch.full_like(res, float("nan")) if use_aux else None
+        ops.gemm(x, w, b, epilogue=ops.EPI_GATE_RES, res=r0, aux=aux0, out=r0, **kw)
+        for a in adds:
+            ops.add_rows(r0, a)
+        st = None
+        if use_stats:
+            st = ops.ln_stats_buffer(M, N, dev())
+            st.fill_(float("nan"))
+        ops.gemm_gate_res_add(x, w, b, res=r1, aux=aux1, adds=adds, stats=st, out=r1, **kw)
+        assert torch.equal(r0, r1), (use_gate, nadd, use_aux, use_stats)
+        if use_aux:
+            assert torch.equal(aux0, aux1)
+        if use_stats:
+            want = ops.ln_stats_buffer(M, N, dev())
+            ops.ln_row_stats(r0, want)
+            assert torch.equal(st, want), "partials of the folded store phase differ from the row pass on the same rows"
+
+
+def test_stdit3_pab_folded_broadcasts_same_bits(ops):
+    """A PAB run with the broadcasts folded into the preceding GEMMs (default) against the same run with one pass per broadcast
+    (model.pab_fold_adds = False): identical outputs at every step, far fewer add_rows launches, with and without the AdaLN fold."""
+    from oracle import stdit3_oracle as O
+    from videosys_amd import pab
+    from videosys_amd.stdit3 import STDiT3, STDiT3Config
+
+    cfg = dict(depth=3, hidden_size=576, num_heads=8, caption_channels=64, model_max_length=16)
+    sd = O.synth_state_dict(**cfg, seed=23)
+    sd = {k: (v if k == "rope.freqs" else v.to(torch.bfloat16).float()) for k, v in sd.items()}
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(2, 4, 5, 16, 16, generator=g).to(torch.bfloat16).float()
+    y = torch.randn(2, 1, 16, 64, generator=g).to(torch.bfloat16).float()
+    mask = torch.zeros(1, 16, dtype=torch.long)
+    mask[:, :11] = 1
+    kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([128.0, 128.0]), width=torch.tensor([128.0, 128.0]))
+    ts = [900, 860, 820, 780, 740, 700, 660, 620, 580, 540, 500, 300]
+
+    def run(fold_adds, adaln_fold, mlp):
+        extra = {}
+        if mlp:
+            extra = dict(mlp_broadcast=True, mlp_spatial_broadcast_config={820: {"block": [0, 1], "skip_count": 2}},
+                         mlp_temporal_broadcast_config={700: {"block": [1, 2], "skip_count": 2}})
+        pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[400, 950], spatial_range=2,
+                                          temporal_broadcast=True, temporal_threshold=[400, 950], temporal_range=3,
+                                          cross_broadcast=True, cross_threshold=[400, 950], cross_range=4, **extra))
+        pab.update_steps(len(ts))
+        try:
+            m = STDiT3(STDiT3Config(**cfg), device="cuda:0")
+            m.load_state_dict(sd)
+            m.pab_fold_adds, m.adaln_fold = fold_adds, adaln_fold
+            real, n = ops.add_rows, [0]
+
+            def counting(a, b_):
+                n[0] += 1
+                return real(a, b_)
+
+            ops.add_rows = counting
+            try:
+                outs = [m(x, torch.tensor([float(t)] * 2), y, all_timesteps=ts, **kw).float().cpu() for t in ts]
+            finally:
+                ops.add_rows = real
+            return outs, n[0], dict(m.program_stats)
+        finally:
+            pab.set_pab_manager(None)
+
+    for adaln_fold in (True, False):
+        for mlp in (False, True):
+            a, na, _ = run(False, adaln_fold, mlp)
+            b, nb, stats = run(True, adaln_fold, mlp)
+            for t, u, v in zip(ts, a, b):
+                assert torch.isfinite(u).all() and torch.equal(u, v), f"t={t} (AdaLN fold {adaln_fold}, MLP broadcast {mlp})"
+            assert nb < 0.5 * na, (na, nb)

@@ -25,6 +25,8 @@ SIGNATURES = {
                        _ptr, _i64, _ptr],
     "vsys_gemm_bf16_ln": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _ptr, _i64, _f32, _ptr],
     "vsys_gemm_bf16_stats": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr, _i64, _ptr],
+    "vsys_gemm_bf16_gate_res_add": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _ptr, _i64, _ptr, _ptr,
+                                    _ptr, _ptr, _i64, _ptr],
     "vsys_adaln_prescale": [_ptr, _i64, _i64, _ptr, _ptr],
     "vsys_ln_row_stats": [_ptr, _i64, _i64, _ptr, _i64, _ptr],
     "vsys_linear_small": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _int, _int, _ptr],

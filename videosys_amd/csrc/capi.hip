@@ -111,6 +111,23 @@ int vsys_gemm_bf16_stats(const void* x, int64_t ldx, const void* w, int64_t ldw,
   return launch_gemm(p, EPI_GATE_RES_STATS, S(stream));
 }
 
+int vsys_gemm_bf16_gate_res_add(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,
+                                int64_t M, int64_t N, int64_t K, const void* gate, int64_t gate_sample_stride, int64_t rows_per_sample,
+                                const void* res, int64_t ldr, void* aux, const void* add1, const void* add2, void* stats,
+                                int64_t stats_ld, void* stream) {
+  if (!x || !w || !out || !res) return VSYS_ERR_ARG;
+  if (!fits_int(M) || !fits_int(N) || !fits_int(K) || !fits_int(rows_per_sample)) return VSYS_ERR_SHAPE;
+  GemmParams p;
+  p.A = B16(x); p.lda = ldx; p.W = B16(w); p.ldw = ldw; p.bias = B16(bias); p.out = B16(out); p.ldo = ldo;
+  p.M = (int)M; p.N = (int)N; p.K = (int)K;
+  p.gate = B16(gate); p.gate_stride = gate_sample_stride; p.res = B16(res); p.ldr = ldr; p.aux = B16(aux); p.ldaux = ldr;
+  p.rows_per_sample = (int)rows_per_sample;
+  p.seg_split = 0; p.gate_alt = 0; p.ks = 0; p.out32 = nullptr; p.slab = 0; p.ldo32 = 0;
+  p.add1 = B16(add1 ? add1 : add2); p.add2 = add1 ? B16(add2) : nullptr;
+  p.stats_out = reinterpret_cast<float2*>(stats); p.stats_ld = stats_ld;
+  return launch_gemm(p, EPI_GATE_RES, S(stream));
+}
+
 int vsys_adaln_prescale(const void* sites, int64_t nsites, int64_t nblocks, const void* mod, void* stream) {
   if (!sites || !mod) return VSYS_ERR_ARG;
   if (!fits_int(nsites)) return VSYS_ERR_SHAPE;

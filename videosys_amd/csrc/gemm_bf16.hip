@@ -603,6 +603,82 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   // Store phase.  Full tiles (every launch on the denoise path: M is a multiple of 256) take the branch-free form:
   // all 12 image reads are issued before the first store, so the stores do not each wait on their own LDS round trip.
   const bool full = row0 + BM_ <= p.M;
+  if constexpr (EPI == EPI_GATE_RES) {
+    if (p.add1 != nullptr || p.stats_out != nullptr) {
+      // Folded PAB broadcasts (GemmParams::add1 / add2) and / or LayerNorm partials next to a PAB slab copy: the general form of the
+      // store phase.  The extra operands are fetched in one burst while the image is read; the stored chunk goes back into the
+      // image so that the statistics pass below finds x_new where a lane owns a token row (the layout of EPI_GATE_RES_STATS).
+      uint4 val[12], r1[12], r2[12];
+#pragma unroll
+      for (int it = 0; it < 12; ++it) {
+        const int q = lane + 64 * it;
+        const int m_local = q / 12, c = q - m_local * 12;
+        int grow = row0 + wm * 64 + m_local;
+        grow = grow < p.M ? grow : p.M - 1;
+        const int64_t off = (int64_t)grow * p.ldr + ncol0 + c * 8;
+        r1[it] = p.add1 != nullptr ? *reinterpret_cast<const uint4*>(p.add1 + off) : make_uint4(0, 0, 0, 0);
+        r2[it] = p.add2 != nullptr ? *reinterpret_cast<const uint4*>(p.add2 + off) : make_uint4(0, 0, 0, 0);
+        val[it] = *reinterpret_cast<const uint4*>(st + m_local * OUT_ROW_BYTES + c * 16);
+      }
+#pragma unroll
+      for (int it = 0; it < 12; ++it) {
+        const int q = lane + 64 * it;
+        const int m_local = q / 12, c = q - m_local * 12;
+        const int grow = row0 + wm * 64 + m_local;
+        const int gcol = ncol0 + c * 8;
+        const bool ok = grow < p.M;
+        uint4 v = val[it];
+        if (p.aux != nullptr && ok) *reinterpret_cast<uint4*>(p.aux + (int64_t)grow * p.ldaux + gcol) = v;
+        float a[8], b[8];
+        if (p.res != nullptr) {
+          unpack8(v, a);
+          unpack8(rres[it], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          v = pack8(a);
+        }
+        if (p.add1 != nullptr) {
+          unpack8(v, a);
+          unpack8(r1[it], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          v = pack8(a);
+        }
+        if (p.add2 != nullptr) {
+          unpack8(v, a);
+          unpack8(r2[it], b);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] += b[e];
+          v = pack8(a);
+        }
+        if (ok) *reinterpret_cast<uint4*>(p.out + (int64_t)grow * p.ldo + gcol) = v;
+        if (p.stats_out != nullptr) *reinterpret_cast<uint4*>(st + m_local * OUT_ROW_BYTES + c * 16) = v;
+      }
+      if (p.stats_out != nullptr) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int m_local = i * 32 + l31;
+          LnAcc lacc;
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {   // the lane's 48 columns in the order of the EPI_GATE_RES_STATS accumulator pass
+              const uint2 o = *reinterpret_cast<const uint2*>(st + m_local * OUT_ROW_BYTES + (j * 32 + 8 * g + 4 * hi) * 2);
+              if (j == 0 && g == 0) lacc.init(bflo(o.x));
+              lacc.add(bflo(o.x)); lacc.add(bfhi(o.x)); lacc.add(bflo(o.y)); lacc.add(bfhi(o.y));
+            }
+          const float2 mine = lacc.finish(48.f);
+          const float2 other = make_float2(__shfl_xor(mine.x, 32, 64), __shfl_xor(mine.y, 32, 64));
+          const float2 blk = ln_merge_equal(mine, other, 48.f);
+          const int grow = row0 + wm * 64 + m_local;
+          if (hi == 0 && grow < p.M) p.stats_out[(int64_t)(ncol0 / LN_BLOCK) * p.stats_ld + grow] = blk;
+        }
+      }
+      return;
+    }
+  }
   if (full) {
     uint4 val[12];
 #pragma unroll
@@ -777,6 +853,12 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   const bool ln = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
   if (ln && (!p.cs || !p.cv || !p.ln_stats || p.ln_nb < 1 || p.ln_nb > 12 || p.ln_nb * LN_BLOCK != p.K || p.ln_ld < p.M)) return VSYS_ERR_SHAPE;
   if (epi == EPI_GATE_RES_STATS && (!p.stats_out || p.stats_ld < p.M || p.aux)) return VSYS_ERR_ARG;
+  if (epi != EPI_GATE_RES && (p.add1 || p.add2)) return VSYS_ERR_ARG;
+  if (epi == EPI_GATE_RES && (p.add1 || p.add2 || p.stats_out)) {   // folded broadcasts / statistics beside a slab copy: gemm_kernel only
+    if ((p.add2 && !p.add1) || ((p.add1 || p.add2) && (!p.res || (p.ldr % 8))) || (p.stats_out && p.stats_ld < p.M)) return VSYS_ERR_ARG;
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+    return launch_gemm_t<8, 256>(p, epi, stream);
+  }
   // the statistics-emitting epilogue lives in gemm_kernel only (lab / forced variants of other kernel families fall back to it)
   if (epi == EPI_GATE_RES_STATS) {
     if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);

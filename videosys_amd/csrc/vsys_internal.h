@@ -67,6 +67,11 @@ struct GemmParams {
   const float* cs = nullptr; const float* cv = nullptr;
   const float2* ln_stats = nullptr; int64_t ln_ld = 0; int ln_nb = 0; float ln_eps = 0.f;
   float2* stats_out = nullptr; int64_t stats_ld = 0;
+  // EPI_GATE_RES only: up to two more rows-of-x operands (leading dimension ldr) added AFTER the residual, each with its own bf16
+  // rounding — out = bf16(bf16(bf16(res + u) + add1) + add2): the `x += slab` passes of PAB broadcasts that follow this GEMM in
+  // program order, folded into its store phase.  With stats_out set the same epilogue also emits the LayerNorm partials of what it
+  // stored (same bits as EPI_GATE_RES_STATS / ln_row_stats give for those rows).
+  const bf16_t* add1 = nullptr; const bf16_t* add2 = nullptr;
   // tile raster (common.h gemm_raster), filled in by launch_gemm: column-group width / panel-chunk height; 6 / 0 = the default
   int raster_gw = 6, raster_ph = 0;
 };

@@ -113,6 +113,29 @@ def gemm_stats(x, w, bias, stats, *, gate=None, gate_stride=0, rows_per_sample=0
     return out
 
 
+def gemm_gate_res_add(x, w, bias, *, res, gate=None, gate_stride=0, rows_per_sample=0, aux=None, adds=(), stats=None, out=None):
+    """gemm(..., epilogue=EPI_GATE_RES) whose store phase also performs the ``out += a`` passes (one bf16 rounding each, in order) of
+    up to two tensors ``adds`` shaped like ``res`` — the PAB broadcasts that follow the GEMM in program order — and, with ``stats``,
+    writes the LayerNorm partials of what it stored (gemm_stats format)."""
+    adds = tuple(adds)
+    assert len(adds) <= 2 and res is not None
+    _chk(x, w, bias, gate, res, aux, out, stats, *adds)
+    _bf16(x, w, bias, gate, res, aux, out, *adds)
+    assert x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
+    M, K = x.shape
+    N = w.shape[0]
+    for t in adds + ((aux,) if aux is not None else ()):
+        assert t.shape == res.shape and t.stride() == res.stride()
+    if stats is not None:
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[0] == N // LN_BLOCK and stats.shape[1] >= M
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _call("vsys_gemm_bf16_gate_res_add", _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(gate),
+          gate_stride, rows_per_sample, _p(res), res.stride(0), _p(aux), _p(adds[0]) if adds else None, _p(adds[1]) if len(adds) > 1 else None,
+          _p(stats), stats.shape[1] if stats is not None else 0)
+    return out
+
+
 def adaln_prescale(sites, nblocks, mod):
     """sites: int64 device tensor [nsites, 10] (include/videosys_amd.h, vsys_adaln_prescale); mod: the step's modulation table."""
     _chk(sites, mod)

@@ -148,6 +148,10 @@ class STDiT3:
         # launch programs (program.py): a step is recorded once per (geometry, PAB decision pattern, parallel layout) and replayed
         # through vsys_program_run afterwards; VSYS_PROGRAMS=0 issues every launch from Python every step
         self.pab_elide_unused = os.environ.get("VSYS_PAB_ELIDE", "1") != "0"   # see _pab_plan: slabs nobody will read are not written
+        # PAB broadcasts (`x = x + cached_output`) that follow a gate+residual GEMM in program order ride in that GEMM's store phase
+        # (ops.gemm_gate_res_add) instead of being 270 MB passes of their own; same roundings, same bits (_block, `upcoming`)
+        self.pab_fold_adds = os.environ.get("VSYS_PAB_FOLD", "1") != "0"
+        self._bc, self._folded = None, {}
         self.use_programs = os.environ.get("VSYS_PROGRAMS", "1") != "0"
         # AdaLN folded into the qkv / fc1 GEMMs (csrc/adaln_fold.hip): pre-scaled weights per step, row statistics from the
         # producing epilogue; VSYS_ADALN_FOLD=0 keeps the separate LayerNorm-modulate pass everywhere
@@ -573,6 +577,11 @@ class STDiT3:
             xe = ops.patch_embed(xz, w["x_embedder.proj.weight"], w["x_embedder.proj.bias"], pos, B, self.patch_size, C)
         xcur = xe.view(B * T * S, C)
 
+        # which sub-blocks (attention, cross, MLP) of which block are PAB broadcasts this step: what `upcoming` in _block looks ahead
+        # into.  (A hidden-state tap reads x between blocks: nothing may then be applied ahead of its place.)
+        self._bc, self._folded = None, {}
+        if plan is not None and self.pab_fold_adds and self._hidden_tap is None:
+            self._bc = [(d[0], d[1], d[2], d[4]) for d in plan[:2 * valid_depth]]
         for d in range(valid_depth):
             for i in (2 * d, 2 * d + 1):
                 xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, None if plan is None else plan[i], timestep_int,
@@ -645,6 +654,51 @@ class STDiT3:
             Wp, cs, cv = ftab["bufs"][site]
             return ops.gemm_ln(x, Wp, cs, cv, stats, gelu=gelu, out=out)
 
+        def upcoming(k):
+            """The cached outputs of the (at most two) broadcast sub-blocks that directly follow sub-block ``k`` (0 attention,
+            1 cross, 2 MLP) of this block in program order — the next reader of x comes after them.  They are marked as applied:
+            the GEMM that writes x at sub-block k adds them in its store phase, in order, one bf16 rounding each."""
+            got = []
+            if self._bc is None:
+                return got
+            j, kk = i, k
+            while len(got) < 2:
+                kk += 1
+                if kk == 3:
+                    j, kk = j + 1, 0
+                if j >= len(self._bc) or not self._bc[j][kk]:
+                    break
+                sj = self.states[j]
+                if kk == 2:
+                    cached = pab.get_mlp_output(self._bc[j][3], timestep=timestep_int, block_idx=sj.block_idx, is_temporal=sj.temporal)
+                else:
+                    cached = sj.last_attn if kk == 0 else sj.last_cross
+                if cached is None or cached.shape != x.shape or cached.stride() != x.stride():
+                    if kk == 2:
+                        self._folded[(j, kk)] = (cached, False)   # fetched (the store may have dropped it) but not applied
+                    break
+                self._folded[(j, kk)] = (cached, True)
+                got.append(cached)
+            return got
+
+        def applied(k):   # was this broadcast sub-block already added by an earlier GEMM's store phase?
+            return self._folded.get((i, k), (None, False))[1]
+
+        def write_x(a, wname, k, gate=None, aux=None, want_stats=False):
+            """x = x + gate * Linear(a) (+ the broadcasts that follow) — the GEMM that closes sub-block k"""
+            adds = upcoming(k)
+            W, bias = w[wname + ".weight"], w[wname + ".bias"]
+            gk = dict(gate=gate, gate_stride=C6, rows_per_sample=rps) if gate is not None else {}
+            if adds or (fold and aux is not None and (want_stats or adds)):
+                ops.gemm_gate_res_add(a, W, bias, res=x, aux=aux, adds=adds, stats=stats if fold else None, out=x, **gk)
+                self._stats_fresh = fold
+            elif fold and aux is None and want_stats:
+                ops.gemm_stats(a, W, bias, stats, res=x, out=x, **gk)
+                self._stats_fresh = True
+            else:
+                ops.gemm(a, W, bias, epilogue=ops.EPI_GATE_RES, res=x, aux=aux, out=x, **gk)
+                self._stats_fresh = False
+
         # which form the qkv site of this block takes (see _fold_ok)
         sp_order = None
         if sp is not None and not temporal:
@@ -654,8 +708,9 @@ class STDiT3:
 
         # ---------------- self attention
         if broadcast_attn:
-            ops.add_rows(x, st.last_attn)
-            self._stats_fresh = False
+            if not applied(0):
+                ops.add_rows(x, st.last_attn)
+                self._stats_fresh = False
         else:
             xm = None
             if fold_attn and sp_order is None:
@@ -684,14 +739,13 @@ class STDiT3:
                 if fold_attn:   # (order "qkv") the folded GEMM at rest produces what travels
                     qkv_rest = folded(p + ".attn.qkv", False, self._buf("qkv_rest", (N, 3 * C)))
                 ao = self._spatial_attn_sharded(p, xm, B, T, S, S_full, qkv_rest=qkv_rest)
-            ops.gemm(ao, w[p + ".attn.proj.weight"], w[p + ".attn.proj.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_msa,
-                     gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
-            self._stats_fresh = False
+            write_x(ao, p + ".attn.proj", 0, gate=gate_msa, aux=aux)   # (cross attention reads x next: no statistics wanted)
 
         # ---------------- cross attention (no norm, no modulation, no gate)
         if broadcast_cross:
-            ops.add_rows(x, st.last_cross)
-            self._stats_fresh = False
+            if not applied(1):
+                ops.add_rows(x, st.last_cross)
+                self._stats_fresh = False
         else:
             q = ops.gemm(x, w[p + ".cross_attn.q_linear.weight"], w[p + ".cross_attn.q_linear.bias"], out=_buf("xm", (N, C)))
             ao = _buf("attn_out", (N, C))
@@ -700,21 +754,20 @@ class STDiT3:
             if use_pab and keep_cross:
                 st.last_cross = slab(st.last_cross)
                 aux = st.last_cross
-            if fold and aux is None and not broadcast_mlp:   # the MLP's norm2 reads this x next: emit its statistics here
-                ops.gemm_stats(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], stats, res=x, out=x)
-                self._stats_fresh = True
-            else:
-                ops.gemm(ao, w[p + ".cross_attn.proj.weight"], w[p + ".cross_attn.proj.bias"], epilogue=ops.EPI_GATE_RES,
-                         res=x, aux=aux, out=x)
-                self._stats_fresh = False
+            # the MLP's norm2 reads this x next (unless the MLP is a broadcast nobody folded): emit its statistics here
+            write_x(ao, p + ".cross_attn.proj", 1, aux=aux, want_stats=not broadcast_mlp or self._bc is not None)
 
         # ---------------- MLP (+ PAB MLP broadcast, open_sora_transformer_3d.py:232-280 / pab_mgr.py:93-174: inside a configured
         # window the block replays gate_mlp * mlp(...) of the window's first timestep).  ``all_timesteps`` reaches the blocks
         # here; the reference's STDiT3.forward forgets to pass it on and raises TypeError with mlp_broadcast=True.
         if broadcast_mlp:
-            slab = pab.get_mlp_output(skip_range, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal)
-            ops.add_rows(x, slab)
-            self._stats_fresh = False
+            if (i, 2) in self._folded:   # looked at by an earlier GEMM of this step (the store hands an entry out once at a window's end)
+                slab = self._folded[(i, 2)][0]
+            else:
+                slab = pab.get_mlp_output(skip_range, timestep=timestep_int, block_idx=st.block_idx, is_temporal=temporal)
+            if not applied(2):
+                ops.add_rows(x, slab)
+                self._stats_fresh = False
             if timestep_int == skip_range[-1]:   # the window closed (the store dropped the entry): the slab is free again,
                 self._ws.setdefault("mlp_slab_pool", []).append(slab)   # in stream order behind the add above
             return x
@@ -726,14 +779,7 @@ class STDiT3:
             hbuf = ops.gemm(xm, w[p + ".mlp.fc1.weight"], w[p + ".mlp.fc1.bias"], epilogue=ops.EPI_BIAS_GELU,
                             out=_buf("mlp_h", (N, hdim)))
         aux = self._mlp_slab(x) if broadcast_next else None   # the post-gate output, written by the fc2 epilogue
-        if fold and aux is None:   # the next block's norm1 reads this x: emit its statistics here
-            ops.gemm_stats(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], stats, gate=gate_mlp, gate_stride=C6,
-                           rows_per_sample=rps, res=x, out=x)
-            self._stats_fresh = True
-        else:
-            ops.gemm(hbuf, w[p + ".mlp.fc2.weight"], w[p + ".mlp.fc2.bias"], epilogue=ops.EPI_GATE_RES, gate=gate_mlp,
-                     gate_stride=C6, rows_per_sample=rps, res=x, aux=aux, out=x)
-            self._stats_fresh = False
+        write_x(hbuf, p + ".mlp.fc2", 2, gate=gate_mlp, aux=aux, want_stats=True)   # the next block's norm1 reads this x
         if broadcast_next:
             pab.save_mlp_output(timestep=timestep_int, block_idx=st.block_idx, ff_output=aux, is_temporal=temporal)
         return x
