@@ -390,7 +390,7 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=80.0):
     """The reference's CPU PyTorch path on this box's host cores, as SURVEY.md §8(d) prescribes: the oracle (an fp32 port of the
     reference STDiT3, ``kind: "port"``) on the FULL config-2 token count, timed with ``valid_depth`` 1 and 2 (what the reference
     itself honours, open_sora_transformer_3d.py:608), warm-up + 3 repeats each, and fitted as fixed + depth x per-pair — after a
-    thread-count sweep over {physical/4, physical/2, physical, logical} cores (a 256-thread pool on a cold process is 200x slower
+    thread-count sweep over {physical/16 .. physical, logical} cores on a 2-frame slice (a 256-thread pool on a cold process is 200x slower
     than the same cores used well).  The host's fp32 GEMM rate is measured beside it so the figure can be sanity-checked:
     a CPU step cannot beat 89.4 TFLOP / that rate.  Frames are reduced (and said so) only if a full-token pair would not fit
     the time budget."""
@@ -423,9 +423,8 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=80.0):
             m.forward(x, t, y, valid_depth=depth, **kw)
             return time.perf_counter() - t0
 
-    # thread-count sweep, two stages: a 2-frame slice finds the neighbourhood cheaply; the three pool sizes around its best are
-    # then compared on a 6-frame slice (12 288 rows per GEMM: a pool that loses on 4096 rows can still win on the real size);
-    # then the measurement on as many of the 19 frames as the budget allows
+    # thread-count sweep on a 2-frame slice (the pool gets slower beyond ~physical/4 on this class of host), then the measurement
+    # on as many of the 19 frames as the budget allows: 1 warm-up + 2 x (depth 1 + depth 2) = 7 single-pair passes
     probe = torch.randn(2, 4, 2, Hl, Wl, generator=g)
     sweep = {}
     for n in cands:
@@ -433,25 +432,15 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=80.0):
         run(probe, 1)                  # warm-up at this pool size
         sweep[n] = run(probe, 1)
         if sweep[n] > 1.5 * min(sweep.values()) or time.perf_counter() - t_start > budget_s * 0.2:
-            break   # past the knee (on this class of host the pool gets slower beyond ~physical/4) or out of sweep time
-    best2 = min(sweep, key=sweep.get)
-    i2 = cands.index(best2)
-    probe6 = torch.randn(2, 4, min(6, T), Hl, Wl, generator=g)
-    sweep6 = {}
-    for n in cands[max(0, i2 - 1):i2 + 3]:
-        if time.perf_counter() - t_start > budget_s * 0.45:
-            break
-        torch.set_num_threads(n)
-        run(probe6, 1)
-        sweep6[n] = run(probe6, 1)
-    best = min(sweep6, key=sweep6.get) if sweep6 else best2
+            break   # past the knee or out of sweep time
+    best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    per_frame = (sweep6[best] / probe6.shape[2]) if sweep6 else sweep[best] / 2
+    per_frame = 1.3 * sweep[best] / 2     # (a full-size pass is a little slower per frame than the 2-frame slice)
     left = budget_s * 0.85 - (time.perf_counter() - t_start)
-    Ts = max(2, min(T, int(left / (per_frame * 13))))    # 1 warm-up + 3 x (depth 1 + depth 2) = ~13 single-pair passes
+    Ts = max(2, min(T, int(left / (per_frame * 7.5))))
     x = torch.randn(2, 4, Ts, Hl, Wl, generator=g)
     run(x, 1)
-    reps = 3
+    reps = 2
     t1 = sorted(run(x, 1) for _ in range(reps))
     t2 = sorted(run(x, 2) for _ in range(reps))
     pair = max(t2[0] - t1[0], 1e-9)
@@ -473,7 +462,6 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=80.0):
                                                             "depth": cfg.depth},
         "valid_depth_1_s": [round(v, 3) for v in t1], "valid_depth_2_s": [round(v, 3) for v in t2],
         "thread_sweep_2_frames_depth1_s": {str(k): round(v, 3) for k, v in sweep.items()},
-        "thread_sweep_6_frames_depth1_s": {str(k): round(v, 3) for k, v in sweep6.items()},
         "cpu_step_tflops": round(89.4 / step_s, 3) if cfg.depth == 28 and L == 300 else None,
         "host_fp32_gemm_tflops": round(gemm_tf, 3),
         "lower_bound_s_at_gemm_rate": round(89.4 / gemm_tf, 2),

@@ -121,6 +121,13 @@ def sdpa(q: Tensor, k: Tensor, v: Tensor, key_len: Optional[Sequence[int]] = Non
             for i, m in enumerate(key_len):
                 attn_mask[i, :, :, :m] = True
         return F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask)
+    # a score tensor past ~8 GB (720p x 128f: 76 frames x 16 heads x 3600^2 fp32 = 63 GB) is computed in slices of the leading
+    # axis — every op below is per (batch, head, row), so the slices give the same values
+    per = q.shape[1] * q.shape[-2] * k.shape[-2] * 4 if q.dim() == 4 else 0
+    if q.dim() == 4 and q.shape[0] > 1 and per * q.shape[0] > (8 << 30):
+        step = max(1, (8 << 30) // per)
+        return torch.cat([sdpa(q[i:i + step], k[i:i + step], v[i:i + step],
+                               None if key_len is None else list(key_len[i:i + step]), native) for i in range(0, q.shape[0], step)], 0)
     s = (q @ k.transpose(-2, -1)) * (d**-0.5)
     if key_len is not None:
         L = k.shape[-2]

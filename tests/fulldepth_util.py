@@ -8,7 +8,7 @@ tests/test_oracle_vs_golden.py) is plain PyTorch, so it runs ON THE GPU AS THE C
   * ``floor`` = the same oracle executed with torch's bf16 kernels, i.e. how the reference itself runs this model
                 (``model.to(bf16)``); its distance from ``ref`` is the bf16 noise floor of the REFERENCE;
   * ``hip``   = the product (hand-written HIP kernels through the C ABI).
-Stated tolerance: rel-rms(hip, ref) <= 1.5 x rel-rms(floor, ref) on the output latents AND on every block pair's hidden state,
+Stated tolerance: rel-rms(hip, ref) <= 1.15 x rel-rms(floor, ref) on the output latents (1.5 x on every block pair's hidden state),
 and cosine(hip, ref) >= 0.999 whenever the reference's own bf16 run reaches 0.999 (with untrained random weights a 56-block
 stack amplifies rounding noise; where the floor itself drops below 0.999 the requirement is cosine(hip) >= cosine(floor) - 5e-4).
 """
@@ -32,6 +32,15 @@ def bf16_round(sd):
 def opensora_inputs(T=19, HW=64, L=300, caption_channels=4096, seed=0):
     """SURVEY §8d 'C2': z ~ N(0,1) [1,4,T,HW,HW] with manual_seed(0), y = 0.1 randn [1,1,300,4096], mask = L ones."""
     g = torch.Generator().manual_seed(seed)
+    if isinstance(HW, tuple):   # (latent height, latent width, frames): a non-square geometry, e.g. configs[3] 720p x 128f = (90, 160, 128)
+        Hl, Wl, frames = HW
+        z = torch.randn(1, 4, T, Hl, Wl, generator=g).to(torch.bfloat16).float()
+        y = (torch.randn(1, 1, 300, caption_channels, generator=g) * 0.1).to(torch.bfloat16).float()
+        mask = torch.zeros(1, 300, dtype=torch.long)
+        mask[:, :L] = 1
+        geom = dict(fps=torch.tensor([24.0]), height=torch.tensor([float(Hl * 8)]), width=torch.tensor([float(Wl * 8)]),
+                    num_frames=torch.tensor([float(frames)]))
+        return z, y, mask, geom
     z = torch.randn(1, 4, T, HW, HW, generator=g).to(torch.bfloat16).float()
     y = (torch.randn(1, 1, 300, caption_channels, generator=g) * 0.1).to(torch.bfloat16).float()
     mask = torch.zeros(1, 300, dtype=torch.long)
@@ -148,7 +157,7 @@ def latte_config1(depth=28, device="cuda:0", t_value=500, seed=4321):
     return dict(out_hip=stats(out_hip, out_ref), out_floor=stats(out_floor, out_ref), per_pair=rows)
 
 
-def verdict(hip: dict, floor: dict, factor=1.5) -> str:
+def verdict(hip: dict, floor: dict, factor=1.15) -> str:
     """'' if the product is inside the stated tolerance, else the reason."""
     if not hip["rel_rms"] <= factor * floor["rel_rms"]:
         return f"rel-rms {hip['rel_rms']:.4e} > {factor} x reference-bf16 floor {floor['rel_rms']:.4e}"

@@ -2,7 +2,7 @@
 pipeline's latents within a stated fp tolerance on fixed seeds").
 
 Checker = the oracle run in fp32 ON THE GPU; noise floor = the same oracle run with torch's bf16 kernels (how the reference
-itself executes the model).  Stated tolerance (tests/fulldepth_util.py): rel-rms(hip) <= 1.5 x rel-rms(reference-bf16) and
+itself executes the model).  Stated tolerance (tests/fulldepth_util.py): rel-rms(hip) <= 1.15 x rel-rms(reference-bf16) on outputs (1.5 x per pair) and
 cosine >= 0.999 (or >= the floor's cosine - 5e-4 where the reference's own bf16 run is below 0.999).
 
   * config 2 exactly: STDiT3-XL/2 depth 28, latent [4,19,64,64] -> 38 912 token rows, 300 text tokens, weights seed 1234:

@@ -25,6 +25,15 @@ def main():
     res = {"method": U.__doc__.split("Method.")[1].strip()}
     t0 = time.time()
     hip, ref, floor, y_null = U.opensora_models(depth=28, seed=1234)
+    if "--720p128f" in sys.argv:   # configs[3] geometry, all 28 pairs, one step: 2 x 38 x 3600 = 273 600 token rows
+        z, y, mask, geom = U.opensora_inputs(T=38, HW=(90, 160, 128), L=300)
+        res["geometry"] = "720p x 128f: latent [4, 38, 90, 160], CFG batch 2 = 273 600 token rows, 300 text tokens, depth 28"
+        r = U.opensora_one_step(hip, ref, floor, y_null, z, y, mask, geom, t_value=700.0)
+        res["configs3_geometry_one_step"] = r
+        res["configs3_geometry_one_step_verdict"] = U.verdict(r["out_hip"], r["out_floor"]) or "within tolerance"
+        res["seconds"] = time.time() - t0
+        print(json.dumps(res, indent=1))
+        return
     z, y, mask, geom = U.opensora_inputs(T=19, HW=64, L=300)
     z5, y5, mask5, geom5 = U.opensora_inputs(T=5, HW=64, L=120)
 

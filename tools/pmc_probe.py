@@ -40,6 +40,24 @@ kp, vt = ops.alloc_kv_buffers(38, H, 1024, dev)
 for _ in range(3):
     ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kp, vt, 38, H, 1024)
     ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024)
+_lib.load().vsys_tune_flash_variant(16)   # the persistent 64-rows-per-wave instruction stream (attention_w64.hip), opt-in in the product
+for _ in range(3):
+    ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, 38, H, 1024, 1024)
+_lib.load().vsys_tune_flash_variant(0)
+# the AdaLN-folded forms of qkv / fc1 (LayerNorm + modulation in the epilogue) and the statistics-emitting gate + residual GEMM
+st = ops.ln_stats_buffer(N, C, dev)
+ops.ln_row_stats(x, st)
+for name, n, gelu in (("qkv_ln", 3 * C, False), ("fc1_ln", 4 * C, True)):
+    wp = rnd(n, C, scale=1 / math.sqrt(C))
+    cs, cv = wp.float().sum(1).contiguous(), torch.zeros(n, dtype=torch.float32, device=dev)
+    out = torch.empty(N, n, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        ops.gemm_ln(x, wp, cs, cv, st, gelu=gelu, out=out)
+for k_, a_ in ((C, x), (4 * C, h)):
+    w, b = rnd(C, k_, scale=1 / math.sqrt(k_)), rnd(C, scale=0.1)
+    out = torch.empty(N, C, dtype=torch.bfloat16, device=dev)
+    for _ in range(3):
+        ops.gemm_stats(a_, w, b, st, gate=mod[0, 2 * C:3 * C], gate_stride=6 * C, rows_per_sample=N // 2, res=resid, out=out)
 kv = rnd(600, 2 * C)   # cross attention: 300 text keys per sample (resident-K/V kernel)
 kpc, vtc = ops.alloc_kv_buffers(2, H, 300, dev)
 ops.attn_prep_kv(kv[:, :C], kv[:, C:], None, kpc, vtc, 2, H, 300)
