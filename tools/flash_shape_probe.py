@@ -1,0 +1,56 @@
+"""Spatial flash attention (d = 72, q = kv = S tokens per frame) at an arbitrary shape, per vsys_tune_flash_variant id: median ms and
+algorithmic TFLOP/s (4 frames heads S^2 72).  Every variant's output is compared with variant 15 (the 32-row kernel).
+    python tools/flash_shape_probe.py --frames 76 --tokens 3600 --variants 15,141,15,141"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from videosys_amd import _lib, ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=76)
+    ap.add_argument("--tokens", type=int, default=3600)
+    ap.add_argument("--variants", default="15,141,15,141")
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    F, S, H, C = a.frames, a.tokens, 16, 1152
+    qkv = torch.randn(F * S, 3 * C, generator=g).to(torch.bfloat16).to(dev)
+    qw = (torch.randn(72, generator=g) * 0.1 + 1).to(torch.bfloat16).to(dev)
+    kp, vt = ops.alloc_kv_buffers(F, H, S, dev)
+    ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], qw, kp, vt, F, H, S)
+    ao = torch.empty(F * S, C, dtype=torch.bfloat16, device=dev)
+    flops = 4.0 * F * H * S * S * 72
+    ref, out = None, []
+    for v in [int(x) for x in a.variants.split(",")]:
+        lib.vsys_tune_flash_variant(v)
+        for _ in range(2):
+            ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, F, H, S, S)
+        ts = []
+        for _ in range(a.reps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            ops.flash_attn(qkv[:, :C], qw, kp, vt, ao, F, H, S, S)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+        ts.sort()
+        if ref is None:
+            ref = ao.float().clone()
+        err = (ao.float() - ref).abs().max().item()
+        out.append({"variant": v, "ms_med": round(ts[len(ts) // 2], 4), "ms_min": round(ts[0], 4),
+                    "tflops_med": round(flops / (ts[len(ts) // 2] * 1e-3) / 1e12, 1), "max_abs_diff_vs_first": err})
+    lib.vsys_tune_flash_variant(0)
+    print(json.dumps({"frames": F, "tokens": S, "heads": H, "results": out}, indent=1))
+
+
+if __name__ == "__main__":
+    main()

@@ -1003,7 +1003,11 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
     return launch_flash_attn_d72_w64p(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
                                       g_flash_variant == 146, stream);
   constexpr int W64_DEFAULT_VAR = 1;   // 140 / 141 / 143 select placement variant 0 / 1 / 3 (lab builds: 148 / 149 = ablations 8 / 9)
-  if ((g_flash_variant == 14 || g_flash_variant >= 140) &&
+  // Long key sequences (720p frames: 3600 keys = 57 tiles per item) amortise the one-item form's seams: 1003 vs 915 TFLOP/s against
+  // the 32-row kernel at 76 x 16 x 3600^2, same bits (profiles/r04_flash_w64_720p.json); at 1024 keys it loses 5 %.
+  static const bool w64_off = [] { const char* e = getenv("VSYS_FLASH_W64"); return e && e[0] == '0'; }();
+  const bool w64_long = g_flash_variant == 0 && kv_len >= 2048 && !w64_off;
+  if ((g_flash_variant == 14 || g_flash_variant >= 140 || w64_long) &&
       flash_w64_supports(q_len, kv_len, kv_pad))
     return launch_flash_attn_d72_w64(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
                                      g_flash_variant >= 140 ? g_flash_variant - 140 : W64_DEFAULT_VAR, stream);
