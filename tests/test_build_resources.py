@@ -88,14 +88,20 @@ def test_w64_flash_kernel_owns_its_accumulator_registers(tmp_path):
     u = _usage("attention_w64.hip")
     hits = {k: v for k, v in u.items() if "flash_attn_d72_w64" in k}
     assert len(hits) >= 4      # the three placement variants + the persistent form
+    u64 = {k: v for k, v in _usage("attention64_w64.hip").items() if "flash_attn_d64_w64" in k}
+    assert len(u64) == 1       # the head_dim 64 form of the same stream
+    hits.update(u64)
     for name, res in hits.items():
         assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) == 0, (name, res)
         assert res.get("VGPRs", 0) <= 256 and 224 <= res.get("AGPRs", 0) <= 256, (name, res)
-    out = str(tmp_path / "w64.s")
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
-                    os.path.join(CSRC, "attention_w64.hip")], check=True, capture_output=True)
     inside, bad = False, []
-    for ln in open(out):
+    text = []
+    for src in ("attention_w64.hip", "attention64_w64.hip"):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
+                        os.path.join(CSRC, src)], check=True, capture_output=True)
+        text += open(out).read().split("\n")
+    for ln in text:
         if "#ASMSTART" in ln:
             inside = True
         elif "#ASMEND" in ln:

@@ -74,6 +74,56 @@ def test_flash_attn_d64_joint_sequence(B, H, Lt, Lv, norm, rope):
         assert torch.equal(out3, out), f"{what} ring (d64) differs from the shipped three-stage kernel"
 
 
+@pytest.mark.parametrize("B,H,Lt,Lv,norm,rope", [(1, 3, 226, 2100, True, True), (2, 2, 20, 300, True, True), (1, 2, 7, 2553, False, True),
+                                                  (1, 2, 0, 2304, True, False)])
+def test_flash_attn_d64_w64_stream(B, H, Lt, Lv, norm, rope):
+    """The 64-rows-per-wave instruction stream generated for head_dim 64 (attention64_w64.hip; default from 2048 keys, flash variant
+    14 forces it from 256): against fp32 torch on the same bf16 inputs and against the 32-row kernel (variant 15) — same P
+    rounding, the row sum on the matrix pipe instead of the VALU, so equal to within one bf16 step of the output.  Ragged last
+    tiles (2326 = 36 x 64 + 22; 320 = 5 tiles), query rows past the last 256-block, with / without norm and RoPE."""
+    from videosys_amd import _lib, ops
+
+    D, L = 64, Lt + Lv
+    C = H * D
+    g = torch.Generator().manual_seed(B * 100 + H + L)
+    qkv = bf(torch.randn(B * L, 3 * C, generator=g))
+    qw, qb = bf(1 + 0.2 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
+    kw, kb = bf(1 + 0.2 * torch.randn(D, generator=g)), bf(0.1 * torch.randn(D, generator=g))
+    ang = torch.rand(max(Lv, 1), D // 2, generator=g) * 6.0
+    cos, sin = ang.cos().repeat_interleave(2, -1).contiguous(), ang.sin().repeat_interleave(2, -1).contiguous()
+    qd = qkv.to(dev())
+    kp, vt = ops.alloc_kv_buffers64(B, H, L, dev())
+    cd, sd = (cos.to(dev()), sin.to(dev())) if rope else (None, None)
+    nq, nb = (qw.to(dev()), qb.to(dev())) if norm else (None, None)
+    ops.attn_prep_kv64(qd[:, C:2 * C], qd[:, 2 * C:], kw.to(dev()) if norm else None, kb.to(dev()) if norm else None, cd, sd, Lt,
+                       kp, vt, B, H, L)
+    outs = {}
+    lib = _lib.load()
+    try:
+        for fv in (14, 15):
+            assert lib.vsys_tune_flash_variant(fv) == 0
+            o = torch.full((B * L, C), float("nan"), dtype=torch.bfloat16, device=dev())
+            ops.flash_attn64(qd[:, :C], nq, nb, cd, sd, Lt, kp, vt, o, B, H, L, L)
+            torch.cuda.synchronize()
+            outs[fv] = o
+    finally:
+        lib.vsys_tune_flash_variant(0)
+    q, k, v = [t.float().view(B, L, H, D).transpose(1, 2) for t in qkv.split(C, dim=1)]
+    if norm:
+        q = bf(torch.nn.functional.layer_norm(q, (D,), qw.float(), qb.float(), 1e-6)).float()
+        k = bf(torch.nn.functional.layer_norm(k, (D,), kw.float(), kb.float(), 1e-6)).float()
+    if rope:
+        q = torch.cat([q[:, :, :Lt], bf(rope_ref(q[:, :, Lt:], cos, sin)).float()], 2)
+        k = torch.cat([k[:, :, :Lt], bf(rope_ref(k[:, :, Lt:], cos, sin)).float()], 2)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(D), -1) @ v).transpose(1, 2).reshape(B * L, C)
+    check(outs[14], ref, what=f"flash d64 w64 B{B} H{H} L{Lt}+{Lv}")
+    a, b_ = outs[14].float().cpu(), outs[15].float().cpu()
+    assert torch.isfinite(a).all()
+    err14, err15 = (a - ref).abs().max().item(), (b_ - ref).abs().max().item()
+    assert err14 <= 1.25 * err15 + 1e-3, (err14, err15)
+    assert (a - b_).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
+
+
 def test_ln_modulate_two_segments_and_plain():
     from videosys_amd import ops
 

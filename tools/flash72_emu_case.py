@@ -242,3 +242,83 @@ def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None
         ref = reference(q, k, vt, kv_len)
         errs.append(float(np.abs(out - ref).max() / np.abs(ref).max()))
     return errs, viol, {"barriers": wg.waves[0].nbarrier, "counts": wg.waves[0].count}
+
+
+# ------------------------------------------------------------------------------------------------ head_dim 64 (attention64_w64.hip)
+def make_case64(kv_len, seed=0, spike=False, qscale=1.0):
+    """Q [256][64] bf16 (normed + rotated), K [kv_pad][64] (normed, rotated, scaled: exp2 domain), V [kv_pad][64]"""
+    rng = np.random.default_rng(seed)
+    kv_pad = (kv_len + 63) // 64 * 64
+    q = E.bf16_to_f32(E.bf16_round(rng.standard_normal((256, 64)).astype(np.float32) * qscale))
+    k = E.bf16_to_f32(E.bf16_round(rng.standard_normal((kv_pad, 64)).astype(np.float32) * 0.35))
+    vv = E.bf16_to_f32(E.bf16_round(rng.standard_normal((kv_pad, 64)).astype(np.float32)))
+    k[kv_len:] = 0
+    vv[kv_len:] = 0
+    if spike:
+        k[kv_len - 70] = E.bf16_to_f32(E.bf16_round(q[5] * 3.0))
+        k[130] = E.bf16_to_f32(E.bf16_round(q[200] * 2.0))
+    return q, k, vv, kv_pad
+
+
+def run64(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qscale=1.0, lb=0):
+    """One workgroup of flash_attn_d64_w64_kernel: the layouts of attn_prep_kv64 (K rows of 128 bytes, 16-byte chunk c of row r at
+    chunk c ^ ((r >> 1) & 7); Vt [64][kv_pad]), the third 32-row block of every stage's Vt image constant (ones rows 72 / 76)."""
+    KT, ST = 8192, 8192 + 96 * 128
+    q, k, vv, kv_pad = make_case64(kv_len, seed, spike, qscale)
+    ntiles = (kv_len + 63) // 64
+    lines = G.generate(1, d64=True)
+    ksw = np.zeros_like(k)
+    for r in range(kv_pad):
+        for c in range(8):
+            pc = c ^ ((r >> 1) & 7)
+            ksw[r, 8 * pc:8 * pc + 8] = k[r, 8 * c:8 * c + 8]
+    kbytes = to_bytes_bf16(ksw)
+    vbytes = to_bytes_bf16(np.ascontiguousarray(vv.T))
+    KID, VID = (0x1000, 1), (0x2000, 2)
+    lane = np.arange(64)
+    l31, hi = lane & 31, lane >> 5
+    bind = {"rk": "s[4:7]", "rv": "s[8:11]", "wl": "s16", "sv0": "s17", "sv1": "s18", "lb": "s22", "nt": "s23", "lim": "v213",
+            "kvo": "v214", "vvo": "v215", "kfa0": "v216", "kfa1": "v217", "kfa2": "v218", "kfa3": "v219", "vfa0": "v220", "vfa1": "v221",
+            "vfa2": "v222", "vfa3": "v223"}
+    wg = E.Workgroup(lines, [dict(bind) for _ in range(4)], late_vm=late_vm, late_ds=late_ds)
+    wg.lds[:] = 0xAB
+    one = np.full(64, 0x3f80, dtype=np.uint16).view(np.uint8)
+    for st in range(4):   # the C++ prologue: rows 64..95 of every stage's Vt image = 0, rows 72 and 76 = 1.0
+        o = lb + st * ST + KT + 64 * 128
+        wg.lds[o:o + 32 * 128] = 0
+        for row in (72, 76):
+            o = lb + st * ST + KT + row * 128
+            wg.lds[o:o + 128] = one
+    for w, wave in enumerate(wg.waves):
+        wg.bufs[KID], wg.bufs[VID] = kbytes, vbytes
+        wave.s.update({4: KID[0], 5: KID[1], 6: kv_pad * 128, 7: 0x20000, 8: VID[0], 9: VID[1], 10: 64 * kv_pad * 2, 11: 0x20000})
+        wave.s.update({16: w * 1024, 17: w * 8 * kv_pad * 2, 18: (w + 4) * 8 * kv_pad * 2, 22: lb, 23: ntiles})
+        k_voff = lane * 16
+        v_voff = ((lane >> 3) * kv_pad * 2 + (((lane & 7) ^ (lane >> 4)) << 4)) ^ ((w & 1) << 6)
+        krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3)
+        k_roff = krow * 128 + ((hi ^ ((krow >> 1) & 7)) << 4)
+        v_roff = KT + l31 * 128 + (((2 * hi) ^ ((l31 >> 1) & 7)) << 4)
+        for reg, val in ((213, kv_len - (ntiles - 1) * 64 - 16 * hi), (214, k_voff), (215, v_voff), (216, k_roff), (217, k_roff ^ 32),
+                         (218, k_roff ^ 64), (219, k_roff ^ 96), (220, v_roff ^ 0), (221, v_roff ^ 16), (222, v_roff ^ 64), (223, v_roff ^ 80)):
+            wave.v[reg] = np.asarray(val).astype(np.int64).astype(np.uint32)
+        for blk in range(2):
+            rows = 64 * w + 32 * blk + l31
+            for c in range(4):
+                for j in range(4):
+                    d = 16 * c + 8 * hi + 2 * j
+                    wave.a[96 + 20 * blk + 4 * c + j] = (E.bf16_round(q[rows, d]) | (E.bf16_round(q[rows, d + 1]) << 16)).astype(np.uint32)
+    viol = wg.run(order=order)
+    out = np.zeros((256, 64), dtype=np.float32)
+    for w, wave in enumerate(wg.waves):
+        for blk in range(2):
+            base = 48 * blk
+            l_ = E.f32(wave.a[base + 32 + 4])
+            for dt in range(2):
+                for r in range(16):
+                    d = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * hi
+                    out[64 * w + 32 * blk + l31, d] = E.f32(wave.a[base + 16 * dt + r]) / l_
+    s_ = q.astype(np.float64) @ k[:kv_len].astype(np.float64).T
+    p_ = np.exp2(s_ - s_.max(1, keepdims=True))
+    ref = (p_ @ vv[:kv_len].astype(np.float64)) / p_.sum(1, keepdims=True)
+    err = np.abs(out - ref).max() / np.abs(ref).max()
+    return err, viol, {"barriers": wg.waves[0].nbarrier, "counts": wg.waves[0].count}

@@ -18,10 +18,14 @@ def main():
     ap.add_argument("--tokens", type=int, default=3600)
     ap.add_argument("--variants", default="15,141,15,141")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--d64", action="store_true", help="head_dim 64 joint attention (CogVideoX-5B: --frames 2 --tokens 17776 --heads 48)")
+    ap.add_argument("--heads", type=int, default=16)
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
+    if a.d64:
+        return d64(a, dev, lib, g)
     F, S, H, C = a.frames, a.tokens, 16, 1152
     qkv = torch.randn(F * S, 3 * C, generator=g).to(torch.bfloat16).to(dev)
     qw = (torch.randn(72, generator=g) * 0.1 + 1).to(torch.bfloat16).to(dev)
@@ -50,6 +54,42 @@ def main():
                     "tflops_med": round(flops / (ts[len(ts) // 2] * 1e-3) / 1e12, 1), "max_abs_diff_vs_first": err})
     lib.vsys_tune_flash_variant(0)
     print(json.dumps({"frames": F, "tokens": S, "heads": H, "results": out}, indent=1))
+
+
+def d64(a, dev, lib, g):
+    B, L, H, D = a.frames, a.tokens, a.heads, 64
+    C = H * D
+    qkv = torch.randn(B * L, 3 * C, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(D, generator=g) * 0.1 + 1).to(torch.bfloat16).to(dev)
+    bia = (torch.randn(D, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    Lt = 226 if L > 226 else 0
+    ang = torch.rand(L - Lt, D // 2, generator=g) * 6.0
+    cos, sin = ang.cos().repeat_interleave(2, -1).contiguous().to(dev), ang.sin().repeat_interleave(2, -1).contiguous().to(dev)
+    kp, vt = ops.alloc_kv_buffers64(B, H, L, dev)
+    ops.attn_prep_kv64(qkv[:, C:2 * C], qkv[:, 2 * C:], w, bia, cos, sin, Lt, kp, vt, B, H, L)
+    ao = torch.empty(B * L, C, dtype=torch.bfloat16, device=dev)
+    flops = 4.0 * B * H * L * L * D
+    ref, out = None, []
+    for v in [int(x) for x in a.variants.split(",")]:
+        lib.vsys_tune_flash_variant(v)
+        for _ in range(2):
+            ops.flash_attn64(qkv[:, :C], w, bia, cos, sin, Lt, kp, vt, ao, B, H, L, L)
+        ts = []
+        for _ in range(a.reps):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            ops.flash_attn64(qkv[:, :C], w, bia, cos, sin, Lt, kp, vt, ao, B, H, L, L)
+            e.record()
+            torch.cuda.synchronize()
+            ts.append(s.elapsed_time(e))
+        ts.sort()
+        if ref is None:
+            ref = ao.float().clone()
+        out.append({"variant": v, "ms_med": round(ts[len(ts) // 2], 4), "ms_min": round(ts[0], 4),
+                    "tflops_med": round(flops / (ts[len(ts) // 2] * 1e-3) / 1e12, 1),
+                    "max_abs_diff_vs_first": (ao.float() - ref).abs().max().item()})
+    lib.vsys_tune_flash_variant(0)
+    print(json.dumps({"head_dim": 64, "batch": B, "tokens": L, "heads": H, "results": out}, indent=1))
 
 
 if __name__ == "__main__":

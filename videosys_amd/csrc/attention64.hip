@@ -10,6 +10,8 @@
 // rides on K) with the d64 geometry: 4 QK^T chunks of 16, 2 PV tiles of 32 (no padding rows, so the softmax denominator
 // is summed on the VALU), K rows of 128 bytes whose 16-byte chunks are XOR-swizzled by (row>>1)&7 — the swizzle is
 // written by attn_prep_kv64 into the HBM image, so the tile stays one contiguous 8 KiB LDS-DMA.
+#include <cstdlib>
+
 #include "common.h"
 #include "vsys_internal.h"
 
@@ -477,6 +479,12 @@ int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w,
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
   if (nblk > 0x7fffffff) return VSYS_ERR_SHAPE;
   const int fv = get_flash_variant();
+  // long key sequences (CogVideoX: 17 776): 64 query rows per wave, one wave per SIMD, hand-allocated instruction stream
+  // (attention64_w64.hip); 15 = never (the A/B id of the measurement tools), 14 = wherever it is supported
+  static const bool w64_off = [] { const char* e = getenv("VSYS_FLASH_W64"); return e && e[0] == '0'; }();
+  if (((fv == 0 && kv_len >= 2048 && !w64_off) || fv == 14) && flash64_w64_supports(q_len, kv_len))
+    return launch_flash_attn_d64_w64(q, q_stride, ln_w, ln_b, rope_cos, rope_sin, rope_start, rope_len, kp, vt, out, out_stride, batch,
+                                     heads, q_len, kv_len, kv_pad, eps, stream);
   if (fv == 12)        // A/B id (see set_flash_variant): the two-stage ring
     hipLaunchKernelGGL(flash_attn_d64_kernel<2>, dim3((unsigned)nblk), dim3(256), 2 * KV_STAGE, stream, p);
   else

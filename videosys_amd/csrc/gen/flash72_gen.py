@@ -23,6 +23,13 @@ import os
 import sys
 
 K_TILE, STAGE, NSTAGE = 9216, 21504, 4
+# head_dim 64 (flash_attn_d64_w64, csrc/attention64_w64.hip; set by generate(d64=True)): 4 QK^T chunks, K rows of 128 bytes whose 16-byte
+# chunks are XOR-swizzled (four fragment address registers instead of one + immediates), 8 + 8 LDS-DMA pieces per tile (four per
+# wave), the third 32-row block of the Vt image (ones rows 72 / 76: the row sum) constant in LDS instead of fetched
+HD64 = False
+NCC = 5            # QK^T chunks of 16 dims
+NPIECE = 5         # LDS-DMA pieces per wave and tile
+KADDR64 = [196, 210, 211, 212]
 O = {"A": 0, "B": 48}
 Q = {"A": 96, "B": 116}
 KF, VF = 136, 176
@@ -132,7 +139,7 @@ def place(e, mfmas, streams):
 
 def qk_mfmas(nxt):
     out = []
-    for c in range(5):
+    for c in range(NCC):
         for blk in ("A", "B"):
             for kt in range(2):
                 d = v(sreg(nxt, blk, kt), 16)
@@ -171,7 +178,22 @@ def v_reads():
 
 
 def k_reads():
+    if HD64:
+        return [f"ds_read_b128 {a(kf(kt, cc), 4)}, {v(KADDR64[cc])} offset:{kt * 4096}" for kt in range(2) for cc in range(4)]
     return [f"ds_read_b128 {a(kf(kt, cc), 4)}, {v(KADDR)} offset:{kt * 4608 + cc * 32}" for kt in range(2) for cc in range(5)]
+
+
+def k_addr(stage_sreg, plus=0):
+    """the K fragment read address(es) of the tile in the stage at s[stage_sreg] (+ ``plus`` bytes)"""
+    if HD64:
+        out = [f"v_add_u32_e32 {v(KADDR64[cc])}, {s(stage_sreg)}, %[kfa{cc}]" for cc in range(4)]
+        if plus:
+            out += [f"v_add_u32_e32 {v(KADDR64[cc])}, {plus}, {v(KADDR64[cc])}" for cc in range(4)]
+        return out
+    out = [f"v_add_u32_e32 {v(KADDR)}, {s(stage_sreg)}, %[kfa]"]
+    if plus:
+        out.append(f"v_add_u32_e32 {v(KADDR)}, {plus}, {v(KADDR)}")
+    return out
 
 
 def max_chain(buf, blk):
@@ -204,7 +226,7 @@ def dma_ops():
     """the wave's five LDS-DMA pieces of the next tile into the stage at s[S_ST] (+ soff advance); (text, after) tuples spread by
     the caller.  An independent instruction sits between every M0 write and the load that reads it."""
     rk, rv, r4 = (sq(DK), sq(DV), sq(D4)) if PERSIST else ("%[rk]", "%[rv]", "%[r4]")
-    return [
+    ops = [
         f"s_add_i32 {s(S_DST)}, {s(S_ST)}, %[wl]",
         f"s_mov_b32 m0, {s(S_DST)}",
         f"s_add_i32 {s(S_T2)}, {s(S_DST)}, 4096",
@@ -223,6 +245,7 @@ def dma_ops():
         f"buffer_load_dwordx4 %[v4o], {r4}, {s(S_E)} offen lds",
         f"s_add_i32 {s(S_E)}, {s(S_E)}, %[st4]",
     ]
+    return ops[:13] + [ops[14]] if HD64 else ops   # (d64: four pieces — K w, K w + 4, Vt w, Vt w + 4)
 
 
 def soff_reset(tile):
@@ -322,7 +345,7 @@ def body(e, tag, p, masked, resc, variant=0):
     cur, nxt = p, 1 - p
     nodma, novalu = variant in (8, 9), variant == 9
     dma = [] if nodma else dma_ops()
-    dma_groups = [] if nodma else [dma[0:4], dma[4:7], dma[7:10], dma[10:13], dma[13:17]]   # (M0 setup, load, soff advance) per piece
+    dma_groups = [] if nodma else ([dma[0:4], dma[4:7], dma[7:10], dma[10:14]] if HD64 else [dma[0:4], dma[4:7], dma[7:10], dma[10:13], dma[13:17]])   # (M0 setup, load, soff advance) per piece
     flat = lambda gs: [t for g in gs for t in g]
     # ---- X
     e("s_waitcnt lgkmcnt(0)")        # K(i+1) fragments (read during Y_{i-1})
@@ -332,12 +355,13 @@ def body(e, tag, p, masked, resc, variant=0):
         pu += p_unit(cur, blk, kt, cc)
     if novalu:
         pu = []
-    kaddr = [f"v_add_u32_e32 {v(KADDR)}, {s(S_ST2)}, %[kfa]"]
-    streams = [(v_reads(), 0, 7), (pu[:24], 0, 7), (pu[24:], 8, 19), (kaddr, 10, 10)]
+    kaddr = k_addr(S_ST2)
+    nq = 4 * NCC     # MFMAs of X
+    streams = [(v_reads(), 0, 7), (pu[:24], 0, 7), (pu[24:], 8, nq - 1), (kaddr, 10, 10 + len(kaddr) - 1)]
     if variant == 3:
-        streams.append((flat(dma_groups[:2]), 11, 18))
+        streams.append((flat(dma_groups[:2]), 11, nq - 2))
     place(e, qk_mfmas(nxt), [st for st in streams if st[0]])
-    e("s_waitcnt vmcnt(5) lgkmcnt(0)" if not nodma else "s_waitcnt lgkmcnt(0)")   # Vt(i) fragments; this wave's pieces of tile i+2
+    e(f"s_waitcnt vmcnt({NPIECE}) lgkmcnt(0)" if not nodma else "s_waitcnt lgkmcnt(0)")   # Vt(i) fragments; this wave's pieces of tile i+2
     e("s_barrier")                       # ... and everybody else's; every wave is done reading stage(i)
     # ---- Y
     pv = [m for m, _, _ in pv_mfmas()]
@@ -489,7 +513,8 @@ def prologue(e):
     e(f"s_add_i32 {s(S_KB)}, %[wl], 4096")
     e(f"s_mov_b32 {s(S_VC)}, %[sv0]")
     e(f"s_mov_b32 {s(S_VD)}, %[sv1]")
-    e(f"s_mov_b32 {s(S_E)}, %[s4]")
+    if not HD64:
+        e(f"s_mov_b32 {s(S_E)}, %[s4]")
     e(f"s_add_u32 {s(S_WRAP)}, %[lb], {NSTAGE * STAGE}")
     e(f"s_mov_b32 {s(S_ST)}, %[lb]")
     for t in range(4):    # tiles 0..3 into stages 0..3
@@ -500,30 +525,36 @@ def prologue(e):
     e(f"s_add_u32 {s(S_ST2)}, %[lb], {2 * STAGE}")
     e(f"s_sub_u32 {s(S_CNT)}, %[nt], 2")
     # tile 0: K fragments, S(0) = K(0) Q^T (-m = 0), adopt its row max
-    e("s_waitcnt vmcnt(15)")
+    e(f"s_waitcnt vmcnt({3 * NPIECE})")
     e("s_barrier")
-    e(f"v_add_u32_e32 {v(KADDR)}, {s(S_ST)}, %[kfa]")
+    for t in k_addr(S_ST):
+        e(t)
     for t in k_reads():
         e(t)
     e("s_waitcnt lgkmcnt(0)")
     for m in qk_mfmas(0):
         e(m)
-    e("s_waitcnt vmcnt(10)")
+    e(f"s_waitcnt vmcnt({2 * NPIECE})")
     e("s_barrier")
-    e(f"v_add_u32_e32 {v(KADDR)}, {s(S_ST)}, %[kfa]")
-    e(f"v_add_u32_e32 {v(KADDR)}, {STAGE}, {v(KADDR)}")
+    for t in k_addr(S_ST, STAGE):
+        e(t)
     for t in k_reads():
         e(t)
     adopt(e)
 
 
-def generate(variant=0, persist=False, pstamp=False):
-    global PERSIST, PSTAMP
+def generate(variant=0, persist=False, pstamp=False, d64=False):
+    global PERSIST, PSTAMP, HD64, NCC, NPIECE, K_TILE, STAGE, NV
+    assert not (d64 and persist)
     PERSIST, PSTAMP = persist, pstamp
+    keep = (HD64, NCC, NPIECE, K_TILE, STAGE, NV)
+    if d64:
+        HD64, NCC, NPIECE, K_TILE, STAGE, NV = True, 4, 4, 8192, 8192 + 96 * 128, 213
     try:
         return _generate(variant)
     finally:
         PERSIST = PSTAMP = False
+        HD64, NCC, NPIECE, K_TILE, STAGE, NV = keep
 
 
 def _generate(variant):
@@ -589,9 +620,9 @@ OPERANDS = ["rk", "rv", "r4", "wl", "sv0", "sv1", "s4", "st4", "l4", "lb", "nt",
             "vfa2", "vfa3"]
 
 
-def clobbers():
+def clobbers(d64=False):
     sregs = list(range(40, 55)) + list(range(60, 74)) + list(range(76, 82))   # (76..81: the stamp variant's s_memtime pairs)
-    return [f"v{i}" for i in range(NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in sregs] + ["vcc", "memory"]
+    return [f"v{i}" for i in range(213 if d64 else NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in sregs] + ["vcc", "memory"]
 
 
 VARIANTS = (0, 1, 3, 7, 8, 9)   # 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
@@ -619,6 +650,12 @@ def write_inc(path):
             f.write('  "' + ln + '\\n\\t" \\\n')
         f.write('  ""\n')
         f.write("#define FLASH72_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers()) + "\n")
+        f.write("// FLASH64_W64_ASM: the head_dim 64 form (flash_attn_d64_w64_kernel, csrc/attention64_w64.hip), placement variant 1.\n")
+        f.write("#define FLASH64_W64_ASM \\\n")
+        for ln in generate(1, d64=True):
+            f.write('  "' + ln + '\\n\\t" \\\n')
+        f.write('  ""\n')
+        f.write("#define FLASH64_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers(True)) + "\n")
     return generate(0)
 
 
