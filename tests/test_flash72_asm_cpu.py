@@ -92,13 +92,14 @@ def test_emulated_persistent_walk_matches_numpy_attention(kv_len, nitems, late_v
     (300, True, 1.0, True, False, None),            # ragged last tile
     (448, False, 6.0, False, True, [3, 2, 1, 0]),
 ])
-def test_emulated_workgroup_head_dim_64(kv_len, spike, qscale, late_vm, late_ds, order):
+@pytest.mark.parametrize("variant", [1, 4])
+def test_emulated_workgroup_head_dim_64(kv_len, spike, qscale, late_vm, late_ds, order, variant):
     """The stream generated for head_dim 64 (FLASH64_W64_ASM, csrc/attention64_w64.hip): swizzled 128-byte K rows, four LDS-DMA
     pieces per wave and tile, the ones rows in the constant third block of the Vt image."""
     import flash72_emu_case as C
 
     with np.errstate(all="ignore"):
-        err, viol, stats = C.run64(kv_len, spike=spike, qscale=qscale, late_vm=late_vm, late_ds=late_ds, order=order)
+        err, viol, stats = C.run64(kv_len, spike=spike, qscale=qscale, late_vm=late_vm, late_ds=late_ds, order=order, variant=variant)
     assert not viol, viol[:5]
     assert err <= 2.0 ** -8, err
     assert stats["counts"].get("buffer_load_dwordx4", 0) >= 16

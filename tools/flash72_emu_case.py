@@ -260,13 +260,13 @@ def make_case64(kv_len, seed=0, spike=False, qscale=1.0):
     return q, k, vv, kv_pad
 
 
-def run64(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qscale=1.0, lb=0):
+def run64(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qscale=1.0, lb=0, variant=1):
     """One workgroup of flash_attn_d64_w64_kernel: the layouts of attn_prep_kv64 (K rows of 128 bytes, 16-byte chunk c of row r at
     chunk c ^ ((r >> 1) & 7); Vt [64][kv_pad]), the third 32-row block of every stage's Vt image constant (ones rows 72 / 76)."""
     KT, ST = 8192, 8192 + 96 * 128
     q, k, vv, kv_pad = make_case64(kv_len, seed, spike, qscale)
     ntiles = (kv_len + 63) // 64
-    lines = G.generate(1, d64=True)
+    lines = G.generate(variant, d64=True)
     ksw = np.zeros_like(k)
     for r in range(kv_pad):
         for c in range(8):

@@ -933,7 +933,7 @@ static unsigned long long* g_flash_dbg = nullptr;
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 140: case 141: case 143: break;
+    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 140: case 141: case 143: case 144: break;
 #ifdef VSYS_LAB
     case 1: case 2: case 146: case 147: case 148: case 149: break;
 #endif
@@ -1010,7 +1010,7 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   if ((g_flash_variant == 14 || g_flash_variant >= 140 || w64_long) &&
       flash_w64_supports(q_len, kv_len, kv_pad))
     return launch_flash_attn_d72_w64(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
-                                     g_flash_variant >= 140 ? g_flash_variant - 140 : W64_DEFAULT_VAR, stream);
+                                     g_flash_variant >= 140 && g_flash_variant != 144 ? g_flash_variant - 140 : W64_DEFAULT_VAR, stream);
   // three workgroups per CU pay for long, unmasked key sequences (spatial attention: 0.241 vs 0.251 ms); with a masked last tile
   // the 168-register variant spills in the peeled tile (cross shape 0.156 vs 0.099 ms)
   static const bool wps3_ok = [] { const char* e = getenv("VSYS_FLASH_WPS3"); return !(e && e[0] == '0'); }();

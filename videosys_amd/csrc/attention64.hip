@@ -482,9 +482,10 @@ int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w,
   // long key sequences (CogVideoX: 17 776): 64 query rows per wave, one wave per SIMD, hand-allocated instruction stream
   // (attention64_w64.hip); 15 = never (the A/B id of the measurement tools), 14 = wherever it is supported
   static const bool w64_off = [] { const char* e = getenv("VSYS_FLASH_W64"); return e && e[0] == '0'; }();
-  if (((fv == 0 && kv_len >= 2048 && !w64_off) || fv == 14) && flash64_w64_supports(q_len, kv_len))
+  constexpr int W64_DEFAULT_VAR = 4;   // 141 / 144 select placement variant 1 / 4 (4: +0.5-1 %, profiles/r04_flash64_w64_cvx5b.json)
+  if (((fv == 0 && kv_len >= 2048 && !w64_off) || fv == 14 || fv == 141 || fv == 144) && flash64_w64_supports(q_len, kv_len))
     return launch_flash_attn_d64_w64(q, q_stride, ln_w, ln_b, rope_cos, rope_sin, rope_start, rope_len, kp, vt, out, out_stride, batch,
-                                     heads, q_len, kv_len, kv_pad, eps, stream);
+                                     heads, q_len, kv_len, kv_pad, eps, fv >= 140 ? fv - 140 : W64_DEFAULT_VAR, stream);
   if (fv == 12)        // A/B id (see set_flash_variant): the two-stage ring
     hipLaunchKernelGGL(flash_attn_d64_kernel<2>, dim3((unsigned)nblk), dim3(256), 2 * KV_STAGE, stream, p);
   else

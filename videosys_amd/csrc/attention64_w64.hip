@@ -47,6 +47,8 @@ __device__ __forceinline__ u32x4 make_rsrc64(const void* base, unsigned bytes) {
   return r;
 }
 
+// VAR: placement variant of the generated stream (flash72_gen.py body(): 1 = as the d72 kernel, 4 = one more P unit in the PV phase)
+template <int VAR>
 __global__ __launch_bounds__(256, 1) void flash_attn_d64_w64_kernel(Flash64W64Params p) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -171,12 +173,16 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d64_w64_kernel(Flash64W64Pa
 #undef QW
 
   // ---- the tile loop
-  asm volatile(FLASH64_W64_ASM
-               :
-               : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [lb] "s"(lb), [nt] "s"(ntiles),
-                 [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff), [kfa0] "v"(kfa0), [kfa1] "v"(kfa1), [kfa2] "v"(kfa2),
-                 [kfa3] "v"(kfa3), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)
-               : FLASH64_W64_CLOBBERS);
+#define W64_LOOP(TEXT_)                                                                                                          \
+  asm volatile(TEXT_                                                                                                             \
+               :                                                                                                                 \
+               : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [lb] "s"(lb), [nt] "s"(ntiles), \
+                 [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff), [kfa0] "v"(kfa0), [kfa1] "v"(kfa1), [kfa2] "v"(kfa2),       \
+                 [kfa3] "v"(kfa3), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)                         \
+               : FLASH64_W64_CLOBBERS)
+  if constexpr (VAR == 4) W64_LOOP(FLASH64_W64_ASM_V4);
+  else W64_LOOP(FLASH64_W64_ASM_V1);
+#undef W64_LOOP
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi; 16-byte stores through v_permlane32_swap
 #pragma unroll
@@ -226,7 +232,8 @@ bool flash64_w64_supports(int q_len, int kv_len) { return kv_len >= 256 && q_len
 
 int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
                               const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
-                              int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, hipStream_t stream) {
+                              int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, int var,
+                              hipStream_t stream) {
   Flash64W64Params p;
   p.q = q; p.q_stride = q_stride; p.ln_w = ln_w; p.ln_b = ln_b; p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   p.rope_start = rope_start; p.rope_len = rope_len; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
@@ -236,9 +243,12 @@ int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* l
   if (nblk > 0x7fffffff || (int64_t)kv_pad * HD * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = (size_t)W64_STAGES * KV_STAGE;   // 81920
   static std::atomic<unsigned long long> attr_seen{0};
-  if (first_use_on_this_device(attr_seen))
-    (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(flash_attn_d64_w64_kernel, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+  if (first_use_on_this_device(attr_seen)) {
+    (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
+  if (var == 4) hipLaunchKernelGGL(flash_attn_d64_w64_kernel<4>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL(flash_attn_d64_w64_kernel<1>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 

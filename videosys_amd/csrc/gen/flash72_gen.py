@@ -350,6 +350,10 @@ def body(e, tag, p, masked, resc, variant=0):
     # ---- X
     e("s_waitcnt lgkmcnt(0)")        # K(i+1) fragments (read during Y_{i-1})
     units = [("A", 0, 0), ("A", 0, 1), ("A", 1, 0), ("A", 1, 1), ("B", 0, 0), ("B", 0, 1)]
+    late = [("B", 1, 0), ("B", 1, 1)]
+    if variant == 4:   # (d64: X has 16 MFMAs for the same softmax work) one more P unit moves to Y: A's keys 48..63, needed by its 16th MFMA
+        units, late = units[:3] + units[4:], [("A", 1, 1)] + late
+        variant = 1
     pu = []
     for blk, kt, cc in units:
         pu += p_unit(cur, blk, kt, cc)
@@ -365,7 +369,7 @@ def body(e, tag, p, masked, resc, variant=0):
     e("s_barrier")                       # ... and everybody else's; every wave is done reading stage(i)
     # ---- Y
     pv = [m for m, _, _ in pv_mfmas()]
-    pb = [] if novalu else p_unit(cur, "B", 1, 0) + p_unit(cur, "B", 1, 1)
+    pb = [] if novalu else [t for u in late for t in p_unit(cur, *u)]
     ca, cb = max_chain(nxt, "A"), max_chain(nxt, "B")
     adv = stage_advance()
     chains = ca + [f"v_mov_b32_e32 {v(TT['A'])}, {v(MX['A'])}"] + cb
@@ -385,7 +389,7 @@ def body(e, tag, p, masked, resc, variant=0):
         chains = []
         tail = [t for t in tail if t.startswith("s_") or t.startswith("v_add_u32") or t.startswith("v_cmp")]
         tail = [f"v_mov_b32_e32 {v(TMP[0])}, 0"] + tail
-    streams = [(k_reads(), 0, 4), (pb, 0, 7)]
+    streams = [(k_reads(), 0, 4), (pb, 0, 7 if len(late) == 2 else 11)]
     if masked:
         streams.append((mask_ops(nxt), 2, 10))
     streams.append((chains, 5, 17))
@@ -651,10 +655,11 @@ def write_inc(path):
         f.write('  ""\n')
         f.write("#define FLASH72_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers()) + "\n")
         f.write("// FLASH64_W64_ASM: the head_dim 64 form (flash_attn_d64_w64_kernel, csrc/attention64_w64.hip), placement variant 1.\n")
-        f.write("#define FLASH64_W64_ASM \\\n")
-        for ln in generate(1, d64=True):
-            f.write('  "' + ln + '\\n\\t" \\\n')
-        f.write('  ""\n')
+        for var in (1, 4):   # 4: one more P unit in the PV phase (the QK^T phase has 16 MFMAs here for the same softmax work)
+            f.write(f"#define FLASH64_W64_ASM_V{var} \\\n")
+            for ln in generate(var, d64=True):
+                f.write('  "' + ln + '\\n\\t" \\\n')
+            f.write('  ""\n')
         f.write("#define FLASH64_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers(True)) + "\n")
     return generate(0)
 

@@ -188,7 +188,8 @@ int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q
 bool flash64_w64_supports(int q_len, int kv_len);
 int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
                               const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
-                              int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, hipStream_t stream);
+                              int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, int var,
+                              hipStream_t stream);
 bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride);   // persistent form of the w64 kernel
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                                int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, bool stamp,
