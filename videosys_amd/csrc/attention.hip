@@ -935,7 +935,7 @@ int set_flash_variant(int v) {
   switch (v) {
     case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 140: case 141: case 143: case 144: break;
 #ifdef VSYS_LAB
-    case 1: case 2: case 146: case 147: case 148: case 149: break;
+    case 1: case 2: case 146: case 147: case 148: case 149: case 150: break;
 #endif
     default: return VSYS_ERR_ARG;
   }

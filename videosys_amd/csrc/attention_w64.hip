@@ -182,6 +182,14 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
                  : FLASH72_W64_CLOBBERS);
     stamp[4] = __builtin_amdgcn_s_memtime();
   }
+  else if constexpr (VAR == 10) {   // per-phase cycle sums of the loop tiles: X, wait + barrier, Y
+    asm volatile(FLASH72_W64_ASM_V10
+                 : [t0] "=s"(stamp[1]), [t1] "=s"(stamp[2]), [t2] "=s"(stamp[3])
+                 : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [r4] "s"(rsrc_4), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [s4] "s"(s4),
+                   [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff),
+                   [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)
+                 : FLASH72_W64_CLOBBERS);
+  }
   else if constexpr (VAR == 8) W64_LOOP(FLASH72_W64_ASM_V8);
   else if constexpr (VAR == 9) W64_LOOP(FLASH72_W64_ASM_V9);
 #endif
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
       }
     }
   }
-  if constexpr (VAR == 7) {
+  if constexpr (VAR == 7 || VAR == 10) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left
     stamp[5] = __builtin_amdgcn_s_memtime();
     if (lane == 0 && p.dbg != nullptr) {
@@ -589,6 +597,7 @@ int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q
     case 3: return launch_w64_t<3>(p, (unsigned)nblk, lds, stream);
 #ifdef VSYS_LAB
     case 7: return launch_w64_t<7>(p, (unsigned)nblk, lds, stream);
+    case 10: return launch_w64_t<10>(p, (unsigned)nblk, lds, stream);
     case 8: return launch_w64_t<8>(p, (unsigned)nblk, lds, stream);
     case 9: return launch_w64_t<9>(p, (unsigned)nblk, lds, stream);
 #endif

@@ -79,6 +79,7 @@ def preg(blk, kt, cc):
     return P[blk] + (kt * 2 + cc) * 4
 
 
+PHASE = False     # lab (variant 10): s_memtime around the two phases of every loop tile, summed per wave: X, wait + barrier, Y
 PSTAMP = False    # lab: s_memtime behind the opening wait + barrier and at the loop head of the persistent form
 PERSIST = False   # set by generate(): the persistent (workgroup walks several work items) form of the statement
 S_QP, S_QM, S_QO = 52, 53, 54
@@ -348,6 +349,8 @@ def body(e, tag, p, masked, resc, variant=0):
     dma_groups = [] if nodma else ([dma[0:4], dma[4:7], dma[7:10], dma[10:14]] if HD64 else [dma[0:4], dma[4:7], dma[7:10], dma[10:13], dma[13:17]])   # (M0 setup, load, soff advance) per piece
     flat = lambda gs: [t for g in gs for t in g]
     # ---- X
+    if PHASE:
+        e("s_memtime s[76:77]")
     e("s_waitcnt lgkmcnt(0)")        # K(i+1) fragments (read during Y_{i-1})
     units = [("A", 0, 0), ("A", 0, 1), ("A", 1, 0), ("A", 1, 1), ("B", 0, 0), ("B", 0, 1)]
     late = [("B", 1, 0), ("B", 1, 1)]
@@ -365,8 +368,12 @@ def body(e, tag, p, masked, resc, variant=0):
     if variant == 3:
         streams.append((flat(dma_groups[:2]), 11, nq - 2))
     place(e, qk_mfmas(nxt), [st for st in streams if st[0]])
+    if PHASE:
+        e("s_memtime s[78:79]")
     e(f"s_waitcnt vmcnt({NPIECE}) lgkmcnt(0)" if not nodma else "s_waitcnt lgkmcnt(0)")   # Vt(i) fragments; this wave's pieces of tile i+2
     e("s_barrier")                       # ... and everybody else's; every wave is done reading stage(i)
+    if PHASE:
+        e("s_memtime s[80:81]")
     # ---- Y
     pv = [m for m, _, _ in pv_mfmas()]
     pb = [] if novalu else [t for u in late for t in p_unit(cur, *u)]
@@ -405,6 +412,17 @@ def body(e, tag, p, masked, resc, variant=0):
         streams.append(([q_prefetch_hook(tag, 5)], 22, 22))
     streams.append((tail, 18, 23))
     place(e, pv, [st for st in streams if st[0]])
+    if PHASE:
+        def acc(dst, hi_pair, lo_pair):
+            e(f"s_sub_u32 s90, s{hi_pair}, s{lo_pair}")
+            e(f"s_subb_u32 s91, s{hi_pair + 1}, s{lo_pair + 1}")
+            e(f"s_add_u32 s{dst}, s{dst}, s90")
+            e(f"s_addc_u32 s{dst + 1}, s{dst + 1}, s91")
+        e("s_memtime s[82:83]")
+        e("s_waitcnt lgkmcnt(0)")
+        acc(84, 78, 76)
+        acc(86, 80, 78)
+        acc(88, 82, 80)
     e(f"s_cbranch_vccnz RESC_{tag}_%=")
     e.label(f"BACK_{tag}_%=")
     resc.append((tag, nxt))
@@ -548,16 +566,19 @@ def prologue(e):
 
 
 def generate(variant=0, persist=False, pstamp=False, d64=False):
-    global PERSIST, PSTAMP, HD64, NCC, NPIECE, K_TILE, STAGE, NV
+    global PERSIST, PSTAMP, HD64, NCC, NPIECE, K_TILE, STAGE, NV, PHASE
     assert not (d64 and persist)
     PERSIST, PSTAMP = persist, pstamp
     keep = (HD64, NCC, NPIECE, K_TILE, STAGE, NV)
     if d64:
         HD64, NCC, NPIECE, K_TILE, STAGE, NV = True, 4, 4, 8192, 8192 + 96 * 128, 213
     try:
+        if variant == 10:
+            PHASE = True
+            return _generate(1)
         return _generate(variant)
     finally:
-        PERSIST = PSTAMP = False
+        PERSIST = PSTAMP = PHASE = False
         HD64, NCC, NPIECE, K_TILE, STAGE, NV = keep
 
 
@@ -569,6 +590,9 @@ def _generate(variant):
         variant = 1
         e("s_memtime s[76:77]")
     prologue(e)
+    if PHASE:
+        for r in range(84, 90):
+            e(f"s_mov_b32 s{r}, 0")
     if stamps or PSTAMP:
         e("s_memtime s[78:79]")
 
@@ -611,6 +635,10 @@ def _generate(variant):
         e("s_waitcnt lgkmcnt(0)")
         e("s_mov_b64 %[t0], s[76:77]")
         e("s_mov_b64 %[t1], s[78:79]")
+    if PHASE:
+        e("s_mov_b64 %[t0], s[84:85]")
+        e("s_mov_b64 %[t1], s[86:87]")
+        e("s_mov_b64 %[t2], s[88:89]")
     if stamps:
         e("s_memtime s[80:81]")
         e("s_waitcnt lgkmcnt(0)")
@@ -625,11 +653,11 @@ OPERANDS = ["rk", "rv", "r4", "wl", "sv0", "sv1", "s4", "st4", "l4", "lb", "nt",
 
 
 def clobbers(d64=False):
-    sregs = list(range(40, 55)) + list(range(60, 74)) + list(range(76, 82))   # (76..81: the stamp variant's s_memtime pairs)
+    sregs = list(range(40, 55)) + list(range(60, 74)) + list(range(76, 92))   # (76..91: the stamp variants' s_memtime pairs and sums)
     return [f"v{i}" for i in range(213 if d64 else NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in sregs] + ["vcc", "memory"]
 
 
-VARIANTS = (0, 1, 3, 7, 8, 9)   # 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
+VARIANTS = (0, 1, 3, 7, 8, 9, 10)   # 7, 10: lab stamps; 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
 
 
 def write_inc(path):
