@@ -207,6 +207,18 @@ int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, c
                         int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
                         float eps, void* stream);
 
+/* vsys_flash_attn_d72 with a promise about the keys: k_norm_bound >= the Euclidean norm of every Kp row (as stored: normed, scaled
+ * by log2(e) / sqrt(72)).  For an RMS-normed key that is sqrt(72) max|k_norm.weight| log2(e) / sqrt(72) (1 + rounding), a property
+ * of the WEIGHTS (normalization.py:28-33): the caller computes it once per block.  By Cauchy-Schwarz m_i = |q_i| k_norm_bound bounds
+ * every logit of query row i, and softmax is invariant under the choice of the subtracted m: the kernels that take the promise
+ * (64 rows per wave, attention_w64.hip) use exp2(s - m_i) with no running maximum and no rescale of the accumulator.  The caller
+ * must also guarantee |q_i| k_norm_bound <= 60 for every query row (RMS-normed q: sqrt(72) max|q_norm.weight| k_norm_bound):
+ * 2 m < 126 keeps every row sum representable.  k_norm_bound = 0: exactly vsys_flash_attn_d72.  q_norm_w == NULL: the bound is
+ * ignored.  The BITS of vsys_flash_attn_d72 are not promised (P is rounded to bf16 at another scale): the same tolerance is. */
+int vsys_flash_attn_d72_kb(const void* q, int64_t q_stride, const void* q_norm_w, const void* kp, const void* vt, void* out,
+                           int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
+                           float eps, float k_norm_bound, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * CogVideoX: joint [text | video] blocks, head_dim 64.
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -417,7 +429,8 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
 #define VSYS_OP_ADALN_PRESCALE      25
 #define VSYS_OP_LN_ROW_STATS        26
 #define VSYS_OP_GEMM_BF16_GATE_RES_ADD 27
-#define VSYS_OP_COUNT              28
+#define VSYS_OP_FLASH_ATTN_D72_KB   28
+#define VSYS_OP_COUNT              29
 
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */

@@ -103,3 +103,32 @@ def test_emulated_workgroup_head_dim_64(kv_len, spike, qscale, late_vm, late_ds,
     assert not viol, viol[:5]
     assert err <= 2.0 ** -8, err
     assert stats["counts"].get("buffer_load_dwordx4", 0) >= 16
+
+
+@pytest.mark.parametrize("kv_len,late_vm,late_ds,order", [(256, True, True, None), (300, False, False, [3, 2, 1, 0]), (448, True, False, None),
+                                                          (320, False, True, [3, 2, 1, 0])])
+@pytest.mark.parametrize("d64", [False, True])
+def test_emulated_workgroup_without_running_max(kv_len, late_vm, late_ds, order, d64):
+    """Variant 5 of the stream (both head sizes): the caller's per-row bound |q_i| max_j |k_j| as the subtracted constant — no row
+    max, no rescale block, four / five of the eight P units of a tile in the PV phase.  Same tolerance as the running-max stream."""
+    import flash72_emu_case as C
+
+    run = C.run64 if d64 else C.run
+    with np.errstate(all="ignore"):
+        err, viol, stats = run(kv_len, late_vm=late_vm, late_ds=late_ds, order=order, variant=5)
+    assert not viol, viol[:5]
+    assert err <= 2.0 ** -8, err
+    assert stats["counts"].get("v_max3_f32", 0) == 0 and stats["counts"].get("v_exp_f32_e32", 0) >= 64 * ((kv_len + 63) // 64)
+
+
+def test_stream_without_running_max_is_lighter():
+    import flash72_gen as G
+
+    for d64, limit in ((False, 3.6), (True, 3.9)):
+        lines = G.generate(5, d64=d64)
+        top, tail = lines.index("TOP_%=:"), lines.index("TAIL0_%=:")
+        loop = [ln for ln in lines[top:tail] if not ln.endswith(":")]
+        n_mfma = sum(1 for ln in loop if ln.startswith("v_mfma"))
+        assert n_mfma == (80 if d64 else 88)
+        assert (len(loop) - n_mfma) / n_mfma <= limit      # 4.3 with the row max (test_steady_state_gaps...)
+        assert not any("RESC" in ln for ln in lines)

@@ -323,11 +323,11 @@ def test_cfg_euler_and_add(ops):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def _run_flash(ops, q2d, k2d, v2d, qw, kw_, batch, heads, q_len, kv_len):
+def _run_flash(ops, q2d, k2d, v2d, qw, kw_, batch, heads, q_len, kv_len, k_norm_bound=None):
     kp, vt = ops.alloc_kv_buffers(batch, heads, kv_len, dev())
     ops.attn_prep_kv(k2d, v2d, kw_, kp, vt, batch, heads, kv_len)
-    out = torch.empty(batch * q_len, heads * 72, dtype=torch.bfloat16, device=dev())
-    ops.flash_attn(q2d, qw, kp, vt, out, batch, heads, q_len, kv_len)
+    out = torch.full((batch * q_len, heads * 72), float("nan"), dtype=torch.bfloat16, device=dev())
+    ops.flash_attn(q2d, qw, kp, vt, out, batch, heads, q_len, kv_len, k_norm_bound=k_norm_bound)
     return out
 
 
@@ -498,6 +498,56 @@ def test_flash_w64_matches_default_and_torch(ops, q_len, kv_len, heads, batch, n
             ref = O.sdpa(qq.float()[None], kk.float()[None], vv[None])[0]
             check(res[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"w64 flash b{bi} h{h}")
             check(base[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"32-row flash b{bi} h{h}")
+
+
+@pytest.mark.parametrize("q_len,kv_len,heads,batch,wscale,fv", [
+    (1024, 1024, 16, 40, 1.0, 18),     # config-2 spatial shape, persistent walk (2560 items)
+    (1024, 1024, 16, 40, 1.0, 0),      # ... as the dispatch picks it when the promise is given
+    (600, 3600, 2, 1, 1.0, 17),        # 720p frame: one item per workgroup, ragged last tile and last query block
+    (700, 2304, 4, 2, 2.0, 0),         # larger norm weights (logit bound ~50): default dispatch from 2048 keys
+    (512, 512, 8, 40, 0.3, 18),        # small weights: the bound is far above nothing, P stays well inside bf16's range
+])
+def test_flash_w64_without_running_max(ops, q_len, kv_len, heads, batch, wscale, fv):
+    """vsys_flash_attn_d72_kb: with the caller's bound on the key norms (ops.rms_key_bound, from the norm weights) the w64
+    kernels subtract m_i = |q_i| k_bound instead of a running maximum (flash72_gen.py variant 5).  Softmax does not depend on the
+    subtracted constant, so the result must agree with the running-max kernels to the tolerance both have against fp32 torch; forced
+    one-item (17) / persistent (18) forms and the default dispatch."""
+    from videosys_amd import _lib
+
+    lib = _lib.load()
+    C = heads * 72
+    g = torch.Generator().manual_seed(q_len + kv_len + heads + fv)
+    q = torch.randn(batch * q_len, C, generator=g).to(torch.bfloat16).to(dev())
+    k = torch.randn(batch * kv_len, C, generator=g).to(torch.bfloat16).to(dev())
+    v = torch.randn(batch * kv_len, C, generator=g).to(torch.bfloat16).to(dev())
+    qw = (wscale * (1 + 0.1 * torch.randn(72, generator=g))).to(torch.bfloat16).to(dev())
+    kw_ = (wscale * (1 + 0.1 * torch.randn(72, generator=g))).to(torch.bfloat16).to(dev())
+    kb = ops.rms_key_bound(qw, kw_)
+    assert kb is not None and kb > 0
+    try:
+        assert lib.vsys_tune_flash_variant(15) == 0
+        base = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        assert lib.vsys_tune_flash_variant(fv) == 0
+        res = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len, k_norm_bound=kb)
+        res2 = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len, k_norm_bound=kb)
+        torch.cuda.synchronize()
+    finally:
+        lib.vsys_tune_flash_variant(0)
+    assert torch.isfinite(res.float()).all()
+    assert torch.equal(res, res2), "two launches differ (a race)"
+    scale = base.float().abs().max().item()
+    assert (res.float() - base.float()).abs().max().item() <= 2.0 ** -6 * scale
+    for bi, h in ((0, 0), (batch - 1, heads - 1)):
+        qq = O.rms_norm(q[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], qw.float())
+        kk = O.rms_norm(k[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72], kw_.float())
+        vv = v[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72].float()
+        ref = O.sdpa(qq.float()[None], kk.float()[None], vv[None])[0]
+        sl = (slice(bi * q_len, (bi + 1) * q_len), slice(h * 72, (h + 1) * 72))
+        e_new, e_old = (res[sl].float().cpu() - ref.cpu()).abs().max().item(), (base[sl].float().cpu() - ref.cpu()).abs().max().item()
+        check(res[sl], ref, tol=2.0 ** -6, what=f"flash without running max b{bi} h{h}")
+        assert e_new <= 1.5 * e_old + 1e-3, (e_new, e_old)
+    # weights the promise cannot be derived from: no bound
+    assert ops.rms_key_bound(qw * 8, kw_ * 8) is None
 
 
 @pytest.mark.parametrize("q_len,kv_len,heads,batch,norm,qscale", [

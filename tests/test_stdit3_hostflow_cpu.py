@@ -158,8 +158,13 @@ class FakeOps:
         self._n("attn_prep_kv")
         assert k.shape[0] == v.shape[0] == batch * kv_len and kp.shape[0] == batch and kp.shape[2] >= kv_len
 
-    def flash_attn(self, q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
+    def rms_key_bound(self, q_norm_w, k_norm_w, head_dim=72):
+        assert q_norm_w.shape == k_norm_w.shape == (head_dim,)
+        return 1.5
+
+    def flash_attn(self, q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6, k_norm_bound=None):
         self._n("flash_attn")
+        assert k_norm_bound is None or q_norm_w is not None
         assert q.shape[0] == out.shape[0] == batch * q_len and kp.shape[0] == batch and kp.shape[2] >= kv_len, (q.shape, batch, q_len, kp.shape)
         return out
 

@@ -64,7 +64,7 @@ def run(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qsc
         s4j = 8 if w == 1 else 9
         binds.append({"rk": "s[4:7]", "rv": "s[8:11]", "r4": "s[12:15]", "wl": "s16", "sv0": "s17", "sv1": "s18", "s4": "s19",
                       "st4": "s20", "l4": "s21", "lb": "s22", "nt": "s23", "lim": "v210", "kvo": "v211", "vvo": "v212", "v4o": "v213",
-                      "kfa": "v214", "vfa0": "v215", "vfa1": "v216", "vfa2": "v217", "vfa3": "v218"})
+                      "kfa": "v214", "vfa0": "v215", "vfa1": "v216", "vfa2": "v217", "vfa3": "v218", "nma": "v219", "nmb": "v220"})
     wg = E.Workgroup(lines, binds, late_vm=late_vm, late_ds=late_ds)
     wg.lds[:] = 0xAB   # garbage: anything the kernel relies on must have been written
     # the C++ prologue zeroes rows 80..95 of every stage's Vt image
@@ -90,6 +90,11 @@ def run(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, qsc
         for reg, val in ((210, kv_len - (ntiles - 1) * 64 - 16 * hi), (211, k_voff), (212, v_voff), (213, voff_4), (214, kfa),
                          (215, v_roff ^ 0), (216, v_roff ^ 16), (217, v_roff ^ 64), (218, v_roff ^ 80)):
             wave.v[reg] = np.asarray(val).astype(np.int64).astype(np.uint32)
+        # (variant 5) the caller's row bound: -|q_i| max_j |k_j| (1 + 2^-6), splat per query row = per lane & 31
+        kmax = float(np.sqrt((k.astype(np.float64) ** 2).sum(1)).max())
+        for blk, reg in ((0, 219), (1, 220)):
+            rows_ = 64 * w + 32 * blk + l31
+            wave.v[reg] = (-(np.sqrt((q[rows_].astype(np.float64) ** 2).sum(1)) * kmax * (1 + 2.0 ** -6))).astype(np.float32).view(np.uint32)
         # Q fragments -> a[96:135]: block blk, chunk c, word j holds d = 16c + 8hi + 2j, +1 of row 64w + 32blk + l31
         for blk in range(2):
             rows = 64 * w + 32 * blk + l31
@@ -279,7 +284,7 @@ def run64(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, q
     l31, hi = lane & 31, lane >> 5
     bind = {"rk": "s[4:7]", "rv": "s[8:11]", "wl": "s16", "sv0": "s17", "sv1": "s18", "lb": "s22", "nt": "s23", "lim": "v213",
             "kvo": "v214", "vvo": "v215", "kfa0": "v216", "kfa1": "v217", "kfa2": "v218", "kfa3": "v219", "vfa0": "v220", "vfa1": "v221",
-            "vfa2": "v222", "vfa3": "v223"}
+            "vfa2": "v222", "vfa3": "v223", "nma": "v224", "nmb": "v225"}
     wg = E.Workgroup(lines, [dict(bind) for _ in range(4)], late_vm=late_vm, late_ds=late_ds)
     wg.lds[:] = 0xAB
     one = np.full(64, 0x3f80, dtype=np.uint16).view(np.uint8)
@@ -301,6 +306,10 @@ def run64(kv_len, seed=0, spike=False, late_vm=True, late_ds=True, order=None, q
         for reg, val in ((213, kv_len - (ntiles - 1) * 64 - 16 * hi), (214, k_voff), (215, v_voff), (216, k_roff), (217, k_roff ^ 32),
                          (218, k_roff ^ 64), (219, k_roff ^ 96), (220, v_roff ^ 0), (221, v_roff ^ 16), (222, v_roff ^ 64), (223, v_roff ^ 80)):
             wave.v[reg] = np.asarray(val).astype(np.int64).astype(np.uint32)
+        kmax = float(np.sqrt((k.astype(np.float64) ** 2).sum(1)).max())
+        for blk, reg in ((0, 224), (1, 225)):
+            rows_ = 64 * w + 32 * blk + l31
+            wave.v[reg] = (-(np.sqrt((q[rows_].astype(np.float64) ** 2).sum(1)) * kmax * (1 + 2.0 ** -6))).astype(np.float32).view(np.uint32)
         for blk in range(2):
             rows = 64 * w + 32 * blk + l31
             for c in range(4):

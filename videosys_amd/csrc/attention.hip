@@ -933,7 +933,7 @@ static unsigned long long* g_flash_dbg = nullptr;
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 140: case 141: case 143: case 144: break;
+    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 17: case 18: case 19: case 140: case 141: case 143: case 144: break;
 #ifdef VSYS_LAB
     case 1: case 2: case 146: case 147: case 148: case 149: case 150: break;
 #endif
@@ -959,7 +959,7 @@ int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int6
 
 int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt,
                           bf16_t* out, int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad,
-                          float eps, hipStream_t stream) {
+                          float eps, float k_bound, hipStream_t stream) {
   if (batch <= 0 || heads <= 0 || q_len <= 0) return 0;
   if (kv_len <= 0 || kv_pad % 64 != 0 || kv_pad < kv_len || (q_stride % 8) || (out_stride % 4)) return VSYS_ERR_SHAPE;
   FlashParams p;
@@ -997,20 +997,30 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   // 16 = the persistent form of the w64 kernel (one workgroup per CU walks the query blocks; whole 256-key groups)
   // It is the default where every workgroup walks at least four items (the seams of an item are what the walk amortises); the
   // one-item-per-workgroup form below is selectable only (it loses to the 32-row kernel: profiles/r04_flash_w64_placement_kbench.txt).
-  const bool w64p_default = g_flash_variant == 0 && w64_default && kv_len >= 512 &&
-                            (int64_t)batch * heads * ((q_len + 255) / 256) >= 4ll * cu_count_this_device();
-  if ((g_flash_variant == 16 || g_flash_variant == 146 || w64p_default) && flash_w64p_supports(q_len, kv_len, kv_pad, q_stride))
+  // With the caller's bound on the Kp row norms (k_bound > 0, vsys_flash_attn_d72_kb) the statements run WITHOUT the running max
+  // (FlashW64Params::k_bound): 17 / 18 force the one-item / persistent form of that, 19 ignores the bound.
+  static const bool static_ok = [] { const char* e = getenv("VSYS_FLASH_STATIC"); return !(e && e[0] == '0'); }();
+  const bool bounded = k_bound > 0.f && q_norm_w != nullptr && static_ok && g_flash_variant != 19 && g_flash_variant != 15;
+  const bool many_items = (int64_t)batch * heads * ((q_len + 255) / 256) >= 4ll * cu_count_this_device();
+  const bool w64p_default = g_flash_variant == 0 && kv_len >= 512 && many_items && (w64_default || (bounded && kv_len < 2048));
+  if ((g_flash_variant == 16 || g_flash_variant == 146 || g_flash_variant == 18 || w64p_default) &&
+      flash_w64p_supports(q_len, kv_len, kv_pad, q_stride))
     return launch_flash_attn_d72_w64p(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
-                                      g_flash_variant == 146, stream);
+                                      g_flash_variant == 146, bounded && g_flash_variant != 16 && g_flash_variant != 146 ? k_bound : 0.f,
+                                      stream);
   constexpr int W64_DEFAULT_VAR = 1;   // 140 / 141 / 143 select placement variant 0 / 1 / 3 (lab builds: 148 / 149 = ablations 8 / 9)
   // Long key sequences (720p frames: 3600 keys = 57 tiles per item) amortise the one-item form's seams: 1003 vs 915 TFLOP/s against
   // the 32-row kernel at 76 x 16 x 3600^2, same bits (profiles/r04_flash_w64_720p.json); at 1024 keys it loses 5 %.
   static const bool w64_off = [] { const char* e = getenv("VSYS_FLASH_W64"); return e && e[0] == '0'; }();
   const bool w64_long = g_flash_variant == 0 && kv_len >= 2048 && !w64_off;
-  if ((g_flash_variant == 14 || g_flash_variant >= 140 || w64_long) &&
-      flash_w64_supports(q_len, kv_len, kv_pad))
-    return launch_flash_attn_d72_w64(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,
-                                     g_flash_variant >= 140 && g_flash_variant != 144 ? g_flash_variant - 140 : W64_DEFAULT_VAR, stream);
+  if ((g_flash_variant == 14 || g_flash_variant == 17 || g_flash_variant >= 140 || w64_long) &&
+      flash_w64_supports(q_len, kv_len, kv_pad)) {
+    int var = g_flash_variant >= 140 && g_flash_variant != 144 ? g_flash_variant - 140 : W64_DEFAULT_VAR;
+    if (bounded && (g_flash_variant == 17 || g_flash_variant == 0)) var = 5;
+    if (g_flash_variant == 17 && var != 5) return VSYS_ERR_ARG;
+    return launch_flash_attn_d72_w64(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps, var,
+                                     k_bound, stream);
+  }
   // three workgroups per CU pay for long, unmasked key sequences (spatial attention: 0.241 vs 0.251 ms); with a masked last tile
   // the 168-register variant spills in the peeled tile (cross shape 0.156 vs 0.099 ms)
   static const bool wps3_ok = [] { const char* e = getenv("VSYS_FLASH_WPS3"); return !(e && e[0] == '0'); }();

@@ -32,6 +32,10 @@ struct FlashW64Params {
   bf16_t* out; int64_t out_stride;
   int heads, q_len, kv_len, kv_pad, nqb;
   float eps;
+  // VAR 5 / the _S persistent statement: an upper bound on the Euclidean norm of every Kp row of this launch (as stored: normed and
+  // scaled into the exp2 domain).  -|q_i| k_bound (1 + 2^-6) replaces the running max of query row i; the caller guarantees
+  // |q_i| k_bound <= 60 for every row (2 m < 126: no term of a row can underflow to zero while its sum is still representable).
+  float k_bound;
   unsigned long long* dbg;   // lab variant 7: per wave 8 s_memtime stamps
 };
 
@@ -95,6 +99,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
 
   // ---- Q fragments of the two 32-row blocks (B operand: lane holds Q[row][16c + 8hi .. +8], c = 0..4, d >= 72 -> 0), RMS-normed
   unsigned qw[2][20];
+  float nmv[2] = {0.f, 0.f};   // VAR 5: -(row bound) of this lane's query row in block A / B
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
     int qs = q0 + 32 * blk + l31;
@@ -127,6 +132,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
           for (int e = 0; e < 8; ++e) x[c][e] = bf2f(f2bf(x[c][e] * rstd)) * w[e];
         }
       }
+    }
+    if constexpr (VAR == 5) {
+      float qn2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 5; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qn2 += x[c][e] * x[c][e];
+      qn2 += __shfl_xor(qn2, 32, 64);
+      nmv[blk] = -(sqrtf(qn2) * p.k_bound * 1.015625f);
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
@@ -170,6 +184,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
                  [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)       \
                : FLASH72_W64_CLOBBERS)
   if constexpr (VAR == 0) W64_LOOP(FLASH72_W64_ASM_V0);
+  else if constexpr (VAR == 5) {   // no running max: the row bounds ride in as the -m splat
+    asm volatile(FLASH72_W64_ASM_V5
+                 :
+                 : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [r4] "s"(rsrc_4), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [s4] "s"(s4),
+                   [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff),
+                   [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3),
+                   [nma] "v"(nmv[0]), [nmb] "v"(nmv[1])
+                 : FLASH72_W64_CLOBBERS);
+  }
   else if constexpr (VAR == 1) W64_LOOP(FLASH72_W64_ASM_V1);
   else if constexpr (VAR == 3) W64_LOOP(FLASH72_W64_ASM_V3);
 #ifdef VSYS_LAB
@@ -274,7 +297,8 @@ __device__ __forceinline__ unsigned long long uniform_addr(const void* ptr) {
 }
 
 // STAMP (lab): per wave the s_memtime cycles of an item's phases, summed over the items it walked, into p.dbg[wave][8]
-template <bool STAMP>
+// SM: the statement without the running max (FlashW64Params::k_bound)
+template <bool STAMP, bool SM = false>
 __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Params p, int total_items) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -369,6 +393,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
     if constexpr (STAMP) t1 = __builtin_amdgcn_s_memtime();
     // ---- Q fragments from the image [chunk][row]: lane holds Q[row][16c + 8hi .. +8] = chunk 2c + hi of row 32 blk + l31
     unsigned qw[2][20];
+    float nmv[2] = {0.f, 0.f};
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {
       const char* qimg = smem + W64_STAGES * KV_STAGE + wave_u * W64P_QIMG + (32 * blk + l31) * 16;
@@ -399,6 +424,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
             for (int e = 0; e < 8; ++e) x[c][e] = bf2f(f2bf(x[c][e] * rstd)) * w[e];
           }
         }
+      }
+      if constexpr (SM) {
+        float qn2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) qn2 += x[c][e] * x[c][e];
+        qn2 += __shfl_xor(qn2, 32, 64);
+        nmv[blk] = -(sqrtf(qn2) * p.k_bound * 1.015625f);
       }
 #pragma unroll
       for (int c = 0; c < 5; ++c) {
@@ -454,7 +488,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
                    : FLASH72_W64_CLOBBERS);
 #endif
       t3 = __builtin_amdgcn_s_memtime();
-    } else
+    } else if constexpr (SM)
+    asm volatile(FLASH72_W64P_ASM_S
+                 :
+                 : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
+                   [s4] "s"(s4), [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [qlds] "s"(qlds), [kvo] "v"(k_voff),
+                   [vvo] "v"(v_voff), [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2),
+                   [vfa3] "v"(vfa3), [qvo] "v"(qvo), [nma] "v"(nmv[0]), [nmb] "v"(nmv[1])
+                 : FLASH72_W64_CLOBBERS);
+    else
     asm volatile(FLASH72_W64P_ASM
                  :
                  : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
@@ -550,10 +592,10 @@ bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride) {
 
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                                int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, bool stamp,
-                               hipStream_t stream) {
+                               float k_bound, hipStream_t stream) {
   FlashW64Params p;
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
-  p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
+  p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps; p.k_bound = k_bound;
   p.dbg = nullptr;
   p.nqb = (q_len + 255) / 256;
   const int64_t total = (int64_t)p.nqb * batch * heads;
@@ -564,6 +606,7 @@ int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* 
   static std::atomic<unsigned long long> attr_seen{0};
   if (first_use_on_this_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #ifdef VSYS_LAB
     (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #endif
@@ -576,16 +619,19 @@ int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* 
   }
 #endif
   (void)stamp;
-  hipLaunchKernelGGL(flash_attn_d72_w64p_kernel<false>, dim3(grid), dim3(256), lds, stream, p, (int)total);
+  if (k_bound > 0.f && q_norm_w != nullptr)
+    hipLaunchKernelGGL((flash_attn_d72_w64p_kernel<false, true>), dim3(grid), dim3(256), lds, stream, p, (int)total);
+  else
+    hipLaunchKernelGGL(flash_attn_d72_w64p_kernel<false>, dim3(grid), dim3(256), lds, stream, p, (int)total);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
 int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, int var,
-                              hipStream_t stream) {
+                              float k_bound, hipStream_t stream) {
   FlashW64Params p;
   p.q = q; p.q_stride = q_stride; p.q_norm_w = q_norm_w; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
-  p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
+  p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps; p.k_bound = k_bound;
   p.dbg = reinterpret_cast<unsigned long long*>(get_lab_debug_buffer());
   p.nqb = (q_len + 255) / 256;
   const int64_t nblk = (int64_t)p.nqb * batch * heads;
@@ -595,6 +641,7 @@ int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q
     case 0: return launch_w64_t<0>(p, (unsigned)nblk, lds, stream);
     case 1: return launch_w64_t<1>(p, (unsigned)nblk, lds, stream);
     case 3: return launch_w64_t<3>(p, (unsigned)nblk, lds, stream);
+    case 5: return k_bound > 0.f && q_norm_w != nullptr ? launch_w64_t<5>(p, (unsigned)nblk, lds, stream) : VSYS_ERR_ARG;
 #ifdef VSYS_LAB
     case 7: return launch_w64_t<7>(p, (unsigned)nblk, lds, stream);
     case 10: return launch_w64_t<10>(p, (unsigned)nblk, lds, stream);

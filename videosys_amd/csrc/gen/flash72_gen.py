@@ -79,6 +79,11 @@ def preg(blk, kt, cc):
     return P[blk] + (kt * 2 + cc) * 4
 
 
+# STATIC (variant 5): no running max.  The caller hands in, per query row, an upper bound m_i >= max_j s_ij (Cauchy-Schwarz on the
+# normed rows: |q_i| * max_j |k_j|) as the -m splat; P = exp2(s - m_i) <= 1 needs no row max, no rescale branch and no adoption of the
+# first tile — softmax is invariant under the choice of m as long as nothing under- or overflows (the caller checks 2 m_i < 126).
+STATIC = False
+NLATE = 2         # P units (of the 8 of a tile) computed in the PV phase
 PHASE = False     # lab (variant 10): s_memtime around the two phases of every loop tile, summed per wave: X, wait + barrier, Y
 PSTAMP = False    # lab: s_memtime behind the opening wait + barrier and at the loop head of the persistent form
 PERSIST = False   # set by generate(): the persistent (workgroup walks several work items) form of the statement
@@ -354,6 +359,9 @@ def body(e, tag, p, masked, resc, variant=0):
     e("s_waitcnt lgkmcnt(0)")        # K(i+1) fragments (read during Y_{i-1})
     units = [("A", 0, 0), ("A", 0, 1), ("A", 1, 0), ("A", 1, 1), ("B", 0, 0), ("B", 0, 1)]
     late = [("B", 1, 0), ("B", 1, 1)]
+    if STATIC:   # in the order the PV MFMAs need them: unit j is read by MFMA 3 j of Y
+        order = [("A", 0, 0), ("A", 0, 1), ("B", 0, 0), ("B", 0, 1), ("A", 1, 0), ("A", 1, 1), ("B", 1, 0), ("B", 1, 1)]
+        units, late = order[:8 - NLATE], order[8 - NLATE:]
     if variant == 4:   # (d64: X has 16 MFMAs for the same softmax work) one more P unit moves to Y: A's keys 48..63, needed by its 16th MFMA
         units, late = units[:3] + units[4:], [("A", 1, 1)] + late
         variant = 1
@@ -365,6 +373,8 @@ def body(e, tag, p, masked, resc, variant=0):
     kaddr = k_addr(S_ST2)
     nq = 4 * NCC     # MFMAs of X
     streams = [(v_reads(), 0, 7), (pu[:24], 0, 7), (pu[24:], 8, nq - 1), (kaddr, 10, 10 + len(kaddr) - 1)]
+    if STATIC:
+        streams = [(v_reads(), 0, 7), (pu, 0, nq - 1), (kaddr, 10, 10 + len(kaddr) - 1)]
     if variant == 3:
         streams.append((flat(dma_groups[:2]), 11, nq - 2))
     place(e, qk_mfmas(nxt), [st for st in streams if st[0]])
@@ -397,6 +407,10 @@ def body(e, tag, p, masked, resc, variant=0):
         tail = [t for t in tail if t.startswith("s_") or t.startswith("v_add_u32") or t.startswith("v_cmp")]
         tail = [f"v_mov_b32_e32 {v(TMP[0])}, 0"] + tail
     streams = [(k_reads(), 0, 4), (pb, 0, 7 if len(late) == 2 else 11)]
+    if STATIC:
+        chains = []
+        tail = adv + [t for t in tail if t.startswith("v_add_u32")]
+        streams = [(k_reads(), 0, 4), (pb, 0, 19)]
     if masked:
         streams.append((mask_ops(nxt), 2, 10))
     streams.append((chains, 5, 17))
@@ -423,9 +437,10 @@ def body(e, tag, p, masked, resc, variant=0):
         acc(84, 78, 76)
         acc(86, 80, 78)
         acc(88, 82, 80)
-    e(f"s_cbranch_vccnz RESC_{tag}_%=")
-    e.label(f"BACK_{tag}_%=")
-    resc.append((tag, nxt))
+    if not STATIC:
+        e(f"s_cbranch_vccnz RESC_{tag}_%=")
+        e.label(f"BACK_{tag}_%=")
+        resc.append((tag, nxt))
 
 
 def final(e, p):
@@ -464,7 +479,7 @@ def prologue_persist(e):
         e(f"v_accvgpr_write_b32 {a(i)}, 0")
     for blk in ("A", "B"):
         for i in range(16):
-            e(f"v_mov_b32_e32 {v(NM[blk] + i)}, 0")
+            e(f"v_mov_b32_e32 {v(NM[blk] + i)}, " + (f"%[nm{blk.lower()}]" if STATIC else "0"))
     # descriptors of the tiles this item still has to fetch (4 .. n-1): its own K / Vt
     e(f"s_mul_i32 {s(S_KNR)}, %[kvp2], 72")
     e(f"s_mul_i32 {s(S_VNR)}, %[kvp2], 96")
@@ -500,6 +515,11 @@ def prologue_persist(e):
 
 
 def adopt(e):
+    if STATIC:     # S(0) was computed against the caller's bound: nothing to adopt
+        e("s_nop 15")
+        for k in range(4):
+            e(f"v_add_u32_e32 {v(VADDR[k])}, {s(S_ST)}, %[vfa{k}]")
+        return
     e("s_nop 7")
     for t in max_chain(0, "A"):
         e(t)
@@ -529,7 +549,7 @@ def prologue(e):
         e(f"v_accvgpr_write_b32 {a(i)}, 0")
     for blk in ("A", "B"):
         for i in range(16):
-            e(f"v_mov_b32_e32 {v(NM[blk] + i)}, 0")
+            e(f"v_mov_b32_e32 {v(NM[blk] + i)}, " + (f"%[nm{blk.lower()}]" if STATIC else "0"))
     # DMA soff registers of tile 0
     e(f"s_mov_b32 {s(S_KA)}, %[wl]")
     e(f"s_add_i32 {s(S_KB)}, %[wl], 4096")
@@ -566,7 +586,7 @@ def prologue(e):
 
 
 def generate(variant=0, persist=False, pstamp=False, d64=False):
-    global PERSIST, PSTAMP, HD64, NCC, NPIECE, K_TILE, STAGE, NV, PHASE
+    global PERSIST, PSTAMP, HD64, NCC, NPIECE, K_TILE, STAGE, NV, PHASE, STATIC, NLATE
     assert not (d64 and persist)
     PERSIST, PSTAMP = persist, pstamp
     keep = (HD64, NCC, NPIECE, K_TILE, STAGE, NV)
@@ -576,9 +596,13 @@ def generate(variant=0, persist=False, pstamp=False, d64=False):
         if variant == 10:
             PHASE = True
             return _generate(1)
+        if variant == 5:
+            STATIC, NLATE = True, (5 if d64 else 4)
+            return _generate(1)
         return _generate(variant)
     finally:
-        PERSIST = PSTAMP = PHASE = False
+        PERSIST = PSTAMP = PHASE = STATIC = False
+        NLATE = 2
         HD64, NCC, NPIECE, K_TILE, STAGE, NV = keep
 
 
@@ -657,7 +681,7 @@ def clobbers(d64=False):
     return [f"v{i}" for i in range(213 if d64 else NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in sregs] + ["vcc", "memory"]
 
 
-VARIANTS = (0, 1, 3, 7, 8, 9, 10)   # 7, 10: lab stamps; 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
+VARIANTS = (0, 1, 3, 5, 7, 8, 9, 10)   # 5: no running max (the caller's row bound); 7, 10: lab stamps; 8, 9: lab ablations (results not valid), compiled under VSYS_LAB only
 
 
 def write_inc(path):
@@ -677,13 +701,17 @@ def write_inc(path):
         for ln in generate(1, persist=True):
             f.write('  "' + ln + '\\n\\t" \\\n')
         f.write('  ""\n')
+        f.write("#define FLASH72_W64P_ASM_S \\\n")     # the persistent form without the running max (variant 5)
+        for ln in generate(5, persist=True):
+            f.write('  "' + ln + '\\n\\t" \\\n')
+        f.write('  ""\n')
         f.write("#define FLASH72_W64P_ASM_STAMP \\\n")
         for ln in generate(1, persist=True, pstamp=True):
             f.write('  "' + ln + '\\n\\t" \\\n')
         f.write('  ""\n')
         f.write("#define FLASH72_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers()) + "\n")
         f.write("// FLASH64_W64_ASM: the head_dim 64 form (flash_attn_d64_w64_kernel, csrc/attention64_w64.hip), placement variant 1.\n")
-        for var in (1, 4):   # 4: one more P unit in the PV phase (the QK^T phase has 16 MFMAs here for the same softmax work)
+        for var in (1, 4, 5):   # 4: one more P unit in the PV phase; 5: no running max (the QK^T phase has 16 MFMAs here for the same softmax work)
             f.write(f"#define FLASH64_W64_ASM_V{var} \\\n")
             for ln in generate(var, d64=True):
                 f.write('  "' + ln + '\\n\\t" \\\n')

@@ -179,12 +179,12 @@ int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int6
                         hipStream_t stream);
 int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt,
                           bf16_t* out, int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad,
-                          float eps, hipStream_t stream);
+                          float eps, float k_bound, hipStream_t stream);   // k_bound: see FlashW64Params::k_bound (0 = none)
 // 64 query rows per wave, one wave per SIMD, hand-allocated tile loop (attention_w64.hip); same contract as launch_flash_attn_d72
 bool flash_w64_supports(int q_len, int kv_len, int kv_pad);
 int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, int var,
-                              hipStream_t stream);   // var: LDS-DMA placement variant 0 / 1 / 3 (lab builds: 8, 9 ablations)
+                              float k_bound, hipStream_t stream);   // var: LDS-DMA placement variant 0 / 1 / 3, 5 = no running max (k_bound)
 bool flash64_w64_supports(int q_len, int kv_len);
 int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
                               const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
@@ -193,7 +193,7 @@ int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* l
 bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride);   // persistent form of the w64 kernel
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                                int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, bool stamp,
-                               hipStream_t stream);   // stamp: lab builds only (cycle accounting into the lab debug buffer)
+                               float k_bound, hipStream_t stream);   // stamp: lab builds only (cycle accounting into the lab debug buffer)
 int launch_attn_prep_kv64(const bf16_t* k, int64_t k_stride, const bf16_t* v, int64_t v_stride, const bf16_t* ln_w,
                           const bf16_t* ln_b, const float* rope_cos, const float* rope_sin, int rope_start, int rope_len,
                           bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps, hipStream_t stream);

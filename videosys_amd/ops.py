@@ -358,16 +358,32 @@ def attn_prep_kv(k, v, k_norm_w, kp, vt, batch, heads, kv_len, eps=1e-6):
                                      kv_len, kv_pad, eps)
 
 
-def flash_attn(q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
-    """q/out: 2-D row-strided views [batch*q_len, >= heads*72]."""
+def flash_attn(q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6, k_norm_bound=None):
+    """q/out: 2-D row-strided views [batch*q_len, >= heads*72].  ``k_norm_bound``: the caller's promise about the norms of the Kp
+    rows (include/videosys_amd.h, vsys_flash_attn_d72_kb; see rms_key_bound); None = no promise."""
     _chk(q, q_norm_w, kp, vt, out)
     _bf16(q, q_norm_w, kp, vt, out)
     assert q.stride(1) == 1 and out.stride(1) == 1
     kv_pad = kp.shape[2]
-    lib = _lib.load()
-    _call("vsys_flash_attn_d72", _p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
-                                       q_len, kv_len, kv_pad, eps)
+    if k_norm_bound:
+        _call("vsys_flash_attn_d72_kb", _p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
+              q_len, kv_len, kv_pad, eps, float(k_norm_bound))
+    else:
+        _call("vsys_flash_attn_d72", _p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
+              q_len, kv_len, kv_pad, eps)
     return out
+
+
+def rms_key_bound(q_norm_w, k_norm_w, head_dim=HEAD_DIM):
+    """The k_norm_bound of flash_attn for RMS-normed q and k (LlamaRMSNorm, normalization.py:28-33: x / rms(x) has norm sqrt(d), then
+    the weight elementwise), or None when the promise |q_i| k_norm_bound <= 60 cannot be given from the weights alone.  Host-side,
+    once per block at load time (two 72-element reads)."""
+    import math
+
+    wq, wk = float(q_norm_w.float().abs().max()), float(k_norm_w.float().abs().max())
+    kb = math.sqrt(head_dim) * wk * (math.log2(math.e) / math.sqrt(head_dim)) * (1.0 + 2.0 ** -6)   # Kp rows: normed, scaled, rounded
+    qb = math.sqrt(head_dim) * wq * (1.0 + 2.0 ** -6)
+    return kb if qb * kb * (1.0 + 2.0 ** -5) <= 60.0 else None
 
 
 def attn_temporal(qkv, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, B, T, S, heads, eps=1e-6):

@@ -152,6 +152,7 @@ class STDiT3:
         # (ops.gemm_gate_res_add) instead of being 270 MB passes of their own; same roundings, same bits (_block, `upcoming`)
         self.pab_fold_adds = os.environ.get("VSYS_PAB_FOLD", "1") != "0"
         self._bc, self._folded = None, {}
+        self._kbounds = {}
         self.use_programs = os.environ.get("VSYS_PROGRAMS", "1") != "0"
         # AdaLN folded into the qkv / fc1 GEMMs (csrc/adaln_fold.hip): pre-scaled weights per step, row statistics from the
         # producing epilogue; VSYS_ADALN_FOLD=0 keeps the separate LayerNorm-modulate pass everywhere
@@ -172,6 +173,7 @@ class STDiT3:
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
         need = self.expected_keys()
+        self._kbounds = {}     # (promises derived from the norm weights)
         missing = [k for k in need if k not in sd]
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:8]}{'...' if len(missing) > 8 else ''}")
@@ -378,7 +380,7 @@ class STDiT3:
     def _fold_tables(self, B):
         """Site table of vsys_adaln_prescale for a modulation table laid out [2*depth, B, 6C] (sample-0 rows) and the per-site
         W' / cs / cv buffers (allocated once: 2 x the qkv + fc1 weight bytes)."""
-        f = self._fold
+        f = self._fold or None     # (HostOffload empties it when the weights leave the device: their addresses are in the table)
         if f is not None and f["B"] == B:
             return f
         w, C, dev = self.w, self.hidden_size, self.device
@@ -733,7 +735,7 @@ class STDiT3:
                 kp, vt = self._kv_spatial(B * T, S)
                 ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, B * T, H, S)
                 ao = _buf("attn_out", (N, C))
-                ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * T, H, S, S)
+                ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, B * T, H, S, S, k_norm_bound=self._kbound(p))
             else:
                 qkv_rest = None
                 if fold_attn:   # (order "qkv") the folded GEMM at rest produces what travels
@@ -838,7 +840,7 @@ class STDiT3:
             kp, vt = self._ws[key]
             ops.attn_prep_kv(qkv[:, C:2 * C], qkv[:, 2 * C:], w[p + ".attn.k_norm.weight"], kp, vt, nf, H, S_full)
             ao = self._buf(f"attn_out_o{i}", (Na, C))
-            ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, nf, H, S_full, S_full)
+            ops.flash_attn(qkv[:, :C], w[p + ".attn.q_norm.weight"], kp, vt, ao, nf, H, S_full, S_full, k_norm_bound=self._kbound(p))
             return ao.view(Bc, Tc, S_full, C)
 
         if len(chunks) == 1:
@@ -873,6 +875,17 @@ class STDiT3:
             self._ws[key] = dsp.choose_spatial_switch(B, T, S_full, self.hidden_size, self._sp.P, overlapped=bool(self._overlap),
                                                       scatter="sample")["order"]   # (called with the scattered view's B, T)
         return self._ws[key]
+
+    def _kbound(self, p):
+        """The promise about block ``p``'s spatial keys that lets the attention kernels drop the running max (ops.rms_key_bound:
+        from the q / k norm weights, once; None = no promise, e.g. weights with outliers).  VSYS_FLASH_STATIC=0 never promises."""
+        kb = self._kbounds.get(p, 0)
+        if kb == 0:
+            kb = None
+            if os.environ.get("VSYS_FLASH_STATIC", "1") != "0":
+                kb = ops.rms_key_bound(self.w[p + ".attn.q_norm.weight"], self.w[p + ".attn.k_norm.weight"])
+            self._kbounds[p] = kb
+        return kb
 
     def _kv_spatial(self, batch, kv_len):
         key = ("kv_spatial", batch, kv_len)

@@ -283,7 +283,8 @@ class HostOffload:
     Works on any of this package's weight holders: it walks attributes, dicts, lists, tuples and SimpleNamespaces, moves every CUDA
     tensor it finds and preserves aliasing (one tensor object referenced from two places stays one tensor)."""
 
-    def __init__(self, obj, device=None, skip=("_ws", "_text_cache", "_rope_cache", "_pos_cache", "_fps_cache", "_bias_cache", "_padded")):
+    def __init__(self, obj, device=None, skip=("_ws", "_text_cache", "_rope_cache", "_pos_cache", "_fps_cache", "_bias_cache", "_padded",
+                                               "_fold")):   # (_fold: a device table of weight ADDRESSES — rebuilt after the weights return)
         self.obj = obj
         self.skip = set(skip)
         self.device = torch.device(device) if device is not None else getattr(obj, "device", torch.device("cuda"))
