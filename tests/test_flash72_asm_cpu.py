@@ -132,3 +132,32 @@ def test_stream_without_running_max_is_lighter():
         assert n_mfma == (80 if d64 else 88)
         assert (len(loop) - n_mfma) / n_mfma <= limit      # 4.3 with the row max (test_steady_state_gaps...)
         assert not any("RESC" in ln for ln in lines)
+
+
+def test_persistent_walk_without_running_max():
+    import flash72_emu_case as C
+
+    with np.errstate(all="ignore"):
+        errs, viol, _ = C.run_persist(512, nitems=3, late_vm=False, late_ds=True, order=[3, 2, 1, 0], static=True)
+    assert not viol, viol[:5]
+    assert max(errs) <= 2.0 ** -8, errs
+
+
+def test_every_scc_reader_sits_behind_its_compare():
+    """An s_cselect / s_cbranch_scc* reads SCC; every SALU add / sub / shift overwrites it.  The placement spreads independent
+    streams over the MFMA gaps, so the pair must be emitted as one item — in EVERY generated statement the instruction in front of
+    an SCC reader is its s_cmp (the hardware failure this guards: the LDS ring of variant 5 never wrapped; the emulator models SCC
+    since)."""
+    import flash72_gen as G
+
+    texts = [G.generate(v) for v in G.VARIANTS] + [G.generate(1, persist=True), G.generate(5, persist=True),
+                                                    G.generate(1, d64=True), G.generate(4, d64=True), G.generate(5, d64=True)]
+    for lines in texts:
+        code = [ln for ln in lines if not ln.endswith(":")]
+        for i, ln in enumerate(code):
+            if ln.startswith(("s_cselect", "s_cbranch_scc")):
+                j = i - 1
+                while not code[j].startswith("s_cmp"):     # only instructions that leave SCC alone may sit in between
+                    assert not code[j].startswith(("s_add", "s_sub", "s_lsh", "s_and", "s_or", "s_xor", "s_min", "s_max", "s_bf", "s_ash")), (code[j], ln)
+                    j -= 1
+                    assert j >= 0 and i - j < 8, ln

@@ -133,7 +133,7 @@ if __name__ == "__main__":
     print({k: c[k] for k in sorted(c) if c[k] > 20})
 
 
-def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None, qscale=1.0, spike=False, switch_kv_at=2):
+def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None, qscale=1.0, spike=False, switch_kv_at=2, static=False):
     """``nitems`` consecutive work items of one workgroup in the PERSISTENT form (FLASH72_W64P_ASM): items < switch_kv_at share one
     (batch, head)'s K / Vt, the others use a second one; every item has its own 256 query rows.  Between the statements the numpy
     code does what the C++ of flash_attn_d72_w64p_kernel does: Q(k) from the wave's LDS image into a[96:135], O read-out, output
@@ -144,7 +144,7 @@ def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None
     cases = [make_case(kv_len, seed + 17 * j, spike and j == 1, qscale) for j in range(nitems)]
     kvsets = [cases[0], cases[-1]]                      # two (batch, head)s
     kv_of = [0 if j < switch_kv_at else 1 for j in range(nitems)]
-    lines = G.generate(1, persist=True)
+    lines = G.generate(5 if static else 1, persist=True)   # static: no running max (the row bounds ride in as v220 / v221)
     lane = np.arange(64)
     l31, hi = lane & 31, lane >> 5
     binds = []
@@ -152,7 +152,7 @@ def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None
         binds.append({"kb": "s[4:5]", "vb": "s[6:7]", "kbn": "s[8:9]", "vbn": "s[10:11]", "rqn": "s[12:15]", "wl": "s16", "kvp2": "s17",
                       "hn": "s18", "s4": "s19", "st4": "s20", "l4": "s21", "lb": "s22", "nt": "s23", "qlds": "s24", "lim": "v210",
                       "kvo": "v211", "vvo": "v212", "v4o": "v213", "kfa": "v214", "vfa0": "v215", "vfa1": "v216", "vfa2": "v217",
-                      "vfa3": "v218", "qvo": "v219"})
+                      "vfa3": "v218", "qvo": "v219", "nma": "v220", "nmb": "v221"})
     wg = E.Workgroup(lines, binds, late_vm=late_vm, late_ds=late_ds)
     wg.lds[:] = 0xAB
     lb, QBASE = 0, 4 * STAGE
@@ -217,6 +217,11 @@ def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None
             nq = ids[("q", j + 1)] if has_next else (0, 0)
             wave.s.update({4: kid[0], 5: kid[1], 6: vid[0], 7: vid[1], 8: nk[0], 9: nk[1], 10: nv[0], 11: nv[1],
                            12: nq[0], 13: nq[1], 14: 256 * 144, 15: 0x20000, 18: 1 if has_next else 0})
+            qj, kj = cases[j][0], kvsets[kv_of[j]][1]
+            kmax = float(np.sqrt((kj.astype(np.float64) ** 2).sum(1)).max())
+            for blk, reg in ((0, 220), (1, 221)):
+                rows_ = 64 * w + 32 * blk + l31
+                wave.v[reg] = (-(np.sqrt((qj[rows_].astype(np.float64) ** 2).sum(1)) * kmax * (1 + 2.0 ** -6))).astype(np.float32).view(np.uint32)
             # Q(j) from the LDS image [chunk][row] -> a[96:135]
             for blk in range(2):
                 for c in range(5):

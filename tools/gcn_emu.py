@@ -238,6 +238,16 @@ class Wave:
                 val = self.ssrc(A[1]) - self.ssrc(A[2])
             else:
                 val = self.ssrc(A[1]) + self.ssrc(A[2])
+            # SCC as the hardware sets it (carry / borrow / signed overflow): an s_cselect separated from its s_cmp by one of these
+            # reads THIS, which is what a placement that splits the pair gets on the GPU
+            if op == "s_add_u32":
+                self.scc = val > 0xFFFFFFFF
+            elif op == "s_sub_u32":
+                self.scc = val < 0
+            elif op == "s_add_i32":
+                x_, y_ = self.ssrc(A[1]) & 0xFFFFFFFF, self.ssrc(A[2]) & 0xFFFFFFFF
+                sx, sy, sr = x_ >> 31, y_ >> 31, ((x_ + y_) & 0xFFFFFFFF) >> 31
+                self.scc = bool(sx == sy and sr != sx)
             val &= 0xFFFFFFFF
             if A[0] == "m0":
                 self.m0 = val
@@ -248,6 +258,8 @@ class Wave:
         if op in ("s_mul_i32", "s_lshr_b32", "s_lshl_b32"):
             x, y = self.ssrc(A[1]), self.ssrc(A[2])
             val = {"s_mul_i32": x * y, "s_lshr_b32": x >> (y & 31), "s_lshl_b32": x << (y & 31)}[op] & 0xFFFFFFFF
+            if op != "s_mul_i32":
+                self.scc = val != 0
             self.s[parse_reg(A[0])[1]] = val
             return
         if op in ("s_mov_b64", "s_cselect_b64"):

@@ -1002,7 +1002,9 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   static const bool static_ok = [] { const char* e = getenv("VSYS_FLASH_STATIC"); return !(e && e[0] == '0'); }();
   const bool bounded = k_bound > 0.f && q_norm_w != nullptr && static_ok && g_flash_variant != 19 && g_flash_variant != 15;
   const bool many_items = (int64_t)batch * heads * ((q_len + 255) / 256) >= 4ll * cu_count_this_device();
-  const bool w64p_default = g_flash_variant == 0 && kv_len >= 512 && many_items && (w64_default || (bounded && kv_len < 2048));
+  // (the persistent form stays opt-in — VSYS_FLASH_W64=1 — also with the promise: 0.228 vs 0.254 ms isolated at the config-2 shape,
+  // but 101.1 vs 100.8 ms per step in situ, profiles/r04_flash_static_max.json)
+  const bool w64p_default = g_flash_variant == 0 && kv_len >= 512 && many_items && w64_default;
   if ((g_flash_variant == 16 || g_flash_variant == 146 || g_flash_variant == 18 || w64p_default) &&
       flash_w64p_supports(q_len, kv_len, kv_pad, q_stride))
     return launch_flash_attn_d72_w64p(q, q_stride, q_norm_w, kp, vt, out, out_stride, batch, heads, q_len, kv_len, kv_pad, eps,

@@ -409,7 +409,9 @@ def body(e, tag, p, masked, resc, variant=0):
     streams = [(k_reads(), 0, 4), (pb, 0, 7 if len(late) == 2 else 11)]
     if STATIC:
         chains = []
-        tail = adv + [t for t in tail if t.startswith("v_add_u32")]
+        # (an s_cmp and the s_cselect that reads its SCC travel as ONE item: the LDS-DMA stream's s_add_i32 of the same gap would
+        # otherwise land between them and overwrite SCC — the stage would never wrap)
+        tail = [adv[0], adv[1] + "\n" + adv[2], adv[3], adv[4], adv[5] + "\n" + adv[6]] + [t for t in tail if t.startswith("v_add_u32")]
         streams = [(k_reads(), 0, 4), (pb, 0, 19)]
     if masked:
         streams.append((mask_ops(nxt), 2, 10))
