@@ -207,7 +207,7 @@ int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, c
                         int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
                         float eps, void* stream);
 
-/* vsys_flash_attn_d72 with a promise about the keys: k_norm_bound >= the Euclidean norm of every Kp row (as stored: normed, scaled
+/* vsys_flash_attn_d72 (attentions.py:75,100) with a promise about the keys: k_norm_bound >= the Euclidean norm of every Kp row (as stored: normed, scaled
  * by log2(e) / sqrt(72)).  For an RMS-normed key that is sqrt(72) max|k_norm.weight| log2(e) / sqrt(72) (1 + rounding), a property
  * of the WEIGHTS (normalization.py:28-33): the caller computes it once per block.  By Cauchy-Schwarz m_i = |q_i| k_norm_bound bounds
  * every logit of query row i, and softmax is invariant under the choice of the subtracted m: the kernels that take the promise
@@ -269,6 +269,15 @@ int vsys_attn_prep_kv64(const void* k, int64_t k_stride, const void* v, int64_t 
 int vsys_flash_attn_d64(const void* q, int64_t q_stride, const void* ln_w, const void* ln_b, const void* rope_cos_f32,
                         const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, const void* kp, const void* vt, void* out,
                         int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad, float eps,
+                        void* stream);
+
+/* vsys_flash_attn_d64 (cogvideox_transformer_3d.py:108-158) with the promise of vsys_flash_attn_d72_kb about the Kp rows (LayerNorm qk-norm with affine weights, rotary
+ * embedding, scale log2(e) / 8: |k| <= (8 max|w| + |b|_2) log2(e) / 8, a property of the block's norm_k weights): no running
+ * maximum in the kernels that take it (attention64_w64.hip).  |q_i| k_norm_bound <= 60 for every query row is the caller's to
+ * guarantee (|q_i| <= 8 max|norm_q.weight| + |norm_q.bias|_2).  0 = exactly vsys_flash_attn_d64. */
+int vsys_flash_attn_d64_kb(const void* q, int64_t q_stride, const void* ln_w, const void* ln_b, const void* rope_cos_f32,
+                        const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, const void* kp, const void* vt, void* out,
+                        int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad, float eps, float k_norm_bound,
                         void* stream);
 
 /* Temporal self-attention over the T frames of every (b, s) token: RMS qk-norm, RoPE (cos/sin fp32 [T, 72], NULL =
@@ -430,7 +439,8 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
 #define VSYS_OP_LN_ROW_STATS        26
 #define VSYS_OP_GEMM_BF16_GATE_RES_ADD 27
 #define VSYS_OP_FLASH_ATTN_D72_KB   28
-#define VSYS_OP_COUNT              29
+#define VSYS_OP_FLASH_ATTN_D64_KB   29
+#define VSYS_OP_COUNT              30
 
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */

@@ -99,11 +99,12 @@ def test_flash_attn_d64_w64_stream(B, H, Lt, Lv, norm, rope):
                        kp, vt, B, H, L)
     outs = {}
     lib = _lib.load()
+    kbound = ops.ln_key_bound(qw, qb, kw, kb) if norm else None   # (no norm: nothing can be promised about the keys)
     try:
-        for fv in (14, 15):
+        for fv in (14, 15) + ((17,) if kbound else ()):
             assert lib.vsys_tune_flash_variant(fv) == 0
             o = torch.full((B * L, C), float("nan"), dtype=torch.bfloat16, device=dev())
-            ops.flash_attn64(qd[:, :C], nq, nb, cd, sd, Lt, kp, vt, o, B, H, L, L)
+            ops.flash_attn64(qd[:, :C], nq, nb, cd, sd, Lt, kp, vt, o, B, H, L, L, k_norm_bound=kbound if fv == 17 else None)
             torch.cuda.synchronize()
             outs[fv] = o
     finally:
@@ -122,6 +123,11 @@ def test_flash_attn_d64_w64_stream(B, H, Lt, Lv, norm, rope):
     err14, err15 = (a - ref).abs().max().item(), (b_ - ref).abs().max().item()
     assert err14 <= 1.25 * err15 + 1e-3, (err14, err15)
     assert (a - b_).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
+    if 17 in outs:   # the same stream without the running max (the caller's bound on the key norms): same tolerance
+        c = outs[17].float().cpu()
+        assert torch.isfinite(c).all()
+        check(outs[17], ref, what=f"flash d64 w64 without running max B{B} H{H} L{Lt}+{Lv}")
+        assert (c - ref).abs().max().item() <= 1.25 * err15 + 1e-3
 
 
 def test_ln_modulate_two_segments_and_plain():

@@ -70,17 +70,19 @@ def d64(a, dev, lib, g):
     kp, vt = ops.alloc_kv_buffers64(B, H, L, dev)
     ops.attn_prep_kv64(qkv[:, C:2 * C], qkv[:, 2 * C:], w, bia, cos, sin, Lt, kp, vt, B, H, L)
     ao = torch.empty(B * L, C, dtype=torch.bfloat16, device=dev)
+    kb = ops.ln_key_bound(w, bia, w, bia)   # ids >= 1000: id - 1000 with the promise (1017 = the stream without the running max)
     flops = 4.0 * B * H * L * L * D
     ref, out = None, []
     for v in [int(x) for x in a.variants.split(",")]:
-        lib.vsys_tune_flash_variant(v)
+        bound = kb if v >= 1000 else None
+        lib.vsys_tune_flash_variant(v % 1000)
         for _ in range(2):
-            ops.flash_attn64(qkv[:, :C], w, bia, cos, sin, Lt, kp, vt, ao, B, H, L, L)
+            ops.flash_attn64(qkv[:, :C], w, bia, cos, sin, Lt, kp, vt, ao, B, H, L, L, k_norm_bound=bound)
         ts = []
         for _ in range(a.reps):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
-            ops.flash_attn64(qkv[:, :C], w, bia, cos, sin, Lt, kp, vt, ao, B, H, L, L)
+            ops.flash_attn64(qkv[:, :C], w, bia, cos, sin, Lt, kp, vt, ao, B, H, L, L, k_norm_bound=bound)
             e.record()
             torch.cuda.synchronize()
             ts.append(s.elapsed_time(e))

@@ -54,6 +54,8 @@ SIGNATURES = {
                             _ptr],
     "vsys_flash_attn_d64": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
                             _f32, _ptr],
+    "vsys_flash_attn_d64_kb": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64,
+                            _f32, _f32, _ptr],
     "vsys_attn_temporal_d72": [_ptr, _i64, _i64, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
     "vsys_gather_rows": [_ptr, _ptr, _ptr, _i64, _i64, _i64, _ptr],
     "vsys_rms_norm_rows": [_ptr, _ptr, _ptr, _i64, _i64, _f32, _ptr],

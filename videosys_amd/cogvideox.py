@@ -84,6 +84,7 @@ class CogVideoXTransformer3DModel:
         self.w: Dict[str, torch.Tensor] = {}
         self.parallel_manager = SimpleNamespace(sp_size=1, cp_size=1, dp_size=1, dp_rank=0, sp_group=None, cp_group=None)
         self._ws = {}
+        self._kbounds = {}   # per block: the promise about its key norms (ops.ln_key_bound), None = none
         self._hidden_tap = None
         pf = (sample_frames - 1) // temporal_compression_ratio + 1
         self._pos3d = None
@@ -108,7 +109,22 @@ class CogVideoXTransformer3DModel:
                 keys += [f"{p}.{l}.weight", f"{p}.{l}.bias"]
         return keys
 
+    def _kbound(self, pre):
+        """What lets the long-sequence attention kernel drop the running max (vsys_flash_attn_d64_kb): from the block's norm_q /
+        norm_k weights, once.  VSYS_FLASH_STATIC=0 never promises."""
+        import os
+
+        if pre not in self._kbounds:
+            kb = None
+            if os.environ.get("VSYS_FLASH_STATIC", "1") != "0":
+                g = self.w.get
+                kb = ops.ln_key_bound(g(pre + ".attn1.norm_q.weight"), g(pre + ".attn1.norm_q.bias"), g(pre + ".attn1.norm_k.weight"),
+                                      g(pre + ".attn1.norm_k.bias"))
+            self._kbounds[pre] = kb
+        return self._kbounds[pre]
+
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        self._kbounds = {}
         missing = [k for k in self.expected_keys() if k not in sd]
         if strict and missing:
             raise KeyError(f"missing keys: {missing[:8]}{'...' if len(missing) > 8 else ''}")
@@ -253,7 +269,7 @@ class CogVideoXTransformer3DModel:
                                    cos, sin, Lt, kp, vt, B, Hl, L)
                 ao = self._buf("attn_out_h" if sp is not None else "attn_out", (B * L, hw))
                 ops.flash_attn64(qkv[:, :hw], w[pre + ".attn1.norm_q.weight"], w[pre + ".attn1.norm_q.bias"], cos, sin, Lt, kp, vt,
-                                 ao, B, Hl, L, L)
+                                 ao, B, Hl, L, L, k_norm_bound=self._kbound(pre))
                 if sp is not None:  # heads -> sequence
                     ao = sp.gather_heads(ao, B, Lt, Lv, C, out=self._buf("attn_out", (B, Ll, C)))
             if use_pab:

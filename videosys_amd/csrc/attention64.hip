@@ -465,7 +465,7 @@ int launch_t5_attention_mfma(const bf16_t* qkv, int64_t row_stride, int inner, c
 
 int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
                           const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
-                          int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps,
+                          int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, float k_bound,
                           hipStream_t stream) {
   if (batch <= 0 || heads <= 0 || q_len <= 0) return 0;
   if (kv_len <= 0 || kv_pad % 64 != 0 || kv_pad < kv_len || (q_stride % 8) || (out_stride % 4)) return VSYS_ERR_SHAPE;
@@ -483,9 +483,16 @@ int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w,
   // (attention64_w64.hip); 15 = never (the A/B id of the measurement tools), 14 = wherever it is supported
   static const bool w64_off = [] { const char* e = getenv("VSYS_FLASH_W64"); return e && e[0] == '0'; }();
   constexpr int W64_DEFAULT_VAR = 4;   // 141 / 144 select placement variant 1 / 4 (4: +0.5-1 %, profiles/r04_flash64_w64_cvx5b.json)
-  if (((fv == 0 && kv_len >= 2048 && !w64_off) || fv == 14 || fv == 141 || fv == 144) && flash64_w64_supports(q_len, kv_len))
+  // k_bound > 0 (vsys_flash_attn_d64_kb): the statement without the running max; 17 forces it, 19 ignores the promise
+  static const bool static_ok = [] { const char* e = getenv("VSYS_FLASH_STATIC"); return !(e && e[0] == '0'); }();
+  const bool bounded = k_bound > 0.f && static_ok && fv != 19;
+  if (((fv == 0 && kv_len >= 2048 && !w64_off) || fv == 14 || fv == 17 || fv == 141 || fv == 144) && flash64_w64_supports(q_len, kv_len)) {
+    int var = fv >= 140 ? fv - 140 : W64_DEFAULT_VAR;
+    if (bounded && (fv == 0 || fv == 17)) var = 5;
+    if (fv == 17 && var != 5) return VSYS_ERR_ARG;
     return launch_flash_attn_d64_w64(q, q_stride, ln_w, ln_b, rope_cos, rope_sin, rope_start, rope_len, kp, vt, out, out_stride, batch,
-                                     heads, q_len, kv_len, kv_pad, eps, fv >= 140 ? fv - 140 : W64_DEFAULT_VAR, stream);
+                                     heads, q_len, kv_len, kv_pad, eps, var, k_bound, stream);
+  }
   if (fv == 12)        // A/B id (see set_flash_variant): the two-stage ring
     hipLaunchKernelGGL(flash_attn_d64_kernel<2>, dim3((unsigned)nblk), dim3(256), 2 * KV_STAGE, stream, p);
   else

@@ -33,6 +33,7 @@ struct Flash64W64Params {
   bf16_t* out; int64_t out_stride;
   int heads, q_len, kv_len, kv_pad, nqb;
   float eps;
+  float k_bound;   // VAR 5: upper bound on the norm of every Kp row (FlashW64Params::k_bound, attention_w64.hip)
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -91,6 +92,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d64_w64_kernel(Flash64W64Pa
   // ---- Q fragments of the two 32-row blocks (B operand: lane holds Q[row][16c + 8hi .. +8], c = 0..3): LayerNorm + RoPE as
   // flash_attn_d64_kernel's prologue
   unsigned qw[2][16];
+  float nmv[2] = {0.f, 0.f};   // VAR 5: -(row bound) of this lane's query row in block A / B
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk) {
     int qs = q0 + 32 * blk + l31;
@@ -145,6 +147,15 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d64_w64_kernel(Flash64W64Pa
         }
       }
     }
+    if constexpr (VAR == 5) {
+      float qn2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qn2 += x[c][e] * x[c][e];
+      qn2 += __shfl_xor(qn2, 32, 64);
+      nmv[blk] = -(sqrtf(qn2) * p.k_bound * 1.015625f);
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const uint4 pk = pack8(x[c]);
@@ -180,7 +191,16 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d64_w64_kernel(Flash64W64Pa
                  [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff), [kfa0] "v"(kfa0), [kfa1] "v"(kfa1), [kfa2] "v"(kfa2),       \
                  [kfa3] "v"(kfa3), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)                         \
                : FLASH64_W64_CLOBBERS)
-  if constexpr (VAR == 4) W64_LOOP(FLASH64_W64_ASM_V4);
+  if constexpr (VAR == 5) {   // no running max: the row bounds ride in as the -m splat
+    asm volatile(FLASH64_W64_ASM_V5
+                 :
+                 : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [lb] "s"(lb), [nt] "s"(ntiles),
+                   [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff), [kfa0] "v"(kfa0), [kfa1] "v"(kfa1), [kfa2] "v"(kfa2),
+                   [kfa3] "v"(kfa3), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3), [nma] "v"(nmv[0]),
+                   [nmb] "v"(nmv[1])
+                 : FLASH64_W64_CLOBBERS);
+  }
+  else if constexpr (VAR == 4) W64_LOOP(FLASH64_W64_ASM_V4);
   else W64_LOOP(FLASH64_W64_ASM_V1);
 #undef W64_LOOP
 
@@ -233,8 +253,9 @@ bool flash64_w64_supports(int q_len, int kv_len) { return kv_len >= 256 && q_len
 int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
                               const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, int var,
-                              hipStream_t stream) {
+                              float k_bound, hipStream_t stream) {
   Flash64W64Params p;
+  p.k_bound = k_bound;
   p.q = q; p.q_stride = q_stride; p.ln_w = ln_w; p.ln_b = ln_b; p.rope_cos = rope_cos; p.rope_sin = rope_sin;
   p.rope_start = rope_start; p.rope_len = rope_len; p.kp = kp; p.vt = vt; p.out = out; p.out_stride = out_stride;
   p.heads = heads; p.q_len = q_len; p.kv_len = kv_len; p.kv_pad = kv_pad; p.eps = eps;
@@ -246,8 +267,12 @@ int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* l
   if (first_use_on_this_device(attr_seen)) {
     (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  if (var == 4) hipLaunchKernelGGL(flash_attn_d64_w64_kernel<4>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+  if (var == 5) {
+    if (!(k_bound > 0.f)) return VSYS_ERR_ARG;
+    hipLaunchKernelGGL(flash_attn_d64_w64_kernel<5>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
+  } else if (var == 4) hipLaunchKernelGGL(flash_attn_d64_w64_kernel<4>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
   else hipLaunchKernelGGL(flash_attn_d64_w64_kernel<1>, dim3((unsigned)nblk), dim3(256), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }

@@ -214,7 +214,22 @@ int vsys_flash_attn_d64(const void* q, int64_t q_stride, const void* ln_w, const
     return VSYS_ERR_SHAPE;
   return launch_flash_attn_d64(B16(q), q_stride, B16(ln_w), B16(ln_b), reinterpret_cast<const float*>(rope_cos_f32),
                                reinterpret_cast<const float*>(rope_sin_f32), (int)rope_start, (int)rope_len, B16(kp), B16(vt),
-                               B16(out), out_stride, (int)batch, (int)heads, (int)q_len, (int)kv_len, (int)kv_pad, eps, S(stream));
+                               B16(out), out_stride, (int)batch, (int)heads, (int)q_len, (int)kv_len, (int)kv_pad, eps, 0.f, S(stream));
+}
+
+int vsys_flash_attn_d64_kb(const void* q, int64_t q_stride, const void* ln_w, const void* ln_b, const void* rope_cos_f32,
+                           const void* rope_sin_f32, int64_t rope_start, int64_t rope_len, const void* kp, const void* vt, void* out,
+                           int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad, float eps,
+                           float k_norm_bound, void* stream) {
+  if (!q || !kp || !vt || !out || !(k_norm_bound >= 0.f)) return VSYS_ERR_ARG;
+  if ((ln_w == nullptr) != (ln_b == nullptr)) return VSYS_ERR_ARG;
+  if (!fits_int(batch) || !fits_int(heads) || !fits_int(q_len) || !fits_int(kv_len) || !fits_int(kv_pad) || !fits_int(rope_start) ||
+      !fits_int(rope_len))
+    return VSYS_ERR_SHAPE;
+  return launch_flash_attn_d64(B16(q), q_stride, B16(ln_w), B16(ln_b), reinterpret_cast<const float*>(rope_cos_f32),
+                               reinterpret_cast<const float*>(rope_sin_f32), (int)rope_start, (int)rope_len, B16(kp), B16(vt),
+                               B16(out), out_stride, (int)batch, (int)heads, (int)q_len, (int)kv_len, (int)kv_pad, eps, k_norm_bound,
+                               S(stream));
 }
 
 int vsys_linear_small(const void* x, int64_t ldx, const void* w, int64_t ldw, const void* bias, void* out, int64_t ldo,

@@ -37,6 +37,7 @@ constexpr OpInfo kOps[VSYS_OP_COUNT] = {
     {5, 0},   // LN_ROW_STATS
     {20, 0},  // GEMM_BF16_GATE_RES_ADD
     {12, 2},  // FLASH_ATTN_D72_KB
+    {17, 2},  // FLASH_ATTN_D64_KB
 };
 }  // namespace
 
@@ -128,6 +129,10 @@ int vsys_program_run(const vsys_cmd* cmds, int64_t n, void* const* streams, int6
           break;
         case VSYS_OP_ADALN_PRESCALE: rc = vsys_adaln_prescale(CP(0), I(1), I(2), CP(3), st); break;
         case VSYS_OP_LN_ROW_STATS: rc = vsys_ln_row_stats(CP(0), I(1), I(2), P(3), I(4), st); break;
+        case VSYS_OP_FLASH_ATTN_D64_KB:
+          rc = vsys_flash_attn_d64_kb(CP(0), I(1), CP(2), CP(3), CP(4), CP(5), I(6), I(7), CP(8), CP(9), P(10), I(11), I(12), I(13), I(14),
+                                      I(15), I(16), c.f[0], c.f[1], st);
+          break;
         case VSYS_OP_FLASH_ATTN_D72_KB:
           rc = vsys_flash_attn_d72_kb(CP(0), I(1), CP(2), CP(3), CP(4), P(5), I(6), I(7), I(8), I(9), I(10), I(11), c.f[0], c.f[1], st);
           break;

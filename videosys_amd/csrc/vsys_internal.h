@@ -189,7 +189,7 @@ bool flash64_w64_supports(int q_len, int kv_len);
 int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
                               const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                               int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, int var,
-                              hipStream_t stream);
+                              float k_bound, hipStream_t stream);
 bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride);   // persistent form of the w64 kernel
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
                                int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, bool stamp,
@@ -199,7 +199,7 @@ int launch_attn_prep_kv64(const bf16_t* k, int64_t k_stride, const bf16_t* v, in
                           bf16_t* kp, bf16_t* vt, int batch, int heads, int kv_len, int kv_pad, float eps, hipStream_t stream);
 int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w, const bf16_t* ln_b, const float* rope_cos,
                           const float* rope_sin, int rope_start, int rope_len, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
-                          int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps,
+                          int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad, float eps, float k_bound,
                           hipStream_t stream);
 int launch_ln_modulate(const bf16_t* x, const bf16_t* ln_w, const bf16_t* ln_b, const bf16_t* shift, const bf16_t* scale,
                        bf16_t* y, int64_t rows, int C, int64_t rows_per_sample, int64_t mod_stride, int64_t seg_split,

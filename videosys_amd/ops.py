@@ -480,15 +480,36 @@ def attn_prep_kv64(k, v, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, bat
                                        rope_start, rope_len, _p(kp), _p(vt), batch, heads, kv_len, kp.shape[2], eps)
 
 
-def flash_attn64(q, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6):
+def flash_attn64(q, ln_w, ln_b, rope_cos, rope_sin, rope_start, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6, k_norm_bound=None):
+    """``k_norm_bound``: the promise about the Kp row norms (vsys_flash_attn_d64_kb; ln_key_bound); None = none."""
     _chk(q, ln_w, ln_b, rope_cos, rope_sin, kp, vt, out)
     _bf16(q, ln_w, ln_b, kp, vt, out)
     assert q.stride(1) == 1 and out.stride(1) == 1
     rope_len = 0 if rope_cos is None else rope_cos.shape[0]
-    lib = _lib.load()
-    _call("vsys_flash_attn_d64", _p(q), q.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin), rope_start, rope_len,
-                                       _p(kp), _p(vt), _p(out), out.stride(0), batch, heads, q_len, kv_len, kp.shape[2], eps)
+    if k_norm_bound:
+        _call("vsys_flash_attn_d64_kb", _p(q), q.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin), rope_start, rope_len,
+              _p(kp), _p(vt), _p(out), out.stride(0), batch, heads, q_len, kv_len, kp.shape[2], eps, float(k_norm_bound))
+    else:
+        _call("vsys_flash_attn_d64", _p(q), q.stride(0), _p(ln_w), _p(ln_b), _p(rope_cos), _p(rope_sin), rope_start, rope_len,
+              _p(kp), _p(vt), _p(out), out.stride(0), batch, heads, q_len, kv_len, kp.shape[2], eps)
     return out
+
+
+def ln_key_bound(q_w, q_b, k_w, k_b, head_dim=64):
+    """The k_norm_bound of flash_attn64 for LayerNorm-ed q and k with affine weights (diffusers Attention qk_norm="layer_norm"; the
+    rotary embedding rotates pairs: norms unchanged): |LN(x) w + b| <= sqrt(d) max|w| + |b|_2.  None when |q| |k| <= 60 cannot be
+    promised from the weights, or when a norm is missing.  Host-side, once per block."""
+    import math
+
+    if q_w is None or k_w is None:
+        return None
+
+    def side(w, b):
+        return math.sqrt(head_dim) * float(w.float().abs().max()) + (float(b.float().norm()) if b is not None else 0.0)
+
+    kb = side(k_w, k_b) * (math.log2(math.e) / math.sqrt(head_dim)) * (1.0 + 2.0 ** -6)
+    qb = side(q_w, q_b) * (1.0 + 2.0 ** -6)
+    return kb if qb * kb * (1.0 + 2.0 ** -5) <= 60.0 else None
 
 
 # ------------------------------------------------------------------------------------------------ VAE decode (row a14)
