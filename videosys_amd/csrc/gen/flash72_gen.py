@@ -678,8 +678,10 @@ OPERANDS = ["rk", "rv", "r4", "wl", "sv0", "sv1", "s4", "st4", "l4", "lb", "nt",
             "vfa2", "vfa3"]
 
 
-def clobbers(d64=False):
-    sregs = list(range(40, 55)) + list(range(60, 74)) + list(range(76, 92))   # (76..91: the stamp variants' s_memtime pairs and sums)
+def clobbers(d64=False, phase=False):
+    # (76..81: the stamp variants' s_memtime pairs; 82..91: the sums of the per-phase stamp variant 10 only — every SGPR listed here
+    # is one the compiler cannot keep a value in across the statement)
+    sregs = list(range(40, 55)) + list(range(60, 74)) + list(range(76, 92 if phase else 82))
     return [f"v{i}" for i in range(213 if d64 else NV)] + [f"a{i}" for i in range(NA)] + [f"s{i}" for i in sregs] + ["vcc", "memory"]
 
 
@@ -712,6 +714,7 @@ def write_inc(path):
             f.write('  "' + ln + '\\n\\t" \\\n')
         f.write('  ""\n')
         f.write("#define FLASH72_W64_CLOBBERS " + ", ".join('"' + c + '"' for c in clobbers()) + "\n")
+        f.write("#define FLASH72_W64_CLOBBERS_PHASE " + ", ".join('"' + c + '"' for c in clobbers(phase=True)) + "\n")
         f.write("// FLASH64_W64_ASM: the head_dim 64 form (flash_attn_d64_w64_kernel, csrc/attention64_w64.hip), placement variant 1.\n")
         for var in (1, 4, 5):   # 4: one more P unit in the PV phase; 5: no running max (the QK^T phase has 16 MFMAs here for the same softmax work)
             f.write(f"#define FLASH64_W64_ASM_V{var} \\\n")
