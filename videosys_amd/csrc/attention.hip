@@ -1054,7 +1054,7 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
   const size_t lds = per_wave * wpb;
   const float scale = 0.11785113019775793f;
   const int g_flash_variant = g_flash_variant_a.load(std::memory_order_relaxed);
-  if (T <= 32 && g_flash_variant != 9 && g_flash_variant != 4)   // the MFMA formulation (attention_t3.hip); 4 = force the v2 kernel
+  if (T <= 64 && g_flash_variant != 9 && g_flash_variant != 4)   // the MFMA formulation (attention_t3.hip: one 32-frame tile, or two); 4 = force the v2 kernel
     return launch_attn_temporal_d72_v3(qkv, row_stride, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps,
                                        scale, stream);
   if (T <= 20 && g_flash_variant != 9) {

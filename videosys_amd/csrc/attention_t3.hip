@@ -241,12 +241,259 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// attn_temporal_d72_v4: the same formulation for 32 < T <= 64 frames (720p x 128f: T = 38, which attn_temporal_d72_v3 cannot hold in
+// one 32-row tile and which ran on the VALU kernel at 1.0 TB/s, 8 % of that step: profiles/r04_720p128f_kernel_stats.txt).
+// Two key blocks and two query blocks of 32: K fragments of both key blocks are built once per head, then per query block
+//   S^T = K Q^T     2 x 5 v_mfma_f32_32x32x16_bf16  (key block kb: accumulator r of a lane <-> key 32 kb + 8 hi + r + 8 (r >= 8))
+//   O^T = V^T P^T   3 x 4                           (four 16-key chunks: chunk 2 kb + j = accumulators 8 j .. 8 j + 7 of key block kb)
+// V^T image per wave: [96 dims][64 keys], 144-byte pitch (13.5 KiB); compact RoPE table for 64 positions: two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int VT4_PITCH = 144;
+constexpr int VT4_BYTES = 96 * VT4_PITCH;    // 13824
+constexpr int TAB4_BYTES = 64 * TAB_ROW * 4;  // 9216
+constexpr int LDS4_HEAD = 2 * TAB4_BYTES + 2 * W_BYTES;
+
+__global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
+    const bf16_t* __restrict__ qkv, int64_t row_stride, int C, const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, bf16_t* __restrict__ out, int64_t out_stride, int B, int T,
+    int S, int heads, float eps, float scale, int hsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  float* cosc = reinterpret_cast<float*>(smem);
+  float* sinc = reinterpret_cast<float*>(smem + TAB4_BYTES);
+  bf16_t* qw = reinterpret_cast<bf16_t*>(smem + 2 * TAB4_BYTES);
+  bf16_t* kw = reinterpret_cast<bf16_t*>(smem + 2 * TAB4_BYTES + W_BYTES);
+  char* vt = smem + LDS4_HEAD + wave * VT4_BYTES;
+  const bool has_norm = q_norm_w != nullptr, has_rope = rope_cos != nullptr;
+  if (has_rope) {
+    for (int i = tid; i < T * TAB_ROW; i += 256) {
+      const int t = i / TAB_ROW, j = i - t * TAB_ROW;
+      cosc[i] = rope_cos[t * HD + 2 * j];
+      sinc[i] = rope_sin[t * HD + 2 * j];
+    }
+  }
+  if (has_norm && tid < HD) {
+    qw[tid] = q_norm_w[tid];
+    kw[tid] = k_norm_w[tid];
+  }
+  for (int i = lane * 16; i < VT4_BYTES; i += 64 * 16) *reinterpret_cast<uint4*>(vt + i) = make_uint4(0, 0, 0, 0);
+  __syncthreads();
+
+  const int64_t bs = blockIdx.x / hsplit;
+  const int hg = (int)(blockIdx.x - bs * hsplit);
+  const int hpg = (heads + hsplit - 1) / hsplit;
+  const int h_end = (hg + 1) * hpg < heads ? (hg + 1) * hpg : heads;
+  const int s = (int)(bs % S), b = (int)(bs / S);
+  const int r_of_m = (l31 & 3) + 4 * (l31 >> 3);
+  const int krow0 = 8 * ((l31 >> 2) & 1) + r_of_m + (r_of_m >= 8 ? 8 : 0);   // key of MFMA row l31 inside a 32-key block
+  int qrow[2], krow[2];
+  bool q_ok[2], k_ok[2];
+  const bf16_t* qbase[2];
+  const bf16_t* kbase[2];
+  bf16_t* obase[2];
+#pragma unroll
+  for (int blk = 0; blk < 2; ++blk) {
+    q_ok[blk] = 32 * blk + l31 < T;
+    k_ok[blk] = 32 * blk + krow0 < T;
+    qrow[blk] = q_ok[blk] ? 32 * blk + l31 : T - 1;
+    krow[blk] = k_ok[blk] ? 32 * blk + krow0 : T - 1;
+    qbase[blk] = qkv + (((int64_t)b * T + qrow[blk]) * S + s) * row_stride + 8 * hi;
+    kbase[blk] = qkv + (((int64_t)b * T + krow[blk]) * S + s) * row_stride + C + 8 * hi;
+    obase[blk] = out + (((int64_t)b * T + qrow[blk]) * S + s) * out_stride + 8 * hi;
+  }
+
+  // norm + RoPE (+ q scale) of one row's pieces on packed bf16 pairs: as attn_temporal_d72_v3_kernel::make_frags
+  auto make_frags = [&](const uint4 (&raw)[5], bf16x8 (&frag)[5], const bf16_t* w, int pos, bool zero_row, bool scaled) {
+    float rstd = 1.f;
+    if (has_norm) {
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const t3_bf16x2 pr = __builtin_bit_cast(t3_bf16x2, u[e]);
+          ss = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, ss, false);
+        }
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      rstd = rsqrtf(ss / (float)HD + eps);
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+      if (c < 4 || hi == 0) {
+        if (has_norm) {
+          const uint4 wv = *reinterpret_cast<const uint4*>(w + 16 * c + 8 * hi);
+          const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t n1 = pk_bf16(bflo(u[e]) * rstd, bfhi(u[e]) * rstd);
+            u[e] = pk_bf16(bflo(n1) * bflo(wu[e]), bfhi(n1) * bfhi(wu[e]));
+          }
+        }
+        if (has_rope) {
+          const float4 cs = *reinterpret_cast<const float4*>(cosc + pos * TAB_ROW + 8 * c + 4 * hi);
+          const float4 sn = *reinterpret_cast<const float4*>(sinc + pos * TAB_ROW + 8 * c + 4 * hi);
+          const float cv[4] = {cs.x, cs.y, cs.z, cs.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float x0 = bflo(u[e]), x1 = bfhi(u[e]);
+            const t3_f32x2 r = __builtin_elementwise_fma(t3_f32x2{-x1, x0}, t3_f32x2{sv[e], sv[e]}, t3_f32x2{x0, x1} * t3_f32x2{cv[e], cv[e]});
+            u[e] = pk_bf16(r.x, r.y);
+          }
+        }
+        if (scaled) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) u[e] = pk_bf16(bflo(u[e]) * scale, bfhi(u[e]) * scale);
+        }
+      }
+      if (zero_row) u[0] = u[1] = u[2] = u[3] = 0u;
+      frag[c] = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
+    }
+  };
+
+  for (int h = hg * hpg + wave; h < h_end; h += 4) {
+    // ---- one round trip: q, k, v pieces of both 32-row blocks
+    uint4 rq[2][5], rk[2][5], rv[2][5];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        rq[blk][c] = rk[blk][c] = rv[blk][c] = make_uint4(0, 0, 0, 0);
+        if (c < 4 || hi == 0) {
+          rk[blk][c] = *reinterpret_cast<const uint4*>(kbase[blk] + h * HD + 16 * c);
+          rv[blk][c] = *reinterpret_cast<const uint4*>(qbase[blk] + 2 * C + h * HD + 16 * c);
+          rq[blk][c] = *reinterpret_cast<const uint4*>(qbase[blk] + h * HD + 16 * c);
+        }
+      }
+    // ---- V: transposed into the wave's LDS image [dim][key] (real frames only)
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+      if (q_ok[blk]) {
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+          if (c < 4 || hi == 0) {
+            const uint32_t u[4] = {rv[blk][c].x, rv[blk][c].y, rv[blk][c].z, rv[blk][c].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const bf16_t val = (bf16_t)((e & 1) ? (u[e >> 1] >> 16) : (u[e >> 1] & 0xffffu));
+              *reinterpret_cast<bf16_t*>(vt + (16 * c + 8 * hi + e) * VT4_PITCH + (32 * blk + l31) * 2) = val;
+            }
+          }
+        }
+      }
+    }
+    // ---- K fragments of both key blocks
+    bf16x8 kf[2][5];
+    make_frags(rk[0], kf[0], kw, krow[0], !k_ok[0], false);
+    make_frags(rk[1], kf[1], kw, krow[1], !k_ok[1], false);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      if (32 * qb >= T) break;          // (wave-uniform)
+      bf16x8 qf[5];
+      make_frags(rq[qb], qf, qw, qrow[qb], false, true);
+      f32x16 sacc[2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 5; ++c) sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][c], qf[c], sacc[kb], 0, 0, 0);
+      }
+      // ---- softmax over the 64 keys of this lane's query (32 here, 32 in lane ^ 32)
+      float m = NEG_BIG;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * kb + 8 * hi + r + (r >= 8 ? 8 : 0);
+          if (key >= T) sacc[kb][r] = NEG_BIG;
+          m = fmaxf(m, sacc[kb][r]);
+        }
+      m = fmaxf(m, __shfl_xor(m, 32, 64));
+      float l = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          sacc[kb][r] = __builtin_amdgcn_exp2f((sacc[kb][r] - m) * 1.4426950408889634f);
+          l += sacc[kb][r];
+        }
+      l += __shfl_xor(l, 32, 64);
+      const float inv = 1.0f / l;
+      bf16x8 pf[4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          pf[2 * kb][e] = (__bf16)(sacc[kb][e] * inv);          // attn.to(dtype) before attn @ v (attentions.py:117)
+          pf[2 * kb + 1][e] = (__bf16)(sacc[kb][8 + e] * inv);
+        }
+      // ---- O^T = V^T P^T
+      f32x16 oacc[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          const bf16x8 vfrag = *reinterpret_cast<const bf16x8*>(vt + (d * 32 + l31) * VT4_PITCH + ch * 32 + hi * 16);
+          oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfrag, pf[ch], oacc[d], 0, 0, 0);
+        }
+      }
+      // ---- store (as attn_temporal_d72_v3_kernel)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        uint2 o[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          o[g].x = pack2bf(oacc[d][4 * g], oacc[d][4 * g + 1]);
+          o[g].y = pack2bf(oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          auto sx = __builtin_amdgcn_permlane32_swap(o[2 * k].x, o[2 * k + 1].x, false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(o[2 * k].y, o[2 * k + 1].y, false, false);
+          const int dim0 = 32 * d + 16 * k;
+          if (q_ok[qb] && dim0 + 8 * hi + 8 <= HD)
+            *reinterpret_cast<uint4*>(obase[qb] + h * HD + dim0) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+        }
+      }
+    }
+    // the image is rewritten by the next head: its reads above must have been issued, and the compiler must not move the next
+    // iteration's writes up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 }  // namespace
 
 int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
                                 const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T, int S,
                                 int heads, float eps, float scale, hipStream_t stream) {
-  if (T > 32 || T < 1) return VSYS_ERR_SHAPE;
+  if (T > 64 || T < 1) return VSYS_ERR_SHAPE;
+  if (T > 32) {   // two key / query blocks (attn_temporal_d72_v4_kernel)
+    int hsplit4 = 1;
+    const int64_t slots4 = 2LL * cu_count_this_device();
+    while (hsplit4 < 4 && (int64_t)B * S * hsplit4 < slots4 && heads % (hsplit4 * 2 * 4) == 0) hsplit4 *= 2;
+    const int64_t grid4 = (int64_t)B * S * hsplit4;
+    if (grid4 > 0x7fffffff) return VSYS_ERR_SHAPE;
+    const int lds4 = LDS4_HEAD + 4 * VT4_BYTES;   // 74048
+    static std::atomic<unsigned long long> attr_seen{0};
+    if (first_use_on_this_device(attr_seen))
+      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+    hipLaunchKernelGGL(attn_temporal_d72_v4_kernel, dim3((unsigned)grid4), dim3(256), lds4, stream, qkv, row_stride, C, q_norm_w, k_norm_w,
+                       rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit4);
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
   // fewer than ~3 workgroups per CU: split the heads of a token over 2 or 4 workgroups (every wave still owns whole heads)
   int hsplit = 1;
   const int64_t slots = 3LL * cu_count_this_device();
