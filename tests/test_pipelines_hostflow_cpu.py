@@ -196,3 +196,19 @@ def test_cogvideox_generate_host_flow_matches_the_reference_sampling_fixture():
             pipe.generate(negative_prompt_embeds=fx["neg"], callback_on_step_end_tensor_inputs=["frames"], **kw)
         with pytest.raises(NotImplementedError):
             pipe.generate(eta=0.3, **kw)
+
+
+def test_component_names_typo_paths_raise_hub_ids_warn(caplog):
+    """config.transformer / config.vae: a Hugging Face hub id (the reference's defaults) cannot be fetched offline and is replaced with
+    a logged warning; a string that looks like a filesystem path and does not exist is a typo and raises instead of silently
+    producing video from random weights."""
+    import logging
+
+    from videosys_amd.pipeline_open_sora import OpenSoraPipeline
+
+    for bad in ("/no/such/dir", "./ckpts/stdit3", "~/models/x", "checkpoints", "a/b/c"):
+        with pytest.raises(FileNotFoundError):
+            OpenSoraPipeline._hub_fallback(bad, "transformer", "synthetic:1234")
+    with caplog.at_level(logging.WARNING, logger="videosys_amd"):
+        OpenSoraPipeline._hub_fallback("hpcai-tech/OpenSora-STDiT-v3", "transformer", "synthetic:1234")
+    assert any("hub id" in r.getMessage() for r in caplog.records)

@@ -605,3 +605,39 @@ def test_pipeline_adopts_the_reference_transformer_module():
         assert torch.equal(m.rope_freqs, ref.state_dict()["rope.freqs"].float())
         own = STDiT3.from_pretrained("synthetic:3", device="cpu", **cfg)                # this build's own object: used as it is
         assert OpenSoraPipeline(OpenSoraConfig(), transformer=own, device="cpu").transformer is own
+
+
+def test_pab_broadcast_of_an_elided_slab_recomputes():
+    """A caller that leaves the schedule it announced (the same timestep twice: the reference's counters then ask for a broadcast at a
+    call whose predecessor elided its slab because the SCHEDULE said nobody would read it) gets a recompute, never a stale or missing
+    slab: _pab_plan downgrades a broadcast whose slab is not valid."""
+    from videosys_amd import pab
+
+    x, y, kw = _inputs()
+    ts = [900, 800, 700, 600, 500, 400]
+    pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[450, 930], spatial_range=2,
+                                      temporal_broadcast=True, temporal_threshold=[450, 930], temporal_range=2,
+                                      cross_broadcast=True, cross_threshold=[450, 930], cross_range=2))
+    pab.update_steps(len(ts))
+    try:
+        with fake_ops() as f:
+            m = _model()
+            m.use_programs = False
+            seen = []
+            real_add = f.add_rows
+            from videosys_amd import ops
+
+            def add_rows(x_, y_):
+                seen.append(y_ is not None)
+                assert y_ is not None, "a broadcast read a slab that was never written"
+                return real_add(x_, y_)
+
+            ops.add_rows = add_rows
+            # 900 computes (and keeps: 800 will broadcast), 800 broadcasts; 700 computes and ELIDES nothing it should keep ... then the
+            # caller repeats 700 and jumps to 400: every decision must still find its slab or recompute
+            for t in (900, 800, 700, 700, 400, 400, 600):
+                m(x, torch.tensor([float(t)] * 2), y, all_timesteps=ts, **kw)
+            plan_states = [(st.attn_valid, st.cross_valid) for st in m.states]
+            assert all(isinstance(a, bool) and isinstance(c, bool) for a, c in plan_states)
+    finally:
+        pab.set_pab_manager(None)

@@ -985,7 +985,7 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
       p.chunks = chunks;
       p.nqb = nqb;
       static std::atomic<unsigned long long> attr_seen{0};
-      if (first_use_on_this_device(attr_seen))
+      for (DeviceOnce once(attr_seen); once.todo(); once.done())
         (void)hipFuncSetAttribute((const void*)flash_attn_d72_kernel<0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES);
       hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES, stream, p);
       return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;

@@ -264,7 +264,7 @@ int launch_flash_attn_d64_w64(const bf16_t* q, int64_t q_stride, const bf16_t* l
   if (nblk > 0x7fffffff || (int64_t)kv_pad * HD * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
   const size_t lds = (size_t)W64_STAGES * KV_STAGE;   // 81920
   static std::atomic<unsigned long long> attr_seen{0};
-  if (first_use_on_this_device(attr_seen)) {
+  for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
     (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)flash_attn_d64_w64_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -488,7 +488,7 @@ int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, co
     if (grid4 > 0x7fffffff) return VSYS_ERR_SHAPE;
     const int lds4 = LDS4_HEAD + 4 * VT4_BYTES;   // 74048
     static std::atomic<unsigned long long> attr_seen{0};
-    if (first_use_on_this_device(attr_seen))
+    for (DeviceOnce once(attr_seen); once.todo(); once.done())
       (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
     hipLaunchKernelGGL(attn_temporal_d72_v4_kernel, dim3((unsigned)grid4), dim3(256), lds4, stream, qkv, row_stride, C, q_norm_w, k_norm_w,
                        rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit4);

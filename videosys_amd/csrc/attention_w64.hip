@@ -579,7 +579,7 @@ bool flash_w64_supports(int q_len, int kv_len, int kv_pad) {
 template <int VAR>
 static int launch_w64_t(const FlashW64Params& p, unsigned nblk, size_t lds, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_seen{0};
-  if (first_use_on_this_device(attr_seen))
+  for (DeviceOnce once(attr_seen); once.todo(); once.done())
     (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64_kernel<VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(flash_attn_d72_w64_kernel<VAR>, dim3(nblk), dim3(256), lds, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -604,7 +604,7 @@ int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* 
   const unsigned grid = (unsigned)(total < ncu ? total : ncu);
   const size_t lds = (size_t)W64_STAGES * KV_STAGE + 4 * W64P_QIMG;
   static std::atomic<unsigned long long> attr_seen{0};
-  if (first_use_on_this_device(attr_seen)) {
+  for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
     (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)flash_attn_d72_w64p_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 #ifdef VSYS_LAB

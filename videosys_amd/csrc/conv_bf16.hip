@@ -289,7 +289,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   const int64_t nbm = ((int64_t)p.M + BM - 1) / BM, nbn = p.N / BN;
   if (nbm * nbn > 0x7fffffff || p.batch > 65535) return VSYS_ERR_SHAPE;
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
-  if (first_use_on_this_device(attr_seen)) {
+  for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
     (void)hipFuncSetAttribute((const void*)conv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)conv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }

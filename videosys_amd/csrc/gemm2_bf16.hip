@@ -456,7 +456,7 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / G::BN;
   const int grid = nbm * nbn;
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
-  if (first_use_on_this_device(attr_seen)) {
+  for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
@@ -502,7 +502,7 @@ int launch_gemm2_slices(const GemmParams& p, int slices, hipStream_t stream) {
   if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 768 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
   const int nbm = (p.M + BM - 1) / BM, nbn = p.N / G::BN;
   static std::atomic<unsigned long long> attr_seen{0};
-  if (first_use_on_this_device(attr_seen))
+  for (DeviceOnce once(attr_seen); once.todo(); once.done())
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_F32_SLICES, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
   hipLaunchKernelGGL((gemm2_kernel<EPI_F32_SLICES, 4>), dim3(nbm * nbn * slices), dim3(G::NT), G::LDS_BYTES, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;

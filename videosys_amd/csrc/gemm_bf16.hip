@@ -815,7 +815,7 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   const bool lnl = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
   const size_t lds = ((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (lnl && BM_ == 256 ? (BM_ + BN) * 8 : 0);
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
-  if (first_use_on_this_device(attr_seen)) {
+  for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
     const int lds = (int)(((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (BM_ == 256 ? (BM_ + BN) * 8 : 0));
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

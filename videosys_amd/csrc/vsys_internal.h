@@ -13,14 +13,28 @@ namespace vsys {
 typedef uint16_t bf16_t;
 
 // One-time per-DEVICE work of a launcher (hipFuncSetAttribute for > 64 KiB of dynamic LDS is a per-device property of the
-// function): true exactly once per device per ``seen`` word, thread safe.  Not a stream operation, so it is legal while a
-// stream is being captured into a hipGraph.
-inline bool first_use_on_this_device(std::atomic<unsigned long long>& seen) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;
-  const unsigned long long bit = 1ull << dev;
-  return (seen.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
-}
+// function).  Use:  for (DeviceOnce once(seen); once.todo(); once.done()) { ...attribute calls... }
+// The device's bit in ``seen`` is set AFTER the body ran: a second host thread that arrives while the first is still inside the body
+// runs the (idempotent) body itself instead of launching before the limit is raised — the bit used to be set before the body.
+// Not a stream operation, so it is legal while a stream is being captured into a hipGraph.
+class DeviceOnce {
+ public:
+  explicit DeviceOnce(std::atomic<unsigned long long>& seen) : seen_(seen) {
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev <= 63) bit_ = 1ull << dev;
+    todo_ = bit_ == 0 || (seen_.load(std::memory_order_acquire) & bit_) == 0;
+  }
+  bool todo() const { return todo_; }
+  void done() {
+    if (bit_ != 0) seen_.fetch_or(bit_, std::memory_order_release);
+    todo_ = false;
+  }
+
+ private:
+  std::atomic<unsigned long long>& seen_;
+  unsigned long long bit_ = 0;
+  bool todo_ = false;
+};
 // multiprocessor count of the current device (cached per device)
 inline int cu_count_this_device() {
   static std::atomic<int> cache[64];

@@ -129,6 +129,8 @@ class OpenSoraPipeline(VideoSysPipeline):
         if transformer is None:
             name = config.transformer   # a local checkpoint directory or "synthetic:<seed>"; a hub id cannot be fetched: seeded weights
             local = isinstance(name, str) and (name.startswith("synthetic:") or bool(glob.glob(os.path.join(name, "*.safetensors"))))
+            if not local:
+                self._hub_fallback(name, "transformer", "synthetic:1234")
             transformer = STDiT3.from_pretrained(name if local else "synthetic:1234", device=self._device,
                                                  **(config.transformer_config or {}))
         elif is_foreign_module(transformer, STDiT3):   # e.g. the reference's own STDiT3 module: geometry + weights are taken over
@@ -178,7 +180,21 @@ class OpenSoraPipeline(VideoSysPipeline):
         try:
             return OpenSoraVAE_V1_2(from_pretrained=name, device=self._device)
         except FileNotFoundError:
+            self._hub_fallback(name, "vae", "no VAE: generate() returns latents")
             return None
+
+    @staticmethod
+    def _hub_fallback(name, what, instead):
+        """A component name that is neither a local checkpoint directory nor ``synthetic:<seed>``: a Hugging Face hub id
+        (``org/name``, the reference's defaults) cannot be fetched offline and is replaced — loudly; anything that looks like a
+        filesystem path and does not exist is a typo and raises."""
+        n = str(name)
+        pathlike = n.startswith(("/", "./", "../", "~")) or n.count("/") != 1     # a hub id is exactly "org/name"
+        if pathlike:
+            raise FileNotFoundError(f"config.{what} = {name!r}: no such checkpoint directory (expected *.safetensors inside, or 'synthetic:<seed>')")
+        import logging
+
+        logging.getLogger("videosys_amd").warning("config.%s = %r is a hub id and cannot be fetched offline: using %s", what, name, instead)
 
     def _set_parallel(self, dp_size: Optional[int] = None, sp_size: Optional[int] = None, enable_cp: bool = False):
         """pipeline_open_sora.py:253-267: dp=1, sp=world."""

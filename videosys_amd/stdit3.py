@@ -102,6 +102,10 @@ class _BlockState:
         self.temporal = temporal
         self.attn_count = 0
         self.cross_count = 0
+        # does last_attn / last_cross hold the output of this block's LAST computed call?  (slab elision writes a slab only when the
+        # next schedule entry will broadcast it: a caller that leaves the schedule must not be served a stale one)
+        self.attn_valid = False
+        self.cross_valid = False
         self.mlp_count = 0
         self.last_attn: Optional[torch.Tensor] = None
         self.last_cross: Optional[torch.Tensor] = None
@@ -531,8 +535,18 @@ class STDiT3:
             if mlp_on:
                 b_mlp, st.mlp_count, b_next, rng = pab.if_broadcast_mlp(timestep_int, st.mlp_count, st.block_idx, ats,
                                                                          is_temporal=st.temporal)
-            plan.append((bool(b_attn), bool(b_cross), bool(b_mlp), bool(b_next), rng,
-                         kept(kind, st.attn_count), kept("cross", st.cross_count)))
+            # a broadcast of a slab that was never written (or was elided at the block's last computed call because the schedule
+            # said nobody would read it): recompute instead — direct transformer use, a sampler that repeats or skips a step
+            if b_attn and not st.attn_valid:
+                b_attn = False
+            if b_cross and not st.cross_valid:
+                b_cross = False
+            keep_a, keep_c = kept(kind, st.attn_count), kept("cross", st.cross_count)
+            if not b_attn:
+                st.attn_valid = keep_a       # (this call computes; the slab is written iff it is kept)
+            if not b_cross:
+                st.cross_valid = keep_c
+            plan.append((bool(b_attn), bool(b_cross), bool(b_mlp), bool(b_next), rng, keep_a, keep_c))
         return plan
 
     def _forward_device(self, xz, ts, static, plan, timestep_int, valid_depth, cp, x_mask=None, fold=False):
@@ -908,6 +922,7 @@ class STDiT3:
         prompt replay them)."""
         for st in self.states:
             st.attn_count = st.cross_count = st.mlp_count = 0
+            st.attn_valid = st.cross_valid = False
         if pab.PAB_MANAGER is not None:
             pab.PAB_MANAGER.config.mlp_spatial_outputs.clear()
             pab.PAB_MANAGER.config.mlp_temporal_outputs.clear()
