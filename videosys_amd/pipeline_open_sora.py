@@ -298,7 +298,10 @@ class OpenSoraPipeline(VideoSysPipeline):
         seed = self._set_seed(seed)   # (:253-257) -1 draws a fresh seed on rank 0 and broadcasts it; + dp_rank in a process group
 
         # ---- conditioning inputs: one entry per prompt (:528-535)
+        if prompt is None and prompt_embeds is None:
+            raise ValueError("Provide either `prompt` or `prompt_embeds`. Cannot leave both `prompt` and `prompt_embeds` undefined.")
         prompts = None if prompt is None else ([prompt] if isinstance(prompt, str) else list(prompt))
+        given_embeds = prompt_embeds is not None        # the caller's embeddings win over `prompt` for EVERY clip of a loop
         n = len(prompts) if prompts is not None else prompt_embeds.shape[0]
         per_prompt = lambda v: list(v) if isinstance(v, (list, tuple)) and len(v) == n and not torch.is_tensor(v) \
             and all(isinstance(e, (str, list, tuple, type(None))) for e in v) else [v] * n
@@ -325,7 +328,7 @@ class OpenSoraPipeline(VideoSysPipeline):
         clips = []
         samples = None
         for loop_i in range(loop):
-            if prompt_embeds is None or (loop_i > 0 and prompts is not None):
+            if prompt_embeds is None or (loop_i > 0 and prompts is not None and not given_embeds):
                 if self.text_encoder is None:
                     raise RuntimeError("no text encoder attached: pass prompt_embeds=[B,1,L,4096] (+ prompt_mask), or give "
                                        "OpenSoraConfig(text_encoder=<local T5 checkpoint directory>)")
