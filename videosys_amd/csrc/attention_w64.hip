@@ -217,14 +217,6 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
   else if constexpr (VAR == 9) W64_LOOP(FLASH72_W64_ASM_V9);
 #endif
 #undef W64_LOOP
-#if 0
-  asm volatile(FLASH72_W64_ASM
-               :
-               : [rk] "s"(rsrc_k), [rv] "s"(rsrc_v), [r4] "s"(rsrc_4), [wl] "s"(wl), [sv0] "s"(sv0), [sv1] "s"(sv1), [s4] "s"(s4),
-                 [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [lim] "v"(lim), [kvo] "v"(k_voff), [vvo] "v"(v_voff),
-                 [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2), [vfa3] "v"(vfa3)
-               : FLASH72_W64_CLOBBERS);
-#endif
 
   // ---- epilogue: O[q][d] = O^T[d][q] / l ; lane holds d = 32dt + (r&3) + 8(r>>2) + 4hi; 16-byte stores through
   // v_permlane32_swap (as flash_attn_d72_kernel::store_o)
