@@ -93,7 +93,7 @@ def test_w64_flash_kernel_owns_its_accumulator_registers(tmp_path):
     hits.update(u64)
     for name, res in hits.items():
         # (a few SGPRs parked in VGPR lanes are fine — the persistent forms carry ~40 scalars across the statement; scratch is not)
-        assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) <= 8, (name, res)
+        assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) <= 16, (name, res)
         assert res.get("VGPRs", 0) <= 256 and 224 <= res.get("AGPRs", 0) <= 256, (name, res)
     inside, bad = False, []
     text = []

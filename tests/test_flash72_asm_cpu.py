@@ -161,3 +161,16 @@ def test_every_scc_reader_sits_behind_its_compare():
                     assert not code[j].startswith(("s_add", "s_sub", "s_lsh", "s_and", "s_or", "s_xor", "s_min", "s_max", "s_bf", "s_ash")), (code[j], ln)
                     j -= 1
                     assert j >= 0 and i - j < 8, ln
+
+
+@pytest.mark.parametrize("kv_len,nitems,static", [(320, 4, False), (300, 3, True), (448, 3, True), (576, 2, False)])
+def test_persistent_walk_any_tile_count(kv_len, nitems, static):
+    """The ring continues from item to item: tile 0 of the k-th item sits in stage (k ntiles) mod 4 (5, 7 and 9 tiles here), a
+    ragged key count is walked as whole tiles of zero-padded keys — with and without the running max."""
+    import flash72_emu_case as C
+
+    with np.errstate(all="ignore"):
+        errs, viol, _ = C.run_persist(kv_len, nitems=nitems, late_vm=kv_len % 128 == 0, late_ds=True,
+                                      order=[3, 2, 1, 0] if nitems == 3 else None, static=static)
+    assert not viol, viol[:5]
+    assert max(errs) <= 2.0 ** -8, errs

@@ -138,9 +138,8 @@ def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None
     (batch, head)'s K / Vt, the others use a second one; every item has its own 256 query rows.  Between the statements the numpy
     code does what the C++ of flash_attn_d72_w64p_kernel does: Q(k) from the wave's LDS image into a[96:135], O read-out, output
     stores (as operations in flight: the next statement's opening wait has to cover them)."""
-    assert kv_len % 256 == 0
-    ntiles = kv_len // 64
-    kv_pad = kv_len
+    ntiles = (kv_len + 63) // 64          # (any tile count >= 4: the ring continues from item to item; padded keys are zero rows of
+    kv_pad = ntiles * 64                  # Kp with zero Vt columns incl. the ones rows, so nothing is masked)
     cases = [make_case(kv_len, seed + 17 * j, spike and j == 1, qscale) for j in range(nitems)]
     kvsets = [cases[0], cases[-1]]                      # two (batch, head)s
     kv_of = [0 if j < switch_kv_at else 1 for j in range(nitems)]
@@ -152,7 +151,7 @@ def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None
         binds.append({"kb": "s[4:5]", "vb": "s[6:7]", "kbn": "s[8:9]", "vbn": "s[10:11]", "rqn": "s[12:15]", "wl": "s16", "kvp2": "s17",
                       "hn": "s18", "s4": "s19", "st4": "s20", "l4": "s21", "lb": "s22", "nt": "s23", "qlds": "s24", "lim": "v210",
                       "kvo": "v211", "vvo": "v212", "v4o": "v213", "kfa": "v214", "vfa0": "v215", "vfa1": "v216", "vfa2": "v217",
-                      "vfa3": "v218", "qvo": "v219", "nma": "v220", "nmb": "v221"})
+                      "vfa3": "v218", "qvo": "v219", "nma": "v220", "nmb": "v221", "st0": "s25", "st1": "s26", "st2": "s27"})
     wg = E.Workgroup(lines, binds, late_vm=late_vm, late_ds=late_ds)
     wg.lds[:] = 0xAB
     lb, QBASE = 0, 4 * STAGE
@@ -215,8 +214,10 @@ def run_persist(kv_len, nitems=3, seed=0, late_vm=True, late_ds=True, order=None
             kid, vid = ids[("k", kv_of[j])], ids[("v", kv_of[j])]
             nk, nv = (ids[("k", kv_of[j + 1])], ids[("v", kv_of[j + 1])]) if has_next else ((0, 0), (0, 0))
             nq = ids[("q", j + 1)] if has_next else (0, 0)
+            r0 = (j * ntiles) & 3
             wave.s.update({4: kid[0], 5: kid[1], 6: vid[0], 7: vid[1], 8: nk[0], 9: nk[1], 10: nv[0], 11: nv[1],
-                           12: nq[0], 13: nq[1], 14: 256 * 144, 15: 0x20000, 18: 1 if has_next else 0})
+                           12: nq[0], 13: nq[1], 14: 256 * 144, 15: 0x20000, 18: 1 if has_next else 0,
+                           25: lb + r0 * STAGE, 26: lb + ((r0 + 1) & 3) * STAGE, 27: lb + ((r0 + 2) & 3) * STAGE})
             qj, kj = cases[j][0], kvsets[kv_of[j]][1]
             kmax = float(np.sqrt((kj.astype(np.float64) ** 2).sum(1)).max())
             for blk, reg in ((0, 220), (1, 221)):

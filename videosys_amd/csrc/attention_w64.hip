@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
 // 11k cycles of Q fetch + norm, 4.3k of LDS-DMA issue + landing + pipeline fill, 3.5k of output stores against 27k in the tile loop,
 // none of it covered at one workgroup per CU) is taken out of the seam where it can be: the tail of an item's tile loop already
 // fetches the NEXT item's first four K / Vt tiles and its Q rows (LDS-DMA into a wave-private [chunk][row] image), so an item
-// starts with everything on chip.  Whole tiles only (kv_len % 256 == 0: the ring position of tile 0 is then the same for every item).
+// starts with everything on chip.  Any tile count >= 4: the ring continues from item to item (tile 0 of the k-th item of a workgroup
+// sits in stage (k ntiles) mod 4); nothing is masked — padded keys are zero Kp rows against zero Vt columns, ones rows included.
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int W64P_QIMG = 64 * KROW;   // 9216 bytes per wave: 9 chunks x 64 rows x 16 B
 
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
   const int l4 = s4k ? 8 * 1024 : K_TILE_BYTES + s4j * 1024;
   const int lb = (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
   const int qlds = lb + W64_STAGES * KV_STAGE + wave_u * W64P_QIMG;
-  const int ntiles = p.kv_len >> 6;
+  const int ntiles = (p.kv_len + 63) >> 6;   // whole tiles: padded keys are zero rows of Kp against zero Vt columns (ones rows included)
   for (int u = tid; u < W64_STAGES * 128; u += 256)
     *reinterpret_cast<uint4*>(smem + (u >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (u & 127) * 16) = make_uint4(0, 0, 0, 0);
   const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
     qnw[c] = (p.q_norm_w != nullptr && d0 < HD) ? *reinterpret_cast<const uint4*>(p.q_norm_w + d0) : make_uint4(0, 0, 0, 0);
   }
   unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta = 0, tb = 0;
+  int ring = 0;   // stage of this item's tile 0: the ring continues from item to item, (items walked x ntiles) mod 4
   for (int it = i0; it < i1; it += istep) {
     const int bh = item_bh(it), qb = it - bh * p.nqb;
     const int b = bh / p.heads, h = bh - b * p.heads;
@@ -468,6 +470,8 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
     const u32x4 rqn = q_rsrc(nit);
     const int qvo = q_voff(nit);
     const int hn = __builtin_amdgcn_readfirstlane(has_next ? 1 : 0);
+    const int st0 = lb + ring * KV_STAGE, st1 = lb + ((ring + 1) & 3) * KV_STAGE, st2 = lb + ((ring + 2) & 3) * KV_STAGE;
+    ring = (ring + ntiles) & 3;
     if constexpr (STAMP) {
       t2 = __builtin_amdgcn_s_memtime();
 #ifdef VSYS_LAB
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
                    : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
                      [s4] "s"(s4), [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [qlds] "s"(qlds), [kvo] "v"(k_voff),
                      [vvo] "v"(v_voff), [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2),
-                     [vfa3] "v"(vfa3), [qvo] "v"(qvo)
+                     [vfa3] "v"(vfa3), [qvo] "v"(qvo), [st0] "s"(st0), [st1] "s"(st1), [st2] "s"(st2)
                    : FLASH72_W64_CLOBBERS);
 #endif
       t3 = __builtin_amdgcn_s_memtime();
@@ -486,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
                  : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
                    [s4] "s"(s4), [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [qlds] "s"(qlds), [kvo] "v"(k_voff),
                    [vvo] "v"(v_voff), [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2),
-                   [vfa3] "v"(vfa3), [qvo] "v"(qvo), [nma] "v"(nmv[0]), [nmb] "v"(nmv[1])
+                   [vfa3] "v"(vfa3), [qvo] "v"(qvo), [nma] "v"(nmv[0]), [nmb] "v"(nmv[1]), [st0] "s"(st0), [st1] "s"(st1), [st2] "s"(st2)
                  : FLASH72_W64_CLOBBERS);
     else
     asm volatile(FLASH72_W64P_ASM
@@ -494,7 +498,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
                  : [kb] "s"(kb), [vb] "s"(vb), [kbn] "s"(kbn), [vbn] "s"(vbn), [rqn] "s"(rqn), [wl] "s"(wl), [kvp2] "s"(kvp2), [hn] "s"(hn),
                    [s4] "s"(s4), [st4] "s"(st4), [l4] "s"(l4), [lb] "s"(lb), [nt] "s"(ntiles), [qlds] "s"(qlds), [kvo] "v"(k_voff),
                    [vvo] "v"(v_voff), [v4o] "v"(voff_4), [kfa] "v"(kfa), [vfa0] "v"(vfa0), [vfa1] "v"(vfa1), [vfa2] "v"(vfa2),
-                   [vfa3] "v"(vfa3), [qvo] "v"(qvo)
+                   [vfa3] "v"(vfa3), [qvo] "v"(qvo), [st0] "s"(st0), [st1] "s"(st1), [st2] "s"(st2)
                  : FLASH72_W64_CLOBBERS);
 
     // ---- epilogue (as the one-item kernel)
@@ -579,7 +583,8 @@ static int launch_w64_t(const FlashW64Params& p, unsigned nblk, size_t lds, hipS
 
 // persistent form: whole 256-key groups only, 32-bit Q row offsets
 bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride) {
-  return kv_len >= 256 && kv_len % 256 == 0 && kv_pad == kv_len && q_len >= 256 && (int64_t)q_len * q_stride * 2 < 0x7fffffff;
+  // (any tile count >= 4; kv_pad must be the tile-padded length: the kernel walks whole tiles of zero-padded keys)
+  return kv_len >= 256 && kv_pad == (kv_len + 63) / 64 * 64 && q_len >= 256 && (int64_t)q_len * q_stride * 2 < 0x7fffffff;
 }
 
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,

@@ -500,9 +500,12 @@ def prologue_persist(e):
     e(f"s_mul_i32 {s(S_QP)}, %[hn], 9")
     e(f"s_mov_b32 {s(S_QM)}, %[qlds]")
     e(f"s_mov_b32 {s(S_QO)}, 0")
+    # The ring simply continues from item to item (the tail of the previous item put this item's tiles 0..3 into the four stages that
+    # follow ITS last tile): tile 0 of the k-th item of a workgroup sits in stage (k ntiles) mod 4 — the C++ hands the three stage
+    # addresses the prologue needs (tiles 0, 1, 2); any tile count >= 4 works, not only multiples of four.
     e(f"s_add_u32 {s(S_WRAP)}, %[lb], {NSTAGE * STAGE}")
-    e(f"s_mov_b32 {s(S_ST)}, %[lb]")
-    e(f"s_add_u32 {s(S_ST2)}, %[lb], {2 * STAGE}")
+    e(f"s_mov_b32 {s(S_ST)}, %[st0]")
+    e(f"s_mov_b32 {s(S_ST2)}, %[st2]")
     e(f"s_sub_u32 {s(S_CNT)}, %[nt], 2")
     e(f"v_add_u32_e32 {v(KADDR)}, {s(S_ST)}, %[kfa]")
     for t in k_reads():
@@ -510,7 +513,7 @@ def prologue_persist(e):
     e("s_waitcnt lgkmcnt(0)")
     for m in qk_mfmas(0):
         e(m)
-    e(f"v_add_u32_e32 {v(KADDR)}, {STAGE}, {v(KADDR)}")
+    e(f"v_add_u32_e32 {v(KADDR)}, %[st1], %[kfa]")
     for t in k_reads():
         e(t)
     adopt(e)
