@@ -994,7 +994,7 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   // long key sequences: 64 query rows per wave, one wave per SIMD, hand-allocated instruction stream (attention_w64.hip)
   // (opt-in, VSYS_FLASH_W64=1 or variant 16: in situ it ties the 32-row kernel — 104.9 vs 104.6 ms per step, profiles/r04_flash_w64p_insitu.txt)
   static const bool w64_default = [] { const char* e = getenv("VSYS_FLASH_W64"); return e && e[0] == '1'; }();
-  // 16 = the persistent form of the w64 kernel (one workgroup per CU walks the query blocks; whole 256-key groups)
+  // 16 = the persistent form of the w64 kernel (one workgroup per CU walks the query blocks; any tile count >= 4)
   // It is the default where every workgroup walks at least four items (the seams of an item are what the walk amortises); the
   // one-item-per-workgroup form below is selectable only (it loses to the 32-row kernel: profiles/r04_flash_w64_placement_kbench.txt).
   // With the caller's bound on the Kp row norms (k_bound > 0, vsys_flash_attn_d72_kb) the statements run WITHOUT the running max

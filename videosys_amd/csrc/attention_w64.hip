@@ -581,7 +581,7 @@ static int launch_w64_t(const FlashW64Params& p, unsigned nblk, size_t lds, hipS
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
-// persistent form: whole 256-key groups only, 32-bit Q row offsets
+// persistent form: >= 4 tiles of tile-padded keys, 32-bit Q row offsets
 bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride) {
   // (any tile count >= 4; kv_pad must be the tile-padded length: the kernel walks whole tiles of zero-padded keys)
   return kv_len >= 256 && kv_pad == (kv_len + 63) / 64 * 64 && q_len >= 256 && (int64_t)q_len * q_stride * 2 < 0x7fffffff;
