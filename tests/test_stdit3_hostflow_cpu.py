@@ -641,3 +641,40 @@ def test_pab_broadcast_of_an_elided_slab_recomputes():
             assert all(isinstance(a, bool) and isinstance(c, bool) for a, c in plan_states)
     finally:
         pab.set_pab_manager(None)
+
+
+def test_sequence_parallel_with_pab_folds_broadcasts_on_every_rank():
+    """PAB under DSP, four ranks in one process with faked kernels: every rank makes the same PAB decisions (they depend on the
+    timestep only), so every rank folds the same broadcasts into the GEMM in front of them, walks the same collective sequence (a
+    mismatch would deadlock the barrier) and hands slabs of its OWN shard shape to the folded store phase."""
+    from types import SimpleNamespace
+
+    from test_host_cpu import torch_copy_executor
+    from tools.local_group import LocalWorld
+    from videosys_amd import pab
+
+    x, y, kw = _inputs(T=5, HW=12)
+    P = 4
+    ts = [900, 800, 700, 600, 500]
+    pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[450, 930], spatial_range=2,
+                                      temporal_broadcast=True, temporal_threshold=[450, 930], temporal_range=3,
+                                      cross_broadcast=True, cross_threshold=[450, 930], cross_range=4))
+    pab.update_steps(len(ts))
+
+    def rank_fn(r, group):
+        m = _model()
+        pm = SimpleNamespace(sp_size=P, cp_size=1, dp_size=1, dp_rank=0, sp_rank=r, cp_rank=0, sp_group=group, cp_group=None)
+        m.enable_parallel(parallel_mgr=pm, copy_executor=torch_copy_executor, overlap=False)
+        for t in ts:
+            out = m(x, torch.tensor([float(t)] * 2), y, all_timesteps=ts, **kw)
+            assert out.shape == (2, 8, 5, 12, 12)
+        return dict(m.program_stats)
+
+    try:
+        with fake_ops() as f:
+            stats = LocalWorld(P, timeout=120).run(rank_fn)
+            folded, passes = f.calls.get("folded_adds", 0), f.calls.get("add_rows", 0)
+    finally:
+        pab.set_pab_manager(None)
+    assert all(s["eager"] == 0 for s in stats), stats
+    assert folded > 0 and folded % P == 0, (folded, passes)      # the same number on every rank
