@@ -378,17 +378,19 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
     if (t == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0) {  // wave-uniform
       asm volatile("; rescale path (rare): kept out of line" ::: "memory");  // not if-convertible
       const float delta = t == 0 ? mx : fmaxf(mx, 0.f);  // first tile: adopt its max (signed); later: only raise
-      const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
       for (int r = 0; r < 16; ++r) minit[r] -= delta;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kt][r] -= delta;
+      if (t != 0) {   // (the first tile adopts its max into the accumulator INIT: O is still zero, nothing to scale — and exp2(-max) of a
+        const float alpha = __builtin_amdgcn_exp2f(-delta);   // very negative first max would be inf x 0)
 #pragma unroll
-      for (int dt = 0; dt < 3; ++dt)
+        for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
     }
     FLASH_STAMP(1);
     // ---- P = exp2(s - m), O^T += Vt P^T: the exps of keys 32..63 run under the MFMAs of keys 0..31
@@ -440,6 +442,8 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
     // every KV tile is resident: walk this workgroup's query blocks (256 rows each) with nothing but tile() in the loop
     const int nqb = (p.q_len + 255) >> 8;
     const int qb0 = (int)((int64_t)qb * nqb / p.chunks), qb1 = (int)((int64_t)(qb + 1) * nqb / p.chunks);
+    // (The mask of a ragged last tile stays: kv_len may be SHORTER than what the K / Vt buffers were prepared for — Latte's per-sample
+    // text lengths inside one buffer, test_flash_attn_short_key_length_inside_a_longer_buffer — so the keys behind it are not zero.)
     const bool ragged = (p.kv_len & 63) != 0;
     // The Q rows of query block i + 1 travel HBM -> LDS (wave-private 5 KiB image: 32 rows x 144 B, contiguous 16-byte units) by
     // LDS-DMA under the tiles of block i: a register prefetch (20 VGPRs) makes hipcc spill inside tile(), and without a prefetch
@@ -529,17 +533,19 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
           if (t == 0 || __builtin_amdgcn_ballot_w64(mx > defer_thr) != 0) {
             asm volatile("; rescale path (rare): kept out of line" ::: "memory");
             const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
             for (int r = 0; r < 16; ++r) minit[r] -= delta;
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
               for (int r = 0; r < 16; ++r) d[kt][r] -= delta;
+            if (t != 0) {   // (first tile: O is still zero — the adoption is folded into the accumulator init)
+              const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-            for (int dt = 0; dt < 3; ++dt)
+              for (int dt = 0; dt < 3; ++dt)
 #pragma unroll
-              for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            }
           }
         };
 #define RES_SGB(mask_, n_) __builtin_amdgcn_sched_group_barrier(mask_, n_, 0)

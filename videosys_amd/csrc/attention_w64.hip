@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64_kernel(FlashW64Para
 // none of it covered at one workgroup per CU) is taken out of the seam where it can be: the tail of an item's tile loop already
 // fetches the NEXT item's first four K / Vt tiles and its Q rows (LDS-DMA into a wave-private [chunk][row] image), so an item
 // starts with everything on chip.  Any tile count >= 4: the ring continues from item to item (tile 0 of the k-th item of a workgroup
-// sits in stage (k ntiles) mod 4); nothing is masked — padded keys are zero Kp rows against zero Vt columns, ones rows included.
+// sits in stage (k ntiles) mod 4); whole tiles of real keys only (kv_len % 64 == 0: nothing is masked).
 // ---------------------------------------------------------------------------------------------------------------------------
 constexpr int W64P_QIMG = 64 * KROW;   // 9216 bytes per wave: 9 chunks x 64 rows x 16 B
 
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void flash_attn_d72_w64p_kernel(FlashW64Par
   const int l4 = s4k ? 8 * 1024 : K_TILE_BYTES + s4j * 1024;
   const int lb = (int)(unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
   const int qlds = lb + W64_STAGES * KV_STAGE + wave_u * W64P_QIMG;
-  const int ntiles = (p.kv_len + 63) >> 6;   // whole tiles: padded keys are zero rows of Kp against zero Vt columns (ones rows included)
+  const int ntiles = p.kv_len >> 6;   // whole tiles (flash_w64p_supports)
   for (int u = tid; u < W64_STAGES * 128; u += 256)
     *reinterpret_cast<uint4*>(smem + (u >> 7) * KV_STAGE + K_TILE_BYTES + 80 * VROW + (u & 127) * 16) = make_uint4(0, 0, 0, 0);
   const int krow = 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3);
@@ -583,8 +583,9 @@ static int launch_w64_t(const FlashW64Params& p, unsigned nblk, size_t lds, hipS
 
 // persistent form: >= 4 tiles of tile-padded keys, 32-bit Q row offsets
 bool flash_w64p_supports(int q_len, int kv_len, int kv_pad, int64_t q_stride) {
-  // (any tile count >= 4; kv_pad must be the tile-padded length: the kernel walks whole tiles of zero-padded keys)
-  return kv_len >= 256 && kv_pad == (kv_len + 63) / 64 * 64 && q_len >= 256 && (int64_t)q_len * q_stride * 2 < 0x7fffffff;
+  // Any tile count >= 4, but WHOLE tiles of real keys only: the walk does not mask, and the keys behind kv_len inside a buffer are not
+  // necessarily zero (a caller may pass a key count shorter than what the buffers were prepared for: Latte's per-sample text lengths).
+  return kv_len >= 256 && kv_len % 64 == 0 && q_len >= 256 && (int64_t)q_len * q_stride * 2 < 0x7fffffff;
 }
 
 int launch_flash_attn_d72_w64p(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,
