@@ -56,8 +56,29 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(n: int) -> int:
+    """``python bench.py --gpus N`` with N > 1 and no launcher around it: start the N ranks ourselves (one process per GPU under
+    ``torch.distributed.run``, rendezvous on 127.0.0.1 at a free port) with this command line, let rank 0's JSON line pass
+    through on stdout, and return the launcher's exit code.  The reference's engine spawns its own workers the same way
+    (videosys/core/engine/engine.py:40-72)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this driver (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ and "LOCAL_RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -238,6 +238,27 @@ def test_bench_two_ranks_dry_run():
     assert d["step_ms_overlap_off"] > 0 and d["step_ms_overlap_on"] > 0
 
 
+def test_bench_plain_form_launches_its_own_ranks():
+    """``python bench.py --gpus 2`` WITHOUT torchrun around it (how the driver launches the N = 1 bench): bench.py starts its own
+    ranks and still prints exactly one JSON line (engine.py:40-72 spawns the reference's workers the same way)."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["VSYS_BENCH_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--depth", "2",
+           "--no-cpu-baseline", "--no-vae", "--no-t5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
+
+
 def test_batched_copy_executor_matches_plan_semantics():
     """hip_copy_executor (one vsys_copy_4d_batch launch per plan) against the element-wise definition of a copy plan, on the
     pack / unpack plans of a 4-way DSP switch and of the Ulysses exchange (padding on the last shard in both)."""

@@ -1485,3 +1485,39 @@ def test_gemm_tile_raster_is_a_bijection_for_every_setting():
         lib.vsys_gemm_raster_probe(t, 152, 18, 6, 0, ctypes.byref(bm), ctypes.byref(bn))
         cols.add(bn.value)
     assert cols == set(range(6))
+
+
+def test_bench_plain_form_starts_its_own_ranks(monkeypatch):
+    """``python bench.py --gpus N`` (N > 1) with no launcher in the environment re-executes itself under torch.distributed.run with
+    one process per GPU on 127.0.0.1 and hands back the launcher's exit code; under a launcher (RANK set) it does not."""
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "5", "--warmup", "2"])
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        monkeypatch.delenv(k, raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-6:] == ["--gpus", "4", "--steps", "5", "--warmup", "2"]
+    assert os.path.basename(cmd[-7]) == "bench.py" and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # under a launcher the same command line goes on to the measurement (which refuses a box without devices)
+    seen.clear()
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    if not torch.cuda.is_available():
+        with pytest.raises(AssertionError, match="needs MI355X"):
+            bench.main()
+        assert not seen
