@@ -95,22 +95,33 @@ def test_w64_flash_kernel_owns_its_accumulator_registers(tmp_path):
         # (a few SGPRs parked in VGPR lanes are fine — the persistent forms carry ~40 scalars across the statement; scratch is not)
         assert res.get("ScratchSize", 0) == 0 and res.get("VGPRs Spill", 0) == 0 and res.get("SGPRs Spill", 0) <= 16, (name, res)
         assert res.get("VGPRs", 0) <= 256 and 224 <= res.get("AGPRs", 0) <= 256, (name, res)
-    inside, bad = False, []
-    text = []
-    for src in ("attention_w64.hip", "attention64_w64.hip"):
-        out = str(tmp_path / (src + ".s"))
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", out,
-                        os.path.join(CSRC, src)], check=True, capture_output=True)
-        text += open(out).read().split("\n")
-    for ln in text:
-        if "#ASMSTART" in ln:
-            inside = True
-        elif "#ASMEND" in ln:
-            inside = False
-        elif not inside and not ln.lstrip().startswith((".", ";")):
-            code = ln.split(";")[0]
-            # (a224 and up are the compiler's: the persistent form parks loop-invariant values there)
-            regs = [int(m) for m in re.findall(r"\ba\[?(\d+)", code)]
-            if any(r < 224 for r in regs) or ("v_accvgpr" in code and not regs) or "scratch_" in code:
-                bad.append(ln.strip())
-    assert not bad, bad[:5]
+    # the register-ownership audit itself is part of the build (__graft_entry__.compile_library runs it on every compile of these
+    # sources and fails the build); here it runs once more on the current tree
+    import __graft_entry__ as ge
+
+    for src in ge.ASM_OWNED:
+        ge.audit_asm_register_ownership(os.path.join(CSRC, src))
+
+
+def test_build_cache_is_keyed_on_content_not_mtime(tmp_path):
+    """compile_library's object cache: a source whose mtime moves but whose bytes do not is NOT rebuilt; the key changes with the
+    source bytes, the header bytes, the flags and the compiler."""
+    import __graft_entry__ as ge
+
+    ge.build()
+    src = os.path.join(CSRC, "program.hip")
+    st = os.stat(src)
+    try:
+        os.utime(src, None)                                   # fresh mtime, same bytes
+        assert ge.compile_library(ge.LIB, lab=ge.LAB) is False
+    finally:
+        os.utime(src, (st.st_atime, st.st_mtime))
+    a = tmp_path / "a.hip"
+    a.write_text("int x;")
+    k0 = ge._digest(str(a), b"hdr", ["-O3"], "cc")
+    assert k0 == ge._digest(str(a), b"hdr", ["-O3"], "cc")
+    a.write_text("int y;")
+    assert ge._digest(str(a), b"hdr", ["-O3"], "cc") != k0
+    a.write_text("int x;")
+    assert ge._digest(str(a), b"hdr2", ["-O3"], "cc") != k0 and ge._digest(str(a), b"hdr", ["-O2"], "cc") != k0
+    assert ge._digest(str(a), b"hdr", ["-O3"], "cc2") != k0 and ge._digest(str(a), b"hdr", ["-O3"], "cc") == k0

@@ -212,3 +212,16 @@ def test_component_names_typo_paths_raise_hub_ids_warn(caplog):
     with caplog.at_level(logging.WARNING, logger="videosys_amd"):
         OpenSoraPipeline._hub_fallback("hpcai-tech/OpenSora-STDiT-v3", "transformer", "synthetic:1234")
     assert any("hub id" in r.getMessage() for r in caplog.records)
+    # "ckpts/stdit3" has the shape of a hub id, but with a directory ckpts/ beside the caller it is a mistyped relative path
+    import os
+    import tempfile
+
+    cwd = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.mkdir(os.path.join(d, "ckpts"))
+        os.chdir(d)
+        try:
+            with pytest.raises(FileNotFoundError):
+                OpenSoraPipeline._hub_fallback("ckpts/stdit3", "transformer", "synthetic:1234")
+        finally:
+            os.chdir(cwd)

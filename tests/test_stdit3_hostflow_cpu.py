@@ -643,6 +643,43 @@ def test_pab_broadcast_of_an_elided_slab_recomputes():
         pab.set_pab_manager(None)
 
 
+def test_pab_step_that_fails_leaves_no_slab_marked_valid():
+    """_pab_plan marks the slabs a step is about to write while planning; when the step raises half way (launch error, OOM) no slab may
+    stay marked valid, so the next call recomputes instead of broadcasting a slab that was never written."""
+    from videosys_amd import ops, pab
+
+    x, y, kw = _inputs()
+    ts = [900, 800, 700, 600]
+    pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, spatial_threshold=[450, 930], spatial_range=2,
+                                      temporal_broadcast=True, temporal_threshold=[450, 930], temporal_range=2,
+                                      cross_broadcast=True, cross_threshold=[450, 930], cross_range=2))
+    pab.update_steps(len(ts))
+    try:
+        with fake_ops():
+            m = _model()
+            m.use_programs = False
+            real = ops.final_layer
+
+            def boom(*a, **k):
+                raise RuntimeError("launch failed")
+
+            ops.final_layer = boom
+            with pytest.raises(RuntimeError, match="launch failed"):
+                m(x, torch.tensor([900.0] * 2), y, all_timesteps=ts, **kw)
+            assert not any(st.attn_valid or st.cross_valid for st in m.states)
+            ops.final_layer = real
+            real_add = ops.add_rows
+
+            def add_rows(a, b):
+                assert b is not None, "a broadcast read a slab that was never written"
+                return real_add(a, b)
+
+            ops.add_rows = add_rows
+            m(x, torch.tensor([800.0] * 2), y, all_timesteps=ts, **kw)     # the counters ask for broadcasts: all downgraded to recomputes
+    finally:
+        pab.set_pab_manager(None)
+
+
 def test_sequence_parallel_with_pab_folds_broadcasts_on_every_rank():
     """PAB under DSP, four ranks in one process with faked kernels: every rank makes the same PAB decisions (they depend on the
     timestep only), so every rank folds the same broadcasts into the GEMM in front of them, walks the same collective sequence (a

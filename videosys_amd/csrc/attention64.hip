@@ -485,7 +485,7 @@ int launch_flash_attn_d64(const bf16_t* q, int64_t q_stride, const bf16_t* ln_w,
   constexpr int W64_DEFAULT_VAR = 4;   // 141 / 144 select placement variant 1 / 4 (4: +0.5-1 %, profiles/r04_flash64_w64_cvx5b.json)
   // k_bound > 0 (vsys_flash_attn_d64_kb): the statement without the running max; 17 forces it, 19 ignores the promise
   static const bool static_ok = [] { const char* e = getenv("VSYS_FLASH_STATIC"); return !(e && e[0] == '0'); }();
-  const bool bounded = k_bound > 0.f && static_ok && fv != 19;
+  const bool bounded = k_bound > 0.f && ln_w != nullptr && static_ok && fv != 19;   // no q / k LayerNorm: the bound is ignored (as d72 does)
   if (((fv == 0 && kv_len >= 2048 && !w64_off) || fv == 14 || fv == 17 || fv == 141 || fv == 144) && flash64_w64_supports(q_len, kv_len)) {
     int var = fv >= 140 ? fv - 140 : W64_DEFAULT_VAR;
     if (bounded && (fv == 0 || fv == 17)) var = 5;

@@ -849,6 +849,8 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   }
   if (p.N % BN != 0 || p.K % BK != 0 || p.N <= 0 || p.K <= 0) return VSYS_ERR_SHAPE;
   if ((p.lda % 8) || (p.ldw % 8) || (p.ldo % 8) || (p.res && (p.ldr % 8)) || (p.aux && (p.ldaux % 8))) return VSYS_ERR_ALIGN;
+  // tile-relative operand offsets are 32-bit (buffer addressing): checked for EVERY epilogue, in front of the per-epilogue dispatch
+  if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 384 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
   if ((epi == EPI_GATE_RES || epi == EPI_GATE_RES_STATS) && p.gate && p.rows_per_sample <= 0) return VSYS_ERR_SHAPE;
   const bool ln = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
   if (ln && (!p.cs || !p.cv || !p.ln_stats || p.ln_nb < 1 || p.ln_nb > 12 || p.ln_nb * LN_BLOCK != p.K || p.ln_ld < p.M)) return VSYS_ERR_SHAPE;
@@ -869,8 +871,6 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
     if (p.K <= 1536 && p.N >= 2304 && g_gemm_variant_a.load(std::memory_order_relaxed) != 8) return launch_gemm2(p, epi, 0, stream);
     return launch_gemm_t<8, 256>(p, epi, stream);
   }
-  // tile-relative operand offsets are 32-bit (buffer addressing)
-  if (p.lda * 512 + (int64_t)p.K * 2 >= 0x7fffffff || p.ldw * 384 + (int64_t)p.K * 2 >= 0x7fffffff) return VSYS_ERR_SHAPE;
   const int g_gemm_variant = g_gemm_variant_a.load(std::memory_order_relaxed);
   switch (g_gemm_variant == 50 ? 0 : g_gemm_variant) {
     case 6: return launch_gemm_t<6, 256>(p, epi, stream);

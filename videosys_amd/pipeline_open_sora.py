@@ -190,6 +190,8 @@ class OpenSoraPipeline(VideoSysPipeline):
         filesystem path and does not exist is a typo and raises."""
         n = str(name)
         pathlike = n.startswith(("/", "./", "../", "~")) or n.count("/") != 1     # a hub id is exactly "org/name"
+        # "ckpts/stdit3" has the shape of a hub id; when its first component is a directory here it is a mistyped relative path
+        pathlike = pathlike or os.path.isdir(n.split("/", 1)[0])
         if pathlike:
             raise FileNotFoundError(f"config.{what} = {name!r}: no such checkpoint directory (expected *.safetensors inside, or 'synthetic:<seed>')")
         import logging

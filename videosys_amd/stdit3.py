@@ -462,6 +462,19 @@ class STDiT3:
         static = (txt, pos, self._fps_cache[fkey])
         fold = self._fold_ok(ts_host, fkey, x_mask)
 
+        try:
+            return self._issue_step(x, ts_host, static, plan, timestep_int, valid_depth, cp, x_mask, fold, fkey, height, width)
+        except BaseException:
+            # _pab_plan marked the slabs this step was going to write as valid; the step did not finish (launch error, OOM, an
+            # interrupted caller), so no slab may be broadcast until its block has computed again
+            for st in self.states:
+                st.attn_valid = st.cross_valid = False
+            raise
+
+    def _issue_step(self, x, ts_host, static, plan, timestep_int, valid_depth, cp, x_mask, fold, fkey, height, width):
+        """The device side of forward(): eagerly, or through the recorded launch program of this (geometry, PAB pattern, layout)."""
+        dev = self.device
+        B, _, Tx, Hx, Wx = x.shape
         mlp_action = plan is not None and any(d[2] or d[3] for d in plan)   # stores / replays host-side dict entries: eager
         # (a conditioning mask changes from step to step and selects rows with torch ops: the step is issued eagerly)
         if not (self.use_programs and self._hidden_tap is None and not mlp_action and x_mask is None):
