@@ -193,6 +193,35 @@ def test_opensora_vae_decode_matches_reference_golden():
     assert torch.equal(out, out2)
 
 
+def test_opensora_vae_frame_ranges_and_rank_shards_are_the_full_decode_bit_for_bit():
+    """decode(frames=(f0, f1)) on the real kernels: the temporal chunks are independent and the 2-D decoder is per frame, so a range
+    equals the slice of the full decode bit for bit; decode_sharded over 2 / 3 / 8 ranks (threads of this process, tools/local_group)
+    returns the full uint8 video on every rank (autoencoder_kl_open_sora.py:672-695 decodes it whole on every rank)."""
+    from tools.local_group import LocalWorld
+    from videosys_amd.vae_open_sora import OpenSoraVAE, pixels_to_uint8, synth_state_dict
+
+    gold = load_golden("opensora_vae_small.pt")
+    vae = OpenSoraVAE(synth_state_dict(gold["seed"]), device=dev(), frames_per_launch=8)
+    z, F_ = gold["z"].to(dev()), gold["num_frames"]      # 22 frames = one 17-frame chunk + 5
+    full = vae.decode(z, F_)
+    for f0, f1 in ((0, 3), (15, 19), (17, 22), (21, 22), (9, 9)):
+        part = vae.decode(z, F_, frames=(f0, f1))
+        assert torch.equal(part, full[:, :, f0:f1]), (f0, f1)
+    want = pixels_to_uint8(full).cpu()
+    for P in (2, 3, 8):
+        def rank_fn(r, grp):
+            torch.cuda.set_device(0)
+            mine = OpenSoraVAE(synth_state_dict(gold["seed"]), device=dev(), frames_per_launch=8)   # a rank owns its staging buffers
+            with torch.cuda.stream(torch.cuda.Stream()):
+                out = mine.decode_sharded(z, F_, grp)
+                torch.cuda.current_stream().synchronize()
+            return out.cpu()
+
+        outs = LocalWorld(P, timeout=300).run(rank_fn)
+        for r, o in enumerate(outs):
+            assert torch.equal(o, want), (P, r)
+
+
 def test_open_sora_pipeline_latents_to_uint8_video():
     """OpenSoraPipeline.generate end to end on the GPU: prompt embeddings -> RFLOW denoising (small STDiT3) -> OpenSoraVAE decode ->
     uint8 [B, T, H, W, C] on the CPU (pipeline_open_sora.py:638-656), and the same latents decoded directly give the same video."""

@@ -168,3 +168,52 @@ def test_vae_encode_host_flow_on_emulated_kernels():
     assert rel(z, gold["z_fp32"]) <= 0.06, rel(z, gold["z_fp32"])
     cos = torch.nn.functional.cosine_similarity(z.flatten(), gold["z_fp32"].flatten(), dim=0).item()
     assert cos >= 0.998, cos
+
+
+def _fake_decoders(vae):
+    """Stand-ins for the two decoder stages that keep their data dependences (a temporal chunk's frames depend on the whole latent
+    chunk, a pixel frame on its own latent frame only), so the frame-range / shard bookkeeping of decode() can be checked on CPU."""
+    def temporal(z4, num_frames, out, f0):
+        base = z4.float().mean(dim=1, keepdim=True)                                 # [4, 1, H, W]: every frame sees the chunk
+        for i in range(num_frames):
+            out[:, f0 + i] = (base[:, 0] + 0.25 * i + z4.float()[:, min(i // 4, z4.shape[1] - 1)]).to(out.dtype)
+        return num_frames
+
+    def spatial(xz, out, f0, in_scale=1.0):
+        up = xz.float().repeat_interleave(8, dim=2).repeat_interleave(8, dim=3)     # [4, F, 8H, 8W]
+        out[:, f0:f0 + xz.shape[1]] = torch.tanh(up[:3] * 0.7 + up[3:4] * 0.1).to(out.dtype)
+
+    vae._temporal_decode, vae._spatial_decode = temporal, spatial
+
+
+def test_decode_frame_ranges_and_rank_shards_equal_the_full_decode():
+    """OpenSoraVAE.decode(frames=(f0, f1)) runs the temporal VAE for the micro-frame chunks that hold the wanted frames and the 2-D
+    decoder for those frames only; decode_sharded gives every rank of a group a contiguous block of frames and gathers uint8 frames
+    once.  Host bookkeeping checked on CPU with stand-in decoder stages (the kernels' bit-identity is the GPU test's job): every
+    range equals the slice of the full decode, every rank of 2 / 3 / 8 returns the full video (22 and 64 frames: 17-frame chunks)."""
+    from tools.local_group import LocalWorld
+    from vae_cpu_emul import cpu_vae
+    from videosys_amd.vae_open_sora import OpenSoraVAE, pixels_to_uint8, synth_state_dict
+
+    vae = cpu_vae(synth_state_dict(7), encoder=False)
+    vae.frames_per_launch = 3
+    _fake_decoders(vae)
+    g = torch.Generator().manual_seed(3)
+    for frames, tz in ((22, 7), (64, 19), (17, 5)):
+        z = torch.randn(2, 4, tz, 3, 2, generator=g)
+        full = vae.decode(z, frames)
+        assert tuple(full.shape) == (2, 3, frames, 24, 16)
+        for f0, f1 in ((0, frames), (0, 1), (16, min(18, frames)), (min(17, frames), frames), (5, 5), (frames - 1, frames), (3, min(21, frames))):
+            part = vae.decode(z, frames, frames=(f0, f1))
+            assert torch.equal(part, full[:, :, f0:f1]), (frames, f0, f1)
+        with pytest.raises(ValueError):
+            vae.decode(z, frames, frames=(2, frames + 1))
+        want = pixels_to_uint8(full)
+        for P in (2, 3, 8):
+            shards = [OpenSoraVAE.frame_shard(frames, P, r) for r in range(P)]
+            assert shards[0][0] == 0 and shards[-1][1] == frames and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+            outs = LocalWorld(P, timeout=60).run(lambda r, grp: vae.decode_sharded(z, frames, grp))
+            for o in outs:
+                assert o.dtype == torch.uint8 and torch.equal(o, want), (frames, P)
+            outs = LocalWorld(P, timeout=60).run(lambda r, grp: vae.decode_sharded(z, frames, grp, to_uint8=False))
+            assert all(torch.equal(o, full) for o in outs)

@@ -58,8 +58,34 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--fpl", type=int, default=16)
     ap.add_argument("--encode", type=int, default=0, help="N > 0: time OpenSoraVAE.encode of N frames (image / video conditioning) instead")
+    ap.add_argument("--shard", type=int, default=0, help="P > 1: time every rank's share of decode_sharded (wire stubbed: the gather is a "
+                                                         "device copy of the same bytes, tools/local_group.StubGroup) and report the slowest")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
+    if args.shard > 1:
+        from tools.local_group import StubGroup
+
+        vae = OpenSoraVAE(synth_state_dict(0), device=dev, frames_per_launch=args.fpl)
+        Tz = vae.get_latent_size((args.frames, args.hw * 8, args.hw * 8))[0]
+        z = torch.randn(1, 4, Tz, args.hw, args.hw, generator=torch.Generator().manual_seed(0)).to(dev)
+        per_rank = []
+        for r in range(args.shard):
+            grp = StubGroup(args.shard, r)
+            vae.decode_sharded(z, args.frames, grp)
+            ts = []
+            for _ in range(args.iters):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                vae.decode_sharded(z, args.frames, grp)
+                torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+            per_rank.append(round(min(ts), 4))
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        vae.decode(z, args.frames)
+        torch.cuda.synchronize(); whole = time.perf_counter() - t0
+        print(json.dumps({"workload": f"OpenSoraVAE.decode_sharded latent [1,4,{Tz},{args.hw},{args.hw}] -> {args.frames} frames, "
+                                      f"P = {args.shard}, wire stubbed", "sec_per_rank": per_rank, "slowest_rank_s": max(per_rank),
+                          "frames_per_rank": [list(OpenSoraVAE.frame_shard(args.frames, args.shard, r)) for r in range(args.shard)],
+                          "unsharded_s": round(whole, 4), "gathered_bytes": args.frames * (args.hw * 8) ** 2 * 3}))
+        return
     if args.encode:
         vae = OpenSoraVAE(synth_state_dict(0, encoder=True), device=dev, frames_per_launch=args.fpl)
         x = (torch.rand(1, 3, args.encode, args.hw * 8, args.hw * 8, generator=torch.Generator().manual_seed(0)) * 2 - 1).to(dev)

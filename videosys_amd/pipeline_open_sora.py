@@ -95,6 +95,9 @@ class OpenSoraConfig:
         self.pab_config = pab_config if pab_config is not None else OpenSoraPABConfig()
         # extensions (not in the reference): geometry override for tests, e.g. transformer_config=dict(depth=2, ...)
         self.transformer_config = extra.pop("transformer_config", None)
+        # with num_gpus > 1 the VAE decode is sharded over the ranks by output frame and gathered once (the reference decodes the
+        # whole video on every rank: autoencoder_kl_open_sora.py:672-695 under engine.py:85-95); False = the reference's behaviour
+        self.shard_vae_decode = bool(extra.pop("shard_vae_decode", True))
         if extra:
             raise TypeError(f"unexpected OpenSoraConfig kwargs: {sorted(extra)}")
 
@@ -205,6 +208,16 @@ class OpenSoraPipeline(VideoSysPipeline):
         world = dist.get_world_size() if dist.is_initialized() else 1
         if world > 1:
             self.transformer.enable_parallel(dp_size or 1, sp_size or world, enable_cp)
+
+    def _decode_group(self):
+        """The ranks that share one video's VAE decode: the sequence-parallel group of the transformer (every one of its ranks holds
+        the same final latents), None on one GPU or with ``shard_vae_decode=False``."""
+        if not getattr(self._config, "shard_vae_decode", True) or os.environ.get("VSYS_VAE_SHARD") == "0":
+            return None
+        sp = getattr(self.transformer, "_sp", None)
+        if sp is not None and sp.P > 1:
+            return sp.group
+        return None
 
     def null(self, n):
         """pipeline_open_sora.py:294-296."""
@@ -360,6 +373,12 @@ class OpenSoraPipeline(VideoSysPipeline):
             if vae is None or output_type == "latent":
                 break
             self._enter_stage("vae")
+            grp = self._decode_group() if loop == 1 else None      # (loop > 1 re-encodes the decoded clip: every rank needs its pixels)
+            if grp is not None and hasattr(vae, "decode_sharded"):
+                # one video over N GPUs: every rank decodes its block of output frames, one all-gather of uint8 frames
+                video = vae.decode_sharded(samples.to(torch.bfloat16), num_frames, grp, to_uint8=True).to("cpu")
+                self._enter_stage(None)
+                return VideoSysPipelineOutput(video=video) if return_dict else (video,)
             clips.append(vae(samples.to(torch.bfloat16), num_frames=num_frames))
         self._enter_stage(None)
         if not clips:

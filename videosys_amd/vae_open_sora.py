@@ -348,29 +348,77 @@ class OpenSoraVAE:
 
     # ------------------------------------------------------------------------------------------------ public
     @torch.no_grad()
-    def decode(self, z: torch.Tensor, num_frames: int) -> torch.Tensor:
-        """z [B, 4, Tz, H, W] -> video [B, 3, num_frames, 8H, 8W] bf16 (autoencoder_kl_open_sora.py:672-695)."""
-        if not z.is_cuda:
+    def decode(self, z: torch.Tensor, num_frames: int, frames: Optional[tuple] = None) -> torch.Tensor:
+        """z [B, 4, Tz, H, W] -> video [B, 3, num_frames, 8H, 8W] bf16 (autoencoder_kl_open_sora.py:672-695).
+        ``frames = (f0, f1)``: only the output frames f0 <= f < f1 -> [B, 3, f1 - f0, 8H, 8W] — the temporal VAE runs for the
+        micro-frame chunks that hold them (the chunks are independent, :680-690), the 2-D decoder for those frames alone (it is per
+        frame, :522-538): the same values as the slice of the full decode, bit for bit."""
+        if z.device.type != self.device.type:      # (self.device is a HIP device: the constructor refuses anything else)
             raise RuntimeError("OpenSoraVAE.decode needs a HIP device tensor (no CPU path)")
         B, C, Tz, H, W = z.shape
         assert C == 4
+        f_lo, f_hi = (0, num_frames) if frames is None else (int(frames[0]), int(frames[1]))
+        if not (0 <= f_lo <= f_hi <= num_frames):
+            raise ValueError(f"frames {frames} outside [0, {num_frames}]")
         outs = []
         for b in range(B):
+            vid = torch.empty(3, f_hi - f_lo, 8 * H, 8 * W, dtype=torch.bfloat16, device=self.device)
+            if f_hi == f_lo:
+                outs.append(vid)
+                continue
             zb = z[b].to(torch.bfloat16).contiguous()
-            xz = torch.empty(4, num_frames, H, W, dtype=torch.bfloat16, device=self.device)
-            left, f0 = num_frames, 0
-            step = self.micro_z_frame_size if self.micro_frame_size is not None else Tz
-            for i in range(0, Tz, step):
-                nf = min(self.micro_frame_size, left) if self.micro_frame_size is not None else left
-                f0 += self._temporal_decode(zb[:, i:i + step].contiguous(), nf, xz, f0)
-                left -= self.micro_frame_size if self.micro_frame_size is not None else left
-            assert f0 == num_frames, (f0, num_frames)
-            vid = torch.empty(3, num_frames, 8 * H, 8 * W, dtype=torch.bfloat16, device=self.device)
-            for f in range(0, num_frames, self.frames_per_launch):
-                m = min(self.frames_per_launch, num_frames - f)
-                self._spatial_decode(xz[:, f:f + m].contiguous(), vid, f)
+            if self.micro_frame_size is None:
+                chunks = [(0, Tz, 0, num_frames)]
+            else:       # chunk c: latent frames [c * mz, (c + 1) * mz) -> output frames [c * mf, min((c + 1) * mf, num_frames))
+                mf, mz = self.micro_frame_size, self.micro_z_frame_size
+                chunks = [(i, min(i + mz, Tz), (i // mz) * mf, min((i // mz + 1) * mf, num_frames)) for i in range(0, Tz, mz)]
+            chunks = [c for c in chunks if c[3] > f_lo and c[2] < f_hi]          # the chunks that hold a wanted frame
+            base = chunks[0][2]
+            xz = torch.empty(4, chunks[-1][3] - base, H, W, dtype=torch.bfloat16, device=self.device)
+            for z0, z1, o0, o1 in chunks:
+                wrote = self._temporal_decode(zb[:, z0:z1].contiguous(), o1 - o0, xz, o0 - base)
+                assert wrote == o1 - o0, (wrote, o0, o1)
+            if frames is None:
+                assert chunks[-1][3] == num_frames, (chunks[-1][3], num_frames)
+            for f in range(f_lo, f_hi, self.frames_per_launch):
+                m = min(self.frames_per_launch, f_hi - f)
+                self._spatial_decode(xz[:, f - base:f - base + m].contiguous(), vid, f - f_lo)
             outs.append(vid)
         return torch.stack(outs, 0)
+
+    @staticmethod
+    def frame_shard(num_frames: int, P: int, rank: int) -> tuple:
+        """The output frames rank ``rank`` of ``P`` decodes: contiguous blocks of ceil(num_frames / P) (the last ranks may hold
+        fewer, or none)."""
+        per = -(-num_frames // P)
+        return min(rank * per, num_frames), min((rank + 1) * per, num_frames)
+
+    @torch.no_grad()
+    def decode_sharded(self, z: torch.Tensor, num_frames: int, group, to_uint8: bool = True) -> torch.Tensor:
+        """decode() with the output frames sharded over the ranks of ``group`` (dsp.py group protocol: RCCL on a GPU node) and ONE
+        all-gather of the finished frames.  The reference decodes the whole video redundantly on every rank
+        (pipeline_open_sora.py:648-656 after autoencoder_kl_open_sora.py:672-695); once the denoising loop is sequence parallel the
+        unsharded decode is the largest serial term of a video.  ``to_uint8``: gather the frames as uint8 [B, F, 8H, 8W, 3] in the
+        pipeline's output convention ((x.clamp(-1, 1) / 2 + 0.5) * 255 rounded, :648-656) — 1 byte per value on the wire; else
+        bf16 [B, 3, F, 8H, 8W].  Every rank returns the whole video; frames are bit-identical to decode()'s."""
+        from . import dsp
+
+        P, r = dsp.group_size(group), dsp.group_rank(group)
+        f0, f1 = self.frame_shard(num_frames, P, r)
+        per = -(-num_frames // P)
+        part = self.decode(z, num_frames, frames=(f0, f1))                 # [B, 3, n, 8H, 8W]
+        B, _, n, Hh, Ww = part.shape
+        if to_uint8:
+            mine = torch.zeros(B, per, Hh, Ww, 3, dtype=torch.uint8, device=self.device)
+            mine[:, :n] = pixels_to_uint8(part)
+        else:
+            mine = torch.zeros(B, 3, per, Hh, Ww, dtype=torch.bfloat16, device=self.device)
+            mine[:, :, :n] = part
+        allp = torch.empty((P,) + tuple(mine.shape), dtype=mine.dtype, device=self.device)
+        dsp.all_gather_into_tensor(allp, mine, group)
+        if to_uint8:                                                        # [P, B, per, H, W, 3] -> [B, P * per, H, W, 3]
+            return allp.permute(1, 0, 2, 3, 4, 5).reshape(B, P * per, Hh, Ww, 3)[:, :num_frames].contiguous()
+        return allp.permute(1, 2, 0, 3, 4, 5).reshape(B, 3, P * per, Hh, Ww)[:, :, :num_frames].contiguous()
 
 
     # ------------------------------------------------------------------------------------------------ encode
@@ -486,6 +534,12 @@ class OpenSoraVAE:
         return (z - shift) / scale
 
     __call__ = decode
+
+
+def pixels_to_uint8(video: torch.Tensor) -> torch.Tensor:
+    """[B, 3, F, H, W] in [-1, 1] -> uint8 [B, F, H, W, 3]: the output convention of OpenSoraPipeline.generate
+    (pipeline_open_sora.py:648-656: clamp, scale to 0..255, add 0.5, clamp, cast)."""
+    return (video.clamp(-1, 1) * 0.5 + 0.5).mul(255).add_(0.5).clamp_(0, 255).permute(0, 2, 3, 4, 1).to(torch.uint8)
 
 
 def OpenSoraVAE_V1_2(micro_batch_size=4, micro_frame_size=17, from_pretrained=None, freeze_vae_2d=False, cal_loss=False, device="cuda"):
