@@ -356,6 +356,32 @@ def main():
         except Exception as e:  # the extra terms must never cost the bench line
             vae = {"error": f"{type(e).__name__}: {e}"[:300]}
 
+    # ---- N > 1: the VAE decode sharded over the ranks by output frame + one all-gather of uint8 frames (outside the timed region;
+    # the reference decodes the whole video on every rank).  Every rank takes part; the slowest rank's time is reported.
+    if world > 1 and not args.no_vae:
+        import torch.distributed as dist
+
+        try:
+            from videosys_amd.vae_open_sora import OpenSoraVAE, synth_state_dict as vae_synth
+
+            dec = OpenSoraVAE(vae_synth(0), device=dev)
+            zb = z[:1].to(torch.bfloat16)
+            dec.decode_sharded(zb, frames, dist.group.WORLD)
+            barrier()
+            t0 = time.perf_counter()
+            vid = dec.decode_sharded(zb, frames, dist.group.WORLD)
+            torch.cuda.synchronize()
+            tt = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            vae_s = float(tt.item())
+            vae = {"sec_per_video": round(vae_s, 4), "output": list(vid.shape), "sharded_over_ranks": world,
+                   "frames_per_rank": -(-frames // world), "gathered": "uint8 [B, F, H, W, 3], one all-gather",
+                   "videos_per_min_dit_plus_vae": round(60.0 / (STEPS_PER_VIDEO * step_s + vae_s), 4)}
+            del dec, vid
+        except Exception as e:
+            vae = {"error": f"{type(e).__name__}: {e}"[:300]}
+        barrier()
+
     # ---- T5-v1.1-XXL prompt encode (rank 0, N == 1; outside the timed region): 300-token prompt, device-generated weights
     t5 = None
     if rank == 0 and world == 1 and not args.no_t5:

@@ -250,13 +250,15 @@ def test_bench_plain_form_launches_its_own_ranks():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["VSYS_BENCH_ONE_GPU"] = "1"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--depth", "2",
-           "--no-cpu-baseline", "--no-vae", "--no-t5"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+           "--no-cpu-baseline", "--no-t5"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
+    v = j["vae_decode"]      # N > 1: the decode is sharded by output frame and gathered once
+    assert v.get("sharded_over_ranks") == 2 and v["frames_per_rank"] == 32 and v["output"] == [1, 64, 512, 512, 3], v
 
 
 def test_batched_copy_executor_matches_plan_semantics():
