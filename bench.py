@@ -457,6 +457,20 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=80.0):
              model_max_length=300)
     sd = O.synth_state_dict(**c, seed=1)
     m = O.STDiT3Oracle(sd, 2, cfg.hidden_size, cfg.num_heads)
+    kind = "port"
+    try:   # where the reference tree exists (the build container; never the GPU box) its OWN STDiT3 class is what gets timed
+        from oracle import ref_loader
+
+        if ref_loader.reference_available():
+            ref_model = ref_loader.build_reference_stdit3(c, sd)
+
+            class _Ref:    # same call shape as the oracle: forward(x, t, y, valid_depth=, mask=, fps=, height=, width=)
+                def forward(self, x, t, y, **kw_):
+                    return ref_model(x, t, y, **kw_)
+
+            m, kind = _Ref(), "reference"
+    except Exception:
+        kind = "port"
     g = torch.Generator().manual_seed(0)
     y = torch.randn(2, 1, 300, cfg.caption_channels, generator=g) * 0.1
     mask = torch.zeros(1, 300, dtype=torch.long)
@@ -504,7 +518,7 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=80.0):
     O.FUSED_SDPA = False
     return {
         "value": round(60.0 / (STEPS_PER_VIDEO * step_s), 6), "unit": "videos/min", "cores": physical, "threads": best,
-        "logical_cpus": logical, "kind": "port",
+        "logical_cpus": logical, "kind": kind,
         "sec_per_denoise_step": round(step_s, 2), "fit": {"fixed_s": round(fixed * scale, 3), "per_block_pair_s": round(pair * scale, 3),
                                                             "depth": cfg.depth},
         "valid_depth_1_s": [round(v, 3) for v in t1], "valid_depth_2_s": [round(v, 3) for v in t2],
@@ -513,7 +527,9 @@ def cpu_baseline(cfg, T, Hl, Wl, L, budget_s=80.0):
         "host_fp32_gemm_tflops": round(gemm_tf, 3),
         "lower_bound_s_at_gemm_rate": round(89.4 / gemm_tf, 2),
         "sample_seconds": round(time.perf_counter() - t_start, 1),
-        "sample": (f"CPU oracle (fp32 PyTorch port of the reference STDiT3) on {Ts} of {T} latent frames x 1024 tokens, CFG batch 2, "
+        "sample": (("the reference's own STDiT3 class (videosys/models/transformers/open_sora_transformer_3d.py through oracle/ref_loader.py, fp32, CPU)"
+                    if kind == "reference" else "CPU oracle (fp32 PyTorch port of the reference STDiT3)") +
+                   f" on {Ts} of {T} latent frames x 1024 tokens, CFG batch 2, "
                    f"{L} text tokens: valid_depth 1 and 2, warm-up + {reps} repeats each (minimum taken), fitted fixed + 28 x pair"
                    + ("" if Ts == T else f", scaled x{scale:.2f} in tokens")),
     }
