@@ -207,6 +207,19 @@ int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, c
                         int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
                         float eps, void* stream);
 
+/* vsys_flash_attn_d72 for the cross attention against hoisted text K / V (attentions.py:259-270; kv_linear of the packed prompt
+ * :157, :240-258) with a promise about the PADDING: (kp, vt) were written by vsys_attn_prep_kv for exactly this kv_len into
+ * zero-initialised buffers, so every Kp row and Vt column behind kv_len is zero — including the ones rows of Vt.  A padding key then
+ * has logit 0 and weight 0 in numerator and denominator, and the kernels that take the promise (the resident-K/V cross-attention
+ * kernel) drop the mask of the ragged last tile.  Same results as vsys_flash_attn_d72 to the last bit of the tolerance (P of the last
+ * tile may be rounded at another scale when a padding key raises the running max); a row whose real logits all lie ~100 (exp2
+ * domain) below zero is detected and recomputed with the mask.  NOT valid when kv_len is SHORTER than what the buffers were
+ * prepared for (Latte's per-sample text lengths inside one buffer: call vsys_flash_attn_d72).  kv_len % 64 == 0: identical to
+ * vsys_flash_attn_d72. */
+int vsys_flash_attn_d72_exact(const void* q, int64_t q_stride, const void* q_norm_w, const void* kp, const void* vt, void* out,
+                              int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
+                              float eps, void* stream);
+
 /* vsys_flash_attn_d72 (attentions.py:75,100) with a promise about the keys: k_norm_bound >= the Euclidean norm of every Kp row (as stored: normed, scaled
  * by log2(e) / sqrt(72)).  For an RMS-normed key that is sqrt(72) max|k_norm.weight| log2(e) / sqrt(72) (1 + rounding), a property
  * of the WEIGHTS (normalization.py:28-33): the caller computes it once per block.  By Cauchy-Schwarz m_i = |q_i| k_norm_bound bounds
@@ -440,7 +453,8 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
 #define VSYS_OP_GEMM_BF16_GATE_RES_ADD 27
 #define VSYS_OP_FLASH_ATTN_D72_KB   28
 #define VSYS_OP_FLASH_ATTN_D64_KB   29
-#define VSYS_OP_COUNT              30
+#define VSYS_OP_FLASH_ATTN_D72_EXACT 30
+#define VSYS_OP_COUNT              31
 
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */

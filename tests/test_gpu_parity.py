@@ -323,11 +323,11 @@ def test_cfg_euler_and_add(ops):
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def _run_flash(ops, q2d, k2d, v2d, qw, kw_, batch, heads, q_len, kv_len, k_norm_bound=None):
+def _run_flash(ops, q2d, k2d, v2d, qw, kw_, batch, heads, q_len, kv_len, k_norm_bound=None, keys_exact=False):
     kp, vt = ops.alloc_kv_buffers(batch, heads, kv_len, dev())
     ops.attn_prep_kv(k2d, v2d, kw_, kp, vt, batch, heads, kv_len)
     out = torch.full((batch * q_len, heads * 72), float("nan"), dtype=torch.bfloat16, device=dev())
-    ops.flash_attn(q2d, qw, kp, vt, out, batch, heads, q_len, kv_len, k_norm_bound=k_norm_bound)
+    ops.flash_attn(q2d, qw, kp, vt, out, batch, heads, q_len, kv_len, k_norm_bound=k_norm_bound, keys_exact=keys_exact)
     return out
 
 
@@ -452,6 +452,49 @@ def test_flash_resident_matches_streaming_and_torch(ops, q_len, kv_len, heads, b
             ref = O.sdpa(qq.float()[None], kk.float()[None], vv[None])[0]
             # P and the output are bf16: 2^-6 of max|ref| over up to 280 (batch, head) slices (the two kernels agree bit for bit)
             check(res[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"flash b{bi} h{h}")
+
+
+@pytest.mark.parametrize("q_len,kv_len,heads,batch,qscale,mode", [
+    (19456, 300, 16, 2, 1.0, "typical"),    # the cross attention of config 2 (text K / V prepared for exactly 300 keys)
+    (2000, 300, 16, 2, 0.3, "typical"),     # small logits: the padding keys' logit 0 is inside the real range
+    (1500, 120, 40, 7, 1.0, "typical"),     # two tiles, 56 padding keys in the second
+    (1024, 44, 16, 2, 1.0, "typical"),      # ONE tile: the padding keys take part in the first tile's max adoption
+    (1500, 320, 16, 2, 1.0, "typical"),     # whole tiles: the promise changes nothing
+    (2000, 300, 16, 2, 1.0, "all_far_negative"),   # every real logit ~ -300 (exp2 domain): the guard recomputes with the mask
+])
+def test_flash_keys_exact_promise(ops, q_len, kv_len, heads, batch, qscale, mode):
+    """vsys_flash_attn_d72_exact (K / Vt prepared for exactly kv_len on zeroed buffers: no mask on the ragged last tile of the
+    resident-K/V kernel) against the masked kernel and torch fp32.  Whole tiles: same bits.  Ragged: the same tolerance against
+    fp32, and the same bits wherever no padding key raises a tile's max past the rescale threshold (typical logits); rows whose real
+    logits all lie far below the padding keys' 0 are recomputed with the mask (same bits as the masked kernel)."""
+    C = heads * 72
+    g = torch.Generator().manual_seed(q_len + kv_len)
+    q = (torch.randn(batch * q_len, C, generator=g) * qscale).to(torch.bfloat16)
+    k = (torch.randn(batch * kv_len, C, generator=g) * qscale).to(torch.bfloat16)
+    if mode == "all_far_negative":     # q = u + noise, k = -u + noise with |u|^2 / sqrt(72) * log2(e) ~ 300
+        u = torch.randn(1, 72, generator=g)
+        u = u / u.norm() * (300.0 * 72 ** 0.5 / 1.4427) ** 0.5
+        q = (u.repeat(1, heads) + 0.1 * torch.randn(batch * q_len, C, generator=g)).to(torch.bfloat16)
+        k = (-u.repeat(1, heads) + 0.1 * torch.randn(batch * kv_len, C, generator=g)).to(torch.bfloat16)
+    v = torch.randn(batch * kv_len, C, generator=g).to(torch.bfloat16)
+    q, k, v = q.to(dev()), k.to(dev()), v.to(dev())
+    base = _run_flash(ops, q, k, v, None, None, batch, heads, q_len, kv_len)
+    res = _run_flash(ops, q, k, v, None, None, batch, heads, q_len, kv_len, keys_exact=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(res.float()).all()
+    if kv_len % 64 == 0 or mode == "all_far_negative":
+        assert torch.equal(res, base), float((res.float() - base.float()).abs().max())
+    else:
+        differing = (res != base).float().mean().item()
+        assert differing <= (0.25 if kv_len < 64 or qscale < 1.0 else 1e-3), differing    # (a different rounding scale of P where a padding key raised a max)
+    for bi in range(0, batch, max(1, batch - 1)):
+        for h in range(0, heads, max(1, heads - 1)):
+            sl = slice(bi * q_len, bi * q_len + min(q_len, 2048))
+            qq = q[sl, h * 72:(h + 1) * 72].float()
+            kk = k[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72].float()
+            vv = v[bi * kv_len:(bi + 1) * kv_len, h * 72:(h + 1) * 72].float()
+            ref = O.sdpa(qq[None], kk[None], vv[None])[0]
+            check(res[sl, h * 72:(h + 1) * 72], ref, tol=2.0 ** -6, what=f"exact-keys flash b{bi} h{h}")
 
 
 @pytest.mark.parametrize("q_len,kv_len,heads,batch,norm,qscale", [

@@ -162,9 +162,11 @@ class FakeOps:
         assert q_norm_w.shape == k_norm_w.shape == (head_dim,)
         return 1.5
 
-    def flash_attn(self, q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6, k_norm_bound=None):
+    def flash_attn(self, q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6, k_norm_bound=None, keys_exact=False):
         self._n("flash_attn")
         assert k_norm_bound is None or q_norm_w is not None
+        # the padding promise is only ever given for the hoisted text K / V (no q norm), prepared for exactly kv_len keys
+        assert not keys_exact or (q_norm_w is None and kp.shape[2] == -(-kv_len // 64) * 64)
         assert q.shape[0] == out.shape[0] == batch * q_len and kp.shape[0] == batch and kp.shape[2] >= kv_len, (q.shape, batch, q_len, kp.shape)
         return out
 

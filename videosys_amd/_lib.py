@@ -43,6 +43,7 @@ SIGNATURES = {
     "vsys_copy_4d": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "vsys_attn_prep_kv": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _f32, _ptr],
     "vsys_flash_attn_d72": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
+    "vsys_flash_attn_d72_exact": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
     "vsys_flash_attn_d72_kb": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _f32, _ptr],
     "vsys_gemm_bf16_gate2": [_ptr, _i64, _ptr, _i64, _ptr, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64, _i64, _i64, _i64, _ptr, _i64,
                              _ptr, _i64, _ptr],

@@ -156,7 +156,13 @@ struct FlashParams {
 // (DESIGN.md §3.2), which for 5-tile problems is most of the per-tile overhead.  Same tile() code, same arithmetic, same bits.
 constexpr int RES_MAX_TILES = 5;
 constexpr int RES_Q_BYTES = 5 * 1024;   // per-wave Q image (32 rows x 144 B = 4.5 KiB, staged in 5 LDS-DMA pieces)
-template <int ABL, int WPS, bool RES = false>
+// EXACT (RES only; vsys_flash_attn_d72_exact): the caller promises that the Kp rows and Vt columns behind kv_len are the zeros
+// attn_prep_kv wrote for exactly this kv_len.  A padding key then has logit 0 and weight 0 in numerator AND denominator (its Vt
+// column is zero in the ones rows too), so the ragged last tile needs no mask: the mask code (64 compare / select pairs per query
+// block of five tiles) is compiled out.  The only thing a padding key still touches is the running max (it sees the logit 0); that is
+// harmless unless EVERY real logit of a row lies ~100 (exp2 domain) below zero — the block's denominator then underflows, which is
+// detected per block and answered by recomputing that block with the masked tile sequence (cold path, same bits as the masked kernel).
+template <int ABL, int WPS, bool RES = false, bool EXACT = false>
 __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72_kernel(FlashParams p) {
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
     const int qb0 = (int)((int64_t)qb * nqb / p.chunks), qb1 = (int)((int64_t)(qb + 1) * nqb / p.chunks);
     // (The mask of a ragged last tile stays: kv_len may be SHORTER than what the K / Vt buffers were prepared for — Latte's per-sample
     // text lengths inside one buffer, test_flash_attn_short_key_length_inside_a_longer_buffer — so the keys behind it are not zero.)
-    const bool ragged = (p.kv_len & 63) != 0;
+    const bool ragged = !EXACT && (p.kv_len & 63) != 0;
     // The Q rows of query block i + 1 travel HBM -> LDS (wave-private 5 KiB image: 32 rows x 144 B, contiguous 16-byte units) by
     // LDS-DMA under the tiles of block i: a register prefetch (20 VGPRs) makes hipcc spill inside tile(), and without a prefetch
     // the global round trip (~2 us) is exposed once per five tiles.
@@ -610,6 +616,14 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
           step(std::false_type{}, t, sa, sb, false);
         }
 #undef RES_SGB
+      }
+      if constexpr (EXACT) {
+        // (see the template comment) a row whose real logits all sit ~100 below the padding keys' 0: recompute the block masked
+        if (__builtin_amdgcn_ballot_w64(!(o[2][4] >= 0x1p-100f)) != 0) {
+          asm volatile("; exact-keys guard (cold): masked recompute of this query block" ::: "memory");
+          reset_acc();
+          for (int t = 0; t < ntiles; ++t) tile(t, t, t == ntiles - 1 && (p.kv_len & 63) != 0);
+        }
       }
       store_o();
     }
@@ -965,7 +979,7 @@ int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int6
 
 int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt,
                           bf16_t* out, int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad,
-                          float eps, float k_bound, hipStream_t stream) {
+                          float eps, float k_bound, hipStream_t stream, bool keys_exact) {
   if (batch <= 0 || heads <= 0 || q_len <= 0) return 0;
   if (kv_len <= 0 || kv_pad % 64 != 0 || kv_pad < kv_len || (q_stride % 8) || (out_stride % 4)) return VSYS_ERR_SHAPE;
   FlashParams p;
@@ -991,9 +1005,16 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
       p.chunks = chunks;
       p.nqb = nqb;
       static std::atomic<unsigned long long> attr_seen{0};
-      for (DeviceOnce once(attr_seen); once.todo(); once.done())
+      for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
         (void)hipFuncSetAttribute((const void*)flash_attn_d72_kernel<0, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES);
-      hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES, stream, p);
+        (void)hipFuncSetAttribute((const void*)flash_attn_d72_kernel<0, 2, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES);
+      }
+      // the caller's promise about the keys behind kv_len (vsys_flash_attn_d72_exact) only matters for a ragged count; VSYS_FLASH_EXACT=0 ignores it
+      static const bool exact_ok = [] { const char* e = getenv("VSYS_FLASH_EXACT"); return !(e && e[0] == '0'); }();
+      if (keys_exact && exact_ok && (kv_len & 63) != 0)
+        hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES, stream, p);
+      else
+        hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2, true>), dim3((unsigned)(chunks * batch * heads)), dim3(512), RES_MAX_TILES * KV_STAGE + 8 * RES_Q_BYTES, stream, p);
       return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
     }
   }

@@ -362,6 +362,17 @@ int vsys_flash_attn_d72(const void* q, int64_t q_stride, const void* q_norm_w, c
                                (int)heads, (int)q_len, (int)kv_len, (int)kv_pad, eps, 0.f, S(stream));
 }
 
+int vsys_flash_attn_d72_exact(const void* q, int64_t q_stride, const void* q_norm_w, const void* kp, const void* vt, void* out,
+                              int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
+                              float eps, void* stream) {
+  if (!q || !kp || !vt || !out) return VSYS_ERR_ARG;
+  if (!fits_int(batch) || !fits_int(heads) || !fits_int(q_len) || !fits_int(kv_len) || !fits_int(kv_pad) ||
+      batch * heads > 65535)
+    return VSYS_ERR_SHAPE;
+  return launch_flash_attn_d72(B16(q), q_stride, B16(q_norm_w), B16(kp), B16(vt), B16(out), out_stride, (int)batch,
+                               (int)heads, (int)q_len, (int)kv_len, (int)kv_pad, eps, 0.f, S(stream), true);
+}
+
 int vsys_flash_attn_d72_kb(const void* q, int64_t q_stride, const void* q_norm_w, const void* kp, const void* vt, void* out,
                            int64_t out_stride, int64_t batch, int64_t heads, int64_t q_len, int64_t kv_len, int64_t kv_pad,
                            float eps, float k_norm_bound, void* stream) {

@@ -38,6 +38,7 @@ constexpr OpInfo kOps[VSYS_OP_COUNT] = {
     {20, 0},  // GEMM_BF16_GATE_RES_ADD
     {12, 2},  // FLASH_ATTN_D72_KB
     {17, 2},  // FLASH_ATTN_D64_KB
+    {12, 1},  // FLASH_ATTN_D72_EXACT
 };
 }  // namespace
 
@@ -132,6 +133,9 @@ int vsys_program_run(const vsys_cmd* cmds, int64_t n, void* const* streams, int6
         case VSYS_OP_FLASH_ATTN_D64_KB:
           rc = vsys_flash_attn_d64_kb(CP(0), I(1), CP(2), CP(3), CP(4), CP(5), I(6), I(7), CP(8), CP(9), P(10), I(11), I(12), I(13), I(14),
                                       I(15), I(16), c.f[0], c.f[1], st);
+          break;
+        case VSYS_OP_FLASH_ATTN_D72_EXACT:
+          rc = vsys_flash_attn_d72_exact(CP(0), I(1), CP(2), CP(3), CP(4), P(5), I(6), I(7), I(8), I(9), I(10), I(11), c.f[0], st);
           break;
         case VSYS_OP_FLASH_ATTN_D72_KB:
           rc = vsys_flash_attn_d72_kb(CP(0), I(1), CP(2), CP(3), CP(4), P(5), I(6), I(7), I(8), I(9), I(10), I(11), c.f[0], c.f[1], st);

@@ -193,7 +193,8 @@ int launch_attn_prep_kv(const bf16_t* k, int64_t k_stride, const bf16_t* v, int6
                         hipStream_t stream);
 int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt,
                           bf16_t* out, int64_t out_stride, int batch, int heads, int q_len, int kv_len, int kv_pad,
-                          float eps, float k_bound, hipStream_t stream);   // k_bound: see FlashW64Params::k_bound (0 = none)
+                          float eps, float k_bound, hipStream_t stream,    // k_bound: see FlashW64Params::k_bound (0 = none)
+                          bool keys_exact = false);   // the caller's promise of vsys_flash_attn_d72_exact (attention.hip, EXACT)
 // 64 query rows per wave, one wave per SIMD, hand-allocated tile loop (attention_w64.hip); same contract as launch_flash_attn_d72
 bool flash_w64_supports(int q_len, int kv_len, int kv_pad);
 int launch_flash_attn_d72_w64(const bf16_t* q, int64_t q_stride, const bf16_t* q_norm_w, const bf16_t* kp, const bf16_t* vt, bf16_t* out,

@@ -358,14 +358,19 @@ def attn_prep_kv(k, v, k_norm_w, kp, vt, batch, heads, kv_len, eps=1e-6):
                                      kv_len, kv_pad, eps)
 
 
-def flash_attn(q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6, k_norm_bound=None):
+def flash_attn(q, q_norm_w, kp, vt, out, batch, heads, q_len, kv_len, eps=1e-6, k_norm_bound=None, keys_exact=False):
     """q/out: 2-D row-strided views [batch*q_len, >= heads*72].  ``k_norm_bound``: the caller's promise about the norms of the Kp
-    rows (include/videosys_amd.h, vsys_flash_attn_d72_kb; see rms_key_bound); None = no promise."""
+    rows (include/videosys_amd.h, vsys_flash_attn_d72_kb; see rms_key_bound); None = no promise.  ``keys_exact``: the caller's promise
+    that (kp, vt) were prepared by attn_prep_kv for exactly ``kv_len`` on zeroed buffers (vsys_flash_attn_d72_exact: no mask on the
+    ragged last tile) — never with a kv_len shorter than the buffers were prepared for."""
     _chk(q, q_norm_w, kp, vt, out)
     _bf16(q, q_norm_w, kp, vt, out)
     assert q.stride(1) == 1 and out.stride(1) == 1
     kv_pad = kp.shape[2]
-    if k_norm_bound:
+    if keys_exact and not k_norm_bound:
+        _call("vsys_flash_attn_d72_exact", _p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
+              q_len, kv_len, kv_pad, eps)
+    elif k_norm_bound:
         _call("vsys_flash_attn_d72_kb", _p(q), q.stride(0), _p(q_norm_w), _p(kp), _p(vt), _p(out), out.stride(0), batch, heads,
               q_len, kv_len, kv_pad, eps, float(k_norm_bound))
     else:

@@ -778,7 +778,8 @@ class STDiT3:
         else:
             q = ops.gemm(x, w[p + ".cross_attn.q_linear.weight"], w[p + ".cross_attn.q_linear.bias"], out=_buf("xm", (N, C)))
             ao = _buf("attn_out", (N, C))
-            ops.flash_attn(q, None, txt["kp"][i], txt["vt"][i], ao, B, H, T * S, txt["Lk"])
+            # (the hoisted text K / V were prepared for exactly Lk keys on zeroed buffers, _text_kv: the padding promise holds)
+            ops.flash_attn(q, None, txt["kp"][i], txt["vt"][i], ao, B, H, T * S, txt["Lk"], keys_exact=True)
             aux = None
             if use_pab and keep_cross:
                 st.last_cross = slab(st.last_cross)
