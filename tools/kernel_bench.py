@@ -132,6 +132,11 @@ def main():
             ms = timeit(lambda: ops.flash_attn(x, None, kpc, vtc, ao, 2, H, 19456, 300), args.reps)
             res.setdefault("flash_cross_L300" + (f"_v{fv}" if fv else ""), []).append((ms, 4.0 * 2 * H * 19456 * 300 * 72 / (ms * 1e-3) / 1e12))
     lib.vsys_tune_flash_variant(0)
+    # the padding promise (vsys_flash_attn_d72_exact: no mask on the ragged last tile of the resident-K/V kernel) against the masked kernel
+    for rd in range(0 if os.environ.get("VSYS_KB_SPATIAL_ONLY") else args.rounds):
+        for tag, ex in (("masked", False), ("exact", True)):
+            ms = timeit(lambda: ops.flash_attn(x, None, kpc, vtc, ao, 2, H, 19456, 300, keys_exact=ex), args.reps)
+            res.setdefault("flash_cross_L300_" + tag, []).append((ms, 4.0 * 2 * H * 19456 * 300 * 72 / (ms * 1e-3) / 1e12))
     # every flash variant must give the default's bits (they differ in schedule only)
     ref_s, ref_c = torch.empty_like(ao), torch.empty_like(ao)
     ops.flash_attn(qkv[:, :C], qw, kp, vt, ref_s, 38, H, 1024, 1024)
