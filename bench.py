@@ -375,7 +375,7 @@ def main():
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             vae_s = float(tt.item())
             vae = {"sec_per_video": round(vae_s, 4), "output": list(vid.shape), "sharded_over_ranks": world,
-                   "frames_per_rank": -(-frames // world), "gathered": "uint8 [B, F, H, W, 3], one all-gather",
+                   "frames_per_rank": [b_ - a_ for a_, b_ in dec.frame_shards(frames, world)], "gathered": "uint8 [B, F, H, W, 3], one all-gather",
                    "videos_per_min_dit_plus_vae": round(60.0 / (STEPS_PER_VIDEO * step_s + vae_s), 4)}
             del dec, vid
         except Exception as e:

@@ -306,6 +306,34 @@ int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const
  * src_off, dst_off, n0, n1, n2, run, ss0, ss1, ss2, ds0, ds1, ds2, n1_valid, n2_valid (elements; run % 8 == 0). */
 int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* desc, void* stream);
 
+/* The whole layout switch of Dynamic Sequence Parallelism in ONE launch per rank, peer to peer over xGMI (comm.py:104-141 _all_to_all_func
+ * and :282-304 all_to_all_with_pad around open_sora_transformer_3d.py:288-315 dynamic_switch; replaces pack + all_to_all_single + unpack).
+ * Problem i of the batch copies rows of ``src`` straight into the DESTINATION tensor of peer i in its final layout: desc (HOST) holds
+ * nops x 16 int64 — the 14 of vsys_copy_4d_batch (dst_off relative to the problem's own destination), then the destination base
+ * address (this process's mapping of the peer's tensor: vsys_p2p_ipc_open, or a plain device pointer inside one process) and the
+ * address of flag[self_index] in that peer's flag array (0 for the rank's own problem).  After its stores are fenced a problem
+ * release-stores the exchange's sequence number into the peer's flag; the launch ends when every flag q != self_index of
+ * ``my_flags`` (n_flags x uint32, fine-grained memory: vsys_p2p_alloc) has reached that number, i.e. when this rank's own destination
+ * is complete: the consumer is simply the next launch on ``stream``.  ``state``: 32 x uint32 of zeroed device memory private to this
+ * exchange site — [0] the sequence number (advanced by the kernel itself, so a recorded launch program replays unchanged), [31] an
+ * error word (0; 1 + q when peer q's flag did not arrive within ``timeout_ticks`` of the 100 MHz wall clock; sticky: a site that timed
+ * out once no longer waits; timeout_ticks 0 = wait for ever, < 0 = do not wait at all: the caller orders the peers' launches itself).
+ * Every rank of the group must issue the same sequence of exchanges per site. */
+int vsys_p2p_exchange(const void* src, int64_t nops, const int64_t* desc, const void* my_flags, int64_t n_flags, int64_t self_index,
+                      void* state, int64_t timeout_ticks, void* stream);
+/* Set-up of vsys_p2p_exchange (host side, synchronous, never inside a step; no reference counterpart: the reference's exchange is
+ * torch.distributed over NCCL, comm.py:104-141).  Zeroed device memory — fine-grained (flags: polled inside a running kernel while a
+ * peer stores to them) or ordinary. */
+int vsys_p2p_alloc(int64_t bytes, int64_t fine_grained, void** ptr);
+/* Release of vsys_p2p_alloc memory (no reference counterpart). */
+int vsys_p2p_free(void* ptr);
+/* The 64-byte HIP IPC handle of a vsys_p2p_alloc allocation, for the other rank processes (no reference counterpart). */
+int vsys_p2p_ipc_export(const void* ptr, void* handle64);
+/* Mapping of a peer process's handle into this process: a device pointer valid here (no reference counterpart). */
+int vsys_p2p_ipc_open(const void* handle64, void** ptr);
+/* Unmapping of vsys_p2p_ipc_open (no reference counterpart). */
+int vsys_p2p_ipc_close(void* ptr);
+
 /* ---- T5 text encoder (T5EncoderModel of transformers, third-party; called once per prompt at pipeline_open_sora.py:269-287,
  * pipeline_cogvideox.py:211-247, pipeline_latte.py) — the linears are vsys_conv_bf16 with one tap. */
 /* out[i, :] = table[ids[i], :] (nn.Embedding = T5Stack.embed_tokens, transformers, third-party; ids int64 on the device, clamped
@@ -454,7 +482,8 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
 #define VSYS_OP_FLASH_ATTN_D72_KB   28
 #define VSYS_OP_FLASH_ATTN_D64_KB   29
 #define VSYS_OP_FLASH_ATTN_D72_EXACT 30
-#define VSYS_OP_COUNT              31
+#define VSYS_OP_P2P_EXCHANGE       31
+#define VSYS_OP_COUNT              32
 
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */

@@ -19,12 +19,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _stdit3_worker(rank, world, port, outdir, T, HW):
+def _stdit3_worker(rank, world, port, outdir, T, HW, p2p=False):
     import traceback
 
     import torch.distributed as dist
 
     try:
+        if p2p:     # the one-kernel exchange between PROCESSES: tensors and flags mapped through HIP IPC, flags polled on the device
+            os.environ["VSYS_DSP_P2P"] = "1"
+            os.environ["VSYS_P2P_TIMEOUT_S"] = "5"
         from oracle import stdit3_oracle as O
         from videosys_amd import dsp
         from videosys_amd.stdit3 import STDiT3, STDiT3Config
@@ -67,6 +70,10 @@ def _stdit3_worker(rank, world, port, outdir, T, HW):
         model._switch = "auto"
         torch.cuda.synchronize()
         assert torch.equal(out6, ref_full), "qkv-first exchange (the folded qkv GEMM runs at rest: the single-GPU arithmetic)"
+        p2p_launches = 0
+        if model._sp is not None and model._sp.p2p is not None:
+            model._sp.p2p.check()          # no exchange timed out waiting for the other process
+            p2p_launches = model._sp.p2p.launches
         # enable_cp: the CFG pair split over the two ranks (cp = 2, sp = 1), outputs gathered along the batch
         model.enable_parallel(1, world, True)
         assert model.parallel_manager.cp_size == 2 and model.parallel_manager.sp_size == 1 and model._sp is None
@@ -74,6 +81,8 @@ def _stdit3_worker(rank, world, port, outdir, T, HW):
         torch.cuda.synchronize()
         ok = (torch.equal(out, ref) and torch.equal(out, out2) and torch.equal(out3, ref) and torch.equal(out4, ref)
               and torch.equal(out5, ref_full))
+        if p2p:
+            assert p2p_launches > 0, "VSYS_DSP_P2P=1 did not take the peer-to-peer path"
         err = (out - ref).abs().max().item()
         with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
             f.write("ok" if ok else f"mismatch max|diff| {err} of {ref.abs().max().item()}")
@@ -212,6 +221,15 @@ def test_stdit3_dsp_two_ranks_equals_single(T, HW):
     _run(_stdit3_worker, (T, HW))
 
 
+@pytest.mark.parametrize("T,HW", [(5, 16), (4, 12)])
+def test_stdit3_dsp_two_processes_peer_to_peer_over_ipc(T, HW):
+    """The one-kernel peer-to-peer exchange between two PROCESSES sharing the test box's GPU (VSYS_DSP_P2P=1): destination tensors
+    mapped through torch's CUDA IPC, flag arrays through vsys_p2p_ipc_export / _open, sequence flags polled inside the kernel —
+    the path a rank per GPU takes over xGMI.  Same assertions as the RCCL-shaped test above: every layout bit-identical to the
+    single-process output (comm.py:104-141,282-304; open_sora_transformer_3d.py:288-315)."""
+    _run(_stdit3_worker, (T, HW, True))
+
+
 def test_bench_two_ranks_dry_run():
     """bench.py's N > 1 path (rank-0 build, barriers, DSP model, max-over-ranks timing, one JSON line from rank 0), launched the
     way the driver launches it, with both ranks on the one GPU of the test box over gloo (VSYS_BENCH_ONE_GPU=1), depth 2."""
@@ -258,7 +276,7 @@ def test_bench_plain_form_launches_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
     v = j["vae_decode"]      # N > 1: the decode is sharded by output frame and gathered once
-    assert v.get("sharded_over_ranks") == 2 and v["frames_per_rank"] == 32 and v["output"] == [1, 64, 512, 512, 3], v
+    assert v.get("sharded_over_ranks") == 2 and v["frames_per_rank"] == [32, 32] and v["output"] == [1, 64, 512, 512, 3], v
 
 
 def test_batched_copy_executor_matches_plan_semantics():
@@ -335,8 +353,10 @@ def test_dsp_eight_ranks_in_process_equals_single_and_oracle(frames, hl, wl):
     single.fold_spatial_qkv = True
     torch.cuda.synchronize()
 
-    variants = [("flat", "activations", True), ("flat", "activations", False), ("sample", "activations", True),
-                ("sample", "activations", False), ("flat", "qkv", False), ("sample", "qkv", False)]
+    # (scatter, what travels, overlap, one-kernel peer-to-peer exchange or pack + all_to_all_single + unpack)
+    variants = [("flat", "activations", True, True), ("flat", "activations", False, True), ("sample", "activations", True, True),
+                ("sample", "activations", False, True), ("flat", "qkv", False, True), ("sample", "qkv", False, True),
+                ("flat", "activations", True, False), ("sample", "activations", False, False)]
     world = LocalWorld(P, timeout=300)
 
     def rank_fn(r, group):
@@ -344,14 +364,21 @@ def test_dsp_eight_ranks_in_process_equals_single_and_oracle(frames, hl, wl):
         m = STDiT3(STDiT3Config(depth=depth), device="cuda:0")
         m.load_state_dict(sd)
         res = []
-        for scatter, order, overlap in variants:
+        for scatter, order, overlap, p2p in variants:
             m.enable_parallel(parallel_mgr=_rank_manager(group, P, r), overlap=overlap)
             m._scatter, m._switch = scatter, order
             assert m._overlap == overlap
+            assert m._sp.p2p is not None      # in-process groups run the one-kernel exchange (vsys_p2p_exchange) by default
+            if not p2p:
+                m._sp.p2p = None
+            before = 0 if m._sp.p2p is None else m._sp.p2p.launches
             out = m(x, t, yy, **kw)        # recorded (launch program, program.py) ...
             out2 = m(x, t, yy, **kw)       # ... and replayed: collectives and cross-stream events re-issued from the log
             torch.cuda.synchronize()
             assert m.program_stats["replayed"] >= 1
+            if p2p:
+                assert m._sp.p2p.launches > before
+                m._sp.p2p.check()
             want = out_single if order == "qkv" else out_single_act
             res.append(bool(torch.equal(out, want)) and bool(torch.equal(out2, want)))
         S_full = (Hl // 2) * (Wl // 2)

@@ -1521,3 +1521,68 @@ def test_bench_plain_form_starts_its_own_ranks(monkeypatch):
         with pytest.raises(AssertionError, match="needs MI355X"):
             bench.main()
         assert not seen
+
+
+@pytest.mark.parametrize("B,T,S,P,chunks", [(2, 5, 12, 4, False), (1, 38, 36, 8, False), (2, 19, 10, 4, True), (1, 10, 7, 8, True),
+                                            (2, 3, 9, 2, False)])
+def test_p2p_plans_equal_pack_exchange_unpack(B, T, S, P, chunks):
+    """The one-kernel peer-to-peer exchange (dsp.plan_p2p_to_*: one copy per peer, straight from the source tensor into the peer's
+    destination tensor) moves exactly the elements of pack -> all_to_all_single -> unpack (plan_switch_to_*), for padded frames
+    (T % P != 0), padded columns (S % P != 0: the last rank's shard is part padding, or all of it), and chunked switches.  Every
+    destination starts as a sentinel: both paths must write the same positions with the same values (all_to_all_with_pad,
+    comm.py:282-304)."""
+    from videosys_amd import dsp
+
+    C = 8
+    Sl = (S + (P - S % P) % P) // P
+    Tp = (T + (P - T % P) % P) // P
+    g = torch.Generator().manual_seed(B * 100 + T * 10 + S + P)
+    xs = [torch.randn(B, T, Sl, C, generator=g) for _ in range(P)]                       # every rank's S-shard at rest
+    cks = [None] if not chunks else [(0, -(-Tp // 2)), (-(-Tp // 2), Tp)] if Tp >= 2 else [None]
+    for ck in cks:
+        # ---- to the temporal shard
+        packs, recvs = [], []
+        for r in range(P):
+            pack, unpack, sshape, oshape = dsp.plan_switch_to_temporal_shard(B, T, Sl, S, C, P, ck)
+            send = torch.full(sshape, 5.0)
+            torch_copy_executor(xs[r], send, pack)
+            packs.append(send)
+        ref = []
+        for r in range(P):
+            recv = torch.stack([packs[src][r] for src in range(P)], 0)
+            out = torch.full(oshape, 7.0)
+            torch_copy_executor(recv, out, unpack)
+            ref.append(out)
+        got = [torch.full(oshape, 7.0) for _ in range(P)]
+        for me in range(P):
+            ops, osh = dsp.plan_p2p_to_temporal_shard(B, T, Sl, S, C, P, me, ck)
+            assert osh == oshape and len(ops) == P
+            for r, o in enumerate(ops):
+                if o is not None:
+                    torch_copy_executor(xs[me], got[r], [o])
+        for r in range(P):
+            assert torch.equal(got[r], ref[r]), ("to_temporal", r, ck)
+        # ---- and back: every rank's [B, Tc, S, C] into the frames of the S-shards
+        Tc = oshape[1]
+        ys = [torch.randn(B, Tc, S, C, generator=g) for _ in range(P)]
+        packs = []
+        for r in range(P):
+            pack, unpack_r, sshape, oshape2 = dsp.plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, P, ck)
+            send = torch.full(sshape, 5.0)
+            torch_copy_executor(ys[r], send, pack)
+            packs.append(send)
+        ref = []
+        for r in range(P):
+            recv = torch.stack([packs[src][r] for src in range(P)], 0)
+            out = torch.full(oshape2, 7.0)
+            torch_copy_executor(recv, out, unpack_r)
+            ref.append(out)
+        got = [torch.full(oshape2, 7.0) for _ in range(P)]
+        for me in range(P):
+            ops, osh = dsp.plan_p2p_to_spatial_shard(B, Tp, T, S, Sl, C, P, me, ck)
+            assert osh == oshape2
+            for r, o in enumerate(ops):
+                if o is not None:
+                    torch_copy_executor(ys[me], got[r], [o])
+        for r in range(P):
+            assert torch.equal(got[r], ref[r]), ("to_spatial", r, ck)

@@ -193,10 +193,11 @@ def test_decode_frame_ranges_and_rank_shards_equal_the_full_decode():
     range equals the slice of the full decode, every rank of 2 / 3 / 8 returns the full video (22 and 64 frames: 17-frame chunks)."""
     from tools.local_group import LocalWorld
     from vae_cpu_emul import cpu_vae
-    from videosys_amd.vae_open_sora import OpenSoraVAE, pixels_to_uint8, synth_state_dict
+    from videosys_amd.vae_open_sora import pixels_to_uint8, synth_state_dict
 
     vae = cpu_vae(synth_state_dict(7), encoder=False)
     vae.frames_per_launch = 3
+    assert vae.frame_shards(64, 8) == [(0, 9), (9, 17), (17, 26), (26, 34), (34, 43), (43, 51), (51, 58), (58, 64)]
     _fake_decoders(vae)
     g = torch.Generator().manual_seed(3)
     for frames, tz in ((22, 7), (64, 19), (17, 5)):
@@ -210,8 +211,11 @@ def test_decode_frame_ranges_and_rank_shards_equal_the_full_decode():
             vae.decode(z, frames, frames=(2, frames + 1))
         want = pixels_to_uint8(full)
         for P in (2, 3, 8):
-            shards = [OpenSoraVAE.frame_shard(frames, P, r) for r in range(P)]
+            shards = vae.frame_shards(frames, P)
             assert shards[0][0] == 0 and shards[-1][1] == frames and all(a[1] == b[0] for a, b in zip(shards, shards[1:]))
+            assert shards == [vae.frame_shard(frames, P, r) for r in range(P)]
+            if P >= -(-frames // 17):      # as many ranks as 17-frame chunks: no rank's block crosses a chunk border
+                assert all(a // 17 == (b - 1) // 17 for a, b in shards if b > a), shards
             outs = LocalWorld(P, timeout=60).run(lambda r, grp: vae.decode_sharded(z, frames, grp))
             for o in outs:
                 assert o.dtype == torch.uint8 and torch.equal(o, want), (frames, P)

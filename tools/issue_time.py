@@ -89,7 +89,10 @@ def main():
 
             rec.update(dsp_rank=args.dsp_rank, rank=args.rank, scatter=model._scatter, overlap=model._overlap,
                        frames_on_this_rank_padded=dsp.frames_per_rank(2, T, args.dsp_rank, model._scatter),
-                       ideal_frames=round(2 * T / args.dsp_rank, 3), wire="stubbed (device copy recv <- send)")
+                       ideal_frames=round(2 * T / args.dsp_rank, 3),
+                       exchange=("one-kernel peer-to-peer (vsys_p2p_exchange; every peer folded onto this rank: the same bytes, the same "
+                                 "flag traffic)" if model._sp is not None and model._sp.p2p is not None
+                                 else "pack + all_to_all_single + unpack, wire stubbed (device copy recv <- send)"))
         if hasattr(model, "use_programs"):
             rec["launch_program"] = bool(model.use_programs) and not args.x_mask
         if args.x_mask:

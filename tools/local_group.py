@@ -83,6 +83,30 @@ class LocalGroup:
                     cur.wait_event(w.done[r])            # my send buffer may be rewritten only after every reader is through
         w.barrier.wait()                                 # (and the slots may be reused by the next collective)
 
+    def all_gather_object(self, obj):
+        """Set-up rendezvous of the peer-to-peer exchange (dsp.PeerExchange): every rank's object, in rank order.  One address space,
+        so tensors and device addresses are handed over as they are."""
+        w = self.world
+        w.send[self.rank] = (obj, None)
+        w.barrier.wait()
+        out = [o for o, _ in w.send]
+        w.barrier.wait()
+        return out
+
+    def p2p_sync(self):
+        """After this rank enqueued its one-kernel exchange launch (dsp.PeerExchange): order EVERY rank's launch of the same exchange
+        in front of whatever this rank enqueues next — what the kernel's own flag wait does between processes."""
+        w = self.world
+        ev = torch.cuda.Event()
+        ev.record()
+        w.send[self.rank] = (None, ev)
+        w.barrier.wait()
+        cur = torch.cuda.current_stream()
+        for src in range(w.P):
+            if src != self.rank:
+                cur.wait_event(w.send[src][1])
+        w.barrier.wait()
+
     def all_to_all_single(self, recv, send):
         P, r = self.size, self.rank
         rv = recv.view(P, -1)
@@ -99,6 +123,20 @@ class StubGroup:
 
     def __init__(self, P: int, rank: int = 0):
         self.size, self.rank = P, rank
+
+    def all_gather_object(self, obj):
+        return [obj] * self.size      # every "peer" is this rank: the one-kernel exchange writes the same bytes into its own tensors
+
+    def share_flags(self, n):
+        """Flag array of the one-kernel exchange with every peer folded onto this rank: the flag "of this rank in peer r's array" is
+        slot r of this rank's own array, so the launch's wait sees P - 1 arrivals exactly as on a real group."""
+        import ctypes
+
+        from videosys_amd import _lib
+
+        mine = ctypes.c_void_p()
+        _lib.check(_lib.load().vsys_p2p_alloc(4 * n, 1, ctypes.byref(mine)), "vsys_p2p_alloc")
+        return mine.value, [mine.value + 4 * (r - self.rank) for r in range(self.size)]
 
     def all_to_all_single(self, recv, send):
         recv.copy_(send)

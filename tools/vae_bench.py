@@ -83,7 +83,7 @@ def main():
         torch.cuda.synchronize(); whole = time.perf_counter() - t0
         print(json.dumps({"workload": f"OpenSoraVAE.decode_sharded latent [1,4,{Tz},{args.hw},{args.hw}] -> {args.frames} frames, "
                                       f"P = {args.shard}, wire stubbed", "sec_per_rank": per_rank, "slowest_rank_s": max(per_rank),
-                          "frames_per_rank": [list(OpenSoraVAE.frame_shard(args.frames, args.shard, r)) for r in range(args.shard)],
+                          "frames_per_rank": [list(v) for v in vae.frame_shards(args.frames, args.shard)],
                           "unsharded_s": round(whole, 4), "gathered_bytes": args.frames * (args.hw * 8) ** 2 * 3}))
         return
     if args.encode:

@@ -487,6 +487,61 @@ int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* 
   return launch_copy_4d_batch(B16(src), B16(dst), ops, (int)nops, S(stream));
 }
 
+int vsys_p2p_exchange(const void* src, int64_t nops, const int64_t* desc, const void* my_flags, int64_t n_flags, int64_t self_index,
+                      void* state, int64_t timeout_ticks, void* stream) {
+  if (!src || !my_flags || !state || (nops > 0 && !desc)) return VSYS_ERR_ARG;
+  if (nops < 0 || nops > VSYS_COPY_BATCH_MAX || !fits_int(n_flags) || self_index < 0 || self_index >= n_flags) return VSYS_ERR_SHAPE;
+  CopyDesc ops[VSYS_COPY_BATCH_MAX];
+  bf16_t* dsts[VSYS_COPY_BATCH_MAX];
+  unsigned* flags[VSYS_COPY_BATCH_MAX];
+  for (int i = 0; i < (int)nops; ++i) {
+    const int64_t* d = desc + 16 * i;
+    for (int k = 2; k < 6; ++k) if (!fits_int(d[k])) return VSYS_ERR_SHAPE;
+    if (!fits_int(d[12]) || !fits_int(d[13]) || d[0] < 0 || d[1] < 0 || d[14] == 0) return VSYS_ERR_SHAPE;
+    ops[i].src_off = d[0]; ops[i].dst_off = d[1];
+    ops[i].n0 = (int)d[2]; ops[i].n1 = (int)d[3]; ops[i].n2 = (int)d[4]; ops[i].C = (int)d[5];
+    ops[i].ss0 = d[6]; ops[i].ss1 = d[7]; ops[i].ss2 = d[8]; ops[i].ds0 = d[9]; ops[i].ds1 = d[10]; ops[i].ds2 = d[11];
+    ops[i].n1_valid = (int)d[12]; ops[i].n2_valid = (int)d[13];
+    dsts[i] = reinterpret_cast<bf16_t*>(d[14]);
+    flags[i] = reinterpret_cast<unsigned*>(d[15]);
+  }
+  return launch_p2p_exchange(B16(src), ops, dsts, flags, (int)nops, reinterpret_cast<const unsigned*>(my_flags), (int)n_flags,
+                             (int)self_index, reinterpret_cast<unsigned*>(state), (long long)timeout_ticks, S(stream));
+}
+
+int vsys_p2p_alloc(int64_t bytes, int64_t fine_grained, void** ptr) {
+  if (!ptr || bytes <= 0) return VSYS_ERR_ARG;
+  void* p = nullptr;
+  hipError_t e = fine_grained ? hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) : hipMalloc(&p, (size_t)bytes);
+  if (e != hipSuccess || !p) return VSYS_ERR_LAUNCH;
+  if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(p); return VSYS_ERR_LAUNCH; }
+  *ptr = p;
+  return 0;
+}
+
+int vsys_p2p_free(void* ptr) { return (!ptr || hipFree(ptr) == hipSuccess) ? 0 : VSYS_ERR_LAUNCH; }
+
+int vsys_p2p_ipc_export(const void* ptr, void* handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 opaque bytes");
+  if (!ptr || !handle64) return VSYS_ERR_ARG;
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, const_cast<void*>(ptr)) != hipSuccess) return VSYS_ERR_LAUNCH;
+  __builtin_memcpy(handle64, &h, 64);
+  return 0;
+}
+
+int vsys_p2p_ipc_open(const void* handle64, void** ptr) {
+  if (!handle64 || !ptr) return VSYS_ERR_ARG;
+  hipIpcMemHandle_t h;
+  __builtin_memcpy(&h, handle64, 64);
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) return VSYS_ERR_LAUNCH;
+  *ptr = p;
+  return 0;
+}
+
+int vsys_p2p_ipc_close(void* ptr) { return (!ptr || hipIpcCloseMemHandle(ptr) == hipSuccess) ? 0 : VSYS_ERR_LAUNCH; }
+
 int vsys_conv_bf16(const void* a, int64_t lda, const void* w, int64_t ldw, const void* bias, const void* res, int64_t ldr,
                    void* out, void* out_f32, int64_t ldo, int64_t M, int64_t N, int64_t cin, int64_t kt, int64_t kh, int64_t kw,
                    int64_t row_pitch, int64_t plane_pitch, int64_t batch, int64_t batch_a, int64_t batch_w, int64_t batch_o,

@@ -1,0 +1,118 @@
+// One-kernel peer-to-peer layout switch of Dynamic Sequence Parallelism (xGMI is point-to-point: every GPU has a direct link to each
+// of its seven peers, and a store to IPC-mapped peer memory travels over it).
+//
+// Replaces, at the two exchange sites of every spatial block (/root/reference/videosys):
+//   core/distributed/comm.py:104-141        _all_to_all_func: tensor_split + P x contiguous + list all_to_all + cat + contiguous
+//   core/distributed/comm.py:282-304        all_to_all_with_pad: F.pad before, narrow after
+//   models/transformers/open_sora_transformer_3d.py:288-315   dynamic_switch
+// and this repo's own RCCL-shaped path (pack kernel -> all_to_all_single -> unpack kernel: dsp.py), which stays as the fallback.
+//
+// One launch per rank and exchange does everything: problem r of the batch copies the rows this rank owes peer r straight from the
+// source tensor (pack strides, zero fill for the padded frames) into peer r's DESTINATION tensor in its final layout (unpack
+// strides, narrowed) — no send buffer, no receive buffer, no second pass.  When the last workgroup of problem r has fenced its
+// stores it release-stores this exchange's sequence number into flag[me] of peer r; the last workgroup of the whole launch then
+// waits (one lane, s_sleep between polls, wall-clock timeout) until every peer's number has arrived in this rank's own flag array.
+// The kernel therefore ends only when this rank's destination tensor is complete, and the consumer (the qkv GEMM, the projection
+// GEMM) is simply the next launch on the stream.  The sequence number lives in device memory (state[0]) and is advanced by the
+// kernel itself, so a recorded launch program replays the same command every step.
+//
+// Reuse of a destination tensor needs no acknowledgement: a peer reaches exchange site X again only after it has passed the other
+// site of the same block, whose kernel waited for THIS rank's flag there — and this rank raised that flag after (in stream order) the
+// consumers of X's previous data.  (dsp.py PeerExchange states the argument in full.)
+//
+// Flags live in fine-grained memory (vsys_p2p_alloc): a poll inside a running kernel must see a remote store, which the
+// coarse-grained default does not promise before the next kernel boundary.  Payload tensors are ordinary (coarse-grained)
+// allocations: they are only ever read by LATER kernels, whose start invalidates the XCD L2s.
+#include "common.h"
+#include "vsys_internal.h"
+
+namespace vsys {
+
+namespace {
+
+struct P2PDesc {
+  CopyDesc c;            // c.dst_off is relative to this problem's own destination pointer
+  bf16_t* dst;           // peer's (or this rank's own) destination tensor
+  unsigned* peer_flag;   // &flags_of_peer[me]; null for the rank's own problem
+};
+struct P2PBatch {
+  int nops;
+  P2PDesc d[VSYS_COPY_BATCH_MAX];
+};
+
+// state[0] = sequence number of the last finished exchange of this site, state[1] = problems finished in the running launch,
+// state[2 + i] = workgroups of problem i finished, state[31] = error word (0 ok; 1 + q: peer q's flag did not arrive in time)
+__global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, const unsigned* my_flags, int n_flags, int self_index,
+                                    unsigned* state, long long timeout_ticks) {
+  const P2PDesc& pd = b.d[blockIdx.y];
+  const CopyDesc& o = pd.c;
+  const unsigned seq = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+  const int cch = o.C >> 3;
+  const int64_t total = (int64_t)o.n0 * o.n1 * o.n2 * cch;
+  const bf16_t* s = src + o.src_off;
+  bf16_t* d = pd.dst + o.dst_off;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cch);
+    int64_t r = i / cch;
+    const int i2 = (int)(r % o.n2);
+    r /= o.n2;
+    const int i1 = (int)(r % o.n1);
+    const int i0 = (int)(r / o.n1);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i1 < o.n1_valid && i2 < o.n2_valid) v = *reinterpret_cast<const uint4*>(s + i0 * o.ss0 + i1 * o.ss1 + i2 * o.ss2 + c * 8);
+    *reinterpret_cast<uint4*>(d + i0 * o.ds0 + i1 * o.ds1 + i2 * o.ds2 + c * 8) = v;
+  }
+  __threadfence_system();   // this thread's stores are visible system-wide before its workgroup is counted
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  if (atomicAdd(&state[2 + blockIdx.y], 1u) != gridDim.x - 1) return;
+  // ---- last workgroup of this problem: every store of the problem is fenced; tell the peer
+  state[2 + blockIdx.y] = 0;
+  if (pd.peer_flag != nullptr) __hip_atomic_store(pd.peer_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (atomicAdd(&state[1], 1u) != gridDim.y - 1) return;
+  // ---- last problem of the launch: wait for every peer's rows (their flag in MY array), then publish the new sequence number
+  state[1] = 0;
+  const long long t0 = wall_clock64();
+  // (timeout_ticks < 0: the caller orders the peers' launches itself — ranks that are threads of one process rendezvous on the host;
+  //  a site that has already timed out once does not wait again: the error word is sticky and the host raises at its next check)
+  const bool wait = timeout_ticks >= 0 && __hip_atomic_load(state + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  for (int q = 0; wait && q < n_flags; ++q) {
+    if (q == self_index) continue;
+    while ((int)(__hip_atomic_load(my_flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+      __builtin_amdgcn_s_sleep(16);
+      if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) {
+        __hip_atomic_store(state + 31, (unsigned)(1 + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+    }
+  }
+  __hip_atomic_store(state, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+}  // namespace
+
+int launch_p2p_exchange(const bf16_t* src, const CopyDesc* ops, bf16_t* const* dsts, unsigned* const* peer_flags, int nops,
+                        const unsigned* my_flags, int n_flags, int self_index, unsigned* state, long long timeout_ticks,
+                        hipStream_t stream) {
+  if (nops <= 0) return 0;
+  if (nops > VSYS_COPY_BATCH_MAX) return VSYS_ERR_SHAPE;
+  P2PBatch b;
+  b.nops = nops;
+  int64_t most = 0;
+  for (int i = 0; i < nops; ++i) {
+    if (ops[i].C % 8 || ops[i].n0 < 0 || ops[i].n1 < 0 || ops[i].n2 < 0 || dsts[i] == nullptr) return VSYS_ERR_SHAPE;
+    b.d[i].c = ops[i];
+    b.d[i].dst = dsts[i];
+    b.d[i].peer_flag = peer_flags[i];
+    const int64_t t = (int64_t)ops[i].n0 * ops[i].n1 * ops[i].n2 * (ops[i].C / 8);
+    most = t > most ? t : most;
+  }
+  // (an exchange whose every problem is empty still signals and waits: the peers count on this rank's flag)
+  int64_t grid = (most + 255) / 256;
+  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+  hipLaunchKernelGGL(p2p_exchange_kernel, dim3((unsigned)grid, (unsigned)nops), dim3(256), 0, stream, src, b, my_flags, n_flags,
+                     self_index, state, timeout_ticks);
+  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+}
+
+}  // namespace vsys

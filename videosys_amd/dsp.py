@@ -196,6 +196,41 @@ def plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, P, chunk=None):
     return pack, unpack, (P, B, Tc, Sl, C), (B, T, Sl, C)
 
 
+def plan_p2p_to_temporal_shard(B, T, Sl, S, C, P, rank, chunk=None):
+    """The to-temporal-shard switch as ONE copy per peer, straight from this rank's [B,T,Sl,C] into peer r's [B,Tc,S,C]: pack op r of
+    plan_switch_to_temporal_shard composed with the unpack op for source ``rank`` that peer r would run (zero fill for the padded
+    frames from the pack side, the narrowing of the padded columns from the unpack side).  Entry r is None when nothing travels."""
+    Tp = (T + (P - T % P) % P) // P
+    c0, Tc = _chunk(Tp, chunk)
+    run = Sl * C
+    valid_s = max(0, min(Sl, S - rank * Sl))             # columns of MY shard that exist (the last rank's may be padding)
+    ops = []
+    for r in range(P):
+        if valid_s == 0:
+            ops.append(None)
+            continue
+        ops.append(CopyOp((r * Tp + c0) * run, rank * Sl * C, B, Tc, valid_s, C, (T * run, run, C), (Tc * S * C, S * C, C),
+                          max(0, min(Tc, T - r * Tp - c0)), valid_s))
+    return ops, (B, Tc, S, C)
+
+
+def plan_p2p_to_spatial_shard(B, Tp, T, S, Sl, C, P, rank, chunk=None):
+    """The to-spatial-shard switch as ONE copy per peer: this rank's [B,Tc,S,C] (frames c0.. of its block of Tp) into the frames
+    rank*Tp + c0 .. of peer r's [B,T,Sl,C] (columns past S zero-filled on the padded shard, frames past T never written)."""
+    c0, Tc = _chunk(Tp, chunk)
+    run = Sl * C
+    valid_t = max(0, min(Tc, T - rank * Tp - c0))        # frames of MY block that exist
+    ops = []
+    for r in range(P):
+        if valid_t == 0:
+            ops.append(None)
+            continue
+        valid_s = max(0, min(Sl, S - r * Sl))
+        ops.append(CopyOp(r * Sl * C, (rank * Tp + c0) * run, B, valid_t, Sl, C, (Tc * S * C, S * C, C), (T * run, run, C),
+                          valid_t, valid_s))
+    return ops, (B, T, Sl, C)
+
+
 def plan_gather(B, T, Sl, S, C, P):
     """gather_sequence(dim=2): recv [P][B,T,Sl,C] -> [B,T,S,C] (un-padded)."""
     ops = []
@@ -293,6 +328,155 @@ def hip_copy_executor(src: torch.Tensor, dst: torch.Tensor, ops: List[CopyOp]):
                                                       o.n2_valid) for o in ops])
 
 
+# ---------------------------------------------------------------------------------------------------------
+# One-kernel peer-to-peer exchange (vsys_p2p_exchange, csrc/p2p.hip): every rank stores its rows straight into the peers' DESTINATION
+# tensors over xGMI and waits, in the same launch, for the peers' rows to land in its own.  A "peers" object provides the two
+# collective set-up calls (every rank, same order): ``all_gather_object(obj) -> [obj of rank 0 .. P-1]``; in-process groups
+# (tools/local_group.py) hand tensors and addresses over as they are, IpcPeers below maps them through HIP IPC for one process per GPU.
+#
+# Why a destination tensor may be overwritten without an acknowledgement.  A spatial block has two sites: X (to the temporal shard,
+# destination: the attention input) and Y (back, destination: the projection input).  Peer r writes my X destination for block n+1 only
+# after ITS Y kernel of block n returned, which waited for MY flag of Y(n); I raise that flag inside my Y(n) kernel, which my stream runs
+# after the consumers of X(n) (qkv GEMM, K/V prep, attention).  The same argument with X and Y swapped covers the Y destination, and
+# chunked switches (two side streams) use one site pair per chunk.  PAB decisions depend on the timestep only, so every rank skips the
+# same sites in the same steps and the per-site sequence numbers stay in step.
+# ---------------------------------------------------------------------------------------------------------
+class IpcPeers:
+    """Set-up side of the peer-to-peer exchange for ONE PROCESS PER GPU: tensors travel as torch's CUDA-IPC descriptors
+    (torch.multiprocessing.reductions), flag arrays as 64-byte HIP IPC handles (vsys_p2p_ipc_export / _open), both through
+    ``dist.all_gather_object`` on ``group``.  Needs HSA_ENABLE_IPC_MODE_LEGACY=0 on this driver (dmabuf IPC)."""
+
+    def __init__(self, group):
+        self.group = group
+        self.size, self.rank = dist.get_world_size(group), dist.get_rank(group)
+
+    def all_gather_object(self, obj):
+        out = [None] * self.size
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def share_tensor(self, t: torch.Tensor) -> List[torch.Tensor]:
+        from torch.multiprocessing.reductions import reduce_tensor
+
+        fn, args = reduce_tensor(t)
+        every = self.all_gather_object((fn, args))
+        return [t if q == self.rank else f(*a) for q, (f, a) in enumerate(every)]
+
+    def share_flags(self, n: int):
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.load()
+        mine = ctypes.c_void_p()
+        _lib.check(lib.vsys_p2p_alloc(4 * n, 1, ctypes.byref(mine)), "vsys_p2p_alloc")
+        h = (ctypes.c_char * 64)()
+        _lib.check(lib.vsys_p2p_ipc_export(mine, h), "vsys_p2p_ipc_export")
+        every = self.all_gather_object(bytes(h))
+        ptrs = []
+        for q, hb in enumerate(every):
+            if q == self.rank:
+                ptrs.append(mine.value)
+                continue
+            peer = ctypes.c_void_p()
+            _lib.check(lib.vsys_p2p_ipc_open(ctypes.create_string_buffer(hb, 64), ctypes.byref(peer)), "vsys_p2p_ipc_open")
+            ptrs.append(peer.value)
+        return mine.value, ptrs
+
+
+def _share_tensor(peers, t):
+    if hasattr(peers, "share_tensor"):
+        return peers.share_tensor(t)
+    return peers.all_gather_object(t)            # one address space: the tensors themselves
+
+
+def _share_flags(peers, n):
+    if hasattr(peers, "share_flags"):
+        return peers.share_flags(n)
+    import ctypes
+
+    from . import _lib
+
+    mine = ctypes.c_void_p()
+    _lib.check(_lib.load().vsys_p2p_alloc(4 * n, 1, ctypes.byref(mine)), "vsys_p2p_alloc")
+    return mine.value, peers.all_gather_object(mine.value)
+
+
+class PeerExchange:
+    """The exchange sites of one rank.  ``exchange(key, src, out, ops)``: ops[r] (CopyOp or None) moves rows of ``src`` into peer r's
+    ``out`` of the same site; returns when the launch is enqueued — the launch itself ends when this rank's ``out`` is complete."""
+
+    def __init__(self, peers, P: int, rank: int):
+        import os
+
+        self.peers, self.P, self.rank = peers, P, rank
+        self.sites = {}
+        self.timeout_ticks = int(float(os.environ.get("VSYS_P2P_TIMEOUT_S", "20")) * 1e8)    # 100 MHz wall clock
+        self.launches = 0
+
+    def _site(self, key, out):
+        st = self.sites.get(key)
+        if st is None or st["out"].data_ptr() != out.data_ptr():
+            outs = _share_tensor(self.peers, out)                    # collective: every rank creates its sites in the same order
+            my_flags, flag_ptrs = _share_flags(self.peers, self.P)
+            st = dict(out=out, outs=outs, my_flags=my_flags, flag_ptrs=flag_ptrs,
+                      state=torch.zeros(32, dtype=torch.int32, device=out.device))
+            self.sites[key] = st
+        return st
+
+    def exchange(self, key, src, out, ops: List[Optional[CopyOp]]):
+        import ctypes
+
+        from . import ops as vops
+        from . import program
+
+        st = self._site(key, out)
+        flat = []
+        for r in range(self.P):
+            o = ops[r]
+            flag = 0 if r == self.rank else st["flag_ptrs"][r] + 4 * self.rank
+            if o is not None:
+                flat += [o.src_off, o.dst_off, o.n0, o.n1, o.n2, o.run, *o.sstr, *o.dstr, o.n1_valid, o.n2_valid,
+                         st["outs"][r].data_ptr(), flag]
+            elif r != self.rank:     # nothing of mine travels to r (a fully padded shard): an EMPTY problem still raises my flag there
+                flat += [0, 0, 0, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, st["outs"][r].data_ptr(), flag]
+        n = len(flat) // 16
+        arr = (ctypes.c_int64 * len(flat))(*[int(v) for v in flat])
+        program.keep(st)
+        # ranks that are threads of ONE process (tools/local_group) order the launches on the host instead of polling flags on the
+        # device: their streams share a handful of hardware queues, where a polling kernel can sit in front of the launch it waits for
+        host_sync = getattr(self.peers, "p2p_sync", None)
+        vops._call("vsys_p2p_exchange", vops._p(src), n, arr, st["my_flags"], self.P, self.rank, vops._p(st["state"]),
+                   -1 if host_sync is not None else self.timeout_ticks)
+        if host_sync is not None:
+            program.host_call(host_sync)
+        self.launches += 1
+
+    def check(self):
+        """Raise if any exchange timed out waiting for a peer (state[31] of a site; synchronises the device)."""
+        for key, st in self.sites.items():
+            err = int(st["state"][31].item())
+            if err:
+                raise RuntimeError(f"peer-to-peer exchange {key}: rank {self.rank} never received the rows of rank {err - 1} "
+                                   f"(VSYS_P2P_TIMEOUT_S); set VSYS_DSP_P2P=0 to use the RCCL all_to_all_single path")
+
+
+def _make_peer_exchange(group, P, rank, copy_executor):
+    """VSYS_DSP_P2P = 1: peer-to-peer exchange (through HIP IPC when ``group`` is a torch ProcessGroup); 0: the pack + all_to_all_single
+    + unpack path; auto (default): peer-to-peer for in-process groups (which have no wire of their own), RCCL for process groups —
+    the IPC path has not run over xGMI on the build's one-GPU boxes, so it is opt-in there."""
+    import os
+
+    mode = os.environ.get("VSYS_DSP_P2P", "auto")
+    if mode == "0" or copy_executor is not hip_copy_executor or P < 2:
+        return None
+    if hasattr(group, "all_gather_object"):
+        return PeerExchange(group, P, rank)
+    if mode == "1":
+        return PeerExchange(IpcPeers(group), P, rank)
+    return None
+
+
 class SequenceParallel:
     """The DSP data path of one rank: owns the packed send/recv buffers and the side stream."""
 
@@ -302,6 +486,7 @@ class SequenceParallel:
         self.rank = group_rank(group)
         self.exec = copy_executor
         self._bufs = {}
+        self.p2p = _make_peer_exchange(group, self.P, self.rank, copy_executor)   # None: pack + all_to_all_single + unpack
 
     def _buf(self, name, shape, like):
         key = (name, tuple(shape))
@@ -331,6 +516,11 @@ class SequenceParallel:
         """[B,T,Sl,C] -> [B,Tc,S,C]  (before spatial attention).  ``tag`` selects a private pair of staging buffers (two
         switches in flight on different streams must not share them); ``chunk`` as in plan_switch_to_temporal_shard."""
         B, T, Sl, C = x.shape
+        if self.p2p is not None and x.is_cuda and out is not None:      # ONE launch: my rows straight into the peers' ``out``
+            ops_, oshape = plan_p2p_to_temporal_shard(B, T, Sl, S, C, self.P, self.rank, chunk)
+            assert tuple(out.shape) == oshape and out.is_contiguous() and x.is_contiguous()
+            self.p2p.exchange(("T", tag, tuple(x.shape), S, chunk), x, out, ops_)
+            return out
         pack, unpack, sshape, oshape = plan_switch_to_temporal_shard(B, T, Sl, S, C, self.P, chunk)
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)
@@ -346,6 +536,11 @@ class SequenceParallel:
         ``Tp`` and a caller-owned ``out`` (the chunks of a block write disjoint frames of the same buffer)."""
         B, Tc, S, C = x.shape
         Tp = Tc if Tp is None else Tp
+        if self.p2p is not None and x.is_cuda and out is not None:
+            ops_, oshape = plan_p2p_to_spatial_shard(B, Tp, T, S, Sl, C, self.P, self.rank, chunk)
+            assert tuple(out.shape) == oshape and out.is_contiguous() and x.is_contiguous()
+            self.p2p.exchange(("S", tag, tuple(x.shape), T, Sl, chunk, Tp), x, out, ops_)
+            return out
         pack, unpack, sshape, oshape = plan_switch_to_spatial_shard(B, Tp, T, S, Sl, C, self.P, chunk)
         send = self._buf(f"a2a_send{tag}", sshape, x)
         recv = self._buf(f"a2a_recv{tag}", sshape, x)

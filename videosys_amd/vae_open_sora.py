@@ -386,12 +386,32 @@ class OpenSoraVAE:
             outs.append(vid)
         return torch.stack(outs, 0)
 
-    @staticmethod
-    def frame_shard(num_frames: int, P: int, rank: int) -> tuple:
-        """The output frames rank ``rank`` of ``P`` decodes: contiguous blocks of ceil(num_frames / P) (the last ranks may hold
-        fewer, or none)."""
+    def frame_shards(self, num_frames: int, P: int) -> list:
+        """The block of output frames every rank of ``P`` decodes: [(f0, f1)] * P, contiguous, in rank order.  A rank pays one temporal
+        decode (the whole 17-frame micro chunk, ~4 frames' worth of 2-D decoding at 512 x 512) per chunk its block touches, so with at
+        least as many ranks as chunks the blocks are cut INSIDE chunks — ranks are dealt to the chunks by frame count, then a chunk's
+        frames are split evenly over its ranks (64 frames over 8 ranks: 9, 8 | 9, 8 | 9, 8 | 7, 6 — no rank decodes two chunks);
+        with fewer ranks than chunks: equal contiguous blocks."""
+        mf = self.micro_frame_size
         per = -(-num_frames // P)
-        return min(rank * per, num_frames), min((rank + 1) * per, num_frames)
+        even = [(min(r * per, num_frames), min((r + 1) * per, num_frames)) for r in range(P)]
+        if mf is None or num_frames <= mf:
+            return even
+        chunks = [(c0, min(c0 + mf, num_frames)) for c0 in range(0, num_frames, mf)]
+        if P < len(chunks):
+            return even
+        ranks = [1] * len(chunks)
+        for _ in range(P - len(chunks)):          # the next rank goes to the chunk whose ranks hold the most frames each
+            k = max(range(len(chunks)), key=lambda i: (chunks[i][1] - chunks[i][0]) / ranks[i])
+            ranks[k] += 1
+        out = []
+        for (c0, c1), n in zip(chunks, ranks):
+            q = -(-(c1 - c0) // n)
+            out += [(min(c0 + i * q, c1), min(c0 + (i + 1) * q, c1)) for i in range(n)]
+        return out
+
+    def frame_shard(self, num_frames: int, P: int, rank: int) -> tuple:
+        return self.frame_shards(num_frames, P)[rank]
 
     @torch.no_grad()
     def decode_sharded(self, z: torch.Tensor, num_frames: int, group, to_uint8: bool = True) -> torch.Tensor:
@@ -404,8 +424,9 @@ class OpenSoraVAE:
         from . import dsp
 
         P, r = dsp.group_size(group), dsp.group_rank(group)
-        f0, f1 = self.frame_shard(num_frames, P, r)
-        per = -(-num_frames // P)
+        shards = self.frame_shards(num_frames, P)
+        f0, f1 = shards[r]
+        per = max(b - a for a, b in shards)                                 # every rank's piece of the gather has this many frames
         part = self.decode(z, num_frames, frames=(f0, f1))                 # [B, 3, n, 8H, 8W]
         B, _, n, Hh, Ww = part.shape
         if to_uint8:
@@ -414,11 +435,13 @@ class OpenSoraVAE:
         else:
             mine = torch.zeros(B, 3, per, Hh, Ww, dtype=torch.bfloat16, device=self.device)
             mine[:, :, :n] = part
-        allp = torch.empty((P,) + tuple(mine.shape), dtype=mine.dtype, device=self.device)
-        dsp.all_gather_into_tensor(allp, mine, group)
-        if to_uint8:                                                        # [P, B, per, H, W, 3] -> [B, P * per, H, W, 3]
-            return allp.permute(1, 0, 2, 3, 4, 5).reshape(B, P * per, Hh, Ww, 3)[:, :num_frames].contiguous()
-        return allp.permute(1, 2, 0, 3, 4, 5).reshape(B, 3, P * per, Hh, Ww)[:, :, :num_frames].contiguous()
+        # (the gathered tensor is the ranks' pieces stacked along dim 0 — the shape every backend's all_gather_into_tensor accepts)
+        flat = torch.empty((P * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype, device=self.device)
+        dsp.all_gather_into_tensor(flat, mine, group)
+        allp = flat.view((P,) + tuple(mine.shape))
+        if to_uint8:                                                        # [P, B, per, H, W, 3] -> [B, F, H, W, 3]
+            return torch.cat([allp[q, :, :b - a] for q, (a, b) in enumerate(shards)], dim=1)
+        return torch.cat([allp[q, :, :, :b - a] for q, (a, b) in enumerate(shards)], dim=2)
 
 
     # ------------------------------------------------------------------------------------------------ encode
