@@ -330,6 +330,29 @@ class SchedulerMixin:
     pass
 
 
+def randn_tensor(shape, generator=None, device=None, dtype=None, layout=None):
+    """diffusers.utils.torch_utils.randn_tensor (third-party, restated from its published behaviour): standard normal noise of
+    ``shape``; a CPU generator draws on the CPU and the result moves to ``device`` (so a seed gives the same noise on every device); a
+    list of generators draws one batch element each."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    layout = layout or torch.strided
+    rand_device = device
+    if generator is not None:
+        gtype = (generator[0] if isinstance(generator, (list, tuple)) else generator).device.type
+        if gtype != device.type and gtype == "cpu":
+            rand_device = torch.device("cpu")
+        elif gtype != device.type and gtype == "cuda":
+            raise ValueError(f"Cannot generate a {device} tensor from a generator of type {gtype}.")
+    if isinstance(generator, (list, tuple)) and len(generator) == 1:
+        generator = generator[0]
+    if isinstance(generator, (list, tuple)):
+        one = (1,) + tuple(shape[1:])
+        lat = torch.cat([torch.randn(one, generator=generator[i], device=rand_device, dtype=dtype, layout=layout)
+                         for i in range(shape[0])], dim=0)
+        return lat.to(device)
+    return torch.randn(tuple(shape), generator=generator, device=rand_device, dtype=dtype, layout=layout).to(device)
+
+
 class _Unused(nn.Module):
     def __init__(self, *a, **k):
         super().__init__()
@@ -627,7 +650,7 @@ def install():
     _mod("diffusers.models.normalization", AdaLayerNorm=_Unused, AdaLayerNormContinuous=_Unused, AdaLayerNormZero=_Unused)
     _mod("diffusers.utils", USE_PEFT_BACKEND=False, BaseOutput=BaseOutput, deprecate=deprecate,
          is_torch_version=lambda *a, **k: True)
-    _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=maybe_allow_in_graph)
+    _mod("diffusers.utils.torch_utils", maybe_allow_in_graph=maybe_allow_in_graph, randn_tensor=randn_tensor)
     # what videosys/models/autoencoders/autoencoder_kl_cogvideox.py imports (:18-24): no arithmetic except get_activation
     loaders = sys.modules.get("diffusers.loaders") or _mod("diffusers.loaders")
     loaders.__dict__.setdefault("__path__", [])

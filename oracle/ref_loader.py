@@ -228,6 +228,19 @@ def load_reference_cogvideox_scheduler(**kwargs):
     return s
 
 
+def load_reference_cogvideox_dpm_scheduler(**kwargs):
+    """The in-tree CogVideoXDPMScheduler (schedulers/scheduling_dpm_cogvideox.py:119-483; its ``randn_tensor`` is the restated
+    diffusers leaf of oracle/diffusers_stub.py)."""
+    install_stubs()
+    from oracle import diffusers_stub
+
+    diffusers_stub.install()
+    import importlib
+
+    m = importlib.import_module("videosys.schedulers.scheduling_dpm_cogvideox")
+    return m.CogVideoXDPMScheduler(**kwargs)
+
+
 # ---------------------------------------------------------------------------------------------------- Open-Sora VAE
 def build_reference_opensora_vae(state_dict=None, dtype=torch.float32, micro_frame_size=17, micro_batch_size=4):
     """Instantiate the reference VideoAutoencoderPipeline (autoencoder_kl_open_sora.py:620-735) on CPU: the temporal VAE

@@ -95,3 +95,58 @@ def test_oracle_vs_live_reference():
     with torch.no_grad():
         ref = model(x, y, t, image_rotary_emb=rope, return_dict=False)[0]
     torch.testing.assert_close(o(x, y, t, rope), ref, rtol=2e-4, atol=2e-4)
+
+
+def _fake_velocity(z, t):
+    return torch.tanh(z * 0.7 + 0.001 * t) * 0.9 - 0.1 * z.roll(1, dims=-1)        # oracle/make_golden_dpm.py fake_model
+
+
+def _drive(sched, steps, seed, shape):
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(tuple(shape), generator=g)
+    sched.set_timesteps(steps)
+    ts = [int(t) for t in sched.timesteps]
+    old, traj, x0s = None, [], []
+    for i, t in enumerate(ts):
+        z, old = sched.step(_fake_velocity(z, t), old, t, ts[i - 1] if i > 0 else None, z, generator=g, return_dict=False)
+        traj.append(z.clone())
+        x0s.append(old.clone())
+    return ts, traj, x0s
+
+
+def test_dpm_scheduler_matches_the_reference_class():
+    """videosys_amd.pipeline_cogvideox.CogVideoXDPMScheduler against the fixture minted from the reference's own class
+    (schedulers/scheduling_dpm_cogvideox.py:119-483 driven as pipeline_cogvideox.py:679-721 drives it: x0 of the previous step and its
+    timestep handed back in, one seeded CPU generator): timesteps, every step's latents and x0 prediction for the 2b / 5b settings and
+    a leading-spacing schedule without zero terminal SNR — including the infinite log-SNR of the first (zero-SNR) and last steps and
+    the ORDER of the noise draws (a second-order step draws twice and uses the second).  Then the same against the live class."""
+    from videosys_amd.pipeline_cogvideox import CogVideoXDDIMScheduler, CogVideoXDPMScheduler
+
+    fx = load_golden("cogvideox_dpm_small.pt")
+    for name, case in fx["cases"].items():
+        sched = CogVideoXDPMScheduler(**case["kwargs"])
+        assert isinstance(sched, CogVideoXDDIMScheduler)
+        ts, traj, x0s = _drive(sched, case["steps"], case["seed"], fx["shape"])
+        assert ts == case["timesteps"], name
+        for i, (a, b) in enumerate(zip(traj, case["traj"])):
+            assert torch.isfinite(a).all() and (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (name, i)
+        for i, (a, b) in enumerate(zip(x0s, case["x0"])):
+            assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item()), (name, "x0", i)
+        # the multipliers of the first step of a zero-terminal-SNR schedule: h = inf, pure x0 + fresh noise; of the last: x0 exactly
+        sa, sb, m1, m2, m3, m4, mn, second = sched.multipliers(ts[-1], ts[-2])
+        if ts[-1] - 1000 // case["steps"] < 0:      # the step lands on "alpha = 1" (:395-399): a first-order step onto x0 itself
+            assert not second and m1 == 0.0 and m2 == -1.0 and mn == 0.0
+        else:
+            assert second and m3 > 1.0 and m4 > 0.0
+        if case["kwargs"]["rescale_betas_zero_snr"]:
+            sa, sb, m1, m2, m3, m4, mn, second = sched.multipliers(ts[0], None)
+            assert sa == 0.0 and sb == 1.0 and m1 == 0.0 and m3 is None and abs(m2 * m2 + mn * mn - 1.0) < 1e-12
+    from oracle import ref_loader
+
+    if ref_loader.reference_available():
+        kw = dict(prediction_type="v_prediction", timestep_spacing="trailing", rescale_betas_zero_snr=True, snr_shift_scale=1.0)
+        ref = ref_loader.load_reference_cogvideox_dpm_scheduler(**kw)
+        a = _drive(ref, 7, 99, (1, 2, 16, 4, 4))
+        b = _drive(CogVideoXDPMScheduler(**kw), 7, 99, (1, 2, 16, 4, 4))
+        assert a[0] == b[0]
+        assert all((x - y).abs().max().item() <= 2e-5 for x, y in zip(a[1], b[1]))

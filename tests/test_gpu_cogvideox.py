@@ -61,6 +61,47 @@ def test_cogvideox_sampling_golden():
     check(out, fx["out"], rel=5e-2, what=f"cogvideox {fx['steps']}-step latents")
 
 
+def test_cogvideox_sampling_with_the_dpm_scheduler():
+    """CogVideoXPipeline with a CogVideoXDPMScheduler handed in (pipeline_cogvideox.py:679-680,711-721; scheduling_dpm_cogvideox.py:
+    402-447) on the GPU: x0 and the update through two launches of the fused guidance + step kernel, the x0_prev / noise terms as
+    tensor adds, noise from the caller's CPU generator in the reference's order.  Against the same steps written out in torch on
+    the HIP transformer's own outputs (the scheduler class is pinned against the reference's on the CPU)."""
+    from videosys_amd import CogVideoXConfig, CogVideoXPipeline
+    from videosys_amd.pipeline_cogvideox import CogVideoXDPMScheduler
+
+    fx = load_golden("cogvideox_sample_small.pt")
+    skw = dict(snr_shift_scale=1.0)
+    pipe = CogVideoXPipeline(CogVideoXConfig(model_path=f"THUDM/CogVideoX-5b@synthetic:{fx['seed']}", transformer_config=fx["cfg"]),
+                             scheduler=CogVideoXDPMScheduler(**skw), device=dev())
+    steps, guidance = 5, 6.0
+    out = pipe.generate(prompt_embeds=fx["pos"], negative_prompt_embeds=fx["neg"], latents=fx["latents"], height=64, width=96,
+                        num_frames=9, num_inference_steps=steps, guidance_scale=guidance, generator=torch.Generator().manual_seed(3),
+                        output_type="latent").video.float().cpu()
+    sched = CogVideoXDPMScheduler(**skw)
+    sched.set_timesteps(steps)
+    g = torch.Generator().manual_seed(3)
+    z = fx["latents"].float().to(dev())
+    emb = torch.cat([fx["neg"], fx["pos"]], 0)
+    rope = pipe._prepare_rotary_positional_embeddings(64, 96, z.shape[1]) if pipe.transformer.config.use_rotary_positional_embeddings else None
+    x0_old, t_back = None, None
+    pipe.transformer.reset_text_cache()
+    for t in sched.timesteps:
+        o = pipe.transformer(z, emb, torch.full((2,), t, dtype=torch.int64), image_rotary_emb=rope, return_dict=False)[0].float()
+        u, c = o.chunk(2)
+        v = u + guidance * (c - u)
+        sa, sb, m1, m2, m3, m4, mn, second = sched.multipliers(t, t_back)
+        x0 = sa * z - sb * v
+        n = torch.randn(z.shape, generator=g, dtype=torch.bfloat16).float().to(dev())
+        if x0_old is None or not second:
+            z = m1 * z - m2 * x0 + mn * n
+        else:
+            n = torch.randn(z.shape, generator=g, dtype=torch.bfloat16).float().to(dev())
+            z = m1 * z - m2 * (m3 * x0 - m4 * x0_old) + mn * n
+        z = z.to(torch.bfloat16).float()
+        x0_old, t_back = x0, t
+    check(out, z.cpu(), rel=2e-2, what="cogvideox DPM-solver++ latents")
+
+
 def test_cogvideox_without_classifier_free_guidance():
     """guidance_scale <= 1 (pipeline_cogvideox.py:627,706-708 skipped): same latents as the CFG run whose negative prompt equals
     the prompt (cond == uncond bit for bit, so the guidance term vanishes)."""

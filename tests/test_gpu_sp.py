@@ -230,6 +230,70 @@ def test_stdit3_dsp_two_processes_peer_to_peer_over_ipc(T, HW):
     _run(_stdit3_worker, (T, HW, True))
 
 
+def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
+    """The combination BASELINE configs[4] names — CogVideoX + PAB (spatial broadcast) + DSP degree 4 + the 3-D VAE's tiled decode —
+    in one run on a small geometry: four Ulysses ranks as threads of this process (tools/local_group; 8 heads = 2 per rank, 48 video
+    tokens = 12 per rank, text rows replicated), the PAB schedule of the reference fixture (broadcast steps skip the attention AND its
+    two exchanges on every rank alike), every step's output of every rank BIT-identical to the single-process run; rank 0 then
+    decodes its final latents with the tiled decode (4 tiles, blended) and gets the bits of the single-process latents' decode
+    (cogvideox_transformer_3d.py:45-86,112-165; pipeline_cogvideox.py:33-44; autoencoder_kl_cogvideox.py:1161-1239)."""
+    from conftest import load_golden
+    from oracle import cogvideox_oracle as CO
+    from tools.local_group import LocalWorld
+    from videosys_amd import pab
+    from videosys_amd.cogvideox import CogVideoXTransformer3DModel
+    from videosys_amd.vae_cogvideox import CogVideoXVAE, synth_state_dict as vae_synth
+
+    fx = load_golden("cogvideox_pab_small.pt")
+    cfg = dict(fx["cfg"], num_attention_heads=8)
+    sd = {k: v.to(torch.bfloat16).float() for k, v in CO.synth_state_dict(cfg["num_layers"], 8, text_embed_dim=cfg["text_embed_dim"],
+                                                                          seed=fx["seed"]).items()}
+    rope = CO.rope_3d(64, CO.crop_region((4, 6), 45, 30), (4, 6), 3)
+    P = 4
+
+    def run_schedule(m):
+        m.reset_pab_state()
+        return [m(fx["x"], fx["y"], torch.tensor([t, t]), image_rotary_emb=rope, return_dict=False)[0].float().cpu()
+                for t in fx["timesteps"]]
+
+    pab.set_pab_manager(pab.PABConfig(spatial_broadcast=True, **fx["pab"]))
+    try:
+        pab.update_steps(fx["steps"])
+        single = CogVideoXTransformer3DModel(**cfg, device="cuda:0")
+        single.load_state_dict(sd)
+        want = run_schedule(single)
+        assert any(not torch.equal(a, b) for a, b in zip(want, want[1:]))
+
+        def rank_fn(r, group):
+            torch.cuda.set_device(0)
+            m = CogVideoXTransformer3DModel(**cfg, device="cuda:0")
+            m.load_state_dict(sd)
+            m.enable_parallel(parallel_mgr=_rank_manager(group, P, r))
+            assert m._sp is not None and m._sp.P == P
+            outs = run_schedule(m)
+            torch.cuda.synchronize()
+            return outs
+
+        per_rank = LocalWorld(P, timeout=300).run(rank_fn)
+    finally:
+        pab.set_pab_manager(None)
+    for r, outs in enumerate(per_rank):
+        for i, (o, w) in enumerate(zip(outs, want)):
+            assert torch.equal(o, w), f"rank {r}, step {i} (t = {fx['timesteps'][i]}): max|diff| {float((o - w).abs().max()):.3e}"
+    # rank 0 decodes what it sampled: [B, F, C, H, W] latents -> pixels through the tiled decode (tile = half the sample size)
+    vae = CogVideoXVAE(vae_synth(13), device="cuda:0", sample_height=64, sample_width=96, use_tiling=True)
+    lat = per_rank[0][-1][:1].to(torch.bfloat16).to("cuda:0")
+    assert lat.shape[-2] > vae.tile_latent_min_height and lat.shape[-1] > vae.tile_latent_min_width      # the decode really tiles
+    px = vae.decode_latents(lat)
+    px_single = vae.decode_latents(want[-1][:1].to(torch.bfloat16).to("cuda:0"))
+    assert px.shape[0] == 1 and px.shape[1] == 3 and px.shape[-2:] == (64, 96) and torch.isfinite(px.float()).all()
+    assert torch.equal(px, px_single)
+    vae.use_tiling = False
+    plain = vae.decode_latents(lat).float()
+    cos = torch.nn.functional.cosine_similarity(px.float().flatten(), plain.flatten(), dim=0).item()
+    assert cos >= 0.99, cos      # tiles are cross-faded: close to, not equal to, the untiled decode
+
+
 def test_bench_two_ranks_dry_run():
     """bench.py's N > 1 path (rank-0 build, barriers, DSP model, max-over-ranks timing, one JSON line from rank 0), launched the
     way the driver launches it, with both ranks on the one GPU of the test box over gloo (VSYS_BENCH_ONE_GPU=1), depth 2."""

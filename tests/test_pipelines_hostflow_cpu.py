@@ -198,6 +198,55 @@ def test_cogvideox_generate_host_flow_matches_the_reference_sampling_fixture():
             pipe.generate(eta=0.3, **kw)
 
 
+def test_cogvideox_generate_with_the_dpm_scheduler_host_flow():
+    """CogVideoXPipeline.generate with a CogVideoXDPMScheduler handed in (pipeline_cogvideox.py:679-680,711-721): the loop keeps the
+    previous step's x0 and timestep, draws the scheduler's noise from the caller's generator in the reference's order (two draws on a
+    second-order step, the second one used) and expresses x0 and the update through the fused guidance + linear-step kernel.  Checked
+    on CPU (kernel emulated, oracle transformer) against the direct formulas of scheduling_dpm_cogvideox.py:402-447 driven by the same
+    generator — the scheduler class itself is pinned against the reference's in tests/test_cogvideox_cpu.py."""
+    from videosys_amd import CogVideoXConfig, CogVideoXPipeline
+    from videosys_amd.pipeline_cogvideox import CogVideoXDPMScheduler
+
+    fx = load_golden("cogvideox_sample_small.pt")
+    skw = dict(snr_shift_scale=1.0)
+    steps, guidance = 5, 6.0
+    F = (fx["latents"].shape[1] - 1) * 4 + 1
+    with torch_step_kernel():
+        model = OracleCog(fx)
+        pipe = CogVideoXPipeline(CogVideoXConfig(model_path="THUDM/CogVideoX-5b"), transformer=model, scheduler=CogVideoXDPMScheduler(**skw),
+                                 device="cpu")
+        assert isinstance(pipe.scheduler, CogVideoXDPMScheduler)
+        out = pipe.generate(prompt_embeds=fx["pos"], negative_prompt_embeds=fx["neg"], latents=fx["latents"], height=8 * fx["latents"].shape[3],
+                            width=8 * fx["latents"].shape[4], num_frames=F, num_inference_steps=steps, guidance_scale=guidance,
+                            generator=torch.Generator().manual_seed(77), output_type="latent").video
+        # the same loop written out with the scheduler's multipliers
+        sched = CogVideoXDPMScheduler(**skw)
+        sched.set_timesteps(steps)
+        g = torch.Generator().manual_seed(77)
+        z = fx["latents"].float().clone()
+        emb = torch.cat([fx["neg"], fx["pos"]], 0)
+        rope = pipe._prepare_rotary_positional_embeddings(8 * z.shape[3], 8 * z.shape[4], z.shape[1]) \
+            if model.config.use_rotary_positional_embeddings else None
+        x0_old, t_back = None, None
+        for t in sched.timesteps:
+            o = model(z, emb, torch.full((2 * z.shape[0],), t, dtype=torch.int64), image_rotary_emb=rope)[0]
+            u, c = o.chunk(2)
+            v = u + guidance * (c - u)
+            sa, sb, m1, m2, m3, m4, mn, second = sched.multipliers(t, t_back)
+            x0 = sa * z - sb * v
+            n = torch.randn(z.shape, generator=g, dtype=torch.bfloat16).float()
+            if x0_old is None or not second:
+                z = m1 * z - m2 * x0 + mn * n
+            else:
+                n = torch.randn(z.shape, generator=g, dtype=torch.bfloat16).float()
+                z = m1 * z - m2 * (m3 * x0 - m4 * x0_old) + mn * n
+            z = z.to(torch.bfloat16).float()
+            x0_old, t_back = x0, t
+    assert torch.isfinite(out).all()
+    torch.testing.assert_close(out, z, rtol=2e-2, atol=2e-2)
+    assert (out - fx["latents"].float()).abs().max().item() > 0.1
+
+
 def test_component_names_typo_paths_raise_hub_ids_warn(caplog):
     """config.transformer / config.vae: a Hugging Face hub id (the reference's defaults) cannot be fetched offline and is replaced with
     a logged warning; a string that looks like a filesystem path and does not exist is a typo and raises instead of silently

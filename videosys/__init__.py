@@ -31,6 +31,7 @@ _MODULES = {
     "core.engine.mp_utils": "engine",                         # ResultHandler, WorkerMonitor, get_open_port
     "schedulers.scheduling_rflow_open_sora": "rflow",         # RFLOW, timestep_transform
     "schedulers.scheduling_ddim_cogvideox": "pipeline_cogvideox",   # CogVideoXDDIMScheduler
+    "schedulers.scheduling_dpm_cogvideox": "pipeline_cogvideox",    # CogVideoXDPMScheduler
     "models.modules.normalization": "modules",                # LlamaRMSNorm, get_rms_norm
     "models.transformers.open_sora_transformer_3d": "stdit3",       # STDiT3, STDiT3Config, STDiT3_XL_2
     "models.transformers.latte_transformer_3d": "latte",            # LatteT2V

@@ -30,6 +30,8 @@ namespace vsys {
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct P2PDesc {
   CopyDesc c;            // c.dst_off is relative to this problem's own destination pointer
   bf16_t* dst;           // peer's (or this rank's own) destination tensor
@@ -58,18 +60,21 @@ __global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, 
     r /= o.n2;
     const int i1 = (int)(r % o.n1);
     const int i0 = (int)(r / o.n1);
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (i1 < o.n1_valid && i2 < o.n2_valid) v = *reinterpret_cast<const uint4*>(s + i0 * o.ss0 + i1 * o.ss1 + i2 * o.ss2 + c * 8);
-    *reinterpret_cast<uint4*>(d + i0 * o.ds0 + i1 * o.ds1 + i2 * o.ds2 + c * 8) = v;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (i1 < o.n1_valid && i2 < o.n2_valid) v = *reinterpret_cast<const u32x4*>(s + i0 * o.ss0 + i1 * o.ss1 + i2 * o.ss2 + c * 8);
+    // system-scope WRITE-THROUGH store: the rows go to the peer's memory (or this rank's) past the L2, so publishing them needs no
+    // cache write-back — a __threadfence_system() per thread (buffer_wbl2 in every wave) made this kernel 15x slower
+    bf16_t* q = d + i0 * o.ds0 + i1 * o.ds1 + i2 * o.ds2 + c * 8;
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
   }
-  __threadfence_system();   // this thread's stores are visible system-wide before its workgroup is counted
-  __syncthreads();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has been acknowledged by its destination ...
+  __syncthreads();                                   // ... and so have the other waves' of this workgroup
   if (threadIdx.x != 0) return;
-  if (atomicAdd(&state[2 + blockIdx.y], 1u) != gridDim.x - 1) return;
+  if (__hip_atomic_fetch_add(&state[2 + blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
   // ---- last workgroup of this problem: every store of the problem is fenced; tell the peer
   state[2 + blockIdx.y] = 0;
   if (pd.peer_flag != nullptr) __hip_atomic_store(pd.peer_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (atomicAdd(&state[1], 1u) != gridDim.y - 1) return;
+  if (__hip_atomic_fetch_add(&state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.y - 1) return;
   // ---- last problem of the launch: wait for every peer's rows (their flag in MY array), then publish the new sequence number
   state[1] = 0;
   const long long t0 = wall_clock64();
@@ -78,7 +83,7 @@ __global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, 
   const bool wait = timeout_ticks >= 0 && __hip_atomic_load(state + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
   for (int q = 0; wait && q < n_flags; ++q) {
     if (q == self_index) continue;
-    while ((int)(__hip_atomic_load(my_flags + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+    while ((int)(__hip_atomic_load(my_flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {   // (polled relaxed: an acquire per poll would drop the L1 every time)
       __builtin_amdgcn_s_sleep(16);
       if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) {
         __hip_atomic_store(state + 31, (unsigned)(1 + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -102,6 +102,56 @@ class CogVideoXDDIMScheduler:
         return a_coef + b * math.sqrt(a_t), -b * math.sqrt(1 - a_t)
 
 
+class CogVideoXDPMScheduler(CogVideoXDDIMScheduler):
+    """schedulers/scheduling_dpm_cogvideox.py:119-483 — the stochastic DPM-Solver++ (2M) step the reference pipeline runs when a
+    caller hands this scheduler in (pipeline_cogvideox.py:679-680,711-721): same noise schedule and timesteps as the DDIM class;
+    per step  x0 = sqrt(a_t) x - sqrt(1 - a_t) v  and, with h the log-SNR step,
+        first step / last step:   x <- m1 x - m2 x0 + mn n1
+        otherwise:                x <- m1 x - m2 ((1 + 1/2r) x0 - (1/2r) x0_prev) + mn n2      (n1 is drawn and discarded, :439-447)
+    with fresh standard-normal noise every step (two draws on the second-order steps, in this order — the generator's stream is part
+    of the result).  ``multipliers`` holds the coefficient arithmetic in float64 (the reference's 0-dim float64 tensors, :402-415)."""
+
+    def multipliers(self, t: int, t_back: Optional[int]):
+        """(sa, sb, m1, m2, m3, m4, mn, second_order) for timestep ``t`` with the previous step's timestep ``t_back`` (None: first)."""
+        prev_t = t - self.num_train_timesteps // self.num_inference_steps
+        one = torch.tensor(1.0, dtype=torch.float64)
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else one * self.final_alpha_cumprod
+        lam = ((a_t / (1 - a_t)) ** 0.5).log()
+        lam_next = ((a_prev / (1 - a_prev)) ** 0.5).log()
+        h = lam_next - lam
+        m1 = ((1 - a_prev) / (1 - a_t)) ** 0.5 * (-h).exp()
+        m2 = (-2 * h).expm1() * a_prev ** 0.5
+        mn = (1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
+        m3 = m4 = None
+        if t_back is not None:
+            a_back = self.alphas_cumprod[t_back]
+            r = (lam - ((a_back / (1 - a_back)) ** 0.5).log()) / h
+            m3, m4 = float(1 + 1 / (2 * r)), float(1 / (2 * r))
+        return float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(m1), float(m2), m3, m4, float(mn), (t_back is not None and prev_t >= 0)
+
+    @staticmethod
+    def _noise(shape, generator, device, dtype):
+        """diffusers' randn_tensor (third-party): a CPU generator draws on the CPU, then the noise moves to ``device``."""
+        gdev = device if generator is None else generator.device
+        return torch.randn(tuple(shape), generator=generator, device=gdev, dtype=dtype).to(device)
+
+    def step(self, model_output, old_pred_original_sample, timestep, timestep_back, sample, eta: float = 0.0,
+             use_clipped_model_output: bool = False, generator=None, variance_noise=None, return_dict: bool = False):
+        """The reference's signature and return value (:348-457): (prev_sample, pred_original_sample)."""
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        sa, sb, m1, m2, m3, m4, mn, second = self.multipliers(int(timestep), None if timestep_back is None else int(timestep_back))
+        x0 = sa * sample - sb * model_output
+        noise = self._noise(sample.shape, generator, sample.device, sample.dtype)
+        prev = m1 * sample - m2 * x0 + mn * noise
+        if old_pred_original_sample is None or not second:
+            return prev, x0
+        d = m3 * x0 - m4 * old_pred_original_sample
+        noise = self._noise(sample.shape, generator, sample.device, sample.dtype)
+        return m1 * sample - m2 * d + mn * noise, x0
+
+
 def get_resize_crop_region_for_grid(src, tgt_width, tgt_height):
     """pipeline_cogvideox.py:757-775."""
     h, w = src
@@ -368,6 +418,9 @@ class CogVideoXPipeline(VideoSysPipeline):
         self._num_timesteps = len(self.scheduler.timesteps)
         rope = self._prepare_rotary_positional_embeddings(height, width, z.shape[1]) if c.use_rotary_positional_embeddings else None
         zf = z.view(B, 1, -1)  # the step kernel sees [Bz, Cin = 1, thw]: CogVideoX predicts all 16 channels (no sigma half)
+        dpm = isinstance(self.scheduler, CogVideoXDPMScheduler)      # (:679-680) DPM-solver++: the previous step's x0 prediction
+        x0_old, t_back = None, None
+        ndt = getattr(self.transformer, "dtype", torch.bfloat16)    # the noise is drawn in the latents' dtype (randn_tensor(sample.dtype), :437)
         # (:678,737) the reference runs diffusers' progress bar on every call; ``verbose=False`` (an extension) turns it off
         for step_i, t in progress_wrap(list(enumerate(self.scheduler.timesteps)), verbose):
             if self._interrupt:   # (:682-683) a callback may set pipe._interrupt: the remaining steps are skipped
@@ -377,10 +430,26 @@ class CogVideoXPipeline(VideoSysPipeline):
             g_t = guidance_scale
             if use_dynamic_cfg:  # :702-705
                 g_t = 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - t) / num_inference_steps) ** 5.0)) / 2)
-            c_z, c_v = self.scheduler.coeffs(t)
             if not cfg:   # (:706-708 skipped) the step kernel combines two halves: the prediction twice at guidance 1 is the prediction
                 out, g_t = torch.cat([out, out], 0), 1.0
-            ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, c_z, c_v, cond_first=False)
+            if dpm:
+                # (:711-721 -> scheduling_dpm_cogvideox.py:402-447) x0 = sa z - sb v and the update are linear in (z, v): two launches of
+                # the fused guidance + step kernel, then the x0_prev and noise terms (1.1 M latent values) as plain tensor adds
+                sa, sb, m1, m2, m3, m4, mn, second = self.scheduler.multipliers(t, t_back)
+                x0 = z.clone()
+                ops.cfg_linear_step(x0.view(B, 1, -1), out.view(2 * B, 1, -1), g_t, sa, -sb, cond_first=False)
+                noise = self.scheduler._noise(z.shape, generator, z.device, ndt).float()
+                if x0_old is None or not second:
+                    ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, m1 - m2 * sa, m2 * sb, cond_first=False)
+                else:
+                    noise = self.scheduler._noise(z.shape, generator, z.device, ndt).float()   # the second draw is used
+                    ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, m1 - m2 * m3 * sa, m2 * m3 * sb, cond_first=False)
+                    z.add_(x0_old, alpha=m2 * m4)
+                z.add_(noise, alpha=mn)
+                x0_old, t_back = x0, t
+            else:
+                c_z, c_v = self.scheduler.coeffs(t)
+                ops.cfg_linear_step(zf, out.view(2 * B, 1, -1), g_t, c_z, c_v, cond_first=False)
             z.copy_(z.to(torch.bfloat16).float())  # latents = latents.to(prompt_embeds.dtype) (:723)
             if callback_on_step_end is not None:   # (:725-734) "prompt_embeds" is the [negative | prompt] batch the loop runs on
                 have = {"latents": z, "prompt_embeds": emb, "negative_prompt_embeds": negative_prompt_embeds}
