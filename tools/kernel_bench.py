@@ -153,10 +153,11 @@ def main():
     freqs = 1.0 / (10000 ** (torch.arange(0, 72, 2).float() / 72))
     ang = torch.einsum("p,f->pf", torch.arange(19).float(), freqs).repeat_interleave(2, -1)
     cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
-    for fv in sorted(set([0] + [int(v) for v in args.flash_variants.split(',')])):
-        lib.vsys_tune_flash_variant(fv)
-        ms = timeit(lambda: ops.attn_temporal(qkv, C, qw, qw, cos, sin, ao, 2, 19, 1024, H), args.reps)
-        res["attn_temporal" + (f"_v{fv}" if fv else "")] = [(ms, (269.0 + 89.7) / ms)]  # GB/s
+    for rd in range(args.rounds):       # interleaved rounds (21 = the reference's rounding points stage by stage: the round-4 kernel)
+        for fv in sorted(set([0, 21] + [int(v) for v in args.flash_variants.split(',')])):
+            lib.vsys_tune_flash_variant(fv)
+            ms = timeit(lambda: ops.attn_temporal(qkv, C, qw, qw, cos, sin, ao, 2, 19, 1024, H), args.reps)
+            res.setdefault("attn_temporal" + (f"_v{fv}" if fv else ""), []).append((ms, (269.0 + 89.7) / ms))  # GB/s
     lib.vsys_tune_flash_variant(0)
     ms = timeit(lambda: ops.adaln_modulate(x, mod[0, :C], mod[0, C:2 * C], N // 2, 6 * C, out=ao), args.reps)
     res["adaln_modulate"] = [(ms, 179.3 / ms)]  # GB/s

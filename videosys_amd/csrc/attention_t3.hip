@@ -33,7 +33,8 @@ constexpr int VT_BYTES = 96 * VT_PITCH;    // 7680
 constexpr int TAB_ROW = 36;                // floats per position in the compact cos / sin tables
 constexpr int TAB_BYTES = 32 * TAB_ROW * 4;  // 4608
 constexpr int W_BYTES = 160;               // one norm-weight vector (72 bf16, padded)
-constexpr int LDS_HEAD = 2 * TAB_BYTES + 2 * W_BYTES;  // 9536
+constexpr int WF_BYTES = 320;              // the same vector as fp32 (72 floats, padded): the fused path multiplies unpacked pairs by it
+constexpr int LDS_HEAD = 2 * TAB_BYTES + 2 * W_BYTES + 2 * WF_BYTES;  // 10176
 constexpr float NEG_BIG = -1e30f;
 
 typedef __attribute__((ext_vector_type(2))) float t3_f32x2;
@@ -43,6 +44,76 @@ __device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(t3_f32x2{lo, hi}, t3_bf16x2));
 }
 
+// One 16-byte piece (8 dims = 4 rotary pairs) of a q / k row: RMS-norm, weight, rotation, q scale -> the fragment dwords.
+// RP = true keeps every rounding point of the reference's bf16 run (x * rstd -> bf16 (normalization.py:32), * weight -> bf16 (:33),
+// rotation -> bf16 (rotary_embedding_torch, attentions.py:76-78), q * scale -> bf16 (:113)): each stage unpacks its pairs and repacks
+// them, 17 (k) / 21 (q) VALU instructions per dword — 340 of the 653 VALU instructions of a head iteration were these conversions
+// (profiles/r03_isa_mix_attention_t3.txt), and the kernel is VALU-bound.  RP = false (default) carries the pair in fp32 from the
+// unpack to ONE rounding in front of the matrix product: x * (rstd [* scale]) * w, rotated, as four packed fp32 instructions + one
+// v_cvt_pk_bf16_f32 = 7 per dword.  The chain is linear, so the q scale rides on rstd.  Fewer roundings than the reference: the
+// distance to the fp32 oracle shrinks; same tolerance, not the same bits as RP (flash variant 21 selects RP for A/B).
+// MODE: 0 = RP with run-time norm / rope flags; fused forms with the flags at COMPILE time (as run-time conditions hipcc computes both
+// sides and selects: 14 instructions per dword): 1 = norm + rope (Open-Sora), 2 = neither (Latte), 3 = norm only, 4 = rope only.
+template <int MODE>
+__device__ __forceinline__ void t3_piece(uint32_t (&u)[4], const bf16_t* w, const float* wf, const float* cosrow, const float* sinrow,
+                                         int c, int hi, float rstd, float scale, bool has_norm, bool has_rope, bool scaled) {
+  if constexpr (MODE == 0) {
+    if (has_norm) {
+      const uint4 wv = *reinterpret_cast<const uint4*>(w + 16 * c + 8 * hi);
+      const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t n1 = pk_bf16(bflo(u[e]) * rstd, bfhi(u[e]) * rstd);           // .to(input_dtype) (normalization.py:32)
+        u[e] = pk_bf16(bflo(n1) * bflo(wu[e]), bfhi(n1) * bfhi(wu[e]));              // weight * (...)   (:33)
+      }
+    }
+    if (has_rope) {
+      const float4 cs = *reinterpret_cast<const float4*>(cosrow + 8 * c + 4 * hi);
+      const float4 sn = *reinterpret_cast<const float4*>(sinrow + 8 * c + 4 * hi);
+      const float cv[4] = {cs.x, cs.y, cs.z, cs.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {   // (x0, x1) * c + (-x1, x0) * s as one packed multiply + one packed FMA
+        const float x0 = bflo(u[e]), x1 = bfhi(u[e]);
+        const t3_f32x2 r = __builtin_elementwise_fma(t3_f32x2{-x1, x0}, t3_f32x2{sv[e], sv[e]}, t3_f32x2{x0, x1} * t3_f32x2{cv[e], cv[e]});
+        u[e] = pk_bf16(r.x, r.y);
+      }
+    }
+    if (scaled) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) u[e] = pk_bf16(bflo(u[e]) * scale, bfhi(u[e]) * scale);   // q = q * self.scale (attentions.py:113)
+    }
+  } else {
+    constexpr bool NORM = MODE == 1 || MODE == 3, ROPE = MODE == 1 || MODE == 4;
+    if (!NORM && !ROPE && !scaled) return;     // (Latte keys: the raw bf16 pairs are the fragment)
+    const float rs = scaled ? rstd * scale : rstd;
+    float wv[8], cv[4], sv[4];
+    if constexpr (NORM) {
+      const float4 wa = *reinterpret_cast<const float4*>(wf + 16 * c + 8 * hi), wb = *reinterpret_cast<const float4*>(wf + 16 * c + 8 * hi + 4);
+      wv[0] = wa.x; wv[1] = wa.y; wv[2] = wa.z; wv[3] = wa.w; wv[4] = wb.x; wv[5] = wb.y; wv[6] = wb.z; wv[7] = wb.w;
+    }
+    if constexpr (ROPE) {
+      const float4 cs = *reinterpret_cast<const float4*>(cosrow + 8 * c + 4 * hi);
+      const float4 sn = *reinterpret_cast<const float4*>(sinrow + 8 * c + 4 * hi);
+      cv[0] = cs.x; cv[1] = cs.y; cv[2] = cs.z; cv[3] = cs.w; sv[0] = sn.x; sv[1] = sn.y; sv[2] = sn.z; sv[3] = sn.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t3_f32x2 x = t3_f32x2{bflo(u[e]), bfhi(u[e])} * t3_f32x2{rs, rs};
+      if constexpr (NORM) x = x * t3_f32x2{wv[2 * e], wv[2 * e + 1]};
+      if constexpr (ROPE) {
+        // (x0, x1) c + (-x1, x0) s in ONE packed FMA: source 0 is read with its halves swapped (op_sel) and the low result's copy
+        // negated (neg_lo) — written out by hand, hipcc lowers the swapped pair to a v_xor + v_mov in front of the FMA
+        const t3_f32x2 t = x * t3_f32x2{cv[e], cv[e]}, s2 = t3_f32x2{sv[e], sv[e]};
+        t3_f32x2 r;
+        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(s2), "v"(t));
+        x = r;
+      }
+      u[e] = pk_bf16(x.x, x.y);
+    }
+  }
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
     const bf16_t* __restrict__ qkv, int64_t row_stride, int C, const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, bf16_t* __restrict__ out, int64_t out_stride, int B, int T,
@@ -54,6 +125,8 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
   float* sinc = reinterpret_cast<float*>(smem + TAB_BYTES);
   bf16_t* qw = reinterpret_cast<bf16_t*>(smem + 2 * TAB_BYTES);
   bf16_t* kw = reinterpret_cast<bf16_t*>(smem + 2 * TAB_BYTES + W_BYTES);
+  float* qwf = reinterpret_cast<float*>(smem + 2 * TAB_BYTES + 2 * W_BYTES);
+  float* kwf = reinterpret_cast<float*>(smem + 2 * TAB_BYTES + 2 * W_BYTES + WF_BYTES);
   char* vt = smem + LDS_HEAD + wave * VT_BYTES;
   const bool has_norm = q_norm_w != nullptr, has_rope = rope_cos != nullptr;
 
@@ -69,6 +142,8 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
   if (has_norm && tid < HD) {
     qw[tid] = q_norm_w[tid];
     kw[tid] = k_norm_w[tid];
+    qwf[tid] = bf2f(q_norm_w[tid]);
+    kwf[tid] = bf2f(k_norm_w[tid]);
   }
   for (int i = lane * 16; i < VT_BYTES; i += 64 * 16) *reinterpret_cast<uint4*>(vt + i) = make_uint4(0, 0, 0, 0);
   __syncthreads();
@@ -92,7 +167,7 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
   // norm + RoPE (+ q scale) of one row's pieces held by this lane, on PACKED bf16 pairs: every rounding point of the reference
   // (x * rstd -> bf16, * weight -> bf16, rotation -> bf16, q * scale -> bf16) is one v_cvt_pk_bf16_f32 on a pair, and the last
   // one IS the fragment dword.  raw[c] = 8 values at dims 16c + 8hi .. +7 (piece 4 of the hi half is padding).
-  auto make_frags = [&](const uint4 (&raw)[5], bf16x8 (&frag)[5], const bf16_t* w, int pos, bool zero_row, bool scaled) {
+  auto make_frags = [&](const uint4 (&raw)[5], bf16x8 (&frag)[5], const bf16_t* w, const float* wf, int pos, bool zero_row, bool scaled) {
     float rstd = 1.f;
     if (has_norm) {
       // sum of squares on the packed pairs: v_dot2c_f32_bf16 (lo*lo + hi*hi + acc in fp32) — one instruction per dword instead of
@@ -113,32 +188,11 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
       uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
-      if (c < 4 || hi == 0) {
-        if (has_norm) {
-          const uint4 wv = *reinterpret_cast<const uint4*>(w + 16 * c + 8 * hi);
-          const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t n1 = pk_bf16(bflo(u[e]) * rstd, bfhi(u[e]) * rstd);           // .to(input_dtype) (normalization.py:32)
-            u[e] = pk_bf16(bflo(n1) * bflo(wu[e]), bfhi(n1) * bfhi(wu[e]));              // weight * (...)   (:33)
-          }
-        }
-        if (has_rope) {
-          const float4 cs = *reinterpret_cast<const float4*>(cosc + pos * TAB_ROW + 8 * c + 4 * hi);
-          const float4 sn = *reinterpret_cast<const float4*>(sinc + pos * TAB_ROW + 8 * c + 4 * hi);
-          const float cv[4] = {cs.x, cs.y, cs.z, cs.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {   // (x0, x1) * c + (-x1, x0) * s as one packed multiply + one packed FMA
-            const float x0 = bflo(u[e]), x1 = bfhi(u[e]);
-            const t3_f32x2 r = __builtin_elementwise_fma(t3_f32x2{-x1, x0}, t3_f32x2{sv[e], sv[e]}, t3_f32x2{x0, x1} * t3_f32x2{cv[e], cv[e]});
-            u[e] = pk_bf16(r.x, r.y);
-          }
-        }
-        if (scaled) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) u[e] = pk_bf16(bflo(u[e]) * scale, bfhi(u[e]) * scale);   // q = q * self.scale (attentions.py:113)
-        }
-      }
+      if (c < 4 || hi == 0)
+        t3_piece<MODE>(u, w, wf, cosc + pos * TAB_ROW, sinc + pos * TAB_ROW, c, hi, rstd, scale, has_norm, has_rope, scaled);
+      // (the fused path reads 16 table floats per piece: left alone, hipcc hoists the reads of all five pieces of q AND k to the top
+      //  and the kernel spills at its three-waves-per-SIMD budget; one piece's reads at a time keep it at the old footprint)
+      if constexpr (MODE != 0) __builtin_amdgcn_sched_barrier(0);
       if (zero_row) u[0] = u[1] = u[2] = u[3] = 0u;
       frag[c] = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
     }
@@ -172,8 +226,8 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
     }
     // ---- K, then Q: norm, RoPE, (q: scale) -> fragments
     bf16x8 kf[5], qf[5];
-    make_frags(rk, kf, kw, krow_c, !k_ok, false);
-    make_frags(rq, qf, qw, qrow_c, false, true);
+    make_frags(rk, kf, kw, kwf, krow_c, !k_ok, false);
+    make_frags(rq, qf, qw, qwf, qrow_c, false, true);
     f32x16 sacc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -253,8 +307,9 @@ __global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
 constexpr int VT4_PITCH = 144;
 constexpr int VT4_BYTES = 96 * VT4_PITCH;    // 13824
 constexpr int TAB4_BYTES = 64 * TAB_ROW * 4;  // 9216
-constexpr int LDS4_HEAD = 2 * TAB4_BYTES + 2 * W_BYTES;
+constexpr int LDS4_HEAD = 2 * TAB4_BYTES + 2 * W_BYTES + 2 * WF_BYTES;
 
+template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
     const bf16_t* __restrict__ qkv, int64_t row_stride, int C, const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, bf16_t* __restrict__ out, int64_t out_stride, int B, int T,
@@ -266,6 +321,8 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
   float* sinc = reinterpret_cast<float*>(smem + TAB4_BYTES);
   bf16_t* qw = reinterpret_cast<bf16_t*>(smem + 2 * TAB4_BYTES);
   bf16_t* kw = reinterpret_cast<bf16_t*>(smem + 2 * TAB4_BYTES + W_BYTES);
+  float* qwf = reinterpret_cast<float*>(smem + 2 * TAB4_BYTES + 2 * W_BYTES);
+  float* kwf = reinterpret_cast<float*>(smem + 2 * TAB4_BYTES + 2 * W_BYTES + WF_BYTES);
   char* vt = smem + LDS4_HEAD + wave * VT4_BYTES;
   const bool has_norm = q_norm_w != nullptr, has_rope = rope_cos != nullptr;
   if (has_rope) {
@@ -278,6 +335,8 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
   if (has_norm && tid < HD) {
     qw[tid] = q_norm_w[tid];
     kw[tid] = k_norm_w[tid];
+    qwf[tid] = bf2f(q_norm_w[tid]);
+    kwf[tid] = bf2f(k_norm_w[tid]);
   }
   for (int i = lane * 16; i < VT4_BYTES; i += 64 * 16) *reinterpret_cast<uint4*>(vt + i) = make_uint4(0, 0, 0, 0);
   __syncthreads();
@@ -306,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
   }
 
   // norm + RoPE (+ q scale) of one row's pieces on packed bf16 pairs: as attn_temporal_d72_v3_kernel::make_frags
-  auto make_frags = [&](const uint4 (&raw)[5], bf16x8 (&frag)[5], const bf16_t* w, int pos, bool zero_row, bool scaled) {
+  auto make_frags = [&](const uint4 (&raw)[5], bf16x8 (&frag)[5], const bf16_t* w, const float* wf, int pos, bool zero_row, bool scaled) {
     float rstd = 1.f;
     if (has_norm) {
       float ss = 0.f;
@@ -325,32 +384,11 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
       uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
-      if (c < 4 || hi == 0) {
-        if (has_norm) {
-          const uint4 wv = *reinterpret_cast<const uint4*>(w + 16 * c + 8 * hi);
-          const uint32_t wu[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t n1 = pk_bf16(bflo(u[e]) * rstd, bfhi(u[e]) * rstd);
-            u[e] = pk_bf16(bflo(n1) * bflo(wu[e]), bfhi(n1) * bfhi(wu[e]));
-          }
-        }
-        if (has_rope) {
-          const float4 cs = *reinterpret_cast<const float4*>(cosc + pos * TAB_ROW + 8 * c + 4 * hi);
-          const float4 sn = *reinterpret_cast<const float4*>(sinc + pos * TAB_ROW + 8 * c + 4 * hi);
-          const float cv[4] = {cs.x, cs.y, cs.z, cs.w}, sv[4] = {sn.x, sn.y, sn.z, sn.w};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float x0 = bflo(u[e]), x1 = bfhi(u[e]);
-            const t3_f32x2 r = __builtin_elementwise_fma(t3_f32x2{-x1, x0}, t3_f32x2{sv[e], sv[e]}, t3_f32x2{x0, x1} * t3_f32x2{cv[e], cv[e]});
-            u[e] = pk_bf16(r.x, r.y);
-          }
-        }
-        if (scaled) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) u[e] = pk_bf16(bflo(u[e]) * scale, bfhi(u[e]) * scale);
-        }
-      }
+      if (c < 4 || hi == 0)
+        t3_piece<MODE>(u, w, wf, cosc + pos * TAB_ROW, sinc + pos * TAB_ROW, c, hi, rstd, scale, has_norm, has_rope, scaled);
+      // (the fused path reads 16 table floats per piece: left alone, hipcc hoists the reads of all five pieces of q AND k to the top
+      //  and the kernel spills at its three-waves-per-SIMD budget; one piece's reads at a time keep it at the old footprint)
+      if constexpr (MODE != 0) __builtin_amdgcn_sched_barrier(0);
       if (zero_row) u[0] = u[1] = u[2] = u[3] = 0u;
       frag[c] = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
     }
@@ -389,8 +427,8 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
     }
     // ---- K fragments of both key blocks
     bf16x8 kf[2][5];
-    make_frags(rk[0], kf[0], kw, krow[0], !k_ok[0], false);
-    make_frags(rk[1], kf[1], kw, krow[1], !k_ok[1], false);
+    make_frags(rk[0], kf[0], kw, kwf, krow[0], !k_ok[0], false);
+    make_frags(rk[1], kf[1], kw, kwf, krow[1], !k_ok[1], false);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -398,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
     for (int qb = 0; qb < 2; ++qb) {
       if (32 * qb >= T) break;          // (wave-uniform)
       bf16x8 qf[5];
-      make_frags(rq[qb], qf, qw, qrow[qb], false, true);
+      make_frags(rq[qb], qf, qw, qwf, qrow[qb], false, true);
       f32x16 sacc[2];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb) {
@@ -478,20 +516,36 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
 
 int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
                                 const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T, int S,
-                                int heads, float eps, float scale, hipStream_t stream) {
+                                int heads, float eps, float scale, hipStream_t stream, bool ref_rounding) {
   if (T > 64 || T < 1) return VSYS_ERR_SHAPE;
+  // (t3_piece) 0 = the reference's rounding points with run-time flags; else the fused single-rounding form of this norm / rope combination
+  const int mode = ref_rounding ? 0 : (q_norm_w != nullptr ? (rope_cos != nullptr ? 1 : 3) : (rope_cos != nullptr ? 4 : 2));
   if (T > 32) {   // two key / query blocks (attn_temporal_d72_v4_kernel)
     int hsplit4 = 1;
     const int64_t slots4 = 2LL * cu_count_this_device();
     while (hsplit4 < 4 && (int64_t)B * S * hsplit4 < slots4 && heads % (hsplit4 * 2 * 4) == 0) hsplit4 *= 2;
     const int64_t grid4 = (int64_t)B * S * hsplit4;
     if (grid4 > 0x7fffffff) return VSYS_ERR_SHAPE;
-    const int lds4 = LDS4_HEAD + 4 * VT4_BYTES;   // 74048
+    const int lds4 = LDS4_HEAD + 4 * VT4_BYTES;   // 74688
     static std::atomic<unsigned long long> attr_seen{0};
-    for (DeviceOnce once(attr_seen); once.todo(); once.done())
-      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
-    hipLaunchKernelGGL(attn_temporal_d72_v4_kernel, dim3((unsigned)grid4), dim3(256), lds4, stream, qkv, row_stride, C, q_norm_w, k_norm_w,
-                       rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit4);
+    for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
+      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+      (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds4);
+    }
+#define T3_LAUNCH4(M_)                                                                                                          \
+  hipLaunchKernelGGL(attn_temporal_d72_v4_kernel<M_>, dim3((unsigned)grid4), dim3(256), lds4, stream, qkv, row_stride, C, q_norm_w, \
+                     k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit4)
+    switch (mode) {
+      case 0: T3_LAUNCH4(0); break;
+      case 1: T3_LAUNCH4(1); break;
+      case 2: T3_LAUNCH4(2); break;
+      case 3: T3_LAUNCH4(3); break;
+      default: T3_LAUNCH4(4); break;
+    }
+#undef T3_LAUNCH4
     return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
   }
   // fewer than ~3 workgroups per CU: split the heads of a token over 2 or 4 workgroups (every wave still owns whole heads)
@@ -500,9 +554,18 @@ int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, co
   while (hsplit < 4 && (int64_t)B * S * hsplit < slots && heads % (hsplit * 2 * 4) == 0) hsplit *= 2;
   const int64_t grid = (int64_t)B * S * hsplit;
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
-  const int lds = LDS_HEAD + 4 * VT_BYTES;   // 40256
-  hipLaunchKernelGGL(attn_temporal_d72_v3_kernel, dim3((unsigned)grid), dim3(256), lds, stream, qkv, row_stride, C, q_norm_w, k_norm_w,
-                     rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit);
+  const int lds = LDS_HEAD + 4 * VT_BYTES;   // 40896
+#define T3_LAUNCH3(M_)                                                                                                        \
+  hipLaunchKernelGGL(attn_temporal_d72_v3_kernel<M_>, dim3((unsigned)grid), dim3(256), lds, stream, qkv, row_stride, C, q_norm_w, \
+                     k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit)
+  switch (mode) {
+    case 0: T3_LAUNCH3(0); break;
+    case 1: T3_LAUNCH3(1); break;
+    case 2: T3_LAUNCH3(2); break;
+    case 3: T3_LAUNCH3(3); break;
+    default: T3_LAUNCH3(4); break;
+  }
+#undef T3_LAUNCH3
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
