@@ -309,9 +309,10 @@ int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* 
 /* The whole layout switch of Dynamic Sequence Parallelism in ONE launch per rank, peer to peer over xGMI (comm.py:104-141 _all_to_all_func
  * and :282-304 all_to_all_with_pad around open_sora_transformer_3d.py:288-315 dynamic_switch; replaces pack + all_to_all_single + unpack).
  * Problem i of the batch copies rows of ``src`` straight into the DESTINATION tensor of peer i in its final layout: desc (HOST) holds
- * nops x 16 int64 — the 14 of vsys_copy_4d_batch (dst_off relative to the problem's own destination), then the destination base
- * address (this process's mapping of the peer's tensor: vsys_p2p_ipc_open, or a plain device pointer inside one process) and the
- * address of flag[self_index] in that peer's flag array (0 for the rank's own problem).  After its stores are fenced a problem
+ * nops x 17 int64 — the 14 of vsys_copy_4d_batch (dst_off relative to the problem's own destination), then the destination base
+ * address (this process's mapping of the peer's tensor: vsys_p2p_ipc_open, or a plain device pointer inside one process), the
+ * address of flag[self_index] in that peer's flag array (0 for the rank's own problem) and 1 when ANOTHER process or device reads
+ * that destination (its rows then leave as system-scope write-through stores; 0: a reader ordered by launches on this device).  After its stores are fenced a problem
  * release-stores the exchange's sequence number into the peer's flag; the launch ends when every flag q != self_index of
  * ``my_flags`` (n_flags x uint32, fine-grained memory: vsys_p2p_alloc) has reached that number, i.e. when this rank's own destination
  * is complete: the consumer is simply the next launch on ``stream``.  ``state``: 32 x uint32 of zeroed device memory private to this

@@ -232,7 +232,7 @@ def test_stdit3_dsp_two_processes_peer_to_peer_over_ipc(T, HW):
 
 def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
     """The combination BASELINE configs[4] names — CogVideoX + PAB (spatial broadcast) + DSP degree 4 + the 3-D VAE's tiled decode —
-    in one run on a small geometry: four Ulysses ranks as threads of this process (tools/local_group; 8 heads = 2 per rank, 48 video
+    in one run on a small geometry: four Ulysses ranks as threads of this process (tools/local_group; 12 heads = 3 per rank, 48 video
     tokens = 12 per rank, text rows replicated), the PAB schedule of the reference fixture (broadcast steps skip the attention AND its
     two exchanges on every rank alike), every step's output of every rank BIT-identical to the single-process run; rank 0 then
     decodes its final latents with the tiled decode (4 tiles, blended) and gets the bits of the single-process latents' decode
@@ -245,8 +245,8 @@ def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
     from videosys_amd.vae_cogvideox import CogVideoXVAE, synth_state_dict as vae_synth
 
     fx = load_golden("cogvideox_pab_small.pt")
-    cfg = dict(fx["cfg"], num_attention_heads=8)
-    sd = {k: v.to(torch.bfloat16).float() for k, v in CO.synth_state_dict(cfg["num_layers"], 8, text_embed_dim=cfg["text_embed_dim"],
+    cfg = dict(fx["cfg"], num_attention_heads=12)     # hidden 768 = 4 GEMM column tiles; 3 heads per rank
+    sd = {k: v.to(torch.bfloat16).float() for k, v in CO.synth_state_dict(cfg["num_layers"], 12, text_embed_dim=cfg["text_embed_dim"],
                                                                           seed=fx["seed"]).items()}
     rope = CO.rope_3d(64, CO.crop_region((4, 6), 45, 30), (4, 6), 3)
     P = 4

@@ -54,6 +54,8 @@ class LocalWorld:
 
 
 class LocalGroup:
+    same_process = True     # (dsp.PeerExchange: every destination is read by launches ordered on this device)
+
     def __init__(self, world: LocalWorld, rank: int):
         self.world, self.rank, self.size = world, rank, world.P
 
@@ -120,6 +122,8 @@ class LocalGroup:
 
 class StubGroup:
     """One rank of a P-way group, wire stubbed: every collective is a device copy of its own send buffer."""
+
+    same_process = True
 
     def __init__(self, P: int, rank: int = 0):
         self.size, self.rank = P, rank

@@ -494,8 +494,9 @@ int vsys_p2p_exchange(const void* src, int64_t nops, const int64_t* desc, const 
   CopyDesc ops[VSYS_COPY_BATCH_MAX];
   bf16_t* dsts[VSYS_COPY_BATCH_MAX];
   unsigned* flags[VSYS_COPY_BATCH_MAX];
+  int remote[VSYS_COPY_BATCH_MAX];
   for (int i = 0; i < (int)nops; ++i) {
-    const int64_t* d = desc + 16 * i;
+    const int64_t* d = desc + 17 * i;
     for (int k = 2; k < 6; ++k) if (!fits_int(d[k])) return VSYS_ERR_SHAPE;
     if (!fits_int(d[12]) || !fits_int(d[13]) || d[0] < 0 || d[1] < 0 || d[14] == 0) return VSYS_ERR_SHAPE;
     ops[i].src_off = d[0]; ops[i].dst_off = d[1];
@@ -504,8 +505,9 @@ int vsys_p2p_exchange(const void* src, int64_t nops, const int64_t* desc, const 
     ops[i].n1_valid = (int)d[12]; ops[i].n2_valid = (int)d[13];
     dsts[i] = reinterpret_cast<bf16_t*>(d[14]);
     flags[i] = reinterpret_cast<unsigned*>(d[15]);
+    remote[i] = d[16] != 0;
   }
-  return launch_p2p_exchange(B16(src), ops, dsts, flags, (int)nops, reinterpret_cast<const unsigned*>(my_flags), (int)n_flags,
+  return launch_p2p_exchange(B16(src), ops, dsts, flags, remote, (int)nops, reinterpret_cast<const unsigned*>(my_flags), (int)n_flags,
                              (int)self_index, reinterpret_cast<unsigned*>(state), (long long)timeout_ticks, S(stream));
 }
 

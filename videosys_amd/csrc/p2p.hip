@@ -36,6 +36,8 @@ struct P2PDesc {
   CopyDesc c;            // c.dst_off is relative to this problem's own destination pointer
   bf16_t* dst;           // peer's (or this rank's own) destination tensor
   unsigned* peer_flag;   // &flags_of_peer[me]; null for the rank's own problem
+  int remote;            // 1: the destination is read by ANOTHER process / device right after the flag (write-through stores);
+                         // 0: by later launches ordered on this device (the rank itself, ranks that are threads of this process)
 };
 struct P2PBatch {
   int nops;
@@ -62,10 +64,16 @@ __global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, 
     const int i0 = (int)(r / o.n1);
     u32x4 v = {0u, 0u, 0u, 0u};
     if (i1 < o.n1_valid && i2 < o.n2_valid) v = *reinterpret_cast<const u32x4*>(s + i0 * o.ss0 + i1 * o.ss1 + i2 * o.ss2 + c * 8);
-    // system-scope WRITE-THROUGH store: the rows go to the peer's memory (or this rank's) past the L2, so publishing them needs no
-    // cache write-back — a __threadfence_system() per thread (buffer_wbl2 in every wave) made this kernel 15x slower
     bf16_t* q = d + i0 * o.ds0 + i1 * o.ds1 + i2 * o.ds2 + c * 8;
-    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+    if (pd.remote) {
+      // system-scope WRITE-THROUGH store: the rows go to the peer's memory past this GPU's L2, so publishing them needs no cache
+      // write-back (a __threadfence_system() per thread — buffer_wbl2 in every wave — made this kernel 15x slower).  Only for
+      // destinations another process / device reads: into LOCAL memory these stores run at a fraction of the cached rate
+      // (52 us against 7 us per config-2 exchange), and a local reader is ordered by the launch boundary anyway.
+      asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
+    } else {
+      *reinterpret_cast<u32x4*>(q) = v;
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has been acknowledged by its destination ...
   __syncthreads();                                   // ... and so have the other waves' of this workgroup
@@ -96,7 +104,7 @@ __global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, 
 
 }  // namespace
 
-int launch_p2p_exchange(const bf16_t* src, const CopyDesc* ops, bf16_t* const* dsts, unsigned* const* peer_flags, int nops,
+int launch_p2p_exchange(const bf16_t* src, const CopyDesc* ops, bf16_t* const* dsts, unsigned* const* peer_flags, const int* remote, int nops,
                         const unsigned* my_flags, int n_flags, int self_index, unsigned* state, long long timeout_ticks,
                         hipStream_t stream) {
   if (nops <= 0) return 0;
@@ -109,6 +117,7 @@ int launch_p2p_exchange(const bf16_t* src, const CopyDesc* ops, bf16_t* const* d
     b.d[i].c = ops[i];
     b.d[i].dst = dsts[i];
     b.d[i].peer_flag = peer_flags[i];
+    b.d[i].remote = remote[i];
     const int64_t t = (int64_t)ops[i].n0 * ops[i].n1 * ops[i].n2 * (ops[i].C / 8);
     most = t > most ? t : most;
   }

@@ -432,15 +432,17 @@ class PeerExchange:
 
         st = self._site(key, out)
         flat = []
+        same_process = bool(getattr(self.peers, "same_process", False))     # ranks as threads / a stub: plain (cached) stores
         for r in range(self.P):
             o = ops[r]
             flag = 0 if r == self.rank else st["flag_ptrs"][r] + 4 * self.rank
+            remote = int(r != self.rank and not same_process)
             if o is not None:
                 flat += [o.src_off, o.dst_off, o.n0, o.n1, o.n2, o.run, *o.sstr, *o.dstr, o.n1_valid, o.n2_valid,
-                         st["outs"][r].data_ptr(), flag]
+                         st["outs"][r].data_ptr(), flag, remote]
             elif r != self.rank:     # nothing of mine travels to r (a fully padded shard): an EMPTY problem still raises my flag there
-                flat += [0, 0, 0, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, st["outs"][r].data_ptr(), flag]
-        n = len(flat) // 16
+                flat += [0, 0, 0, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, st["outs"][r].data_ptr(), flag, remote]
+        n = len(flat) // 17
         arr = (ctypes.c_int64 * len(flat))(*[int(v) for v in flat])
         program.keep(st)
         # ranks that are threads of ONE process (tools/local_group) order the launches on the host instead of polling flags on the
