@@ -315,9 +315,9 @@ int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* 
  * that destination (its rows then leave as system-scope write-through stores; 0: a reader ordered by launches on this device).  After its stores are fenced a problem
  * release-stores the exchange's sequence number into the peer's flag; the launch ends when every flag q != self_index of
  * ``my_flags`` (n_flags x uint32, fine-grained memory: vsys_p2p_alloc) has reached that number, i.e. when this rank's own destination
- * is complete: the consumer is simply the next launch on ``stream``.  ``state``: 32 x uint32 of zeroed device memory private to this
- * exchange site — [0] the sequence number (advanced by the kernel itself, so a recorded launch program replays unchanged), [31] an
- * error word (0; 1 + q when peer q's flag did not arrive within ``timeout_ticks`` of the 100 MHz wall clock; sticky: a site that timed
+ * is complete: the consumer is simply the next launch on ``stream``.  ``state``: 19 x 32 uint32 (one 128-byte line per word) of zeroed
+ * device memory private to this exchange site — word 0 the sequence number (advanced by the kernel itself, so a recorded launch
+ * program replays unchanged), word 18 (uint32 index 576) an error word (0; 1 + q when peer q's flag did not arrive within ``timeout_ticks`` of the 100 MHz wall clock; sticky: a site that timed
  * out once no longer waits; timeout_ticks 0 = wait for ever, < 0 = do not wait at all: the caller orders the peers' launches itself).
  * Every rank of the group must issue the same sequence of exchanges per site. */
 int vsys_p2p_exchange(const void* src, int64_t nops, const int64_t* desc, const void* my_flags, int64_t n_flags, int64_t self_index,

@@ -300,10 +300,10 @@ class CogVideoXTransformer3DModel:
                              eps=cfgm.norm_eps, out=self._buf("attn_out", (B * Lvl, C)))
         po = ops.gemm(xo, w["_proj_out.weight"], w["_proj_out.bias"], out=self._buf("proj", (B * Lvl, 192)))
         if sp is not None:  # gather_sequence (:569-570) on the projected rows (192 columns instead of C), padding dropped
-            import torch.distributed as dist
+            from . import dsp
 
             parts = torch.empty(sp.P, B, Lvl, 192, dtype=po.dtype, device=dev)
-            dist.all_gather_into_tensor(parts.view(sp.P * B, Lvl, 192), po.view(B, Lvl, 192).contiguous(), group=sp.group)
+            dsp.all_gather_into_tensor(parts.view(sp.P * B, Lvl, 192), po.view(B, Lvl, 192).contiguous(), sp.group)   # (group protocol)
             po = parts.permute(1, 0, 2, 3).reshape(B, sp.P * Lvl, 192)[:, :Lv].reshape(B * Lv, 192).contiguous()
         out = ops.unpatchify_cvx(po, B, Fr, Hp, Wp, cfgm.out_channels, p)
         if not return_dict:

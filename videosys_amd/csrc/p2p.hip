@@ -44,10 +44,13 @@ struct P2PBatch {
   P2PDesc d[VSYS_COPY_BATCH_MAX];
 };
 
-// state[0] = sequence number of the last finished exchange of this site, state[1] = problems finished in the running launch,
-// state[2 + i] = workgroups of problem i finished, state[31] = error word (0 ok; 1 + q: peer q's flag did not arrive in time)
-__global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, const unsigned* my_flags, int n_flags, int self_index,
-                                    unsigned* state, long long timeout_ticks) {
+// state (uint32, one 128-byte line per word so that the counters of different problems do not share an L2 channel):
+//   word 0 = sequence number of the last finished exchange of this site, word 1 = problems finished in the running launch,
+//   word 2 + i = workgroups of problem i finished, word 18 = error word (0 ok; 1 + q: peer q's flag did not arrive in time)
+constexpr int ST = 32;                       // uint32 per word slot
+constexpr int ST_WORDS = 19;
+__global__ __launch_bounds__(256) void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, const unsigned* my_flags, int n_flags,
+                                                           int self_index, unsigned* state, long long timeout_ticks) {
   const P2PDesc& pd = b.d[blockIdx.y];
   const CopyDesc& o = pd.c;
   const unsigned seq = __hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
@@ -68,8 +71,7 @@ __global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, 
     if (pd.remote) {
       // system-scope WRITE-THROUGH store: the rows go to the peer's memory past this GPU's L2, so publishing them needs no cache
       // write-back (a __threadfence_system() per thread — buffer_wbl2 in every wave — made this kernel 15x slower).  Only for
-      // destinations another process / device reads: into LOCAL memory these stores run at a fraction of the cached rate
-      // (52 us against 7 us per config-2 exchange), and a local reader is ordered by the launch boundary anyway.
+      // destinations another process / device reads: a local reader is ordered by the launch boundary anyway.
       asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(q), "v"(v) : "memory");
     } else {
       *reinterpret_cast<u32x4*>(q) = v;
@@ -78,28 +80,32 @@ __global__ void p2p_exchange_kernel(const bf16_t* __restrict__ src, P2PBatch b, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has been acknowledged by its destination ...
   __syncthreads();                                   // ... and so have the other waves' of this workgroup
   if (threadIdx.x != 0) return;
-  if (__hip_atomic_fetch_add(&state[2 + blockIdx.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
-  // ---- last workgroup of this problem: every store of the problem is fenced; tell the peer
-  state[2 + blockIdx.y] = 0;
-  if (pd.peer_flag != nullptr) __hip_atomic_store(pd.peer_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  if (__hip_atomic_fetch_add(&state[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.y - 1) return;
+  // The hand-off is the counter form of cdna_hip_programming.md section 6 Guideline 16: write-through payload, drained, THEN the
+  // relaxed ticket.  No release fence anywhere: a fence is a buffer_wbl2 — with one per workgroup (2880 of them at config 2, all
+  // on one counter line) this launch took 88 us for a 1.4 MB exchange; it is why the grid is at most 32 workgroups per problem
+  // and every counter has a cache line to itself.
+  if (__hip_atomic_fetch_add(&state[ST * (2 + blockIdx.y)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
+  // ---- last workgroup of this problem: every store of the problem has been acknowledged; tell the peer
+  __hip_atomic_store(&state[ST * (2 + blockIdx.y)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (pd.peer_flag != nullptr) __hip_atomic_store(pd.peer_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (__hip_atomic_fetch_add(&state[ST * 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.y - 1) return;
   // ---- last problem of the launch: wait for every peer's rows (their flag in MY array), then publish the new sequence number
-  state[1] = 0;
+  __hip_atomic_store(&state[ST * 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const long long t0 = wall_clock64();
   // (timeout_ticks < 0: the caller orders the peers' launches itself — ranks that are threads of one process rendezvous on the host;
   //  a site that has already timed out once does not wait again: the error word is sticky and the host raises at its next check)
-  const bool wait = timeout_ticks >= 0 && __hip_atomic_load(state + 31, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
+  const bool wait = timeout_ticks >= 0 && __hip_atomic_load(&state[ST * 18], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u;
   for (int q = 0; wait && q < n_flags; ++q) {
     if (q == self_index) continue;
     while ((int)(__hip_atomic_load(my_flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {   // (polled relaxed: an acquire per poll would drop the L1 every time)
       __builtin_amdgcn_s_sleep(16);
       if (timeout_ticks > 0 && wall_clock64() - t0 > timeout_ticks) {
-        __hip_atomic_store(state + 31, (unsigned)(1 + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&state[ST * 18], (unsigned)(1 + q), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         break;
       }
     }
   }
-  __hip_atomic_store(state, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(state, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the next launch of this site reads it: launch boundary)
 }
 
 }  // namespace
@@ -123,7 +129,7 @@ int launch_p2p_exchange(const bf16_t* src, const CopyDesc* ops, bf16_t* const* d
   }
   // (an exchange whose every problem is empty still signals and waits: the peers count on this rank's flag)
   int64_t grid = (most + 255) / 256;
-  grid = grid < 1 ? 1 : (grid > 1024 ? 1024 : grid);
+  grid = grid < 1 ? 1 : (grid > 32 ? 32 : grid);   // <= 32 workgroups per problem: 8 problems fill the chip, 256 tickets per launch
   hipLaunchKernelGGL(p2p_exchange_kernel, dim3((unsigned)grid, (unsigned)nops), dim3(256), 0, stream, src, b, my_flags, n_flags,
                      self_index, state, timeout_ticks);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;

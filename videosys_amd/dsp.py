@@ -420,7 +420,7 @@ class PeerExchange:
             outs = _share_tensor(self.peers, out)                    # collective: every rank creates its sites in the same order
             my_flags, flag_ptrs = _share_flags(self.peers, self.P)
             st = dict(out=out, outs=outs, my_flags=my_flags, flag_ptrs=flag_ptrs,
-                      state=torch.zeros(32, dtype=torch.int32, device=out.device))
+                      state=torch.zeros(19 * 32, dtype=torch.int32, device=out.device))   # one 128-byte line per word (p2p.hip)
             self.sites[key] = st
         return st
 
@@ -457,7 +457,7 @@ class PeerExchange:
     def check(self):
         """Raise if any exchange timed out waiting for a peer (state[31] of a site; synchronises the device)."""
         for key, st in self.sites.items():
-            err = int(st["state"][31].item())
+            err = int(st["state"][18 * 32].item())
             if err:
                 raise RuntimeError(f"peer-to-peer exchange {key}: rank {self.rank} never received the rows of rank {err - 1} "
                                    f"(VSYS_P2P_TIMEOUT_S); set VSYS_DSP_P2P=0 to use the RCCL all_to_all_single path")
