@@ -113,21 +113,25 @@ __device__ __forceinline__ void t3_piece(uint32_t (&u)[4], const bf16_t* w, cons
   }
 }
 
+// The fused forms of the two production combinations (MODE 1: Open-Sora, 2: Latte) fit 128 registers: FOUR workgroups per CU when the
+// launch's LDS allows it (the RoPE tables are sized by T, not by the 32-row tile: 37 KB per workgroup at T = 19) — the kernel waits
+// on one HBM round trip per head with no prefetch, so resident waves are what covers it.
 template <int MODE>
-__global__ __launch_bounds__(256, 3) void attn_temporal_d72_v3_kernel(
+__global__ __launch_bounds__(256, (MODE == 1 || MODE == 2) ? 4 : 3) void attn_temporal_d72_v3_kernel(
     const bf16_t* __restrict__ qkv, int64_t row_stride, int C, const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
     const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, bf16_t* __restrict__ out, int64_t out_stride, int B, int T,
-    int S, int heads, float eps, float scale, int hsplit) {
+    int S, int heads, float eps, float scale, int hsplit, int tab_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hi = lane >> 5;
   float* cosc = reinterpret_cast<float*>(smem);
-  float* sinc = reinterpret_cast<float*>(smem + TAB_BYTES);
-  bf16_t* qw = reinterpret_cast<bf16_t*>(smem + 2 * TAB_BYTES);
-  bf16_t* kw = reinterpret_cast<bf16_t*>(smem + 2 * TAB_BYTES + W_BYTES);
-  float* qwf = reinterpret_cast<float*>(smem + 2 * TAB_BYTES + 2 * W_BYTES);
-  float* kwf = reinterpret_cast<float*>(smem + 2 * TAB_BYTES + 2 * W_BYTES + WF_BYTES);
-  char* vt = smem + LDS_HEAD + wave * VT_BYTES;
+  // (tab_bytes = the bytes of one compact RoPE table for THIS launch's T, a multiple of 16; TAB_BYTES is the 32-row maximum)
+  float* sinc = reinterpret_cast<float*>(smem + tab_bytes);
+  bf16_t* qw = reinterpret_cast<bf16_t*>(smem + 2 * tab_bytes);
+  bf16_t* kw = reinterpret_cast<bf16_t*>(smem + 2 * tab_bytes + W_BYTES);
+  float* qwf = reinterpret_cast<float*>(smem + 2 * tab_bytes + 2 * W_BYTES);
+  float* kwf = reinterpret_cast<float*>(smem + 2 * tab_bytes + 2 * W_BYTES + WF_BYTES);
+  char* vt = smem + 2 * tab_bytes + 2 * W_BYTES + 2 * WF_BYTES + wave * VT_BYTES;
   const bool has_norm = q_norm_w != nullptr, has_rope = rope_cos != nullptr;
 
   // ---- per-workgroup tables (compact RoPE angles, norm weights) and the zeroed V^T image (key columns >= T stay zero for good:
@@ -550,14 +554,15 @@ int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, co
   }
   // fewer than ~3 workgroups per CU: split the heads of a token over 2 or 4 workgroups (every wave still owns whole heads)
   int hsplit = 1;
-  const int64_t slots = 3LL * cu_count_this_device();
+  const int64_t slots = 4LL * cu_count_this_device();
   while (hsplit < 4 && (int64_t)B * S * hsplit < slots && heads % (hsplit * 2 * 4) == 0) hsplit *= 2;
   const int64_t grid = (int64_t)B * S * hsplit;
   if (grid > 0x7fffffff) return VSYS_ERR_SHAPE;
-  const int lds = LDS_HEAD + 4 * VT_BYTES;   // 40896
+  const int tab_bytes = rope_cos != nullptr ? T * TAB_ROW * 4 : 0;   // (T x 144 B: a multiple of 16)
+  const int lds = 2 * tab_bytes + 2 * W_BYTES + 2 * WF_BYTES + 4 * VT_BYTES;   // 37152 at T = 19 (four workgroups per CU), <= 40896
 #define T3_LAUNCH3(M_)                                                                                                        \
   hipLaunchKernelGGL(attn_temporal_d72_v3_kernel<M_>, dim3((unsigned)grid), dim3(256), lds, stream, qkv, row_stride, C, q_norm_w, \
-                     k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit)
+                     k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, hsplit, tab_bytes)
   switch (mode) {
     case 0: T3_LAUNCH3(0); break;
     case 1: T3_LAUNCH3(1); break;
