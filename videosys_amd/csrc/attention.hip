@@ -258,6 +258,11 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
     }
   };
   auto finish_q = [&]() {
+    if (p.q_norm_w == nullptr) {   // (cross attention, Latte: no q norm) the raw bf16 pieces ARE the fragment: no unpack / repack pass
+#pragma unroll
+      for (int c = 0; c < 5; ++c) qf[c] = __builtin_bit_cast(bf16x8, qraw[c]);
+      return;
+    }
     float x[5][8];
     float ss = 0.f;
 #pragma unroll
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
 #pragma unroll
       for (int e = 0; e < 8; ++e) ss += x[c][e] * x[c][e];
     }
-    if (p.q_norm_w != nullptr) {
+    {
       ss += __shfl_xor(ss, 32, 64);
       const float rstd = rsqrtf(ss / (float)HD + p.eps);
 #pragma unroll
