@@ -256,7 +256,7 @@ def main():
         # HBM/fabric bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same
         # kernels and shapes, tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json), config-2 launch mix
         traffic = None
-        tname = next((n for n in ("r04_gemm_traffic.json", "r03_gemm_traffic.json", "r01_gemm_traffic.json")
+        tname = next((n for n in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r01_gemm_traffic.json")
                       if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         if tname is not None and world == 1:
             with open(os.path.join(ROOT, "profiles", tname)) as fh:
