@@ -12,7 +12,12 @@ CSRC = os.path.join(ROOT, "videosys_amd", "csrc")
 HIPCC = "/opt/rocm/bin/hipcc"
 
 
+import functools
+
+
+@functools.lru_cache(maxsize=None)
 def _usage(src):
+    """Per-kernel resource usage of one source (compiled once per test session: several tests read the same file's table)."""
     r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", os.path.join(CSRC, src), "-o", "/dev/null",
                         "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, cwd=CSRC)
     assert r.returncode == 0, r.stderr[-2000:]

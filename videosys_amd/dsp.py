@@ -454,6 +454,25 @@ class PeerExchange:
             program.host_call(host_sync)
         self.launches += 1
 
+    def close(self):
+        """Give the flag arrays back (this rank's allocation; the mappings of the peers' arrays when they came through HIP IPC).  The
+        ranks must have finished their last exchange (a collective barrier, or the end of the run) before anybody closes."""
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.load()
+        ipc = isinstance(self.peers, IpcPeers)
+        for st in self.sites.values():
+            if ipc:
+                for q, ptr in enumerate(st["flag_ptrs"]):
+                    if q != self.rank and ptr:
+                        lib.vsys_p2p_ipc_close(ctypes.c_void_p(ptr))
+            if st.get("my_flags"):
+                lib.vsys_p2p_free(ctypes.c_void_p(st["my_flags"]))
+            st["my_flags"] = 0
+        self.sites.clear()
+
     def check(self):
         """Raise if any exchange timed out waiting for a peer (state[31] of a site; synchronises the device)."""
         for key, st in self.sites.items():

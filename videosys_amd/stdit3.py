@@ -236,6 +236,8 @@ class STDiT3:
         self._programs = {}
         if self.parallel_manager.sp_size > 1:
             kw = {} if copy_executor is None else {"copy_executor": copy_executor}
+            # (a replaced SequenceParallel keeps its few bytes of peer-to-peer flag memory: a peer may still be raising a flag of the old
+            #  layout's last exchange; dsp.PeerExchange.close() is for the owner to call behind a barrier)
             self._sp = dsp.SequenceParallel(self.parallel_manager.sp_group, **kw)
         else:
             self._sp = None
