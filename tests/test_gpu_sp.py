@@ -114,12 +114,15 @@ def _run(worker, args, world=2, timeout=300):
         assert s == "ok", f"rank {r}: {s}"
 
 
-def _latte_worker(rank, world, port, outdir):
+def _latte_worker(rank, world, port, outdir, p2p=False):
     import traceback
 
     import torch.distributed as dist
 
     try:
+        if p2p:
+            os.environ["VSYS_DSP_P2P"] = "1"
+            os.environ["VSYS_P2P_TIMEOUT_S"] = "5"
         from conftest import load_golden
         from oracle import latte_oracle as LO
         from videosys_amd import pab
@@ -146,6 +149,9 @@ def _latte_worker(rank, world, port, outdir):
             m.enable_parallel(1, world, False)
             out = call()
             res.append((frames, torch.equal(out, ref), (out - ref).abs().max().item(), ref.abs().max().item()))
+            if p2p:
+                assert m._sp.p2p is not None and m._sp.p2p.launches > 0, "VSYS_DSP_P2P=1 did not take the peer-to-peer path"
+                m._sp.p2p.check()
         torch.cuda.synchronize()
         bad = [r for r in res if not r[1]]
         with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
@@ -163,12 +169,15 @@ def test_latte_sp_two_ranks_equals_single():
     _run(_latte_worker, ())
 
 
-def _cogvideox_worker(rank, world, port, outdir):
+def _cogvideox_worker(rank, world, port, outdir, p2p=False):
     import traceback
 
     import torch.distributed as dist
 
     try:
+        if p2p:
+            os.environ["VSYS_DSP_P2P"] = "1"
+            os.environ["VSYS_P2P_TIMEOUT_S"] = "5"
         from conftest import load_golden
         from oracle import cogvideox_oracle as CO
         from videosys_amd import pab
@@ -196,6 +205,9 @@ def _cogvideox_worker(rank, world, port, outdir):
             m.enable_parallel(1, world, False)
             out = call()
             res.append((key, torch.equal(out, ref), (out - ref).abs().max().item(), ref.abs().max().item()))
+            if p2p:
+                assert m._sp.p2p is not None and m._sp.p2p.launches > 0, "VSYS_DSP_P2P=1 did not take the peer-to-peer path"
+                m._sp.p2p.check()
         torch.cuda.synchronize()
         bad = [r for r in res if not r[1]]
         with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
@@ -219,6 +231,14 @@ def test_stdit3_dsp_two_ranks_equals_single(T, HW):
     """Open-Sora DSP (open_sora_transformer_3d.py:288-315,598-619): T = 5 needs the temporal zero-pad (5 -> 6 over 2 ranks),
     HW = 12 -> S = 36 tokens per frame split 18 / 18; T = 1 is the image case (the CFG batch is scattered instead of the frame)."""
     _run(_stdit3_worker, (T, HW))
+
+
+def test_latte_and_cogvideox_two_processes_peer_to_peer_over_ipc():
+    """The same one-kernel exchange under Latte's frame-sharded sequence parallelism (the two switches around every temporal block,
+    latte_transformer_3d.py:826-843,1300-1308) and CogVideoX's Ulysses exchange (heads <-> sequence, two problems per peer on the way
+    back, cogvideox_transformer_3d.py:45-86,112-165), two processes over HIP IPC: bit-identical to the single-process outputs."""
+    _run(_latte_worker, (True,))
+    _run(_cogvideox_worker, (True,))
 
 
 @pytest.mark.parametrize("T,HW", [(5, 16), (4, 12)])
@@ -269,9 +289,11 @@ def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
             m = CogVideoXTransformer3DModel(**cfg, device="cuda:0")
             m.load_state_dict(sd)
             m.enable_parallel(parallel_mgr=_rank_manager(group, P, r))
-            assert m._sp is not None and m._sp.P == P
+            assert m._sp is not None and m._sp.P == P and m._sp.p2p is not None   # in process: the one-kernel Ulysses exchange
             outs = run_schedule(m)
             torch.cuda.synchronize()
+            assert m._sp.p2p.launches > 0
+            m._sp.p2p.check()
             return outs
 
         per_rank = LocalWorld(P, timeout=300).run(rank_fn)

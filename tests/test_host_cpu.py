@@ -1586,3 +1586,65 @@ def test_p2p_plans_equal_pack_exchange_unpack(B, T, S, P, chunks):
                     torch_copy_executor(ys[me], got[r], [o])
         for r in range(P):
             assert torch.equal(got[r], ref[r]), ("to_spatial", r, ck)
+
+
+@pytest.mark.parametrize("B,Lt,Lv,heads,P", [(2, 3, 9, 8, 4), (1, 5, 45, 6, 2), (2, 2, 7, 8, 8), (1, 4, 16, 12, 4)])
+def test_p2p_ulysses_plans_equal_pack_exchange_unpack(B, Lt, Lv, heads, P):
+    """The Ulysses head <-> sequence exchange of CogVideoX as peer-to-peer copies (dsp.plan_p2p_heads_scatter / _gather: straight into the
+    peers' destination tensors, two problems per peer on the way back) against pack -> all_to_all_single -> unpack (plan_heads_scatter /
+    plan_heads_gather; cogvideox_transformer_3d.py:45-86,112-123,160-165): same written positions, same values — padded video shards
+    (Lv % P != 0, a rank with no video row at all) included."""
+    from videosys_amd import dsp
+
+    hd = 8
+    C = heads * hd
+    hw = C // P
+    Lvl = -(-Lv // P)
+    Ll, L = Lt + Lvl, Lt + Lv
+    g = torch.Generator().manual_seed(B + Lt * 10 + Lv * 100 + P)
+    qkvs = [torch.randn(B, Ll, 3 * C, generator=g) for _ in range(P)]
+    # ---- sequence -> heads
+    sends, ref = [], []
+    for r in range(P):
+        pack, ul, ur, sshape, oshape = dsp.plan_heads_scatter(B, Lt, Lvl, Lv, C, P, r)
+        send = torch.full(sshape, 5.0)
+        torch_copy_executor(qkvs[r], send, pack)
+        sends.append(send)
+    for r in range(P):
+        pack, ul, ur, sshape, oshape = dsp.plan_heads_scatter(B, Lt, Lvl, Lv, C, P, r)
+        recv = torch.stack([sends[src][r] for src in range(P)], 0)
+        out = torch.full(oshape, 7.0)
+        torch_copy_executor(qkvs[r], out, ul)
+        torch_copy_executor(recv, out, ur)
+        ref.append(out)
+    got = [torch.full(oshape, 7.0) for _ in range(P)]
+    for me in range(P):
+        ops, osh = dsp.plan_p2p_heads_scatter(B, Lt, Lvl, Lv, C, P, me)
+        assert osh == oshape and len(ops) == P
+        for r, mine in enumerate(ops):
+            for o in (mine or []):
+                torch_copy_executor(qkvs[me], got[r], [o])
+    for r in range(P):
+        assert torch.equal(got[r], ref[r]), ("scatter_heads", r)
+    # ---- heads -> sequence
+    aos = [torch.randn(B, L, hw, generator=g) for _ in range(P)]
+    sends, ref = [], []
+    for r in range(P):
+        pack, unpack, sshape, oshape = dsp.plan_heads_gather(B, Lt, Lvl, Lv, C, P)
+        send = torch.full(sshape, 5.0)
+        torch_copy_executor(aos[r], send, pack)
+        sends.append(send)
+    for r in range(P):
+        recv = torch.stack([sends[src][r] for src in range(P)], 0)
+        out = torch.full(oshape, 7.0)
+        torch_copy_executor(recv, out, unpack)
+        ref.append(out)
+    got = [torch.full(oshape, 7.0) for _ in range(P)]
+    for me in range(P):
+        ops, osh = dsp.plan_p2p_heads_gather(B, Lt, Lvl, Lv, C, P, me)
+        assert osh == oshape and all(len(m) == 2 for m in ops)
+        for r, mine in enumerate(ops):
+            for o in mine:
+                torch_copy_executor(aos[me], got[r], [o])
+    for r in range(P):
+        assert torch.equal(got[r], ref[r]), ("gather_heads", r)

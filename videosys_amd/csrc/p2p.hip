@@ -9,9 +9,10 @@
 //
 // One launch per rank and exchange does everything: problem r of the batch copies the rows this rank owes peer r straight from the
 // source tensor (pack strides, zero fill for the padded frames) into peer r's DESTINATION tensor in its final layout (unpack
-// strides, narrowed) — no send buffer, no receive buffer, no second pass.  When the last workgroup of problem r has fenced its
-// stores it release-stores this exchange's sequence number into flag[me] of peer r; the last workgroup of the whole launch then
-// waits (one lane, s_sleep between polls, wall-clock timeout) until every peer's number has arrived in this rank's own flag array.
+// strides, narrowed) — no send buffer, no receive buffer, no second pass.  When the stores of every problem have been acknowledged
+// (write-through stores, drained per wave, counted per workgroup) the launch's last workgroup stores this exchange's sequence number
+// into flag[me] of every peer and then waits (one lane, s_sleep between polls, wall-clock timeout) until every peer's number has
+// arrived in this rank's own flag array.
 // The kernel therefore ends only when this rank's destination tensor is complete, and the consumer (the qkv GEMM, the projection
 // GEMM) is simply the next launch on the stream.  The sequence number lives in device memory (state[0]) and is advanced by the
 // kernel itself, so a recorded launch program replays the same command every step.
@@ -85,12 +86,14 @@ __global__ __launch_bounds__(256) void p2p_exchange_kernel(const bf16_t* __restr
   // on one counter line) this launch took 88 us for a 1.4 MB exchange; it is why the grid is at most 32 workgroups per problem
   // and every counter has a cache line to itself.
   if (__hip_atomic_fetch_add(&state[ST * (2 + blockIdx.y)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.x - 1) return;
-  // ---- last workgroup of this problem: every store of the problem has been acknowledged; tell the peer
+  // ---- last workgroup of this problem: every store of the problem has been acknowledged
   __hip_atomic_store(&state[ST * (2 + blockIdx.y)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (pd.peer_flag != nullptr) __hip_atomic_store(pd.peer_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (__hip_atomic_fetch_add(&state[ST * 1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != gridDim.y - 1) return;
-  // ---- last problem of the launch: wait for every peer's rows (their flag in MY array), then publish the new sequence number
+  // ---- last problem of the launch: EVERY problem's stores have been acknowledged (several problems may feed one peer — the text
+  // and video rows of the Ulysses gather — so a peer is told once, here), then wait for every peer's rows (their flag in MY array)
   __hip_atomic_store(&state[ST * 1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int i = 0; i < b.nops; ++i)
+    if (b.d[i].peer_flag != nullptr) __hip_atomic_store(b.d[i].peer_flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const long long t0 = wall_clock64();
   // (timeout_ticks < 0: the caller orders the peers' launches itself — ranks that are threads of one process rendezvous on the host;
   //  a site that has already timed out once does not wait again: the error word is sticky and the host raises at its next check)

@@ -424,7 +424,8 @@ class PeerExchange:
             self.sites[key] = st
         return st
 
-    def exchange(self, key, src, out, ops: List[Optional[CopyOp]]):
+    def exchange(self, key, src, out, ops):
+        """ops[r]: None, a CopyOp, or a list of CopyOps — the rows of ``src`` that go into peer r's ``out`` (r == rank: this rank's own)."""
         import ctypes
 
         from . import ops as vops
@@ -434,15 +435,17 @@ class PeerExchange:
         flat = []
         same_process = bool(getattr(self.peers, "same_process", False))     # ranks as threads / a stub: plain (cached) stores
         for r in range(self.P):
-            o = ops[r]
+            mine = ops[r]
+            mine = [] if mine is None else (list(mine) if isinstance(mine, (list, tuple)) else [mine])
             flag = 0 if r == self.rank else st["flag_ptrs"][r] + 4 * self.rank
             remote = int(r != self.rank and not same_process)
-            if o is not None:
+            for o in mine:
                 flat += [o.src_off, o.dst_off, o.n0, o.n1, o.n2, o.run, *o.sstr, *o.dstr, o.n1_valid, o.n2_valid,
                          st["outs"][r].data_ptr(), flag, remote]
-            elif r != self.rank:     # nothing of mine travels to r (a fully padded shard): an EMPTY problem still raises my flag there
+            if not mine and r != self.rank:     # nothing of mine travels to r (a fully padded shard): an EMPTY problem still raises my flag there
                 flat += [0, 0, 0, 0, 0, 8, 0, 0, 0, 0, 0, 0, 0, 0, st["outs"][r].data_ptr(), flag, remote]
         n = len(flat) // 17
+        assert n <= 16, "one launch carries at most 16 problems (VSYS_COPY_BATCH_MAX)"
         arr = (ctypes.c_int64 * len(flat))(*[int(v) for v in flat])
         program.keep(st)
         # ranks that are threads of ONE process (tools/local_group) order the launches on the host instead of polling flags on the
@@ -614,6 +617,37 @@ def plan_heads_gather(B, Lt, Lvl, Lv, C, P):
     return pack, unpack, (P, B, Ll, hw), (B, Ll, C)
 
 
+def plan_p2p_heads_scatter(B, Lt, Lvl, Lv, C, P, rank):
+    """scatter_heads as copies straight into the peers' [B, Lt+Lv, 3C/P]: entry r = the head slice r of this rank's video rows into
+    peer r's rows Lt + rank*Lvl ..; entry ``rank`` additionally carries this rank's own text rows (which never travel)."""
+    hw = C // P
+    Ll, L = Lt + Lvl, Lt + Lv
+    valid = max(0, min(Lvl, Lv - rank * Lvl))
+    ops = []
+    for r in range(P):
+        mine = []
+        if valid > 0:
+            mine.append(CopyOp(Lt * 3 * C + r * hw, (Lt + rank * Lvl) * 3 * hw, B, valid, 3, hw, (Ll * 3 * C, 3 * C, C), (L * 3 * hw, 3 * hw, hw),
+                               valid, 3))
+        if r == rank:
+            mine.append(CopyOp(rank * hw, 0, B, Lt, 3, hw, (Ll * 3 * C, 3 * C, C), (L * 3 * hw, 3 * hw, hw), Lt, 3))
+        ops.append(mine or None)
+    return ops, (B, L, 3 * hw)
+
+
+def plan_p2p_heads_gather(B, Lt, Lvl, Lv, C, P, rank):
+    """gather_heads as copies straight into the peers' [B, Lt+Lvl, C] (column block ``rank``): to every peer the text rows of this
+    rank's heads, and to peer r the video rows r owns (zero rows past Lv on the padded shard)."""
+    hw = C // P
+    Ll, L = Lt + Lvl, Lt + Lv
+    ops = []
+    for r in range(P):
+        valid = max(0, min(Lvl, Lv - r * Lvl))
+        ops.append([CopyOp(0, rank * hw, B, Lt, 1, hw, (L * hw, hw, hw), (Ll * C, C, C), Lt, 1),
+                    CopyOp((Lt + r * Lvl) * hw if valid > 0 else 0, Lt * C + rank * hw, B, Lvl, 1, hw, (L * hw, hw, hw), (Ll * C, C, C), valid, 1)])
+    return ops, (B, Ll, C)
+
+
 class UlyssesParallel:
     """Head <-> sequence exchange of one rank (packed buffers + all_to_all_single, like SequenceParallel)."""
 
@@ -623,6 +657,9 @@ class UlyssesParallel:
         self.rank = group_rank(group)
         self.exec = copy_executor
         self._bufs = {}
+        self.p2p = _make_peer_exchange(group, self.P, self.rank, copy_executor)   # None: pack + all_to_all_single + unpack
+        if self.p2p is not None and 2 * self.P > 16:
+            self.p2p = None        # (the gather carries two problems per peer: at most 8 ranks in one launch)
 
     _buf = SequenceParallel._buf
 
@@ -632,6 +669,11 @@ class UlyssesParallel:
     def scatter_heads(self, qkv, B, Lt, Lv, C, out=None):
         """qkv [B*(Lt+Lvl), 3C] (local rows) -> [B*(Lt+Lv), 3C/P] (this rank's heads, whole sequence)."""
         Lvl = self.shard_len(Lv)
+        if self.p2p is not None and qkv.is_cuda and out is not None:
+            ops_, oshape = plan_p2p_heads_scatter(B, Lt, Lvl, Lv, C, self.P, self.rank)
+            assert tuple(out.shape) == oshape and out.is_contiguous() and qkv.is_contiguous()
+            self.p2p.exchange(("HS", B, Lt, Lv, C), qkv, out, ops_)
+            return out.view(oshape[0] * oshape[1], oshape[2])
         pack, unpack_local, unpack_recv, sshape, oshape = plan_heads_scatter(B, Lt, Lvl, Lv, C, self.P, self.rank)
         send = self._buf("u_send", sshape, qkv)
         recv = self._buf("u_recv", sshape, qkv)
@@ -646,6 +688,11 @@ class UlyssesParallel:
     def gather_heads(self, ao, B, Lt, Lv, C, out=None):
         """ao [B*(Lt+Lv), C/P] -> [B*(Lt+Lvl), C] (all heads, local rows)."""
         Lvl = self.shard_len(Lv)
+        if self.p2p is not None and ao.is_cuda and out is not None:
+            ops_, oshape = plan_p2p_heads_gather(B, Lt, Lvl, Lv, C, self.P, self.rank)
+            assert tuple(out.shape) == oshape and out.is_contiguous() and ao.is_contiguous()
+            self.p2p.exchange(("HG", B, Lt, Lv, C), ao, out, ops_)
+            return out.view(oshape[0] * oshape[1], oshape[2])
         pack, unpack, sshape, oshape = plan_heads_gather(B, Lt, Lvl, Lv, C, self.P)
         send = self._buf("g_send", sshape, ao)
         recv = self._buf("g_recv", sshape, ao)
