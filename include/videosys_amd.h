@@ -306,11 +306,6 @@ int vsys_attn_temporal_d72(const void* qkv, int64_t row_stride, int64_t C, const
  * src_off, dst_off, n0, n1, n2, run, ss0, ss1, ss2, ds0, ds1, ds2, n1_valid, n2_valid (elements; run % 8 == 0). */
 int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* desc, void* stream);
 
-/* A cache HINT, not an operator (no reference counterpart: the reference leaves weight residency to the GPU): one read-only sweep
- * over up to 8 device buffers (desc: n x (address, bytes), HOST; addresses 16-byte aligned) that pulls them into the memory-side
- * cache ahead of the GEMMs that will stream them.  Nothing may depend on it; ``sink`` is 4 bytes of device memory it may write. */
-int vsys_prefetch(int64_t n, const int64_t* desc, void* sink, void* stream);
-
 /* The whole layout switch of Dynamic Sequence Parallelism in ONE launch per rank, peer to peer over xGMI (comm.py:104-141 _all_to_all_func
  * and :282-304 all_to_all_with_pad around open_sora_transformer_3d.py:288-315 dynamic_switch; replaces pack + all_to_all_single + unpack).
  * Problem i of the batch copies rows of ``src`` straight into the DESTINATION tensor of peer i in its final layout: desc (HOST) holds
@@ -489,8 +484,7 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
 #define VSYS_OP_FLASH_ATTN_D64_KB   29
 #define VSYS_OP_FLASH_ATTN_D72_EXACT 30
 #define VSYS_OP_P2P_EXCHANGE       31
-#define VSYS_OP_PREFETCH           32
-#define VSYS_OP_COUNT              33
+#define VSYS_OP_COUNT              32
 
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */

@@ -82,7 +82,6 @@ SIGNATURES = {
     "vsys_patch_embed_shard": [_ptr, _i64, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
     "vsys_final_layer_tokens": [_ptr, _ptr, _ptr, _ptr, _ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _f32, _ptr],
     "vsys_unpatchify_tokens": [_ptr, _ptr, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _ptr],
-    "vsys_prefetch": [_i64, _ptr, _ptr, _ptr],
     "vsys_p2p_exchange": [_ptr, _i64, _ptr, _ptr, _i64, _i64, _ptr, _i64, _ptr],
     # set-up of the peer-to-peer exchange (host side; no stream)
     "vsys_p2p_alloc": [_i64, _i64, _ptr], "vsys_p2p_free": [_ptr], "vsys_p2p_ipc_export": [_ptr, _ptr],

@@ -487,17 +487,6 @@ int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* 
   return launch_copy_4d_batch(B16(src), B16(dst), ops, (int)nops, S(stream));
 }
 
-int vsys_prefetch(int64_t n, const int64_t* desc, void* sink, void* stream) {
-  if (n < 0 || n > 8 || (n > 0 && !desc)) return VSYS_ERR_ARG;
-  const void* ptrs[8];
-  int64_t bytes[8];
-  for (int k = 0; k < (int)n; ++k) {
-    ptrs[k] = reinterpret_cast<const void*>(desc[2 * k]);
-    bytes[k] = desc[2 * k + 1];
-  }
-  return launch_prefetch(ptrs, bytes, (int)n, reinterpret_cast<unsigned*>(sink), S(stream));
-}
-
 int vsys_p2p_exchange(const void* src, int64_t nops, const int64_t* desc, const void* my_flags, int64_t n_flags, int64_t self_index,
                       void* state, int64_t timeout_ticks, void* stream) {
   if (!src || !my_flags || !state || (nops > 0 && !desc)) return VSYS_ERR_ARG;

@@ -40,7 +40,6 @@ constexpr OpInfo kOps[VSYS_OP_COUNT] = {
     {17, 2},  // FLASH_ATTN_D64_KB
     {12, 1},  // FLASH_ATTN_D72_EXACT
     {8, 0},   // P2P_EXCHANGE
-    {3, 0},   // PREFETCH
 };
 }  // namespace
 
@@ -139,7 +138,6 @@ int vsys_program_run(const vsys_cmd* cmds, int64_t n, void* const* streams, int6
         case VSYS_OP_FLASH_ATTN_D72_EXACT:
           rc = vsys_flash_attn_d72_exact(CP(0), I(1), CP(2), CP(3), CP(4), P(5), I(6), I(7), I(8), I(9), I(10), I(11), c.f[0], st);
           break;
-        case VSYS_OP_PREFETCH: rc = vsys_prefetch(I(0), reinterpret_cast<const int64_t*>(c.a[1]), P(2), st); break;
         case VSYS_OP_P2P_EXCHANGE:
           rc = vsys_p2p_exchange(CP(0), I(1), reinterpret_cast<const int64_t*>(c.a[2]), CP(3), I(4), I(5), P(6), I(7), st);
           break;

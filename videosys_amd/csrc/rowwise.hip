@@ -592,46 +592,6 @@ __global__ void copy_4d_batch_kernel(const bf16_t* __restrict__ src, bf16_t* __r
 
 }  // namespace
 
-// A read-only sweep over up to 8 buffers: a HINT that pulls the next block's weights through L2 into the memory-side cache
-// (256 MB Infinity Cache) while the current block computes.  A step streams 2.4 GB of weights, ten times what the cache holds, so
-// every weight matrix is cold when its GEMM starts; with 19-38 row panels per column tile (one rank of an 8-way DSP run) the first
-// touch of every K-tile pays an HBM miss that 152 panels amortise on a full-size launch.  Nothing depends on this kernel's result.
-struct PrefetchBatch {
-  int n;
-  const uint4* p[8];
-  int64_t n16[8];   // 16-byte units
-};
-__global__ __launch_bounds__(256) void prefetch_kernel(PrefetchBatch b, unsigned* sink) {
-  unsigned acc = 0;
-  for (int k = 0; k < b.n; ++k) {
-    const uint4* p = b.p[k];
-    // one 16-byte load per 128-byte line is enough to bring the line in: 8x fewer requests than a copy
-    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8; i < b.n16[k]; i += (int64_t)gridDim.x * blockDim.x * 8) {
-      const uint4 v = p[i];      // (a plain load: the line is meant to be kept)
-      acc ^= v.x;
-    }
-  }
-  if (acc == 0x9e3779b9u && sink != nullptr) *sink = acc;   // (keeps the loads alive; practically never taken)
-}
-
-int launch_prefetch(const void* const* ptrs, const int64_t* bytes, int n, unsigned* sink, hipStream_t stream) {
-  if (n <= 0) return 0;
-  if (n > 8) return VSYS_ERR_SHAPE;
-  PrefetchBatch b;
-  b.n = n;
-  int64_t total = 0;
-  for (int k = 0; k < n; ++k) {
-    if (!ptrs[k] || bytes[k] < 0 || ((uintptr_t)ptrs[k] & 15)) return VSYS_ERR_ALIGN;
-    b.p[k] = reinterpret_cast<const uint4*>(ptrs[k]);
-    b.n16[k] = bytes[k] / 16;
-    total += bytes[k];
-  }
-  if (total == 0) return 0;
-  // few workgroups on purpose: the sweep shares the chip with the GEMM it runs beside
-  hipLaunchKernelGGL(prefetch_kernel, dim3(32), dim3(256), 0, stream, b, sink);
-  return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
-}
-
 int launch_copy_4d_batch(const bf16_t* src, bf16_t* dst, const CopyDesc* ops, int nops, hipStream_t stream) {
   if (nops <= 0) return 0;
   if (nops > VSYS_COPY_BATCH_MAX) return VSYS_ERR_SHAPE;

@@ -188,7 +188,6 @@ struct CopyDesc {  // one copy_4d problem relative to a common (src, dst) pair; 
   int n1_valid, n2_valid;
 };
 int launch_copy_4d_batch(const bf16_t* src, bf16_t* dst, const CopyDesc* ops, int nops, hipStream_t stream);
-int launch_prefetch(const void* const* ptrs, const int64_t* bytes, int n, unsigned* sink, hipStream_t stream);
 // one-kernel peer-to-peer DSP exchange (p2p.hip): problem i copies into dsts[i] (+ ops[i].dst_off) and signals peer_flags[i]
 int launch_p2p_exchange(const bf16_t* src, const CopyDesc* ops, bf16_t* const* dsts, unsigned* const* peer_flags, const int* remote, int nops,
                         const unsigned* my_flags, int n_flags, int self_index, unsigned* state, long long timeout_ticks,

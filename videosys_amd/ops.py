@@ -335,22 +335,6 @@ def copy_4d_batch(src, dst, descs):
         _call("vsys_copy_4d_batch", _p(src), _p(dst), len(part), arr)
 
 
-def prefetch(tensors, sink):
-    """Cache hint (vsys_prefetch): a read-only sweep over up to 8 tensors on torch's current stream."""
-    import ctypes
-
-    ts = [t for t in tensors if t is not None][:8]
-    if not ts:
-        return
-    flat = []
-    for t in ts:
-        flat += [t.data_ptr(), t.numel() * t.element_size() // 16 * 16]
-        if program.active() is not None:
-            program.keep(t)
-    arr = (ctypes.c_int64 * len(flat))(*flat)
-    _call("vsys_prefetch", len(ts), arr, _p(sink))
-
-
 def kv_pad_len(kv_len: int) -> int:
     return (kv_len + 63) // 64 * 64
 

@@ -44,7 +44,7 @@ OPCODES = {
     "vsys_flash_attn_d64": 19, "vsys_patch_embed_shard": 20, "vsys_final_layer_tokens": 21, "vsys_unpatchify_tokens": 22,
     "vsys_gemm_bf16_ln": 23, "vsys_gemm_bf16_stats": 24, "vsys_adaln_prescale": 25, "vsys_ln_row_stats": 26,
     "vsys_gemm_bf16_gate_res_add": 27, "vsys_flash_attn_d72_kb": 28,
-    "vsys_flash_attn_d64_kb": 29, "vsys_flash_attn_d72_exact": 30, "vsys_p2p_exchange": 31, "vsys_prefetch": 32,
+    "vsys_flash_attn_d64_kb": 29, "vsys_flash_attn_d72_exact": 30, "vsys_p2p_exchange": 31,
 }
 
 _tls = threading.local()

@@ -164,7 +164,6 @@ class STDiT3:
         self.fold_spatial_qkv = True   # test hook: False = the spatial qkv site keeps the separate AdaLN pass on one GPU too (what a
         #                                sequence-parallel rank whose modulated activations travel computes, bit for bit)
         self._fold = None          # per-B site table + the W' / cs / cv buffers (built on first use)
-        self._pf_stream = self._pf_sink = None   # weight-prefetch hint: side stream + a 16-byte sink (created on first use)
         self._stats_fresh = False  # "the statistics buffer describes the current x" (within one step)
         self._programs = {}
         self.program_stats = dict(recorded=0, replayed=0, eager=0)
@@ -409,30 +408,6 @@ class STDiT3:
         self._fold = dict(B=B, bufs=bufs, sites=torch.tensor(rows, dtype=torch.int64).to(dev), nblocks=blk)
         return self._fold
 
-    def _prefetch_on(self, rows):
-        """VSYS_PREFETCH_WEIGHTS = 1 / 0 / auto (default): the cache hint of ops.prefetch for the next block's weights.  A step streams
-        2.4 GB of weights — ten times the 256 MB memory-side cache — so every matrix is cold when its GEMM starts; few row panels per
-        column tile (a sequence-parallel rank's few thousand rows) cannot amortise the misses.  auto: below 16 384 token rows."""
-        mode = os.environ.get("VSYS_PREFETCH_WEIGHTS", "auto")
-        return torch.device(self.device).type == "cuda" and (mode == "1" or (mode == "auto" and rows < 16384))
-
-    def _prefetch_block(self, i, ftab):
-        p = self.block_prefix(i)
-        w = self.w
-        names = [".attn.qkv", ".attn.proj", ".cross_attn.q_linear", ".cross_attn.proj", ".mlp.fc1", ".mlp.fc2"]
-        ts = []
-        for n in names:
-            site = p + n
-            if ftab is not None and site in ftab["bufs"]:
-                ts.append(ftab["bufs"][site][0])       # this step's pre-scaled W' is what the folded GEMM streams
-            else:
-                ts.append(w[site + ".weight"])
-        if self._pf_stream is None:
-            self._pf_stream = torch.cuda.Stream(device=self.device)
-            self._pf_sink = torch.zeros(4, dtype=torch.int32, device=self.device)
-        with torch.cuda.stream(self._pf_stream):
-            ops.prefetch(ts, self._pf_sink)
-
     def _ln_stats(self, N):
         key = ("ln_stats", N)
         if key not in self._ws:
@@ -640,8 +615,6 @@ class STDiT3:
             self._bc = [(d[0], d[1], d[2], d[4]) for d in plan[:2 * valid_depth]]
         for d in range(valid_depth):
             for i in (2 * d, 2 * d + 1):
-                if self._prefetch_on(B * T * S) and i + 1 < 2 * valid_depth:
-                    self._prefetch_block(i + 1, ftab)      # the NEXT block's weights, on a side stream, beside this block's launches
                 xcur = self._block(i, xcur, mod[i], txt, B, T, S, S_full, None if plan is None else plan[i], timestep_int,
                                    rps=S if x_mask is not None else T * S, ftab=ftab)
             if self._hidden_tap is not None:
