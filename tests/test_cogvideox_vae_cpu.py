@@ -99,3 +99,44 @@ def test_cogvideox_vae_needs_gpu():
         CogVideoXVAE({}, device="cpu")
     with pytest.raises(RuntimeError):
         AutoencoderKLDecoder({}, device="cpu")
+
+
+def test_tiled_decode_with_tiles_shared_out_over_ranks_host_bookkeeping():
+    """CogVideoXVAE._tiled(group=...): tiles r, r + P, ... decoded by rank r, padded to the full tile's pixel shape, gathered once,
+    cut back to their own shapes and blended in the reference's order (autoencoder_kl_cogvideox.py:1161-1239) — on CPU with a stand-in
+    tile decoder and a torch blend (the oracle's), 2 / 3 / 4 ranks as threads: every rank returns the unsharded result, incl. the
+    ragged last tiles of a 9 x 14 latent and more ranks than tiles in a row."""
+    from oracle import cogvideox_vae_oracle as CV
+    from tools.local_group import LocalWorld
+    from videosys_amd import ops
+    from videosys_amd.vae_cogvideox import CogVideoXVAE
+
+    vae = CogVideoXVAE.__new__(CogVideoXVAE)
+    vae.tile_sample_min_height, vae.tile_sample_min_width = 32, 48
+    vae.tile_latent_min_height, vae.tile_latent_min_width = 4, 6
+    vae.tile_overlap_factor_height, vae.tile_overlap_factor_width = 1 / 6, 1 / 5
+
+    def fake_tile(zt):       # [16, T, h, w] -> [3, 4T - 3, 8h, 8w]: a deterministic function of the latent tile alone
+        x = zt.float()[:3].repeat_interleave(8, dim=2).repeat_interleave(8, dim=3)
+        x = torch.cat([x[:, :1]] + [x[:, 1:].repeat_interleave(4, dim=1)], dim=1) if x.shape[1] > 1 else x
+        return torch.tanh(x + 0.05 * zt.float()[3:6].mean()).to(torch.bfloat16).contiguous()
+
+    def torch_blend(a, b, ext, axis):
+        f = CV.blend_v if axis == 0 else CV.blend_h
+        b.copy_(f(a.float()[None], b.float()[None], ext)[0].to(b.dtype))
+        return b
+
+    vae._decode_tile = fake_tile
+    saved = ops.blend_edge
+    ops.blend_edge = torch_blend
+    try:
+        g = torch.Generator().manual_seed(4)
+        for (H, W) in ((8, 12), (9, 14)):
+            zb = torch.randn(16, 3, H, W, generator=g).to(torch.bfloat16)
+            want = vae._tiled(zb.clone())
+            for P in (2, 3, 4):
+                outs = LocalWorld(P, timeout=60).run(lambda r, grp: vae._tiled(zb.clone(), grp))
+                for r, o in enumerate(outs):
+                    assert o.shape == want.shape and torch.equal(o, want), (H, W, P, r)
+    finally:
+        ops.blend_edge = saved

@@ -254,8 +254,9 @@ def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
     """The combination BASELINE configs[4] names — CogVideoX + PAB (spatial broadcast) + DSP degree 4 + the 3-D VAE's tiled decode —
     in one run on a small geometry: four Ulysses ranks as threads of this process (tools/local_group; 12 heads = 3 per rank, 48 video
     tokens = 12 per rank, text rows replicated), the PAB schedule of the reference fixture (broadcast steps skip the attention AND its
-    two exchanges on every rank alike), every step's output of every rank BIT-identical to the single-process run; rank 0 then
-    decodes its final latents with the tiled decode (4 tiles, blended) and gets the bits of the single-process latents' decode
+    two exchanges on every rank alike), every step's output of every rank BIT-identical to the single-process run; the ranks then
+    decode the final latents with the tiled decode, its 9 tiles shared out over the four ranks and gathered once, and get the bits
+    of the unsharded decode of the single-process latents
     (cogvideox_transformer_3d.py:45-86,112-165; pipeline_cogvideox.py:33-44; autoencoder_kl_cogvideox.py:1161-1239)."""
     from conftest import load_golden
     from oracle import cogvideox_oracle as CO
@@ -294,16 +295,22 @@ def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
             torch.cuda.synchronize()
             assert m._sp.p2p.launches > 0
             m._sp.p2p.check()
-            return outs
+            # the tiled decode with its 9 tiles shared out over the four ranks (tiles r, r + 4, ...) and gathered once
+            vae_r = CogVideoXVAE(vae_sd, device="cuda:0", sample_height=64, sample_width=96, use_tiling=True)
+            px_r = vae_r.decode_latents(outs[-1][:1].to(torch.bfloat16).to("cuda:0"), group=group)
+            torch.cuda.synchronize()
+            return outs, px_r.cpu()
 
-        per_rank = LocalWorld(P, timeout=300).run(rank_fn)
+        vae_sd = vae_synth(13)
+        both = LocalWorld(P, timeout=300).run(rank_fn)
+        per_rank, px_ranks = [b[0] for b in both], [b[1] for b in both]
     finally:
         pab.set_pab_manager(None)
     for r, outs in enumerate(per_rank):
         for i, (o, w) in enumerate(zip(outs, want)):
             assert torch.equal(o, w), f"rank {r}, step {i} (t = {fx['timesteps'][i]}): max|diff| {float((o - w).abs().max()):.3e}"
     # rank 0 decodes what it sampled: [B, F, C, H, W] latents -> pixels through the tiled decode (tile = half the sample size)
-    vae = CogVideoXVAE(vae_synth(13), device="cuda:0", sample_height=64, sample_width=96, use_tiling=True)
+    vae = CogVideoXVAE(vae_sd, device="cuda:0", sample_height=64, sample_width=96, use_tiling=True)
     lat = per_rank[0][-1][:1].to(torch.bfloat16).to("cuda:0")
     assert lat.shape[-2] > vae.tile_latent_min_height and lat.shape[-1] > vae.tile_latent_min_width      # the decode really tiles
     px = vae.decode_latents(lat)
@@ -312,6 +319,8 @@ def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
     #  pixels, the last to what it has — 27 + 27 + 16 by 39 + 39 + 32; at the real 60 x 90 latent the same rule gives 480 x 720)
     assert px.shape[0] == 1 and px.shape[1] == 3 and tuple(px.shape[-2:]) == (70, 110) and torch.isfinite(px.float()).all()
     assert torch.equal(px, px_single)
+    for r, pr in enumerate(px_ranks):          # every rank's tile-sharded decode: the same pixels
+        assert torch.equal(pr, px.cpu()), f"rank {r}: tile-sharded decode differs"
 
 
 def test_bench_two_ranks_dry_run():

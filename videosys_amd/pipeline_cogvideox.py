@@ -372,6 +372,11 @@ class CogVideoXPipeline(VideoSysPipeline):
         1 / scaling_factor live in vae_cogvideox.CogVideoXVAE.__call__."""
         if self.vae_decoder is None:
             raise RuntimeError("no VAE attached")
+        # under sequence parallelism every rank holds the same final latents: the tiles of the tiled decode are shared out over the
+        # ranks and gathered once (VSYS_VAE_SHARD=0: every rank decodes every tile, as the reference does)
+        sp = getattr(self.transformer, "_sp", None)
+        if sp is not None and sp.P > 1 and os.environ.get("VSYS_VAE_SHARD") != "0" and hasattr(self.vae_decoder, "_tiles_over_ranks"):
+            return self.vae_decoder.decode_latents(latents.to(torch.bfloat16), group=sp.group)
         return self.vae_decoder(latents.to(torch.bfloat16))
 
     @torch.no_grad()

@@ -206,7 +206,10 @@ class CogVideoXVAE:
 
     # ------------------------------------------------------------------------------------------------ public
     @torch.no_grad()
-    def decode(self, z: torch.Tensor) -> torch.Tensor:
+    def decode(self, z: torch.Tensor, group=None) -> torch.Tensor:
+        """``group`` (dsp.py group protocol; every rank holds the same latents): the TILES of a tiled decode are decoded by the ranks
+        in turn and gathered once — the reference decodes all of them on every rank (pipeline_cogvideox.py:359-364 under
+        engine.py:85-95); an untiled decode is not sharded."""
         if not z.is_cuda:
             raise RuntimeError("CogVideoXVAE.decode needs a HIP device tensor (no CPU path)")
         B, C, T, H, W = z.shape
@@ -215,19 +218,57 @@ class CogVideoXVAE:
         for b in range(B):
             zb = z[b].to(torch.bfloat16).contiguous()
             if self.use_tiling and (W > self.tile_latent_min_width or H > self.tile_latent_min_height):
-                outs.append(self._tiled(zb))
+                outs.append(self._tiled(zb, group))
             else:
                 outs.append(self._decode_tile(zb))
         return torch.stack(outs, 0)
 
-    def _tiled(self, zb: torch.Tensor) -> torch.Tensor:
+    def _tiles_over_ranks(self, zb, coords, tl_h, tl_w, group):
+        """The decoded tiles of ``coords`` with rank r of the group decoding tiles r, r + P, ...: one all-gather of the ranks' tiles
+        (padded to the full tile's pixel shape); every tile is independent (fresh caches), so the bits are the unsharded decode's."""
+        from . import dsp
+
+        P, r = dsp.group_size(group), dsp.group_rank(group)
+        n = len(coords)
+        per = -(-n // P)
+        mine = [t for t in range(n) if t % P == r]
+        dec = {t: self._decode_tile(zb[:, :, coords[t][0]:coords[t][0] + tl_h, coords[t][1]:coords[t][1] + tl_w].contiguous()) for t in mine}
+        # (the frame count of a decoded tile depends on the latent frame count alone: every rank can derive the padded shape only
+        #  once somebody has decoded — rank 0 always owns tile 0, and the shape travels with the data: a fixed-size header gather)
+        shp = torch.zeros(4, dtype=torch.int64, device=zb.device)
+        if dec:
+            any_tile = next(iter(dec.values()))
+            shp[:] = torch.tensor([any_tile.shape[0], any_tile.shape[1], 8 * tl_h, 8 * tl_w])
+        allshp = torch.empty(P * 4, dtype=torch.int64, device=zb.device)
+        dsp.all_gather_into_tensor(allshp, shp, group)
+        Cc, F, TH, TW = (int(v) for v in allshp.view(P, 4)[0].tolist())
+        buf = torch.zeros(per, Cc, F, TH, TW, dtype=torch.bfloat16, device=zb.device)
+        for k, t in enumerate(mine):
+            tile = dec[t]
+            buf[k, :, :, :tile.shape[-2], :tile.shape[-1]] = tile
+        allb = torch.empty(P * per, Cc, F, TH, TW, dtype=torch.bfloat16, device=zb.device)
+        dsp.all_gather_into_tensor(allb, buf, group)
+        H, W = zb.shape[-2:]
+        out = []
+        for t, (i, j) in enumerate(coords):
+            h, w = 8 * min(tl_h, H - i), 8 * min(tl_w, W - j)
+            out.append(allb[(t % P) * per + t // P][:, :, :h, :w].contiguous())
+        return out
+
+    def _tiled(self, zb: torch.Tensor, group=None) -> torch.Tensor:
         """tiled_decode :1161-1239."""
         _, T, H, W = zb.shape
         tl_h, tl_w = self.tile_latent_min_height, self.tile_latent_min_width
         ov_h, ov_w = int(tl_h * (1 - self.tile_overlap_factor_height)), int(tl_w * (1 - self.tile_overlap_factor_width))
         be_h, be_w = int(self.tile_sample_min_height * self.tile_overlap_factor_height), int(self.tile_sample_min_width * self.tile_overlap_factor_width)
         lim_h, lim_w = self.tile_sample_min_height - be_h, self.tile_sample_min_width - be_w
-        rows = [[self._decode_tile(zb[:, :, i:i + tl_h, j:j + tl_w].contiguous()) for j in range(0, W, ov_w)] for i in range(0, H, ov_h)]
+        if group is not None:
+            coords = [(i, j) for i in range(0, H, ov_h) for j in range(0, W, ov_w)]
+            flat = self._tiles_over_ranks(zb, coords, tl_h, tl_w, group)
+            ncol = len(range(0, W, ov_w))
+            rows = [flat[k * ncol:(k + 1) * ncol] for k in range(len(flat) // ncol)]
+        else:
+            rows = [[self._decode_tile(zb[:, :, i:i + tl_h, j:j + tl_w].contiguous()) for j in range(0, W, ov_w)] for i in range(0, H, ov_h)]
         out_rows = []
         for i, row in enumerate(rows):
             res = []
@@ -242,11 +283,11 @@ class CogVideoXVAE:
             out_rows.append(torch.cat(res, dim=3))
         return torch.cat(out_rows, dim=2).contiguous()
 
-    def decode_latents(self, latents: torch.Tensor) -> torch.Tensor:
-        """pipeline_cogvideox.py:359-364: latents [B, T, 16, H, W] -> frames [B, 3, T_out, 8H, 8W]."""
+    def decode_latents(self, latents: torch.Tensor, group=None) -> torch.Tensor:
+        """pipeline_cogvideox.py:359-364: latents [B, T, 16, H, W] -> frames [B, 3, T_out, 8H, 8W] (``group``: see decode)."""
         z = latents.permute(0, 2, 1, 3, 4)
         z = 1 / self.config.scaling_factor * z
-        return self.decode(z)
+        return self.decode(z, group)
 
     __call__ = decode_latents
 
