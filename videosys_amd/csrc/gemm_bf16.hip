@@ -795,7 +795,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 103: break;
+    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 103: case 106: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -889,6 +889,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
       return gemm4_supports(p, epi) ? launch_gemm4(p, epi, 2 + g_gemm_variant - 80, stream) : VSYS_ERR_ARG;
 #endif
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
+    case 106: return launch_gemm_t<6, 128>(p, epi, stream);   // the 128-row geometry on schedule 6 (DMA pieces interleaved with the MFMA pairs)
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
