@@ -411,7 +411,8 @@ class PeerExchange:
 
         self.peers, self.P, self.rank = peers, P, rank
         self.sites = {}
-        self.timeout_ticks = int(float(os.environ.get("VSYS_P2P_TIMEOUT_S", "20")) * 1e8)    # 100 MHz wall clock
+        # (a bound against hanging for ever on a dead peer, not a pace: ranks may reach their first exchange tens of seconds apart)
+        self.timeout_ticks = int(float(os.environ.get("VSYS_P2P_TIMEOUT_S", "120")) * 1e8)    # 100 MHz wall clock
         self.launches = 0
 
     def _site(self, key, out):
