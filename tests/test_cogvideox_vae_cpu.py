@@ -126,6 +126,12 @@ def test_tiled_decode_with_tiles_shared_out_over_ranks_host_bookkeeping():
         b.copy_(f(a.float()[None], b.float()[None], ext)[0].to(b.dtype))
         return b
 
+    # config 5: 3 x 3 tiles of 30 x 45 latent pixels stepping 25 / 36 over 60 x 90 -> the last row / column are 10 / 18 wide
+    areas = [min(30, 60 - i) * min(45, 90 - j) for i in (0, 25, 50) for j in (0, 36, 72)]
+    owner, slot, per = CogVideoXVAE._deal_tiles(areas, 4)
+    loads = [sum(a for a, o in zip(areas, owner) if o == r) for r in range(4)]
+    assert sum(areas) == 7560 and max(loads) == 1980 and per == 3 and owner[0] == 0
+    assert sorted((o, s_) for o, s_ in zip(owner, slot)) == sorted(set((o, s_) for o, s_ in zip(owner, slot)))    # no slot used twice
     vae._decode_tile = fake_tile
     saved = ops.blend_edge
     ops.blend_edge = torch_blend
