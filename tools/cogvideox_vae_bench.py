@@ -44,7 +44,7 @@ def main():
             vae.decode(z, grp)
             torch.cuda.synchronize(); per_rank.append(round(time.perf_counter() - t0, 4))
         rec.update(shard=args.shard, sec_per_rank=per_rank, slowest_rank_s=max(per_rank),
-                   note="tiles r, r + P, ... on rank r; the all-gather is a device copy of the same bytes (results meaningless by construction)")
+                   note="tiles dealt by latent area (CogVideoXVAE._deal_tiles); the all-gather is a device copy of the same bytes (results meaningless by construction)")
     print(json.dumps(rec))
 
 
