@@ -71,7 +71,7 @@ def _gemm_bias(ops, M, N, K):
     check(out, O.gelu_tanh(ref), what="gemm+gelu")
 
 
-@pytest.mark.parametrize("variant", [3, 6, 8, 9, 20, 28, 30, 103])
+@pytest.mark.parametrize("variant", [3, 6, 8, 9, 20, 28, 30, 103, 106])
 def test_gemm_pipeline_variants(ops, variant):
     """Every main-loop schedule of the GEMM (LDS-DMA burst / interleaved, 2-stage / 3+2-slot, 8-wave / 4-wave geometry)
     must give the same result;
