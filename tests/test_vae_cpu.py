@@ -221,3 +221,78 @@ def test_decode_frame_ranges_and_rank_shards_equal_the_full_decode():
                 assert o.dtype == torch.uint8 and torch.equal(o, want), (frames, P)
             outs = LocalWorld(P, timeout=60).run(lambda r, grp: vae.decode_sharded(z, frames, grp, to_uint8=False))
             assert all(torch.equal(o, full) for o in outs)
+
+
+def _sharded_decode_gloo_worker(rank, world, port, ret):
+    """Both sharded decodes through a REAL torch.distributed group (gloo, CPU tensors, stand-in decoder stages): the gathers are
+    dist.all_gather_into_tensor calls with the shapes and dtypes the product issues (uint8 frames stacked along dim 0; an int64 header
+    and bf16 tiles for the CogVideoX tiles)."""
+    try:
+        import torch.distributed as dist
+
+        from oracle import cogvideox_vae_oracle as CV
+        from vae_cpu_emul import cpu_vae
+        from videosys_amd import ops
+        from videosys_amd.vae_cogvideox import CogVideoXVAE
+        from videosys_amd.vae_open_sora import pixels_to_uint8, synth_state_dict
+
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        torch.manual_seed(0)
+        vae = cpu_vae(synth_state_dict(7), encoder=False)
+        vae.frames_per_launch = 4
+        _fake_decoders(vae)
+        g = torch.Generator().manual_seed(3)
+        z = torch.randn(1, 4, 7, 3, 2, generator=g)
+        want = pixels_to_uint8(vae.decode(z, 22))
+        got = vae.decode_sharded(z, 22, dist.group.WORLD)
+        assert got.dtype == torch.uint8 and torch.equal(got, want), "OpenSoraVAE.decode_sharded over gloo"
+        # CogVideoX tiles
+        cv = CogVideoXVAE.__new__(CogVideoXVAE)
+        cv.tile_sample_min_height, cv.tile_sample_min_width = 32, 48
+        cv.tile_latent_min_height, cv.tile_latent_min_width = 4, 6
+        cv.tile_overlap_factor_height, cv.tile_overlap_factor_width = 1 / 6, 1 / 5
+        cv._decode_tile = lambda zt: torch.tanh(zt.float()[:3].repeat_interleave(8, dim=2).repeat_interleave(8, dim=3)).to(torch.bfloat16).contiguous()
+
+        def torch_blend(a, b, ext, axis):
+            f = CV.blend_v if axis == 0 else CV.blend_h
+            b.copy_(f(a.float()[None], b.float()[None], ext)[0].to(b.dtype))
+            return b
+
+        ops.blend_edge = torch_blend
+        zb = torch.randn(16, 2, 9, 14, generator=g).to(torch.bfloat16)
+        want = cv._tiled(zb.clone())
+        got = cv._tiled(zb.clone(), dist.group.WORLD)
+        assert torch.equal(got, want), "CogVideoXVAE._tiled(group) over gloo"
+        ret.put((rank, "ok"))
+    except Exception:  # noqa
+        import traceback
+
+        ret.put((rank, traceback.format_exc()))
+    finally:
+        import torch.distributed as dist
+
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_sharded_decodes_over_a_two_rank_gloo_group():
+    """World size 2 over gloo on the CPU: OpenSoraVAE.decode_sharded (frames) and CogVideoXVAE._tiled(group) (tiles) through
+    torch.distributed itself, every rank returning the unsharded result (autoencoder_kl_open_sora.py:672-695 and
+    autoencoder_kl_cogvideox.py:1161-1239 decode everything on every rank)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_decode_gloo_worker, args=(r, 2, port, ret)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [ret.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, msg in res:
+        assert msg == "ok", f"rank {rank}: {msg}"
