@@ -493,13 +493,18 @@ def _make_peer_exchange(group, P, rank, copy_executor):
     import os
 
     mode = os.environ.get("VSYS_DSP_P2P", "auto")
-    if mode == "0" or copy_executor is not hip_copy_executor or P < 2:
+    if copy_executor is not hip_copy_executor or P < 2:
         return None
     if hasattr(group, "all_gather_object"):
-        return PeerExchange(group, P, rank)
-    if mode == "1":
-        return PeerExchange(IpcPeers(group), P, rank)
-    return None
+        return None if mode == "0" else PeerExchange(group, P, rank)
+    # a torch ProcessGroup: every rank must take the same path (a rank that waits for flags nobody raises would sit out its timeout,
+    # one that waits in all_to_all_single for peers that never call it would hang) — compare the setting once, collectively
+    want = mode == "1"
+    every = [None] * P
+    dist.all_gather_object(every, want, group=group)
+    if any(v != want for v in every):
+        raise RuntimeError(f"VSYS_DSP_P2P differs between the ranks of the sequence-parallel group: {every} (rank order); set it identically")
+    return PeerExchange(IpcPeers(group), P, rank) if want else None
 
 
 class SequenceParallel:
