@@ -798,7 +798,7 @@ int set_gemm_variant(int v) {
     case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 103: case 106: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
-    case 18: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
+    case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
 #endif
     default: return VSYS_ERR_ARG;
   }
@@ -877,6 +877,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
 #ifdef VSYS_LAB
     case 18: return launch_gemm_t<18, 256>(p, epi, stream);
     case 48: return launch_gemm_t<48, 256>(p, epi, stream);
+    case 38: return launch_gemm_t<38, 256>(p, epi, stream);   // every tile streams the A rows of tile 0 (A L2-resident: fabric traffic = W only)
     case 40: return launch_gemm3(p, epi, stream);  // 5-slot ring, fragments always one k-step ahead (gemm3_bf16.hip)
     case 31: return (epi == EPI_BIAS && p.N % 384 == 0) ? launch_gemm2_stamp(p, stream) : VSYS_ERR_ARG;  // lab: cycle stamps
     case 61: case 62: case 63: case 64: return epi == EPI_BIAS ? launch_gemm4_lab(p, g_gemm_variant - 60, 0, stream) : VSYS_ERR_ARG;
