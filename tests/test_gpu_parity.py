@@ -367,7 +367,9 @@ def test_attn_temporal_golden(ops, golden_ops, name):
 
 @pytest.mark.parametrize("B,T,S,H,norm,rope", [(2, 19, 64, 16, True, True), (1, 5, 33, 3, True, False), (1, 32, 16, 4, False, True),
                                                  (1, 1, 8, 2, True, True), (1, 16, 40, 16, False, False), (2, 38, 16, 5, True, True),
-                                                 (1, 33, 9, 16, True, True), (1, 64, 12, 4, False, True), (2, 40, 300, 16, True, False)])
+                                                 (1, 33, 9, 16, True, True), (1, 64, 12, 4, False, True), (2, 40, 300, 16, True, False),
+                                                 (1, 2, 70, 8, True, True), (2, 19, 128, 16, True, True), (1, 11, 300, 12, False, True),
+                                                 (1, 32, 600, 16, True, True), (2, 10, 37, 4, False, False)])
 def test_attn_temporal_kernels_agree_with_oracle(ops, B, T, S, H, norm, rope):
     """The temporal kernels — matrix-pipe (default; attention_t3.hip: one 32-frame tile for T <= 32, two key / query blocks for
     T <= 64), VALU two-pass (flash variant 4, T <= 40) and online-softmax (variant 9) — against the fp32 oracle and each other: with /
@@ -397,7 +399,9 @@ def test_attn_temporal_kernels_agree_with_oracle(ops, B, T, S, H, norm, rope):
     outs = {}
     # (0 = the default: one rounding per q / k element in front of the matrix product; 21 = the same kernels with every rounding point
     #  of the reference's bf16 run; 4 / 9 = the VALU two-pass and online-softmax kernels)
-    for fv in (0, 21, 4, 9) if T <= 40 else (0, 21, 9):
+    # (22 = the per-lane-load kernel where 0 runs the round-6 cooperative LDS-DMA form — heads in groups of four, T <= 32: same
+    #  fragments, same matrix products, so the SAME BITS are required below)
+    for fv in (0, 22, 21, 4, 9) if T <= 40 else (0, 22, 21, 9):
         assert lib.vsys_tune_flash_variant(fv) == 0
         try:
             out = torch.full((B * T * S, C), 7.0, dtype=torch.bfloat16, device=dev())
@@ -410,6 +414,7 @@ def test_attn_temporal_kernels_agree_with_oracle(ops, B, T, S, H, norm, rope):
     scale = ref.abs().max().item()
     assert (outs[0] - outs[9]).abs().max().item() <= 2.0 ** -6 * scale
     assert (outs[0] - outs[21]).abs().max().item() <= 2.0 ** -6 * scale
+    assert torch.equal(outs[0], outs[22]), "the LDS-DMA form of the temporal kernel must reproduce the per-lane-load kernel bit for bit"
     # (the oracle above carries the reference's own cast-before-weight rounding, so the stage-by-stage form may sit a little closer
     #  to it than the single-rounding default: both are held to the same tolerance, neither to the other's bits)
 

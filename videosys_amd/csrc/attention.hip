@@ -958,7 +958,7 @@ static unsigned long long* g_flash_dbg = nullptr;
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 140: case 141: case 143: case 144: break;
+    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 140: case 141: case 143: case 144: break;
 #ifdef VSYS_LAB
     case 1: case 2: case 146: case 147: case 148: case 149: case 150: break;
 #endif
@@ -1088,7 +1088,7 @@ int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const
   const int g_flash_variant = g_flash_variant_a.load(std::memory_order_relaxed);
   if (T <= 64 && g_flash_variant != 9 && g_flash_variant != 4)   // the MFMA formulation (attention_t3.hip: one 32-frame tile, or two); 4 = force the v2 kernel
     return launch_attn_temporal_d72_v3(qkv, row_stride, C, q_norm_w, k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps,
-                                       scale, stream, /* the reference's rounding points, stage by stage (A/B id 21) */ g_flash_variant == 21);
+                                       scale, stream, /* the reference's rounding points, stage by stage (A/B id 21) */ g_flash_variant == 21, /* 22: the per-lane-load kernel instead of the LDS-DMA form */ g_flash_variant == 22);
   if (T <= 20 && g_flash_variant != 9) {
     hipLaunchKernelGGL(attn_temporal_d72_v2_kernel<20>, dim3((unsigned)grid), dim3(64 * wpb), lds, stream, qkv, row_stride, C, q_norm_w,
                        k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, wpb, eps, scale);

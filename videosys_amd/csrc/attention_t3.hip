@@ -103,9 +103,13 @@ __device__ __forceinline__ void t3_piece(uint32_t (&u)[4], const bf16_t* w, cons
       if constexpr (ROPE) {
         // (x0, x1) c + (-x1, x0) s in ONE packed FMA: source 0 is read with its halves swapped (op_sel) and the low result's copy
         // negated (neg_lo) — written out by hand, hipcc lowers the swapped pair to a v_xor + v_mov in front of the FMA
-        const t3_f32x2 t = x * t3_f32x2{cv[e], cv[e]}, s2 = t3_f32x2{sv[e], sv[e]};
+        // The sine comes in as the register PAIR the table read delivered (elements e & ~1, e | 1) and op_sel / op_sel_hi pick the
+        // same half for both results: duplicating it into a pair of its own cost two v_mov per dword (80 of the ~750 VALU
+        // instructions of a head).
+        const t3_f32x2 t = x * t3_f32x2{cv[e], cv[e]}, s2 = t3_f32x2{sv[e & ~1], sv[e | 1]};
         t3_f32x2 r;
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(s2), "v"(t));
+        if (e & 1) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(s2), "v"(t));
+        else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(x), "v"(s2), "v"(t));
         x = r;
       }
       u[e] = pk_bf16(x.x, x.y);
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 2) ? 4 : 3) void attn_te
         }
       }
       ss += __shfl_xor(ss, 32, 64);
-      rstd = rsqrtf(ss / (float)HD + eps);
+      rstd = rsqrtf(ss * (1.0f / (float)HD) + eps);   // (a multiply, not the division sequence)
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(256, (MODE == 1 || MODE == 2) ? 4 : 3) void attn_te
       l += p[r];
     }
     l += __shfl_xor(l, 32, 64);
-    const float inv = 1.0f / l;
+    const float inv = __builtin_amdgcn_rcpf(l);   // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
     bf16x8 p0, p1;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -383,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
         }
       }
       ss += __shfl_xor(ss, 32, 64);
-      rstd = rsqrtf(ss / (float)HD + eps);
+      rstd = rsqrtf(ss * (1.0f / (float)HD) + eps);   // (a multiply, not the division sequence)
     }
 #pragma unroll
     for (int c = 0; c < 5; ++c) {
@@ -469,7 +473,7 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
           l += sacc[kb][r];
         }
       l += __shfl_xor(l, 32, 64);
-      const float inv = 1.0f / l;
+      const float inv = __builtin_amdgcn_rcpf(l);   // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
       bf16x8 pf[4];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -516,11 +520,257 @@ __global__ __launch_bounds__(256, 2) void attn_temporal_d72_v4_kernel(
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// attn_temporal_d72_v5 (round 6): the same arithmetic as attn_temporal_d72_v3 (same fragments, same MFMA order: same bits) with the
+// HBM side rebuilt.  v3 loads every operand straight into fragment layout: a lane owns one frame, so ONE wave load touches T = 19
+// rows that lie S * row_stride * 2 = 7 MB apart and takes 32 bytes from each — 15 loads + 9 stores per head, every one of them 19-38
+// cache-line touches in the CU's texture path for 0.6-1.2 KB of payload.  r05 finding (f): -31 % VALU bought -3 % time; the kernel is
+// bound by that load shape (3.4 TB/s).  Here a workgroup owns (pixel token, group of FOUR heads): per frame the q, k and v bytes of
+// four heads are 576 contiguous bytes each, and the whole operand set of an item (3 T segments) comes in by LDS-DMA
+// (buffer_load_dwordx4 ... lds) as ONE lane-linear image: LDS piece L = 16-byte piece (L % 37) of segment row (L / 37), 37 = 36 real
+// pieces + 1 pad, i.e. a 592-byte row pitch (conflict-free for the 16-byte fragment reads: 592 / 4 = 148 = 20 mod 64 banks per row).
+// 33 wave instructions of 64 pieces bring in the 32.8 KB of an item at T = 19 (v3: 60 instructions for the same four heads), each
+// touching ~2 rows.  The waves then read their K / Q pieces as ds_read_b128 (the registers v3 got from HBM), gather the V^T fragments
+// with 16-bit LDS reads straight from the row-major V rows (no transposed image), and the outputs go back through the (dead) Q rows
+// of the image so that the workgroup stores 576-byte row segments with 16-byte stores.
+// Rows of an image: [V: 0 .. T-1][K: T .. 2T-1][Q / O: 2T .. 3T-1]; the V^T gather of keys >= T runs on into the K / Q rows (finite
+// values, met by probability 0); below 11 frames the rows behind 3T are zero-filled once.
+// Workgroups are persistent (items blockIdx, + gridDim, ...: the tables are staged once) and four fit a CU at T = 19 (39.9 KB).
+// What was measured and not kept (profiles/r06_temporal_v5_probe.txt; probe = tools/temporal_probe.py, v3 110-112 us on those boxes):
+//   * the phases switched off one by one (lab builds, VSYS_T5_ABLATE): 100 us = LDS-DMA alone 50 (6.1 TB/s) / + stores 84 / arithmetic
+//     alone 73: memory and arithmetic each fill ~80 % of the launch, and every workgroup of the launch sits in the same phase at
+//     the same time (the DMA phase ends for everybody when HBM has delivered), so they overlap only partly;
+//   * two images per workgroup with the next item's LDS-DMA under the current item's arithmetic (two workgroups per CU): 110 us —
+//     the arithmetic alone takes 84 us at two waves per SIMD; a start-up stagger of the workgroups of a CU: 94-98 us (inside the noise);
+//   * eight heads per workgroup (1152-byte segments = nine whole 128-byte lines, eight waves): 102 us, no gain over four;
+//   * ds_read_u16_d16_hi for the V^T gather: the register's other half is NOT preserved on this part (SRAM ECC) — wrong fragments.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int V5_PIECES = 37;               // 16-byte pieces per image row (36 + 1 pad)
+constexpr int V5_PITCH = V5_PIECES * 16;    // 592
+
+template <int MODE, int NIW>
+__global__ __launch_bounds__(256, 4) void attn_temporal_d72_v5_kernel(
+    const bf16_t* __restrict__ qkv, int64_t row_stride, int C, const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w,
+    const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, bf16_t* __restrict__ out, int64_t out_stride, int B, int T,
+    int S, int heads, float eps, float scale, int ninstr, int data_bytes, int tab_bytes, int nitems, int ablate) {
+#if __HIP_DEVICE_COMPILE__
+#ifdef VSYS_LAB
+#define V5_ABL ablate
+#else
+#define V5_ABL 0
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int HPG = 4, NTH = 256, NIMG = 1;   // heads (= waves) per workgroup, threads, images
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hi = lane >> 5;
+  // the image, then the tables
+  float* cosc = reinterpret_cast<float*>(smem + data_bytes);
+  float* sinc = reinterpret_cast<float*>(smem + data_bytes + tab_bytes);
+  float* qwf = reinterpret_cast<float*>(smem + data_bytes + 2 * tab_bytes);
+  float* kwf = reinterpret_cast<float*>(smem + data_bytes + 2 * tab_bytes + WF_BYTES);
+  constexpr bool NORM = MODE == 1 || MODE == 3, ROPE = MODE == 1 || MODE == 4;
+
+  // ---- item-independent addressing.  LDS-DMA: instruction ii = wave + HPG i of the workgroup fills pieces 64 ii .. 64 ii + 63
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int frame_bytes = S * (int)row_stride * 2;       // consecutive frames of one pixel token (launcher: T * this < 2^31)
+  int voff[NIW];
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) {
+    const int L = lane + 64 * (wave_u + HPG * i);
+    int row = L / V5_PIECES, piece = L - row * V5_PIECES;
+    piece = piece < V5_PIECES - 1 ? piece : V5_PIECES - 2;                     // the pad slot receives a copy of the last piece
+    row = row < 3 * T ? row : 3 * T - 1;                 // pieces behind the image land in the spare tail of the data region
+    const int seg = row / T, t = row - seg * T;          // 0 = V, 1 = K, 2 = Q
+    voff[i] = t * frame_bytes + (seg == 0 ? 2 * C : (seg == 1 ? C : 0)) * 2 + piece * 16;
+  }
+  const int HG = heads / HPG;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  // LDS-DMA of one item into image ``img`` (this wave owns instructions wave, wave + 4, ... of the workgroup's ninstr)
+  auto dma_item = [&](int item, int) {
+    const int bs = item / HG, hg = item - bs * HG;
+    const int s = bs % S, b = bs / S;
+    const bf16_t* ibase = qkv + ((int64_t)b * T * S + s) * row_stride + hg * (HPG * HD);
+    const int ibytes = (T - 1) * frame_bytes + (2 * C + HPG * HD) * 2;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)ibase, 0, ibytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const int ii = wave_u + HPG * i;
+      if (ii < ninstr && !(V5_ABL & 1))
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)(smem + ii * 1024), 16, voff[i], 0, 0, 0);
+    }
+  };
+  const int lw = xcd_remap(blockIdx.x, gridDim.x);       // neighbouring items (head groups of one token, then the next token) share an XCD's L2
+  if (lw < nitems) dma_item(lw, 0);                       // the first image travels while the tables are built
+
+  if (ROPE) {
+    for (int i = tid; i < T * TAB_ROW; i += NTH) {        // compact table: entry i = (t, j) <-> element 2 i of the [T][72] table
+      cosc[i] = rope_cos[2 * i];
+      sinc[i] = rope_sin[2 * i];
+    }
+  }
+  if (NORM && tid < HD) {
+    qwf[tid] = bf2f(q_norm_w[tid]);
+    kwf[tid] = bf2f(k_norm_w[tid]);
+  }
+  // rows behind the 3 T real ones (reached by the V^T gather below 11 frames) are never written by a real piece: zero them once
+  for (int i = 3 * T * V5_PITCH + tid * 16; i < data_bytes; i += NTH * 16) *reinterpret_cast<uint4*>(smem + i) = make_uint4(0, 0, 0, 0);
+
+  // A-operand row m = l31 of the first product holds this key (attn_temporal_d72_v3_kernel); query / value rows are natural
+  const int r_of_m = (l31 & 3) + 4 * (l31 >> 3);
+  const int krow = 8 * ((l31 >> 2) & 1) + r_of_m + (r_of_m >= 8 ? 8 : 0);
+  const bool q_ok = l31 < T, k_ok = krow < T;
+  const int qrow_c = q_ok ? l31 : T - 1, krow_c = k_ok ? krow : T - 1;
+  const int hoff = wave * (HD * 2);                      // this wave's head inside the 576-byte segments
+  const int koff = (T + krow_c) * V5_PITCH + hoff + 16 * hi;
+  const int qoff = (2 * T + qrow_c) * V5_PITCH + hoff + 16 * hi;      // Q in, O out
+  const int voffl = hoff + l31 * 2 + hi * 8 * V5_PITCH;  // + 64 d + (16 ch + j) * 592: V^T element (dim 32 d + l31, key 16 ch + 8 hi + j)
+  const int npieces_out = T * (V5_PIECES - 1);
+
+  auto make_frags = [&](const uint4 (&raw)[5], bf16x8 (&frag)[5], const float* wf, int pos, bool scaled) {
+    float rstd = 1.f;
+    if (NORM) {
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        const uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const t3_bf16x2 pr = __builtin_bit_cast(t3_bf16x2, u[e]);
+          ss = __builtin_amdgcn_fdot2_f32_bf16(pr, pr, ss, false);
+        }
+      }
+      ss += __shfl_xor(ss, 32, 64);
+      rstd = rsqrtf(ss * (1.0f / (float)HD) + eps);   // (a multiply, not the division sequence)
+    }
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      uint32_t u[4] = {raw[c].x, raw[c].y, raw[c].z, raw[c].w};
+      if (c < 4 || hi == 0)
+        t3_piece<MODE>(u, nullptr, wf, cosc + pos * TAB_ROW, sinc + pos * TAB_ROW, c, hi, rstd, scale, NORM, ROPE, scaled);
+      __builtin_amdgcn_sched_barrier(0);   // (128 registers: one piece's table reads at a time)
+      frag[c] = __builtin_bit_cast(bf16x8, make_uint4(u[0], u[1], u[2], u[3]));
+    }
+  };
+
+  // the store phase of an item: the workgroup stores T row segments of 576 bytes out of the Q / O rows of ``img``
+  auto store_item = [&](int item, const char* img) {
+    const int bs = item / HG, hg = item - bs * HG;
+    const int s = bs % S, b = bs / S;
+    bf16_t* obase = out + ((int64_t)b * T * S + s) * out_stride + hg * (HPG * HD);
+    for (int Lp = tid; Lp < npieces_out; Lp += NTH) {
+      const int row = Lp / (V5_PIECES - 1), piece = Lp - row * (V5_PIECES - 1);
+      const uint4 v = *reinterpret_cast<const uint4*>(img + (2 * T + row) * V5_PITCH + piece * 16);
+      if (!(V5_ABL & 4)) *reinterpret_cast<uint4*>(obase + (int64_t)row * S * out_stride + piece * 8) = v;
+    }
+  };
+  for (int item = lw; item < nitems; item += gridDim.x) {
+    const int next = item + (int)gridDim.x;
+    char* data = smem;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // this item's image has landed everywhere
+    const char* kpiece = data + koff;
+    char* qpiece = data + qoff;
+    const char* vbase = data + voffl;
+
+    if (!(V5_ABL & 2)) {   // (lab builds, VSYS_T5_ABLATE: 1 no LDS-DMA, 2 no arithmetic, 4 no stores — wrong output)
+    // ---- this wave's head: K and Q pieces (the registers v3 loads from HBM)
+    bf16x8 kf[5], qf[5];
+    {
+      uint4 rk[5];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        rk[c] = make_uint4(0, 0, 0, 0);
+        if (c < 4 || hi == 0) rk[c] = *reinterpret_cast<const uint4*>(kpiece + 32 * c);
+      }
+      make_frags(rk, kf, kwf, krow_c, false);   // (rows of keys >= T are the clamped last frame's: finite, and masked below)
+    }
+    {
+      uint4 rq[5];
+#pragma unroll
+      for (int c = 0; c < 5; ++c) {
+        rq[c] = make_uint4(0, 0, 0, 0);
+        if (c < 4 || hi == 0) rq[c] = *reinterpret_cast<const uint4*>(qpiece + 32 * c);
+      }
+      make_frags(rq, qf, qwf, qrow_c, true);
+    }
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[c], qf[c], sacc, 0, 0, 0);
+    float m = NEG_BIG;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = 8 * hi + r + (r >= 8 ? 8 : 0);
+      if (key >= T) sacc[r] = NEG_BIG;
+      m = fmaxf(m, sacc[r]);
+    }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float p[16], l = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p[r] = __builtin_amdgcn_exp2f((sacc[r] - m) * 1.4426950408889634f);
+      l += p[r];
+    }
+    l += __shfl_xor(l, 32, 64);
+    const float inv = __builtin_amdgcn_rcpf(l);   // v_rcp_f32 (1 ulp) instead of the IEEE division sequence
+    bf16x8 p0, p1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      p0[e] = (__bf16)(p[e] * inv);
+      p1[e] = (__bf16)(p[8 + e] * inv);
+    }
+    f32x16 oacc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      // V^T fragments gathered from the row-major V rows: element j <-> key 16 ch + 8 hi + j of dim 32 d + l31.  (Plain 16-bit LDS
+      // reads + one v_perm per dword: ds_read_u16_d16_hi does NOT keep the other half of its register on this part — SRAM ECC —
+      // so the in-place form gives wrong fragments; measured, reverted.)
+      bf16x8 v0, v1;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v0[j] = *reinterpret_cast<const __bf16*>(vbase + 64 * d + j * V5_PITCH);
+        v1[j] = *reinterpret_cast<const __bf16*>(vbase + 64 * d + (16 + j) * V5_PITCH);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+      oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, p0, oacc[d], 0, 0, 0);
+      oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, p1, oacc[d], 0, 0, 0);
+    }
+    // ---- outputs into this wave's own bytes of the Q rows (its Q pieces are in registers; no other wave touches that slice)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      uint2 o[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        o[g].x = pack2bf(oacc[d][4 * g], oacc[d][4 * g + 1]);
+        o[g].y = pack2bf(oacc[d][4 * g + 2], oacc[d][4 * g + 3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        auto sx = __builtin_amdgcn_permlane32_swap(o[2 * k].x, o[2 * k + 1].x, false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(o[2 * k].y, o[2 * k + 1].y, false, false);
+        const int dim0 = 32 * d + 16 * k;   // + 8 hi: the 16 hi bytes inside qpiece
+        if (q_ok && dim0 + 8 * hi + 8 <= HD)
+          *reinterpret_cast<uint4*>(qpiece + dim0 * 2) = make_uint4(sx[0], sy[0], sx[1], sy[1]);
+      }
+    }
+    }
+    __syncthreads();
+    store_item(item, data);
+    __syncthreads();   // (every output piece has been read: the next item's image may land)
+    if (next < nitems) dma_item(next, 0);
+  }
+#undef V5_ABL
+#endif
+}
+
 }  // namespace
 
 int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
                                 const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T, int S,
-                                int heads, float eps, float scale, hipStream_t stream, bool ref_rounding) {
+                                int heads, float eps, float scale, hipStream_t stream, bool ref_rounding, bool no_v5) {
   if (T > 64 || T < 1) return VSYS_ERR_SHAPE;
   // (t3_piece) 0 = the reference's rounding points with run-time flags; else the fused single-rounding form of this norm / rope combination
   const int mode = ref_rounding ? 0 : (q_norm_w != nullptr ? (rope_cos != nullptr ? 1 : 3) : (rope_cos != nullptr ? 4 : 2));
@@ -550,6 +800,50 @@ int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, co
       default: T3_LAUNCH4(4); break;
     }
 #undef T3_LAUNCH4
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
+  // ---- round 6: the cooperative LDS-DMA form (attn_temporal_d72_v5_kernel) for the fused-rounding modes whenever the heads come in
+  // groups of four and a pixel token's frames are addressable with 32-bit offsets (VSYS_TEMPORAL_V5=0 / flash variant 22: the v3 kernel)
+  static const bool v5_env_ok = [] { const char* e = getenv("VSYS_TEMPORAL_V5"); return !(e && e[0] == '0'); }();
+  const int64_t span = (int64_t)T * S * row_stride * 2;
+  if (mode != 0 && mode != 3 /* norm without RoPE: nobody runs it, and it spills at four workgroups per CU */ && v5_env_ok && !no_v5 && heads % 4 == 0 && C % 8 == 0 && span < 0x7fffffff && (int64_t)T * S * out_stride * 2 < 0x7fffffff &&
+      (int64_t)B * S * (heads / 4) <= 0x7fffffff) {
+    const int rows = 3 * T > 35 ? 3 * T : 35;   // (V^T gather reaches image row 31 + the 144-byte overrun of the last head)
+    const int ninstr = (3 * T * V5_PIECES + 63) / 64;
+    const int ninstr_region = (rows * V5_PIECES + 63) / 64;
+    const int data_bytes = (ninstr_region > ninstr ? ninstr_region : ninstr) * 1024;
+    const int tabb = rope_cos != nullptr ? T * TAB_ROW * 4 : 0;
+    const int lds5 = data_bytes + 2 * tabb + 2 * WF_BYTES;
+    const int nitems = B * S * (heads / 4);
+    int per_cu = 160 * 1024 / lds5;
+    per_cu = per_cu > 4 ? 4 : per_cu;
+    int64_t grid5 = (int64_t)per_cu * cu_count_this_device();
+    grid5 = grid5 < nitems ? grid5 : nitems;
+    const bool small = (ninstr + 3) / 4 <= 9;
+    int ablate = 0;
+#ifdef VSYS_LAB
+    static const int ablate_env = [] { const char* e = getenv("VSYS_T5_ABLATE"); return e ? atoi(e) : 0; }();   // measurement only (wrong output)
+    ablate = ablate_env;
+#endif
+    static std::atomic<unsigned long long> attr5_seen{0};
+    for (DeviceOnce once(attr5_seen); once.todo(); once.done()) {
+#define T3_ATTR5(M_)                                                                                                                    \
+  (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v5_kernel<M_, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);     \
+  (void)hipFuncSetAttribute((const void*)attn_temporal_d72_v5_kernel<M_, 14>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+      T3_ATTR5(1); T3_ATTR5(2); T3_ATTR5(4);
+#undef T3_ATTR5
+    }
+#define T3_LAUNCH5_(M_, N_)                                                                                                               \
+  hipLaunchKernelGGL((attn_temporal_d72_v5_kernel<M_, N_>), dim3((unsigned)grid5), dim3(256), lds5, stream, qkv, row_stride, C, q_norm_w,  \
+                     k_norm_w, rope_cos, rope_sin, out, out_stride, B, T, S, heads, eps, scale, ninstr, data_bytes, tabb, nitems, ablate)
+#define T3_LAUNCH5(M_) do { if (small) T3_LAUNCH5_(M_, 9); else T3_LAUNCH5_(M_, 14); } while (0)
+    switch (mode) {
+      case 1: T3_LAUNCH5(1); break;
+      case 2: T3_LAUNCH5(2); break;
+      default: T3_LAUNCH5(4); break;
+    }
+#undef T3_LAUNCH5
+#undef T3_LAUNCH5_
     return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
   }
   // fewer than ~3 workgroups per CU: split the heads of a token over 2 or 4 workgroups (every wave still owns whole heads)

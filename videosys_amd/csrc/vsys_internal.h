@@ -231,7 +231,8 @@ int launch_im2col_patch(const float* z, int Bz, bf16_t* out, int B, int F, int C
 // T <= 32 on the matrix pipe, operands loaded in fragment layout (attention_t3.hip)
 int launch_attn_temporal_d72_v3(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
                                 const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T, int S,
-                                int heads, float eps, float scale, hipStream_t stream, bool ref_rounding = false);
+                                int heads, float eps, float scale, hipStream_t stream, bool ref_rounding = false,
+                                bool no_v5 = false);   // no_v5: keep the per-lane-load kernel (A/B id 22)
 int launch_attn_temporal_d72(const bf16_t* qkv, int64_t row_stride, int C, const bf16_t* q_norm_w, const bf16_t* k_norm_w,
                              const float* rope_cos, const float* rope_sin, bf16_t* out, int64_t out_stride, int B, int T,
                              int S, int heads, float eps, hipStream_t stream);
