@@ -88,13 +88,13 @@ def main():
                     lib.vsys_tune_gemm_variant(variant)
                     same = torch.equal(got, out)
                     print(f"  check gemm_{name} variant {variant} == default: {same}", flush=True)
-                elif rd == 0 and variant == 80:   # stream-K tail: split tiles add fp32 partial sums in another order
+                elif rd == 0 and variant in (80, 24, 16):   # stream-K tail / 16x16x32 MFMAs: fp32 partial sums in another order
                     got = out.clone()
                     lib.vsys_tune_gemm_variant(8)
                     fn()
                     lib.vsys_tune_gemm_variant(variant)
                     d = (got.float() - out.float()).abs()
-                    print(f"  check gemm_{name} variant 80 vs schedule 8: {float((d > 0).float().mean()):.2e} of the elements differ, "
+                    print(f"  check gemm_{name} variant {variant} vs schedule 8: {float((d > 0).float().mean()):.2e} of the elements differ, "
                           f"max |diff| / max |out| = {float(d.max() / out.float().abs().max()):.2e}", flush=True)
     lib.vsys_tune_gemm_variant(0)
     if args.vendor:  # yardstick: the vendor library's plain GEMM + bias (no GELU / gate / residual fusion) on the same operands

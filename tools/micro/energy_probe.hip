@@ -13,17 +13,23 @@
 #include <stdlib.h>
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 __device__ inline unsigned lcg(unsigned& s) { s = s * 1664525u + 1013904223u; return s; }
 
-template <int MODE>
+// W16 (modes + 10): the same ingredients with v_mfma_f32_16x16x32_bf16 (24 accumulators of four registers, same flops per iteration):
+// round 6 — the bare matrix pipe sustains 2.05 PFLOP/s with it against 1.83 for the 32x32x16 form at the same 1400 W cap.
+template <int MODE, bool W16>
 __global__ __launch_bounds__(256, 2) void probe(float* out, const char* __restrict__ stream_buf, size_t stream_bytes, int iters) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 64 KiB: fragment source + DMA landing zone
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  f32x16 acc[12];
-  for (int i = 0; i < 12; ++i)
+  f32x16 acc[W16 ? 1 : 12];
+  f32x4 acc4[W16 ? 24 : 1];
+  for (int i = 0; i < (W16 ? 1 : 12); ++i)
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  for (int i = 0; i < (W16 ? 24 : 1); ++i)
+    for (int r = 0; r < 4; ++r) acc4[i][r] = 0.f;
   bf16x8 a[4], b[4];
   unsigned s = tid * 2654435761u + blockIdx.x;
   for (int k = 0; k < 4; ++k)
@@ -69,34 +75,41 @@ __global__ __launch_bounds__(256, 2) void probe(float* out, const char* __restri
       else if constexpr (NP == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
     }
+    if constexpr (W16) {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[(i + (i >> 2)) & 3], acc[i], 0, 0, 0);
+      for (int i = 0; i < 24; ++i) acc4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i + (i >> 2)) & 3], acc4[i], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[(i + (i >> 2)) & 3], acc[i], 0, 0, 0);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   float t = 0.f;
-  for (int i = 0; i < 12; ++i)
+  for (int i = 0; i < (W16 ? 1 : 12); ++i)
     for (int r = 0; r < 16; ++r) t += acc[i][r];
+  for (int i = 0; i < (W16 ? 24 : 1); ++i)
+    for (int r = 0; r < 4; ++r) t += acc4[i][r];
   out[blockIdx.x * blockDim.x + threadIdx.x] = t;
 #endif
 }
 
-template <int MODE>
+template <int MODE, bool W16 = false>
 void run(const char* buf, size_t bytes) {
   const int blocks = 512, iters = 10000, launches = 150;
   float* out;
   hipMalloc(&out, sizeof(float) * blocks * 256);
-  hipFuncSetAttribute((const void*)probe<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)probe<MODE, W16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int seg = 0; seg < 3; ++seg) {
     hipEventRecord(e0);
-    for (int l = 0; l < launches; ++l) probe<MODE><<<blocks, 256, 65536>>>(out, buf, bytes, iters);
+    for (int l = 0; l < launches; ++l) probe<MODE, W16><<<blocks, 256, 65536>>>(out, buf, bytes, iters);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
     const double flops = 2.0 * 32 * 32 * 16 * 12.0 * iters * 4 * blocks * launches;
-    printf("{\"mode\": %d, \"segment\": %d, \"seconds\": %.2f, \"tflops\": %.1f}\n", MODE, seg, ms / 1e3, flops / ms / 1e9);
+    printf("{\"mfma\": \"%s\", \"mode\": %d, \"segment\": %d, \"seconds\": %.2f, \"tflops\": %.1f}\n", W16 ? "16x16x32" : "32x32x16", MODE, seg, ms / 1e3, flops / ms / 1e9);
     fflush(stdout);
   }
   hipFree(out);
@@ -104,7 +117,7 @@ void run(const char* buf, size_t bytes) {
 
 int main(int argc, char** argv) {
   const int mode = argc > 1 ? atoi(argv[1]) : 0;
-  const size_t bytes = mode == 3 ? (size_t)1900 << 20 : (size_t)8 << 20;  // < 2 GiB: buffer offsets are 32-bit
+  const size_t bytes = mode % 10 == 3 ? (size_t)1900 << 20 : (size_t)8 << 20;  // < 2 GiB: buffer offsets are 32-bit
   char* buf;
   hipMalloc(&buf, bytes);
   hipMemset(buf, 0x3c, bytes);
@@ -115,6 +128,11 @@ int main(int argc, char** argv) {
     case 3: run<3>(buf, bytes); break;
     case 5: run<5>(buf, bytes); break;
     case 6: run<6>(buf, bytes); break;
+    case 10: run<0, true>(buf, bytes); break;
+    case 11: run<1, true>(buf, bytes); break;
+    case 12: run<2, true>(buf, bytes); break;
+    case 13: run<3, true>(buf, bytes); break;
+    case 14: run<4, true>(buf, bytes); break;
     default: run<4>(buf, bytes); break;
   }
   return 0;

@@ -47,7 +47,15 @@ struct G2 {
 
 // STAMP = 1 (lab, variant 31): s_memtime stamps around the four phases of every stage (fragment reads landed / MFMA block issued /
 // counted waits / barrier), summed per wave into p.aux viewed as int64[blocks][waves][8] — the cycle accounting of one stage.
-template <int EPI, int NWN, int STAMP = 0>
+// MF = 1 (round 6): the same tile walk on v_mfma_f32_16x16x32_bf16.  Under the 1400 W cap the matrix pipe itself is ~12 % cheaper per
+// flop in that shape (bare loop, random operands: 2.05 vs 1.83 PFLOP/s; with the fragment reads of this wave tile 1.90 vs 1.67, with
+// the LDS-DMA stream on top 1.26 vs 1.18: tools/micro/mfma_peak.hip, energy_probe.hip modes 10-14) — half the accumulator bytes per
+// flop.  One stage (BK = 32) is ONE k-step: 8 token blocks x 6 column blocks of 16 x 16, taken in two halves of four token blocks so
+// that the fragment registers stay at ten (the cadence of the 32x32x16 loop: six MFMAs = 96 pipe cycles, then a reload + DMA pieces).
+// A lane owns token (16 i + lane % 16) and the four columns 16 j + 4 (lane / 16) ..: the epilogues below index by that.
+// LDS image: chunk c of row r at c ^ F((r >> 2) & 3) with F = (0, 2, 3, 1) — the 16-lane groups of ds_read_b128 ({0-3, 12-15, 20-27}, ...)
+// then meet 16 distinct slots with rows l % 16 and chunk l / 16 (the (r >> 2) & 3 swizzle of the 32-row fragments would 2-way conflict).
+template <int EPI, int NWN, int STAMP = 0, int MF = 0>
 __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   using G = G2<NWN>;
   constexpr int BN = G::BN, NA = G::NA, W_SLOT = G::W_SLOT, WLEAD = G::WLEAD;
@@ -56,6 +64,8 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / NWN, wn = wave % NWN;
   const int l31 = lane & 31, hi = lane >> 5;
+  const int l15 = lane & 15, lq = lane >> 4;   // MF = 1: fragment row / 16-byte k-chunk, accumulator token / column quad
+  static_assert(!MF || (EPI != EPI_F32_SLICES && !STAMP), "the 16x16x32 form covers the token-row epilogues only");
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   // tile order: same W-resident raster as gemm_bf16.hip (column groups of 6 inside 8 row-panel groups)
   const int nbn = p.N / BN;
@@ -77,7 +87,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   // ---- LDS-DMA assignment: a piece = 1 KiB = 16 rows x 64 B; lane l -> row (l>>2), physical chunk l&3, which holds
   // logical chunk (l&3) ^ ((row>>2)&3) = (l&3) ^ ((l>>4)&3) (piece bases are multiples of 16 rows).
   // wave w stages A rows [64w, 64w+64) (4 pieces) and W rows [48w, 48w+48) (3 pieces) of every stage.
-  const int dchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+  const int dchunk = ((lane & 3) ^ (MF ? ((0x78 >> (2 * ((lane >> 4) & 3))) & 3) : ((lane >> 4) & 3))) * 16;
   int a_off[NA], b_off[3];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
@@ -106,17 +116,25 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
 
   // ---- fragment read offsets: row r, k-step ks: logical chunk 2ks + hi at physical chunk ^ ((r>>2)&3); all fragment rows of
   // a lane are l31 + a multiple of 32, so (r>>2)&3 = (l31>>2)&3 and the k-step is an XOR of bit 5
-  const int fsw = ((hi ^ ((l31 >> 2) & 3)) << 4);
-  const int xo = (wm * 128 + l31) * 64 + fsw;           // + i*2048 for m-block i
-  const int wo = W_BASE + (wn * 96 + l31) * 64 + fsw;   // + j*2048 for n-block j
+  const int fsw = MF ? ((lq ^ ((0x78 >> (2 * ((l15 >> 2) & 3))) & 3)) << 4) : ((hi ^ ((l31 >> 2) & 3)) << 4);
+  const int frow = MF ? l15 : l31;
+  const int xo = (wm * 128 + frow) * 64 + fsw;           // + i*2048 for m-block i (MF: + i*1024 for token block i)
+  const int wo = W_BASE + (wn * 96 + frow) * 64 + fsw;   // + j*2048 for n-block j (MF: + j*1024 for column block j)
 
-  f32x16 acc[4][3];
+  f32x16 acc[MF ? 1 : 4][MF ? 1 : 3];
+  f32x4 acc16[MF ? 8 : 1][MF ? 6 : 1];   // MF: token block i (16 tokens), column block j (16 columns)
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < (MF ? 1 : 4); ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < (MF ? 1 : 3); ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (MF ? 8 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (MF ? 6 : 1); ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
 
   constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_GELU;
   float2* ln_lds = reinterpret_cast<float2*>(smem + G::LDS_BYTES);
@@ -170,6 +188,58 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     const char* ab = smem + sa * A_SLOT;
     const char* wb = smem + sw * W_SLOT;
     bf16x8 x0, x1, x2, x3, w0, w1, w2, v0, v1, v2;  // x: A fragments of the current k-step; w / v: W fragments of k-step 0 / 1
+    if constexpr (MF) {
+      // (w0..w2, v0..v2) = the six column blocks, x0..x3 = token blocks 0..3, reloaded with blocks 4..7 behind their MFMAs
+      x0 = *reinterpret_cast<const bf16x8*>(ab + xo);
+      w0 = *reinterpret_cast<const bf16x8*>(wb + wo);
+      w1 = *reinterpret_cast<const bf16x8*>(wb + wo + 1024);
+      w2 = *reinterpret_cast<const bf16x8*>(wb + wo + 2048);
+      v0 = *reinterpret_cast<const bf16x8*>(wb + wo + 3072);
+      v1 = *reinterpret_cast<const bf16x8*>(wb + wo + 4096);
+      v2 = *reinterpret_cast<const bf16x8*>(wb + wo + 5120);
+      x1 = *reinterpret_cast<const bf16x8*>(ab + xo + 1024);
+      x2 = *reinterpret_cast<const bf16x8*>(ab + xo + 2048);
+      x3 = *reinterpret_cast<const bf16x8*>(ab + xo + 3072);
+      __builtin_amdgcn_sched_barrier(0);
+#define G16_ROW(i_, X_)                                                                                \
+  acc16[i_][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, X_, acc16[i_][0], 0, 0, 0);               \
+  acc16[i_][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, X_, acc16[i_][1], 0, 0, 0);               \
+  acc16[i_][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, X_, acc16[i_][2], 0, 0, 0);               \
+  acc16[i_][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, X_, acc16[i_][3], 0, 0, 0);               \
+  acc16[i_][4] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, X_, acc16[i_][4], 0, 0, 0);               \
+  acc16[i_][5] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v2, X_, acc16[i_][5], 0, 0, 0)
+      G16_ROW(0, x0);
+      __builtin_amdgcn_sched_barrier(0);
+      x0 = *reinterpret_cast<const bf16x8*>(ab + xo + 4096);
+      if (n1) { dma_w(0, tw, swn); dma_w(1, tw, swn); }
+      __builtin_amdgcn_sched_barrier(0);
+      G16_ROW(1, x1);
+      __builtin_amdgcn_sched_barrier(0);
+      x1 = *reinterpret_cast<const bf16x8*>(ab + xo + 5120);
+      if (n1) dma_w(2, tw, swn);
+      if (n2) dma_a(0, t + 2, sa2);
+      __builtin_amdgcn_sched_barrier(0);
+      G16_ROW(2, x2);
+      __builtin_amdgcn_sched_barrier(0);
+      x2 = *reinterpret_cast<const bf16x8*>(ab + xo + 6144);
+      if (n2) {
+        dma_a(1, t + 2, sa2);
+        if constexpr (NA > 2) dma_a(2 < NA ? 2 : 0, t + 2, sa2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      G16_ROW(3, x3);
+      __builtin_amdgcn_sched_barrier(0);
+      x3 = *reinterpret_cast<const bf16x8*>(ab + xo + 7168);
+      if constexpr (NA > 3) {
+        if (n2) dma_a(3 < NA ? 3 : 0, t + 2, sa2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      G16_ROW(4, x0);
+      G16_ROW(5, x1);
+      G16_ROW(6, x2);
+      G16_ROW(7, x3);
+#undef G16_ROW
+    } else {
     x0 = *reinterpret_cast<const bf16x8*>(ab + xo);
     w0 = *reinterpret_cast<const bf16x8*>(wb + wo);
     w1 = *reinterpret_cast<const bf16x8*>(wb + wo + 2048);
@@ -225,6 +295,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     G2_ROW(2, x2, v0, v1, v2);
     G2_ROW(3, x3, v0, v1, v2);
 #undef G2_ROW
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (STAMP) {
       const uint64_t now = __builtin_amdgcn_s_memtime();
@@ -287,16 +358,91 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) bb[j][g] = make_uint2(0, 0);
-  if (p.bias != nullptr && EPI != EPI_LN_BIAS && EPI != EPI_LN_GELU) {
+  if (p.bias != nullptr && EPI != EPI_LN_BIAS && EPI != EPI_LN_GELU && !MF) {
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bb[j][g] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * hi);
   }
+  uint2 bb16[6];   // MF: bias of this lane's column quads 16 j + 4 lq ..
+#pragma unroll
+  for (int j = 0; j < 6; ++j) bb16[j] = make_uint2(0, 0);
+  if (MF && p.bias != nullptr && EPI != EPI_LN_BIAS && EPI != EPI_LN_GELU) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bb16[j] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 16 + 4 * lq);
+  }
   const bool full = row0 + BM <= p.M;
 #pragma unroll
   for (int ih = 0; ih < 2; ++ih) {
     const int wrow0 = row0 + wm * 128 + ih * 64;
+    if constexpr (MF) {
+      // ---- 16x16x32 accumulators: lane = token 16 i2 + l15 of this 64-row pass, columns 16 j + 4 lq .. + 3
+      if constexpr (LN) {
+        float mu[4], rs[4];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const float2 ms = ln_lds[wm * 128 + ih * 64 + i2 * 16 + l15];   // staged before the K loop
+          mu[i2] = ms.x;
+          rs[i2] = ms.y;
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const float4* cp = reinterpret_cast<const float4*>(ln_lds + BM + wn * 96 + j * 16 + 4 * lq);   // (cs, cv) of four columns
+          const float4 a = cp[0], b = cp[1];
+          const float c_s[4] = {a.x, a.z, b.x, b.z}, c_v[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+          for (int i2 = 0; i2 < 4; ++i2) {
+            const int i = ih * 4 + i2;
+            const float nmu = -mu[i2], r_ = rs[i2];
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(r_, fmaf(nmu, c_s[r], acc16[i][j][r]), c_v[r]);
+            if (EPI == EPI_LN_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+            }
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(st + (i2 * 16 + l15) * OUT_ROW_BYTES + (j * 16 + 4 * lq) * 2) = o;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const int i = ih * 4 + i2;
+          const int m_local = i2 * 16 + l15;
+          const bf16_t* gate_row = nullptr;
+          if (EPI == EPI_GATE_RES && p.gate != nullptr) {
+            int grow = wrow0 + m_local;
+            grow = grow < p.M ? grow : p.M - 1;
+            const int sample = grow / p.rows_per_sample;
+            gate_row = p.gate + (int64_t)sample * p.gate_stride + ncol0 + 4 * lq;
+            if (p.seg_split > 0 && grow - sample * p.rows_per_sample < p.seg_split) gate_row += p.gate_alt;
+          }
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            uint2 gg = make_uint2(0x3f803f80u, 0x3f803f80u);  // bf16 1.0 pairs
+            if (EPI == EPI_GATE_RES && gate_row != nullptr) gg = *reinterpret_cast<const uint2*>(gate_row + j * 16);
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc16[i][j][r];
+            v[0] += bflo(bb16[j].x); v[1] += bfhi(bb16[j].x); v[2] += bflo(bb16[j].y); v[3] += bfhi(bb16[j].y);
+            if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+            }
+            if (EPI == EPI_GATE_RES) {
+              v[0] *= bflo(gg.x); v[1] *= bfhi(gg.x); v[2] *= bflo(gg.y); v[3] *= bfhi(gg.y);
+            }
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + (j * 16 + 4 * lq) * 2) = o;
+          }
+        }
+      }
+    } else {
     if constexpr (LN) {
       // AdaLN folded into the GEMM: the operand rows were the RAW residual stream and W = bf16(W0 (1 + scale)); the LayerNorm of
       // row m and the shift enter here:  out = rstd_m (acc - mu_m cs[n]) + cv[n]  (vsys_internal.h GemmParams).
@@ -386,6 +532,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
         }
       }
     }
+    }
     // residual rows are fetched only now: the accumulators of this pass are dead, so the 48 registers are free (the
     // other workgroup of the CU covers the latency)
     uint4 rres[12];
@@ -449,7 +596,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
 
 }  // namespace
 
-template <int NWN>
+template <int NWN, int MF = 0>
 static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
   using G = G2<NWN>;
   if (p.N % G::BN != 0) return VSYS_ERR_SHAPE;
@@ -457,18 +604,18 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
   const int grid = nbm * nbn;
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
   for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_BIAS, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_GELU, NWN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_BIAS_GELU, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_BIAS, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
+    (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_GELU, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
   }
   switch (epi) {
-    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
-    case EPI_LN_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
-    case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_BIAS, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
+    case EPI_LN_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_GELU, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -509,7 +656,9 @@ int launch_gemm2_slices(const GemmParams& p, int slices, hipStream_t stream) {
 }
 
 // wide = 0: 256 x 192 tile, two workgroups per CU (variant 20); wide = 1: 256 x 384 tile, one 8-wave workgroup per CU (variant 30)
+// wide = 2: the 256 x 192 tile on v_mfma_f32_16x16x32_bf16 (gemm2_kernel MF = 1)
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream) {
+  if (wide == 2) return launch_gemm2_t<2, 1>(p, epi, stream);
   return wide ? launch_gemm2_t<4>(p, epi, stream) : launch_gemm2_t<2>(p, epi, stream);
 }
 

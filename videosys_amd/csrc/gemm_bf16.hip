@@ -795,7 +795,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 20: case 28: case 30: case 50: case 103: case 106: break;
+    case 0: case 3: case 6: case 8: case 9: case 20: case 24: case 28: case 30: case 50: case 103: case 106: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -839,6 +839,11 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
+static bool mf16_default() {
+  static const bool on = [] { const char* e = getenv("VSYS_GEMM_MF16"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   if (p_.M <= 0) return 0;
   GemmParams p = p_;
@@ -868,7 +873,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   }
   if (ln) {   // same shape dispatch as the store-only epilogues below
     if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
-    if (p.K <= 1536 && p.N >= 2304 && g_gemm_variant_a.load(std::memory_order_relaxed) != 8) return launch_gemm2(p, epi, 0, stream);
+    if (p.K <= 1536 && p.N >= 2304 && g_gemm_variant_a.load(std::memory_order_relaxed) != 8) return launch_gemm2(p, epi, mf16_default() ? 2 : 0, stream);
     return launch_gemm_t<8, 256>(p, epi, stream);
   }
   const int g_gemm_variant = g_gemm_variant_a.load(std::memory_order_relaxed);
@@ -892,6 +897,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 106: return launch_gemm_t<6, 128>(p, epi, stream);   // the 128-row geometry on schedule 6 (DMA pieces interleaved with the MFMA pairs)
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
+    case 24: return launch_gemm2(p, epi, 2, stream);  // the same on v_mfma_f32_16x16x32_bf16 (fp32 summation order inside an MFMA differs: not bit-identical)
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
     case 28: return launch_gemm_t<8, 256, 1, 1>(p, epi, stream);  // schedule 8 + four producer waves (store-only epilogues)
@@ -905,6 +911,10 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
       // 128-row geometry (two 4-wave workgroups per CU, 512 slots) fills the chip; measured at M = 4864 against schedule 8:
       // qkv -7 %, proj -15 %, fc2 -16 %, fc1 -2 % (tools/kernel_bench.py --rows 4864 --variants 8,20,103).
       if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+      // Round 6: the two-workgroup kernel on v_mfma_f32_16x16x32_bf16 (launch_gemm2 wide = 2; same bits, the matrix pipe ~12 % cheaper per
+      // flop under the power cap): qkv 0.297 -> 0.276 ms, fc1 0.425 -> 0.404, and it now also beats schedule 8 on the N = K = 1152
+      // store-only shape (cross-attention q: 0.111 -> 0.095 ms) — profiles/r06_kernel_bench_mf16.txt.  VSYS_GEMM_MF16=0: the 32x32x16 kernels.
+      if (epi != EPI_GATE_RES && p.K <= 1536 && mf16_default()) return launch_gemm2(p, epi, 2, stream);
       if (epi != EPI_GATE_RES && p.K <= 1536 && p.N >= 2304) return launch_gemm2(p, epi, 0, stream);
       if (g_gemm_variant == 50 && p.K >= 2304 && p.N % 384 == 0) return launch_gemm2(p, epi, 1, stream);  // lab: long-K on the wide tile
       return launch_gemm_t<8, 256>(p, epi, stream);
