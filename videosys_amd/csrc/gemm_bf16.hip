@@ -59,7 +59,14 @@ struct Geo {
 // waves only read fragments and issue MFMAs.  A piece costs its issuing wave 60-185 cycles (MI355X_MICROARCH.md), 7 pieces per
 // wave and tile against 24 MFMAs = 768 cycles: with the DMA on a third wave of the SIMD that time no longer comes out of an
 // MFMA-issuing wave.  Needs <= 168 VGPRs (three waves per SIMD), which the store-only epilogues meet (165).
-template <int EPI, int PIPE, int BM_, int RASTER = 1, int PROD = 0>
+// MF = 1 (round 6; schedule 8, 256-row geometry): the same tile walk on v_mfma_f32_16x16x32_bf16 — the matrix pipe is ~12 % cheaper per
+// flop in that shape under the 1400 W cap (gemm2_bf16.hip MF has the measurements), and the results are the SAME BITS.  A K-tile of 64 is
+// two k-steps of 32; a k-step is 4 token blocks x 6 column blocks of 16 x 16 and runs as two PHASES of two token blocks (12 MFMAs = 192
+// pipe cycles = one k-step of the 32x32x16 loop, so the LDS-DMA pieces keep their places).  Fragment registers: W sets A / B (six
+// column blocks each, alternating per k-step) and X pairs A / B (two token blocks, alternating per phase), every set read one phase
+// ahead of its use.  A lane owns token 16 i + lane % 16 and the columns 16 j + 4 (lane / 16) .. + 3: the epilogues index by that;
+// the statistics of EPI_GATE_RES_STATS are taken from the wave's LDS image in the canonical 48-column order (same bits).
+template <int EPI, int PIPE, int BM_, int RASTER = 1, int PROD = 0, int MF = 0>
 __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_kernel(GemmParams p) {
 #if __HIP_DEVICE_COMPILE__  // the buffer-resource type below exists in the device pass only; the host pass needs just the stub
   using G = Geo<BM_>;
@@ -69,6 +76,8 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, hi = lane >> 5;
+  const int l15 = lane & 15, lq = lane >> 4;   // MF: fragment row / 16-byte k-chunk; accumulator token / column quad
+  static_assert(!MF || (PIPE == 8 && BM_ == 256 && !PROD), "the 16x16x32 form exists for schedule 8 on the 256-row geometry");
 
   const int nbn = p.N / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -143,15 +152,37 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
     wo[j] = A_BYTES + (r << 7) + ((hi ^ ((r >> 1) & 7)) << 4);
   }
 
-  f32x16 acc[2][3];
+  f32x16 acc[MF ? 1 : 2][MF ? 1 : 3];
+  f32x4 acc16[MF ? 4 : 1][MF ? 6 : 1];   // MF: token block i, column block j
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < (MF ? 1 : 2); ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < (MF ? 1 : 3); ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (MF ? 4 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (MF ? 6 : 1); ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  // MF fragment offsets: row r, k-step ks (32 wide), chunk 4 ks + lq at slot (4 ks + lq) ^ ((r >> 1) & 7): one base per fragment row, the
+  // k-step is an XOR of bit 6.  (The 16-lane groups of ds_read_b128 — {0-3, 12-15, 20-27}, ... — then meet rows 0-3, 12-15 with chunk c
+  // and rows 4-11 with chunk c ^ 1: eight distinct slots x two row parities.)
+  int xo16[4], wo16[6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = wm * 64 + i * 16 + l15;
+    xo16[i] = (r << 7) + ((lq ^ ((r >> 1) & 7)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int r = wn * 96 + j * 16 + l15;
+    wo16[j] = A_BYTES + (r << 7) + ((lq ^ ((r >> 1) & 7)) << 4);
+  }
 
   auto compute = [&](int cur) {
+    if constexpr (!MF) {
     const char* sb_ = smem + cur * STAGE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -165,6 +196,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+    }
     }
   };
 
@@ -326,6 +358,58 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
     __builtin_amdgcn_s_barrier();
     V8_SB();
     int sa = 0, sw = 0;  // LDS slots of the current tile
+    if constexpr (MF) {
+      bf16x8 wa0, wa1, wa2, wa3, wa4, wa5, wb0, wb1, wb2, wb3, wb4, wb5, xa0, xa1, xb0, xb1;
+#define M16_X(D_, sa_, i_, ks_) D_ = *reinterpret_cast<const bf16x8*>(smem + (sa_) * A_BYTES + (xo16[i_] ^ ((ks_) << 6)))
+#define M16_W(D_, sw_, j_, ks_) D_ = *reinterpret_cast<const bf16x8*>(smem + W_BASE - A_BYTES + (sw_) * B_BYTES + (wo16[j_] ^ ((ks_) << 6)))
+#define M16_MMA(W_, X_, i_, j_) acc16[i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W_, X_, acc16[i_][j_], 0, 0, 0)
+      // one phase: token blocks I0, I0 + 1 (fragments X0, X1) against the six column blocks of set W; DMA statements behind MFMAs 4 and 8
+#define M16_PHASE(W, X0, X1, I0, d0_, d1_)                                                                  \
+  do {                                                                                                      \
+    V8_SB();                                                                                                \
+    M16_MMA(W##0, X0, I0, 0); M16_MMA(W##1, X0, I0, 1); M16_MMA(W##2, X0, I0, 2); M16_MMA(W##3, X0, I0, 3);  \
+    V8_SB();                                                                                                \
+    d0_;                                                                                                    \
+    V8_SB();                                                                                                \
+    M16_MMA(W##4, X0, I0, 4); M16_MMA(W##5, X0, I0, 5); M16_MMA(W##0, X1, I0 + 1, 0); M16_MMA(W##1, X1, I0 + 1, 1); \
+    V8_SB();                                                                                                \
+    d1_;                                                                                                    \
+    V8_SB();                                                                                                \
+    M16_MMA(W##2, X1, I0 + 1, 2); M16_MMA(W##3, X1, I0 + 1, 3); M16_MMA(W##4, X1, I0 + 1, 4); M16_MMA(W##5, X1, I0 + 1, 5); \
+    V8_SB();                                                                                                \
+  } while (0)
+      M16_W(wa0, 0, 0, 0); M16_W(wa1, 0, 1, 0); M16_W(wa2, 0, 2, 0); M16_W(wa3, 0, 3, 0); M16_W(wa4, 0, 4, 0); M16_W(wa5, 0, 5, 0);
+      M16_X(xa0, 0, 0, 0); M16_X(xa1, 0, 1, 0);
+      if (dma_on && nt > 1) { dma_w(0, 1, 1); dma_w(1, 1, 1); }
+      for (int t = 0; t < nt; ++t) {
+        const int sa1 = sa == 2 ? 0 : sa + 1, sa2 = sa1 == 2 ? 0 : sa1 + 1, sw1 = sw ^ 1;
+        const bool n1 = dma_on && (t + 1 < nt), n2 = dma_on && (t + 2 < nt);
+        // phase 0: k-step 0, token blocks 0 1 | ahead: X pair B of k-step 0, first half of W set B (k-step 1)
+        M16_X(xb0, sa, 2, 0); M16_X(xb1, sa, 3, 0); M16_W(wb0, sw, 0, 1); M16_W(wb1, sw, 1, 1); M16_W(wb2, sw, 2, 1);
+        M16_PHASE(wa, xa0, xa1, 0, if (n1) dma_w(2, t + 1, sw1), if (n2) dma_a(0, t + 2, sa2));
+        // phase 1: k-step 0, token blocks 2 3 | ahead: X pair A of k-step 1, second half of W set B
+        M16_X(xa0, sa, 0, 1); M16_X(xa1, sa, 1, 1); M16_W(wb3, sw, 3, 1); M16_W(wb4, sw, 4, 1); M16_W(wb5, sw, 5, 1);
+        M16_PHASE(wa, xb0, xb1, 2, if (n2) dma_a(1, t + 2, sa2), if (n2) dma_a(2, t + 2, sa2));
+        // phase 2: k-step 1, token blocks 0 1 | ahead: X pair B of k-step 1
+        M16_X(xb0, sa, 2, 1); M16_X(xb1, sa, 3, 1);
+        M16_PHASE(wb, xa0, xa1, 0, if (n2) dma_a(3, t + 2, sa2), (void)0);
+        if (n2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        V8_SB();
+        __builtin_amdgcn_s_barrier();  // tile t+1 has landed everywhere; nobody reads the slots of tile t any more
+        V8_SB();
+        // phase 3: k-step 1, token blocks 2 3 | ahead: W set A and X pair A of the NEXT tile's k-step 0
+        M16_W(wa0, sw1, 0, 0); M16_W(wa1, sw1, 1, 0); M16_W(wa2, sw1, 2, 0); M16_W(wa3, sw1, 3, 0); M16_W(wa4, sw1, 4, 0); M16_W(wa5, sw1, 5, 0);
+        M16_X(xa0, sa1, 0, 0); M16_X(xa1, sa1, 1, 0);
+        M16_PHASE(wb, xb0, xb1, 2, if (n2) dma_w(0, t + 2, sw), if (n2) dma_w(1, t + 2, sw));
+        sa = sa1;
+        sw = sw1;
+      }
+#undef M16_X
+#undef M16_W
+#undef M16_MMA
+#undef M16_PHASE
+    } else {
     V8_READ(f0, 0, 0, 0);
     if (dma_on && nt > 1) { dma_w(0, 1, 1); dma_w(1, 1, 1); }
     for (int t = 0; t < nt; ++t) {
@@ -346,6 +430,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
       V8_STEP(f1, if (n2) dma_w(0, t + 2, sw), if (n2) dma_w(1, t + 2, sw));
       sa = sa1;
       sw = sw1;
+    }
     }
     __syncthreads();
 #undef V8_READ
@@ -434,7 +519,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   }
 #undef GEMM_DMA_RANGE
 
-  if constexpr (ABL == 1) {
+  if constexpr (ABL == 1 && !MF) {
     // lab: keep the accumulators alive without an epilogue; lane 0 of a never-true condition writes them
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -479,7 +564,116 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
   }
-  if constexpr (LN) {
+  // the LayerNorm partials of what the wave's image holds (x_new, a lane pair per token row, the 48 columns of a lane in the order of the
+  // 32x32x16 accumulator pass): the form the folded store phase below uses, and what the 16x16x32 accumulator pass cannot do in registers
+  auto stats_from_image = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m_local = i * 32 + l31;
+      LnAcc lacc;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const uint2 o = *reinterpret_cast<const uint2*>(st + m_local * OUT_ROW_BYTES + (j * 32 + 8 * g + 4 * hi) * 2);
+          if (j == 0 && g == 0) lacc.init(bflo(o.x));
+          lacc.add(bflo(o.x)); lacc.add(bfhi(o.x)); lacc.add(bflo(o.y)); lacc.add(bfhi(o.y));
+        }
+      const float2 mine = lacc.finish(48.f);
+      const float2 other = make_float2(__shfl_xor(mine.x, 32, 64), __shfl_xor(mine.y, 32, 64));
+      const float2 blk = ln_merge_equal(mine, other, 48.f);
+      const int grow = row0 + wm * 64 + m_local;
+      if (hi == 0 && grow < p.M) p.stats_out[(int64_t)(ncol0 / LN_BLOCK) * p.stats_ld + grow] = blk;
+    }
+  };
+  if constexpr (MF) {
+    // ---- 16x16x32 accumulators: token 16 i + l15 of the wave's 64 rows, columns 16 j + 4 lq .. + 3
+    if constexpr (LN) {
+      float mu[4], rs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float2 ms = ln_lds[wm * 64 + i * 16 + l15];
+        mu[i] = ms.x;
+        rs[i] = ms.y;
+      }
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const float4* cp = reinterpret_cast<const float4*>(ln_lds + BM_ + wn * 96 + j * 16 + 4 * lq);   // (cs, cv) of four columns
+        const float4 a = cp[0], b = cp[1];
+        const float c_s[4] = {a.x, a.z, b.x, b.z}, c_v[4] = {a.y, a.w, b.y, b.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float nmu = -mu[i], r_ = rs[i];
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(r_, fmaf(nmu, c_s[r], acc16[i][j][r]), c_v[r]);
+          if (EPI == EPI_LN_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(st + (i * 16 + l15) * OUT_ROW_BYTES + (j * 16 + 4 * lq) * 2) = o;
+        }
+      }
+    } else {
+      uint2 bb16[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) bb16[j] = make_uint2(0, 0);
+      if (p.bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) bb16[j] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 16 + 4 * lq);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m_local = i * 16 + l15;
+        uint2 gg[6];
+        if (GATED) {
+#pragma unroll
+          for (int j = 0; j < 6; ++j) gg[j] = make_uint2(0x3f803f80u, 0x3f803f80u);  // bf16 1.0 pairs
+          if (p.gate != nullptr) {
+            int grow = row0 + wm * 64 + m_local;
+            grow = grow < p.M ? grow : p.M - 1;
+            const int sample = grow / p.rows_per_sample;
+            const bf16_t* gate_row = p.gate + (int64_t)sample * p.gate_stride + ncol0 + 4 * lq;
+            if (p.seg_split > 0 && grow - sample * p.rows_per_sample < p.seg_split) gate_row += p.gate_alt;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) gg[j] = *reinterpret_cast<const uint2*>(gate_row + j * 16);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const int n_local = j * 16 + 4 * lq;
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc16[i][j][r];
+          v[0] += bflo(bb16[j].x); v[1] += bfhi(bb16[j].x); v[2] += bflo(bb16[j].y); v[3] += bfhi(bb16[j].y);
+          if (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
+          }
+          if (GATED) {
+            v[0] *= bflo(gg[j].x); v[1] *= bfhi(gg[j].x); v[2] *= bflo(gg[j].y); v[3] *= bfhi(gg[j].y);
+          }
+          uint2 o;
+          o.x = pack2bf(v[0], v[1]);
+          o.y = pack2bf(v[2], v[3]);
+          if constexpr (EPI == EPI_GATE_RES_STATS) {
+            // + residual (same two roundings as the plain epilogue: bf16(u), then bf16(u + res)); the statistics follow from the image
+            const uint2 rr = *reinterpret_cast<const uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2);
+            o.x = pack2bf(bflo(o.x) + bflo(rr.x), bfhi(o.x) + bfhi(rr.x));
+            o.y = pack2bf(bflo(o.y) + bflo(rr.y), bfhi(o.y) + bfhi(rr.y));
+          }
+          *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + n_local * 2) = o;
+        }
+      }
+      if constexpr (EPI == EPI_GATE_RES_STATS) stats_from_image();
+    }
+  }
+  if constexpr (LN && !MF) {
     // AdaLN folded into the GEMM (vsys_internal.h GemmParams): out = rstd_m (acc - mu_m cs[n]) + cv[n]
     if constexpr (BM_ != 256) {
       ln_stage_tile(ln_lds, p.ln_stats, p.ln_ld, p.ln_nb, p.ln_eps, p.M, row0, BM_, p.cs, p.cv, col0, BN, tid, G::NT);
@@ -532,14 +726,14 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int g = 0; g < 4; ++g) bb[j][g] = make_uint2(0, 0);
-  if (p.bias != nullptr && !LN) {
+  if (p.bias != nullptr && !LN && !MF) {
 #pragma unroll
     for (int j = 0; j < 3; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bb[j][g] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 32 + 8 * g + 4 * hi);
   }
 #pragma unroll
-  for (int i = 0; i < (LN ? 0 : 2); ++i) {
+  for (int i = 0; i < ((LN || MF) ? 0 : 2); ++i) {
     const int m_local = i * 32 + l31;
     uint2 gg[3][4];
     LnAcc lacc;
@@ -654,28 +848,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
         if (ok) *reinterpret_cast<uint4*>(p.out + (int64_t)grow * p.ldo + gcol) = v;
         if (p.stats_out != nullptr) *reinterpret_cast<uint4*>(st + m_local * OUT_ROW_BYTES + c * 16) = v;
       }
-      if (p.stats_out != nullptr) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int m_local = i * 32 + l31;
-          LnAcc lacc;
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {   // the lane's 48 columns in the order of the EPI_GATE_RES_STATS accumulator pass
-              const uint2 o = *reinterpret_cast<const uint2*>(st + m_local * OUT_ROW_BYTES + (j * 32 + 8 * g + 4 * hi) * 2);
-              if (j == 0 && g == 0) lacc.init(bflo(o.x));
-              lacc.add(bflo(o.x)); lacc.add(bfhi(o.x)); lacc.add(bflo(o.y)); lacc.add(bfhi(o.y));
-            }
-          const float2 mine = lacc.finish(48.f);
-          const float2 other = make_float2(__shfl_xor(mine.x, 32, 64), __shfl_xor(mine.y, 32, 64));
-          const float2 blk = ln_merge_equal(mine, other, 48.f);
-          const int grow = row0 + wm * 64 + m_local;
-          if (hi == 0 && grow < p.M) p.stats_out[(int64_t)(ncol0 / LN_BLOCK) * p.stats_ld + grow] = blk;
-        }
-      }
+      if (p.stats_out != nullptr) stats_from_image();
       return;
     }
   }
@@ -795,7 +968,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 20: case 24: case 28: case 30: case 50: case 103: case 106: break;
+    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 28: case 30: case 50: case 103: case 106: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -806,10 +979,10 @@ int set_gemm_variant(int v) {
   return 0;
 }
 
-template <int PIPE, int BM_, int RASTER = 1, int PROD = 0>
+template <int PIPE, int BM_, int RASTER = 1, int PROD = 0, int MF = 0>
 static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   using G = Geo<BM_>;
-  if (PROD && epi != EPI_BIAS && epi != EPI_BIAS_GELU) return launch_gemm_t<PIPE, BM_, RASTER, 0>(p, epi, stream);  // 208 VGPRs: no third wave
+  if (PROD && epi != EPI_BIAS && epi != EPI_BIAS_GELU) return launch_gemm_t<PIPE, BM_, RASTER, 0, MF>(p, epi, stream);  // 208 VGPRs: no third wave
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
   const int grid = nbm * nbn;
   const bool lnl = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
@@ -817,23 +990,23 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
   for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
     const int lds = (int)(((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (BM_ == 256 ? (BM_ + BN) * 8 : 0));
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if constexpr (!PROD) {
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
   }
   constexpr int NTH = G::NT + PROD * 256;
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD>), dim3(grid), dim3(NTH), lds, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD>), dim3(grid), dim3(NTH), lds, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_GATE_RES_STATS: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_LN_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD, MF>), dim3(grid), dim3(NTH), lds, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD, MF>), dim3(grid), dim3(NTH), lds, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_GATE_RES_STATS: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_LN_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -842,6 +1015,11 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
 static bool mf16_default() {
   static const bool on = [] { const char* e = getenv("VSYS_GEMM_MF16"); return !(e && e[0] == '0'); }();
   return on;
+}
+
+// schedule 8 on the 256-row geometry: the 16x16x32 form by default (same bits), VSYS_GEMM_MF16=0 / variant 8 the 32x32x16 form
+static int launch_sched8(const GemmParams& p, int epi, hipStream_t stream) {
+  return mf16_default() ? launch_gemm_t<8, 256, 1, 0, 1>(p, epi, stream) : launch_gemm_t<8, 256>(p, epi, stream);
 }
 
 int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
@@ -864,17 +1042,17 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   if (epi == EPI_GATE_RES && (p.add1 || p.add2 || p.stats_out)) {   // folded broadcasts / statistics beside a slab copy: gemm_kernel only
     if ((p.add2 && !p.add1) || ((p.add1 || p.add2) && (!p.res || (p.ldr % 8))) || (p.stats_out && p.stats_ld < p.M)) return VSYS_ERR_ARG;
     if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
-    return launch_gemm_t<8, 256>(p, epi, stream);
+    return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   // the statistics-emitting epilogue lives in gemm_kernel only (lab / forced variants of other kernel families fall back to it)
   if (epi == EPI_GATE_RES_STATS) {
     if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
-    return launch_gemm_t<8, 256>(p, epi, stream);
+    return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   if (ln) {   // same shape dispatch as the store-only epilogues below
     if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
     if (p.K <= 1536 && p.N >= 2304 && g_gemm_variant_a.load(std::memory_order_relaxed) != 8) return launch_gemm2(p, epi, mf16_default() ? 2 : 0, stream);
-    return launch_gemm_t<8, 256>(p, epi, stream);
+    return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   const int g_gemm_variant = g_gemm_variant_a.load(std::memory_order_relaxed);
   switch (g_gemm_variant == 50 ? 0 : g_gemm_variant) {
@@ -899,7 +1077,8 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
     case 24: return launch_gemm2(p, epi, 2, stream);  // the same on v_mfma_f32_16x16x32_bf16 (fp32 summation order inside an MFMA differs: not bit-identical)
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
-    case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 for every shape
+    case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 (32x32x16) for every shape
+    case 16: return launch_gemm_t<8, 256, 1, 0, 1>(p, epi, stream);  // schedule 8 on v_mfma_f32_16x16x32_bf16 for every shape
     case 28: return launch_gemm_t<8, 256, 1, 1>(p, epi, stream);  // schedule 8 + four producer waves (store-only epilogues)
     case 3: return launch_gemm_t<3, 256>(p, epi, stream);
     case 9: return launch_gemm_t<8, 256, 0>(p, epi, stream);  // schedule 8, plain row-major tile order
@@ -917,7 +1096,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
       if (epi != EPI_GATE_RES && p.K <= 1536 && mf16_default()) return launch_gemm2(p, epi, 2, stream);
       if (epi != EPI_GATE_RES && p.K <= 1536 && p.N >= 2304) return launch_gemm2(p, epi, 0, stream);
       if (g_gemm_variant == 50 && p.K >= 2304 && p.N % 384 == 0) return launch_gemm2(p, epi, 1, stream);  // lab: long-K on the wide tile
-      return launch_gemm_t<8, 256>(p, epi, stream);
+      return launch_sched8(p, epi, stream);
   }
 }
 
