@@ -63,11 +63,16 @@ def test_ln_row_stats_matches_torch(ops, M, C, offset):
     assert torch.allclose(st[..., 1].double().cpu().t(), ((blk - blk.mean(2, keepdim=True)) ** 2).sum(2), rtol=5e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("variant", [0, 8, 16, 24])
 @pytest.mark.parametrize("M,N,K,rps", [(1100, 576, 1152, 400), (2048, 1152, 1152, 1024), (300, 1152, 4608, 300), (25856, 1152, 1152, 12928)])
-def test_gemm_stats_same_bits_and_right_statistics(ops, M, N, K, rps):
+def test_gemm_stats_same_bits_and_right_statistics(ops, M, N, K, rps, variant):
     """The statistics-emitting epilogue stores what the plain gate + residual epilogue stores (in place, as the model calls it),
-    and its partials are the statistics of exactly those stored values.  The last shape has >= 400 tiles (the 8-wave kernel),
-    the others take the 128-row geometry."""
+    and its partials are the statistics of exactly those stored values.  The last shape has >= 400 tiles (the 8-wave kernel; variant
+    8 / 16 = its 32x32x16 / 16x16x32 form, 24 = the two-workgroup 16x16x32 kernel, whose partials come from the LDS image), the
+    others take the 128-row geometry under every id."""
+    from videosys_amd import _lib
+
+    lib = _lib.load()
     g = torch.Generator().manual_seed(M)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev())
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev())
@@ -78,11 +83,19 @@ def test_gemm_stats_same_bits_and_right_statistics(ops, M, N, K, rps):
     for use_gate in (True, False):
         r0, r1 = res.clone(), res.clone()
         kw = dict(gate=gate[0] if use_gate else None, gate_stride=N if use_gate else 0, rows_per_sample=rps if use_gate else 0)
-        ops.gemm(x, w, b, epilogue=ops.EPI_GATE_RES, res=r0, out=r0, **kw)
-        st = ops.ln_stats_buffer(M, N, dev())
-        st.fill_(float("nan"))
-        ops.gemm_stats(x, w, b, st, res=r1, out=r1, **kw)
+        assert lib.vsys_tune_gemm_variant(8) == 0      # the reference bits: schedule 8, 32x32x16
+        try:
+            ops.gemm(x, w, b, epilogue=ops.EPI_GATE_RES, res=r0, out=r0, **kw)
+            assert lib.vsys_tune_gemm_variant(variant) == 0
+            st = ops.ln_stats_buffer(M, N, dev())
+            st.fill_(float("nan"))
+            ops.gemm_stats(x, w, b, st, res=r1, out=r1, **kw)
+            r2 = res.clone()
+            ops.gemm(x, w, b, epilogue=ops.EPI_GATE_RES, res=r2, out=r2, **kw)     # the plain gated epilogue of the same kernel family
+        finally:
+            lib.vsys_tune_gemm_variant(0)
         assert torch.equal(r0, r1), "statistics epilogue changed the stored bits"
+        assert torch.equal(r0, r2), f"gate + residual epilogue of variant {variant} differs from schedule 8"
         want = ops.ln_stats_buffer(M, N, dev())
         ops.ln_row_stats(r1, want)
         # the row pass accumulates the same 48-column halves in the same order as the epilogue: the SAME partial bits

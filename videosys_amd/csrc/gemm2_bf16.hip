@@ -408,12 +408,38 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
           }
         }
       } else {
+        constexpr bool GATED16 = EPI == EPI_GATE_RES || EPI == EPI_GATE_RES_STATS;
+        if (GATED16 && p.res != nullptr) {
+          // The residual rows of this pass go INTO the wave's image first (two bursts of six 16-byte units per lane: the accumulators of
+          // both passes are live), so that the accumulator pass sees x_new = bf16(bf16(u) + res) where a lane owns a token — the two
+          // roundings of the 32x32x16 epilogues — and the store phase is a copy.
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            uint4 r6[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const int q = lane + 64 * (6 * half + k);
+              const int m_local = q / 12, c = q - m_local * 12;
+              int grow = wrow0 + m_local;
+              grow = grow < p.M ? grow : p.M - 1;
+              r6[k] = *reinterpret_cast<const uint4*>(p.res + (int64_t)grow * p.ldr + ncol0 + c * 8);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+              const int q = lane + 64 * (6 * half + k);
+              const int m_local = q / 12, c = q - m_local * 12;
+              *reinterpret_cast<uint4*>(st + m_local * OUT_ROW_BYTES + c * 16) = r6[k];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+        }
 #pragma unroll
         for (int i2 = 0; i2 < 4; ++i2) {
           const int i = ih * 4 + i2;
           const int m_local = i2 * 16 + l15;
           const bf16_t* gate_row = nullptr;
-          if (EPI == EPI_GATE_RES && p.gate != nullptr) {
+          if (GATED16 && p.gate != nullptr) {
             int grow = wrow0 + m_local;
             grow = grow < p.M ? grow : p.M - 1;
             const int sample = grow / p.rows_per_sample;
@@ -423,7 +449,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
 #pragma unroll
           for (int j = 0; j < 6; ++j) {
             uint2 gg = make_uint2(0x3f803f80u, 0x3f803f80u);  // bf16 1.0 pairs
-            if (EPI == EPI_GATE_RES && gate_row != nullptr) gg = *reinterpret_cast<const uint2*>(gate_row + j * 16);
+            if (GATED16 && gate_row != nullptr) gg = *reinterpret_cast<const uint2*>(gate_row + j * 16);
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc16[i][j][r];
@@ -432,13 +458,42 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
             }
-            if (EPI == EPI_GATE_RES) {
+            if (GATED16) {
               v[0] *= bflo(gg.x); v[1] *= bfhi(gg.x); v[2] *= bflo(gg.y); v[3] *= bfhi(gg.y);
             }
             uint2 o;
             o.x = pack2bf(v[0], v[1]);
             o.y = pack2bf(v[2], v[3]);
+            if (GATED16 && p.res != nullptr) {
+              const uint2 rr = *reinterpret_cast<const uint2*>(st + m_local * OUT_ROW_BYTES + (j * 16 + 4 * lq) * 2);
+              o.x = pack2bf(bflo(o.x) + bflo(rr.x), bfhi(o.x) + bfhi(rr.x));
+              o.y = pack2bf(bflo(o.y) + bflo(rr.y), bfhi(o.y) + bfhi(rr.y));
+            }
             *reinterpret_cast<uint2*>(st + m_local * OUT_ROW_BYTES + (j * 16 + 4 * lq) * 2) = o;
+          }
+        }
+        if constexpr (EPI == EPI_GATE_RES_STATS) {
+          // LayerNorm partials of the 64 rows of this pass from the image: a lane pair per row, the 48 columns of a lane in the order
+          // of the 32x32x16 accumulator pass of gemm_kernel (same bits as ln_row_stats gives for these rows)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const int m_local = i2 * 32 + l31;
+            LnAcc lacc;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const uint2 o = *reinterpret_cast<const uint2*>(st + m_local * OUT_ROW_BYTES + (j * 32 + 8 * g + 4 * hi) * 2);
+                if (j == 0 && g == 0) lacc.init(bflo(o.x));
+                lacc.add(bflo(o.x)); lacc.add(bfhi(o.x)); lacc.add(bflo(o.y)); lacc.add(bfhi(o.y));
+              }
+            const float2 mine = lacc.finish(48.f);
+            const float2 other = make_float2(__shfl_xor(mine.x, 32, 64), __shfl_xor(mine.y, 32, 64));
+            const float2 blk = ln_merge_equal(mine, other, 48.f);
+            const int grow = wrow0 + m_local;
+            if (hi == 0 && grow < p.M) p.stats_out[(int64_t)(ncol0 / LN_BLOCK) * p.stats_ld + grow] = blk;
           }
         }
       }
@@ -536,7 +591,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
     // residual rows are fetched only now: the accumulators of this pass are dead, so the 48 registers are free (the
     // other workgroup of the CU covers the latency)
     uint4 rres[12];
-    if (EPI == EPI_GATE_RES) {
+    if (EPI == EPI_GATE_RES && !MF) {
 #pragma unroll
       for (int it = 0; it < 12; ++it) rres[it] = make_uint4(0, 0, 0, 0);
       if (p.res != nullptr) {
@@ -567,7 +622,7 @@ __global__ __launch_bounds__(G2<NWN>::NT, 2) void gemm2_kernel(GemmParams p) {
       const int gcol = ncol0 + c * 8;
       const bool ok = full || grow < p.M;
       uint4 v = val[it];
-      if (EPI == EPI_GATE_RES) {
+      if (EPI == EPI_GATE_RES && !MF) {   // (MF: the image already holds x_new; launch_gemm2 takes no aux there)
         if (p.aux != nullptr && ok) *reinterpret_cast<uint4*>(p.aux + grow * p.ldaux + gcol) = v;
         if (p.res != nullptr) {
           float a[8], b[8];
@@ -609,13 +664,23 @@ static int launch_gemm2_t(const GemmParams& p, int epi, hipStream_t stream) {
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_BIAS, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
     (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_LN_GELU, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES + G::LN_BYTES);
+    if constexpr (MF)
+      (void)hipFuncSetAttribute((const void*)gemm2_kernel<EPI_GATE_RES_STATS, NWN, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
   }
   switch (epi) {
     case EPI_LN_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_BIAS, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
     case EPI_LN_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_LN_GELU, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES + G::LN_BYTES, stream, p); break;
     case EPI_BIAS: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
     case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm2_kernel<EPI_BIAS_GELU, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_GATE_RES:
+      if (MF && (p.aux || p.add1 || p.add2 || p.stats_out)) return VSYS_ERR_ARG;   // (the 16x16x32 gated epilogue stores x_new only)
+      hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p); break;
+    case EPI_GATE_RES_STATS:
+      if constexpr (MF) {
+        hipLaunchKernelGGL((gemm2_kernel<EPI_GATE_RES_STATS, NWN, 0, MF>), dim3(grid), dim3(G::NT), G::LDS_BYTES, stream, p);
+        break;
+      }
+      return VSYS_ERR_ARG;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -659,6 +724,7 @@ int launch_gemm2_slices(const GemmParams& p, int slices, hipStream_t stream) {
 // wide = 2: the 256 x 192 tile on v_mfma_f32_16x16x32_bf16 (gemm2_kernel MF = 1)
 int launch_gemm2(const GemmParams& p, int epi, int wide, hipStream_t stream) {
   if (wide == 2) return launch_gemm2_t<2, 1>(p, epi, stream);
+  if (wide == 3) return launch_gemm2_t<4, 1>(p, epi, stream);   // the 256 x 384 tile on 16x16x32 (A/B id 34)
   return wide ? launch_gemm2_t<4>(p, epi, stream) : launch_gemm2_t<2>(p, epi, stream);
 }
 

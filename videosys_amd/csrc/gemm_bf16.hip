@@ -968,7 +968,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 28: case 30: case 50: case 103: case 106: break;
+    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -1047,6 +1047,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   // the statistics-emitting epilogue lives in gemm_kernel only (lab / forced variants of other kernel families fall back to it)
   if (epi == EPI_GATE_RES_STATS) {
     if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+    if (g_gemm_variant_a.load(std::memory_order_relaxed) == 24) return launch_gemm2(p, epi, 2, stream);   // (A/B id: the two-workgroup 16x16x32 kernel)
     return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   if (ln) {   // same shape dispatch as the store-only epilogues below
@@ -1075,8 +1076,11 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 106: return launch_gemm_t<6, 128>(p, epi, stream);   // the 128-row geometry on schedule 6 (DMA pieces interleaved with the MFMA pairs)
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
-    case 24: return launch_gemm2(p, epi, 2, stream);  // the same on v_mfma_f32_16x16x32_bf16 (fp32 summation order inside an MFMA differs: not bit-identical)
+    case 24:   // the same on v_mfma_f32_16x16x32_bf16 (same bits); a gated launch with a slab copy falls back to schedule 8
+      if (epi == EPI_GATE_RES && p.aux) return launch_sched8(p, epi, stream);
+      return launch_gemm2(p, epi, 2, stream);
     case 30: return p.N % 384 == 0 ? launch_gemm2(p, epi, 1, stream) : launch_gemm_t<8, 256>(p, epi, stream);  // 256 x 384 tile
+    case 34: return (p.N % 384 == 0 && !(epi == EPI_GATE_RES && p.aux)) ? launch_gemm2(p, epi, 3, stream) : launch_sched8(p, epi, stream);  // ... on 16x16x32
     case 8: return launch_gemm_t<8, 256>(p, epi, stream);  // force schedule 8 (32x32x16) for every shape
     case 16: return launch_gemm_t<8, 256, 1, 0, 1>(p, epi, stream);  // schedule 8 on v_mfma_f32_16x16x32_bf16 for every shape
     case 28: return launch_gemm_t<8, 256, 1, 1>(p, epi, stream);  // schedule 8 + four producer waves (store-only epilogues)
