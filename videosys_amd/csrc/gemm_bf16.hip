@@ -77,7 +77,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, hi = lane >> 5;
   const int l15 = lane & 15, lq = lane >> 4;   // MF: fragment row / 16-byte k-chunk; accumulator token / column quad
-  static_assert(!MF || (PIPE == 8 && BM_ == 256 && !PROD), "the 16x16x32 form exists for schedule 8 on the 256-row geometry");
+  static_assert(!MF || ((PIPE == 8 && BM_ == 256 && !PROD) || (PIPE == 3 && BM_ == 128)), "the 16x16x32 form exists for schedule 8 on the 256-row geometry and schedule 3 on the 128-row one");
 
   const int nbn = p.N / BN;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -182,8 +182,22 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   }
 
   auto compute = [&](int cur) {
-    if constexpr (!MF) {
     const char* sb_ = smem + cur * STAGE_BYTES;
+    if constexpr (MF) {   // (schedule 3 on the 128-row geometry: two k-steps of 32, 4 x 6 blocks of 16 x 16 each)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xf[4], wf[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb_ + (xo16[i] ^ (ks << 6)));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb_ + (wo16[j] ^ (ks << 6)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc16[i][j], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       bf16x8 xf[2], wf[3];
@@ -591,6 +605,10 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   if constexpr (MF) {
     // ---- 16x16x32 accumulators: token 16 i + l15 of the wave's 64 rows, columns 16 j + 4 lq .. + 3
     if constexpr (LN) {
+      if constexpr (BM_ != 256) {   // (128-row tiles stage the LayerNorm image after the K loop: no room beside the staging slots)
+        ln_stage_tile(ln_lds, p.ln_stats, p.ln_ld, p.ln_nb, p.ln_eps, p.M, row0, BM_, p.cs, p.cv, col0, BN, tid, G::NT);
+        __syncthreads();
+      }
       float mu[4], rs[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -968,7 +986,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: break;
+    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: case 113: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -1017,6 +1035,10 @@ static bool mf16_default() {
   return on;
 }
 
+// the 128-row geometry (few tiles): 16x16x32 by default as well
+static int launch_rows128(const GemmParams& p, int epi, hipStream_t stream) {
+  return mf16_default() ? launch_gemm_t<3, 128, 1, 0, 1>(p, epi, stream) : launch_gemm_t<3, 128>(p, epi, stream);
+}
 // schedule 8 on the 256-row geometry: the 16x16x32 form by default (same bits), VSYS_GEMM_MF16=0 / variant 8 the 32x32x16 form
 static int launch_sched8(const GemmParams& p, int epi, hipStream_t stream) {
   return mf16_default() ? launch_gemm_t<8, 256, 1, 0, 1>(p, epi, stream) : launch_gemm_t<8, 256>(p, epi, stream);
@@ -1041,17 +1063,17 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   if (epi != EPI_GATE_RES && (p.add1 || p.add2)) return VSYS_ERR_ARG;
   if (epi == EPI_GATE_RES && (p.add1 || p.add2 || p.stats_out)) {   // folded broadcasts / statistics beside a slab copy: gemm_kernel only
     if ((p.add2 && !p.add1) || ((p.add1 || p.add2) && (!p.res || (p.ldr % 8))) || (p.stats_out && p.stats_ld < p.M)) return VSYS_ERR_ARG;
-    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
     return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   // the statistics-emitting epilogue lives in gemm_kernel only (lab / forced variants of other kernel families fall back to it)
   if (epi == EPI_GATE_RES_STATS) {
-    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
     if (g_gemm_variant_a.load(std::memory_order_relaxed) == 24) return launch_gemm2(p, epi, 2, stream);   // (A/B id: the two-workgroup 16x16x32 kernel)
     return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   if (ln) {   // same shape dispatch as the store-only epilogues below
-    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
     if (p.K <= 1536 && p.N >= 2304 && g_gemm_variant_a.load(std::memory_order_relaxed) != 8) return launch_gemm2(p, epi, mf16_default() ? 2 : 0, stream);
     return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
@@ -1074,6 +1096,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
       return gemm4_supports(p, epi) ? launch_gemm4(p, epi, 2 + g_gemm_variant - 80, stream) : VSYS_ERR_ARG;
 #endif
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
+    case 113: return launch_gemm_t<3, 128, 1, 0, 1>(p, epi, stream);   // ... on v_mfma_f32_16x16x32_bf16
     case 106: return launch_gemm_t<6, 128>(p, epi, stream);   // the 128-row geometry on schedule 6 (DMA pieces interleaved with the MFMA pairs)
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
     case 24:   // the same on v_mfma_f32_16x16x32_bf16 (same bits); a gated launch with a slab copy falls back to schedule 8
@@ -1093,7 +1116,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
       // Few tiles (one rank of an 8-way DSP run has M = 4864: 114 tiles of 256 rows for the N = 1152 GEMMs on 256 CUs): the
       // 128-row geometry (two 4-wave workgroups per CU, 512 slots) fills the chip; measured at M = 4864 against schedule 8:
       // qkv -7 %, proj -15 %, fc2 -16 %, fc1 -2 % (tools/kernel_bench.py --rows 4864 --variants 8,20,103).
-      if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_gemm_t<3, 128>(p, epi, stream);
+      if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
       // Round 6: the two-workgroup kernel on v_mfma_f32_16x16x32_bf16 (launch_gemm2 wide = 2; same bits, the matrix pipe ~12 % cheaper per
       // flop under the power cap): qkv 0.297 -> 0.276 ms, fc1 0.425 -> 0.404, and it now also beats schedule 8 on the N = K = 1152
       // store-only shape (cross-attention q: 0.111 -> 0.095 ms) — profiles/r06_kernel_bench_mf16.txt.  VSYS_GEMM_MF16=0: the 32x32x16 kernels.
