@@ -312,8 +312,9 @@ int vsys_copy_4d_batch(const void* src, void* dst, int64_t nops, const int64_t* 
  * nops x 17 int64 — the 14 of vsys_copy_4d_batch (dst_off relative to the problem's own destination), then the destination base
  * address (this process's mapping of the peer's tensor: vsys_p2p_ipc_open, or a plain device pointer inside one process), the
  * address of flag[self_index] in that peer's flag array (0 for the rank's own problem) and 1 when ANOTHER process or device reads
- * that destination (its rows then leave as system-scope write-through stores; 0: a reader ordered by launches on this device).  After its stores are fenced a problem
- * release-stores the exchange's sequence number into the peer's flag; the launch ends when every flag q != self_index of
+ * that destination (its rows then leave as system-scope write-through stores; 0: a reader ordered by launches on this device).  After the write-through stores of EVERY problem of the
+ * launch have been acknowledged (drained per wave, counted per workgroup) the launch's last workgroup stores the exchange's sequence number into each
+ * peer's flag (a relaxed system-scope store: the ordering comes from the drained write-through payload, there is no release fence); the launch ends when every flag q != self_index of
  * ``my_flags`` (n_flags x uint32, fine-grained memory: vsys_p2p_alloc) has reached that number, i.e. when this rank's own destination
  * is complete: the consumer is simply the next launch on ``stream``.  ``state``: 19 x 32 uint32 (one 128-byte line per word) of zeroed
  * device memory private to this exchange site — word 0 the sequence number (advanced by the kernel itself, so a recorded launch

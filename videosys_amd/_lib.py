@@ -104,8 +104,14 @@ def load() -> ctypes.CDLL:
             "videosys_amd has no CPU/PyTorch fallback for its kernels."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+    if missing:
+        # (a shipped library from before the current sources — e.g. on a box without hipcc, where build() cannot rebuild it: never run
+        #  old kernels against new host code)
+        raise RuntimeError(f"{LIB_PATH} is stale: it does not export {missing[:6]}{'...' if len(missing) > 6 else ''} that this version of "
+                           "videosys_amd binds; rebuild it on a box with the ROCm compiler (python -c 'import __graft_entry__ as g; g.build()')")
     for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = _int
     if hasattr(lib, "vsys_lab_flash_debug_buffer"):   # -DVSYS_LAB build (include/videosys_amd_lab.h)

@@ -417,7 +417,20 @@ class PeerExchange:
 
     def _site(self, key, out):
         st = self.sites.get(key)
-        if st is None or st["out"].data_ptr() != out.data_ptr():
+        if st is not None and st["out"].data_ptr() != out.data_ptr():
+            # Creating a site is COLLECTIVE (tensor descriptors and flag handles are all-gathered): a rank that re-created one on its own
+            # because ITS destination buffer moved would sit in that all-gather alone.  The callers hand over resident workspaces keyed
+            # by shape, so this only happens when a workspace grew on this rank — which must then have grown on every rank in the same
+            # call, or not at all: say so instead of hanging (or set VSYS_P2P_RESHARE=1 when every rank is known to re-create together).
+            import os
+
+            if os.environ.get("VSYS_P2P_RESHARE") != "1" and not bool(getattr(self.peers, "same_process", False)):
+                raise RuntimeError(f"peer-to-peer exchange site {key}: the destination tensor of rank {self.rank} moved "
+                                   f"({st['out'].data_ptr():#x} -> {out.data_ptr():#x}); a site is shared collectively and cannot be "
+                                   "re-created by one rank (keep the destination resident, or VSYS_DSP_P2P=0)")
+            self._release(st)                                        # (no leak: the old flag array and mappings go back first)
+            st = None
+        if st is None:
             outs = _share_tensor(self.peers, out)                    # collective: every rank creates its sites in the same order
             my_flags, flag_ptrs = _share_flags(self.peers, self.P)
             st = dict(out=out, outs=outs, my_flags=my_flags, flag_ptrs=flag_ptrs,
@@ -461,21 +474,24 @@ class PeerExchange:
     def close(self):
         """Give the flag arrays back (this rank's allocation; the mappings of the peers' arrays when they came through HIP IPC).  The
         ranks must have finished their last exchange (a collective barrier, or the end of the run) before anybody closes."""
+        for st in self.sites.values():
+            self._release(st)
+        self.sites.clear()
+
+    def _release(self, st):
         import ctypes
 
         from . import _lib
 
         lib = _lib.load()
-        ipc = isinstance(self.peers, IpcPeers)
-        for st in self.sites.values():
-            if ipc:
-                for q, ptr in enumerate(st["flag_ptrs"]):
-                    if q != self.rank and ptr:
-                        lib.vsys_p2p_ipc_close(ctypes.c_void_p(ptr))
-            if st.get("my_flags"):
-                lib.vsys_p2p_free(ctypes.c_void_p(st["my_flags"]))
-            st["my_flags"] = 0
-        self.sites.clear()
+        if isinstance(self.peers, IpcPeers):
+            for q, ptr in enumerate(st["flag_ptrs"]):
+                if q != self.rank and ptr:
+                    lib.vsys_p2p_ipc_close(ctypes.c_void_p(ptr))
+        if st.get("my_flags"):
+            lib.vsys_p2p_free(ctypes.c_void_p(st["my_flags"]))
+        st["my_flags"] = 0
+        st["flag_ptrs"] = []
 
     def check(self):
         """Raise if any exchange timed out waiting for a peer (state[31] of a site; synchronises the device)."""
@@ -505,6 +521,16 @@ def _make_peer_exchange(group, P, rank, copy_executor):
     if any(v != want for v in every):
         raise RuntimeError(f"VSYS_DSP_P2P differs between the ranks of the sequence-parallel group: {every} (rank order); set it identically")
     return PeerExchange(IpcPeers(group), P, rank) if want else None
+
+
+def check_exchange(model) -> None:
+    """Raise if a peer-to-peer exchange of ``model``'s sequence-parallel object timed out (PeerExchange.check).  A timed-out site keeps
+    going with an incomplete destination tensor and only sets a sticky error word, so the PRODUCT path asks once per generate(), after
+    the last denoise step and before the decode (one device synchronisation per site; nothing when the RCCL path is in use)."""
+    sp = getattr(model, "_sp", None)
+    p2p = getattr(sp, "p2p", None) if sp is not None else None
+    if p2p is not None:
+        p2p.check()
 
 
 class SequenceParallel:

@@ -19,6 +19,7 @@ import torch
 
 from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, progress_wrap, randn_tensor as _randn, read_component
 from . import ops, pab
+from . import dsp as _dsp
 from .cogvideox import CogVideoXTransformer3DModel, synth_state_dict
 from .pab import PABConfig
 from .pipeline import VideoSysPipeline, VideoSysPipelineOutput, build_text_encoder, is_foreign_module, module_state
@@ -424,6 +425,11 @@ class CogVideoXPipeline(VideoSysPipeline):
         rope = self._prepare_rotary_positional_embeddings(height, width, z.shape[1]) if c.use_rotary_positional_embeddings else None
         zf = z.view(B, 1, -1)  # the step kernel sees [Bz, Cin = 1, thw]: CogVideoX predicts all 16 channels (no sigma half)
         dpm = isinstance(self.scheduler, CogVideoXDPMScheduler)      # (:679-680) DPM-solver++: the previous step's x0 prediction
+        # INTENTIONAL DEVIATION (precision, not semantics): the latents stay fp32 between steps and every scheduler product is rounded
+        # once per step.  The reference hands its scheduler bf16 latents (latents.to(prompt_embeds.dtype)), so mult[0] * sample,
+        # sqrt(alpha) * sample and mult_noise * noise are each rounded to bf16 there (a 0-dim float64 tensor times a bf16 tensor is
+        # bf16): this path is MORE precise than the reference's own trajectory and not bit-equal to it; the golden
+        # (oracle/make_golden_dpm.py) drives the reference scheduler with fp32 samples for the same reason.
         x0_old, t_back = None, None
         ndt = getattr(self.transformer, "dtype", torch.bfloat16)    # the noise is drawn in the latents' dtype (randn_tensor(sample.dtype), :437)
         # (:678,737) the reference runs diffusers' progress bar on every call; ``verbose=False`` (an extension) turns it off
@@ -466,6 +472,7 @@ class CogVideoXPipeline(VideoSysPipeline):
                     emb = back["prompt_embeds"]
                     self.transformer.reset_text_cache()
                 negative_prompt_embeds = back.get("negative_prompt_embeds", negative_prompt_embeds)
+        _dsp.check_exchange(self.transformer)   # a timed-out peer-to-peer exchange left stale rows: raise here, not a corrupt video
         if self.vae_decoder is None or output_type in ("latent", "latents"):
             self._enter_stage(None)
             return VideoSysPipelineOutput(video=z) if return_dict else (z,)

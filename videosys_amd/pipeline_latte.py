@@ -17,6 +17,7 @@ import torch
 
 from .utils import check_prompt_args as _check_prompt_args, ctor_kwargs, progress_wrap, randn_tensor as _randn, read_component
 from . import ops, pab
+from . import dsp as _dsp
 from .latte import LatteT2V, synth_state_dict
 from .pab import PABConfig
 from .pipeline import VideoSysPipeline, VideoSysPipelineOutput, build_text_encoder, is_foreign_module, module_state
@@ -352,6 +353,7 @@ class LattePipeline(VideoSysPipeline):
             ops.cfg_linear_step(z, out, guidance_scale if cfg else 1.0, c_z, c_eps, cond_first=False)
             if callback is not None and step_i % callback_steps == 0:   # (:880-885)
                 callback(step_i, t, z)
+        _dsp.check_exchange(self.transformer)   # a timed-out peer-to-peer exchange left stale rows: raise here, not a corrupt video
         if self.vae_decoder is None or output_type in ("latent", "latents"):
             self._enter_stage(None)
             return VideoSysPipelineOutput(video=z) if return_dict else (z,)

@@ -18,7 +18,7 @@ from typing import Callable, Optional
 
 import torch
 
-from . import pab
+from . import dsp, pab
 from .pab import PABConfig
 from .rflow import RFLOW
 from .stdit3 import STDiT3, STDiT3Config
@@ -370,6 +370,7 @@ class OpenSoraPipeline(VideoSysPipeline):
                     masks = None      # nothing pasted for this loop: the plain sampler (an all-one mask changes no value)
             samples = self.scheduler.sample(self.transformer, z, margs, self.null(B), device=self._device, progress=verbose,
                                             mask=masks)
+            dsp.check_exchange(self.transformer)   # a timed-out peer-to-peer exchange left stale rows: raise here, not a corrupt video
             if vae is None or output_type == "latent":
                 break
             self._enter_stage("vae")
