@@ -454,44 +454,71 @@ int vsys_softmax_rows(const void* s_f32, void* p, int64_t rows, int64_t n, int64
  * vsys_program_run.  Commands run in order; the first failing command stops the run, its index goes to *failed_at and its error
  * code is returned (nothing after it is enqueued).  No allocation, no synchronisation.  Host-side actions between launches
  * (collectives, event record / wait across streams) stay with the caller, which replays the program in segments. */
-#define VSYS_OP_GEMM_BF16           1
-#define VSYS_OP_LINEAR_SMALL        2
-#define VSYS_OP_ADALN_MODULATE      3
-#define VSYS_OP_MOD_TABLE           4
-#define VSYS_OP_TIMESTEP_EMBEDDING  5
-#define VSYS_OP_PATCH_EMBED         6
-#define VSYS_OP_FINAL_LAYER         7
-#define VSYS_OP_CFG_EULER_STEP      8
-#define VSYS_OP_ADD_ROWS            9
-#define VSYS_OP_COPY_4D_BATCH      10   /* a[3] = HOST pointer to the descriptor array: must outlive the program */
-#define VSYS_OP_ATTN_PREP_KV       11
-#define VSYS_OP_FLASH_ATTN_D72     12
-#define VSYS_OP_ATTN_TEMPORAL_D72  13
-#define VSYS_OP_ADD_BCAST_ROWS     14
-#define VSYS_OP_GEMM_BF16_GATE2    15
-#define VSYS_OP_LN_MODULATE        16
-#define VSYS_OP_GATE_ADD_ROWS      17
-#define VSYS_OP_ATTN_PREP_KV64     18
-#define VSYS_OP_FLASH_ATTN_D64     19
-#define VSYS_OP_PATCH_EMBED_SHARD   20
-#define VSYS_OP_FINAL_LAYER_TOKENS  21
-#define VSYS_OP_UNPATCHIFY_TOKENS   22
-#define VSYS_OP_GEMM_BF16_LN        23
-#define VSYS_OP_GEMM_BF16_STATS     24
-#define VSYS_OP_ADALN_PRESCALE      25
-#define VSYS_OP_LN_ROW_STATS        26
-#define VSYS_OP_GEMM_BF16_GATE_RES_ADD 27
-#define VSYS_OP_FLASH_ATTN_D72_KB   28
-#define VSYS_OP_FLASH_ATTN_D64_KB   29
-#define VSYS_OP_FLASH_ATTN_D72_EXACT 30
-#define VSYS_OP_P2P_EXCHANGE       31
-#define VSYS_OP_COUNT              32
+/* >>> VSYS_OP codes (generated: csrc/gen/program_gen.py) */
+#define VSYS_OP_GEMM_BF16                    1
+#define VSYS_OP_LINEAR_SMALL                 2
+#define VSYS_OP_ADALN_MODULATE               3
+#define VSYS_OP_MOD_TABLE                    4
+#define VSYS_OP_TIMESTEP_EMBEDDING           5
+#define VSYS_OP_PATCH_EMBED                  6
+#define VSYS_OP_FINAL_LAYER                  7
+#define VSYS_OP_CFG_EULER_STEP               8
+#define VSYS_OP_ADD_ROWS                     9
+#define VSYS_OP_COPY_4D_BATCH                10
+#define VSYS_OP_ATTN_PREP_KV                 11
+#define VSYS_OP_FLASH_ATTN_D72               12
+#define VSYS_OP_ATTN_TEMPORAL_D72            13
+#define VSYS_OP_ADD_BCAST_ROWS               14
+#define VSYS_OP_GEMM_BF16_GATE2              15
+#define VSYS_OP_LN_MODULATE                  16
+#define VSYS_OP_GATE_ADD_ROWS                17
+#define VSYS_OP_ATTN_PREP_KV64               18
+#define VSYS_OP_FLASH_ATTN_D64               19
+#define VSYS_OP_PATCH_EMBED_SHARD            20
+#define VSYS_OP_FINAL_LAYER_TOKENS           21
+#define VSYS_OP_UNPATCHIFY_TOKENS            22
+#define VSYS_OP_GEMM_BF16_LN                 23
+#define VSYS_OP_GEMM_BF16_STATS              24
+#define VSYS_OP_ADALN_PRESCALE               25
+#define VSYS_OP_LN_ROW_STATS                 26
+#define VSYS_OP_GEMM_BF16_GATE_RES_ADD       27
+#define VSYS_OP_FLASH_ATTN_D72_KB            28
+#define VSYS_OP_FLASH_ATTN_D64_KB            29
+#define VSYS_OP_FLASH_ATTN_D72_EXACT         30
+#define VSYS_OP_P2P_EXCHANGE                 31
+#define VSYS_OP_CFG_LINEAR_STEP              32
+#define VSYS_OP_COPY_4D                      33
+#define VSYS_OP_IM2COL_PATCH                 34
+#define VSYS_OP_UNPATCHIFY_CVX               35
+#define VSYS_OP_GATHER_ROWS                  36
+#define VSYS_OP_RMS_NORM_ROWS                37
+#define VSYS_OP_GEGLU                        38
+#define VSYS_OP_SPLITK_REDUCE_T              39
+#define VSYS_OP_T5_ATTENTION                 40
+#define VSYS_OP_GEMM_SKINNY_SLICES           41
+#define VSYS_OP_SPLITK_REDUCE                42
+#define VSYS_OP_T5_ATTENTION_MFMA            43
+#define VSYS_OP_CONV_BF16                    44
+#define VSYS_OP_GN_STATS                     45
+#define VSYS_OP_GN_APPLY                     46
+#define VSYS_OP_REGRID                       47
+#define VSYS_OP_SUBSAMPLE                    48
+#define VSYS_OP_SPATIAL_NORM_APPLY           49
+#define VSYS_OP_BLEND_EDGE                   50
+#define VSYS_OP_D2S_TIME                     51
+#define VSYS_OP_VAE_FIRST_IM2COL             52
+#define VSYS_OP_EXTRACT_PLANAR               53
+#define VSYS_OP_SOFTMAX_ROWS                 54
+#define VSYS_OP_COUNT 55
+/* <<< VSYS_OP codes */
 
+#define VSYS_CMD_MAX_INT 24
+#define VSYS_CMD_MAX_FLOAT 4
 typedef struct vsys_cmd {
   int32_t op;      /* VSYS_OP_* */
   int32_t stream;  /* index into the streams[] table of vsys_program_run */
-  int64_t a[20];   /* integer and pointer arguments, declaration order, the trailing stream excluded */
-  float f[2];      /* float arguments, declaration order */
+  int64_t a[VSYS_CMD_MAX_INT];   /* integer and pointer arguments, declaration order, the trailing stream excluded */
+  float f[VSYS_CMD_MAX_FLOAT];      /* float arguments, declaration order */
 } vsys_cmd;
 
 /* arity of an op (what the recorder must fill): 0, or VSYS_ERR_ARG for an unknown op.  (vsys_program_*: no reference counterpart —

@@ -705,16 +705,33 @@ print("ok", ran, len(calls))
 
 
 def test_torch_custom_ops_are_registered():
-    """``torch.ops.videosys_amd.*`` (north_star: "through PyTorch-ROCm custom ops"): every op of videosys_amd/torch_ops.py is
-    registered with an out-variant schema that names the tensors it mutates; on CPU tensors it raises (no fallback)."""
-    import videosys_amd.torch_ops as T
+    """``torch.ops.vsys.*`` (north_star: "through PyTorch-ROCm custom ops"; csrc/torch_binding.cpp, a C++ TORCH_LIBRARY fragment built
+    by build()): the fragment loads, both ops carry their schemas, a CPU tensor / a wrong arity / an unknown op code raise from C++
+    (no fallback, no launch), the product's ``ops._call`` routes through it and maps the error to VsysError, and the generated
+    dispatch table is fresh against include/videosys_amd.h."""
+    from videosys_amd import _lib, ops
     from videosys_amd._lib import VsysError
 
-    for name in T.OPS:
-        schema = str(getattr(torch.ops.videosys_amd, name).default._schema)
-        assert schema.startswith(f"videosys_amd::{name}(") and "!)" in schema and schema.endswith("-> ()"), schema
+    tv = _lib.torch_ops()
+    assert tv is not None, "libvideosys_torch.so was not built / loaded (python -c 'import __graft_entry__ as g; g.build()')"
+    assert str(tv.launch.default._schema) == "vsys::launch(int op, Tensor?[] tensors, int[] ints, float[] floats, int stream) -> ()"
+    assert str(tv.program_run.default._schema) == "vsys::program_run(Tensor cmds, int n, int[] streams) -> ()"
+    x = torch.zeros(2, 8, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="HIP device tensors"):
+        tv.launch(9, [x, x, None], [0, 0, 16], [], 0)               # vsys_add_rows on CPU tensors
+    with pytest.raises(RuntimeError, match="takes 3 integer and 0 float"):
+        tv.launch(9, [None], [0], [], 0)
+    with pytest.raises(RuntimeError, match="unknown op code"):
+        tv.launch(9999, [], [], [], 0)
+    with pytest.raises(RuntimeError, match="do not fit"):
+        tv.program_run(torch.zeros(8, dtype=torch.uint8), 1, [0])
     with pytest.raises(VsysError):
-        torch.ops.videosys_amd.add_rows(torch.zeros(2, 8, dtype=torch.bfloat16), torch.zeros(2, 8, dtype=torch.bfloat16))
+        ops.add_rows(x, x)                                           # the wrapper's own device check, same error type
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "videosys_amd", "csrc", "gen", "program_gen.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, "csrc/program_ops.inc / the VSYS_OP block / _opcodes.py are stale: run csrc/gen/program_gen.py\n" + r.stdout
 
 
 def test_launch_program_op_table_matches_header_and_signatures():

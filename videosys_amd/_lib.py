@@ -129,6 +129,32 @@ class VsysError(RuntimeError):
     pass
 
 
+# ---- PyTorch custom-op route (csrc/torch_binding.cpp -> libvideosys_torch.so): torch.ops.vsys.launch / torch.ops.vsys.program_run.
+# The product path: ops._call and program.Program.run go through the dispatcher whenever the fragment is there (build() compiles
+# it); VSYS_TORCH_OPS=0 or a tree without the fragment binds the same extern "C" functions through ctypes instead.
+TORCH_LIB_PATH = os.path.join(_HERE, "libvideosys_torch.so")
+_torch_ops = False   # False = not looked for yet, None = not available
+
+
+def torch_ops():
+    """``torch.ops.vsys`` with the fragment loaded, or None (ctypes route)."""
+    global _torch_ops
+    if _torch_ops is False:
+        _torch_ops = None
+        if os.environ.get("VSYS_TORCH_OPS", "1") != "0" and os.path.exists(TORCH_LIB_PATH) and not os.environ.get("VSYS_LIB"):
+            import torch
+
+            load()                                   # libvideosys_amd.so first: the fragment links against it
+            try:
+                torch.ops.load_library(TORCH_LIB_PATH)
+                _torch_ops = torch.ops.vsys
+            except OSError as e:                     # (a fragment built against another torch: say so once, use ctypes)
+                import warnings
+
+                warnings.warn(f"{TORCH_LIB_PATH} could not be loaded ({e}); the C ABI is bound through ctypes instead")
+    return _torch_ops
+
+
 def check(code: int, what: str):
     if code != 0:
         msg = load().vsys_strerror(code).decode()

@@ -17,12 +17,19 @@ HEAD_DIM = 72
 VT_ROWS = 96
 
 
+class _TPtr(int):
+    """A device address that remembers its tensor: ctypes and the launch-program recorder see the integer, the custom-op route
+    (torch.ops.vsys.launch) hands the TENSOR to the dispatcher."""
+
+
 def _p(t: Optional[torch.Tensor]):
     if t is None:
         return None
     if program.active() is not None:
         program.keep(t)          # a recorded launch holds this address: the program keeps the tensor alive
-    return t.data_ptr()
+    a = _TPtr(t.data_ptr())
+    a.t = t
+    return a
 
 
 def _stream():
@@ -31,13 +38,36 @@ def _stream():
 
 def _call(name: str, *args):
     """One C-ABI launch on torch's current stream (``args`` = the entry point's arguments without the trailing stream); under a
-    launch-program recorder (program.py) the launch is also logged for replay."""
-    lib = _lib.load()
+    launch-program recorder (program.py) the launch is also logged for replay.  Route: ``torch.ops.vsys.launch`` (the TORCH_LIBRARY
+    fragment of csrc/torch_binding.cpp: tensors travel as tensors) for every entry point that has a VSYS_OP code — the whole denoise
+    step — and ctypes for the rest (VAE, T5) or when the fragment is not there."""
+    import ctypes
+
     s = torch.cuda.current_stream()
     rec = program.active()
+    sig = _lib.SIGNATURES[name][:-1]
     if rec is not None:
-        rec.launch(name, args, _lib.SIGNATURES[name][:-1], s)
-    _lib.check(getattr(lib, name)(*args, s.cuda_stream), name)
+        rec.launch(name, args, sig, s)
+    tv = _lib.torch_ops()
+    op = program.OPCODES.get(name) if tv is not None else None
+    if op is None:
+        _lib.check(getattr(_lib.load(), name)(*args, s.cuda_stream), name)
+        return
+    tensors, ints, floats = [], [], []
+    for v, t in zip(args, sig):
+        if t is _lib._f32:
+            floats.append(float(v))
+            continue
+        if isinstance(v, _TPtr):
+            tensors.append(v.t)
+            ints.append(0)
+        else:
+            tensors.append(None)
+            ints.append(ctypes.addressof(v) if isinstance(v, ctypes.Array) else (0 if v is None else int(v)))
+    try:
+        tv.launch(op, tensors, ints, floats, s.cuda_stream)
+    except RuntimeError as e:
+        raise _lib.VsysError(f"{name}: {str(e).splitlines()[0]}") from None
 
 
 def _chk(*ts):
@@ -286,8 +316,8 @@ def cfg_linear_step(z_f32, model_out_f32, guidance, c_z, c_eps, cond_first=False
     assert model_out_f32.shape[0] == 2 * Bz
     thw = z_f32[0, 0].numel()
     lib = _lib.load()
-    _lib.check(lib.vsys_cfg_linear_step(_p(z_f32), _p(model_out_f32), Bz, Cin, Cout, thw, float(guidance), float(c_z),
-                                        float(c_eps), 1 if cond_first else 0, _stream()), "vsys_cfg_linear_step")
+    _call("vsys_cfg_linear_step", _p(z_f32), _p(model_out_f32), Bz, Cin, Cout, thw, float(guidance), float(c_z),
+                                        float(c_eps), 1 if cond_first else 0)
     return z_f32
 
 
@@ -315,9 +345,8 @@ def copy_4d(src, dst, n0, n1, n2, C, sstr, dstr, n1_valid=None, n2_valid=None):
     _chk(src, dst)
     _bf16(src, dst)
     lib = _lib.load()
-    _lib.check(lib.vsys_copy_4d(_p(src), _p(dst), n0, n1, n2, C, sstr[0], sstr[1], sstr[2], dstr[0], dstr[1], dstr[2],
-                                n1 if n1_valid is None else n1_valid, n2 if n2_valid is None else n2_valid, _stream()),
-               "vsys_copy_4d")
+    _call("vsys_copy_4d", _p(src), _p(dst), n0, n1, n2, C, sstr[0], sstr[1], sstr[2], dstr[0], dstr[1], dstr[2],
+                                n1 if n1_valid is None else n1_valid, n2 if n2_valid is None else n2_valid)
     return dst
 
 
@@ -451,7 +480,7 @@ def im2col_patch(z_f32, B, p):
     Bz, F, Cin, H, W = z_f32.shape
     out = torch.empty(B * F * (H // p) * (W // p), Cin * p * p, dtype=torch.bfloat16, device=z_f32.device)
     lib = _lib.load()
-    _lib.check(lib.vsys_im2col_patch(_p(z_f32), Bz, _p(out), B, F, Cin, H, W, p, _stream()), "vsys_im2col_patch")
+    _call("vsys_im2col_patch", _p(z_f32), Bz, _p(out), B, F, Cin, H, W, p)
     return out
 
 
@@ -461,7 +490,7 @@ def unpatchify_cvx(x, B, F, Hp, Wp, Cout, p):
     assert x.stride(1) == 1
     out = torch.empty(B, F, Cout, Hp * p, Wp * p, dtype=torch.float32, device=x.device)
     lib = _lib.load()
-    _lib.check(lib.vsys_unpatchify_cvx(_p(x), x.stride(0), _p(out), B, F, Hp, Wp, Cout, p, _stream()), "vsys_unpatchify_cvx")
+    _call("vsys_unpatchify_cvx", _p(x), x.stride(0), _p(out), B, F, Hp, Wp, Cout, p)
     return out
 
 
@@ -565,9 +594,8 @@ def conv(a, grid: VaeGrid, w, bias, cin, kt, ks, out=None, res=None):
     shift_rows = (grid.Wp + 1) if ks == 3 else 0
     a_ptr = a.data_ptr() - shift_rows * a.stride(0) * 2
     lib = _lib.load()
-    _lib.check(lib.vsys_conv_bf16(a_ptr, a.stride(0), _p(w), w.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
-                                  _p(out), None, out.stride(0), M, N, cin, kt, ks, ks, grid.Wp, grid.plane, 1, 0, 0, 0, 1.0,
-                                  _stream()), "vsys_conv_bf16")
+    _call("vsys_conv_bf16", a_ptr, a.stride(0), _p(w), w.stride(0), _p(bias), _p(res), res.stride(0) if res is not None else 0,
+                                  _p(out), None, out.stride(0), M, N, cin, kt, ks, ks, grid.Wp, grid.plane, 1, 0, 0, 0, 1.0)
     return out
 
 
@@ -583,9 +611,9 @@ def gemm128(a, w, bias=None, res=None, out=None, out_f32=None, out_scale=1.0, ba
         out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
     o = out if out is not None else out_f32
     lib = _lib.load()
-    _lib.check(lib.vsys_conv_bf16(_p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(res), res.stride(-2) if res is not None else 0,
+    _call("vsys_conv_bf16", _p(a), a.stride(-2), _p(w), w.stride(-2), _p(bias), _p(res), res.stride(-2) if res is not None else 0,
                                   _p(out), _p(out_f32), o.stride(-2), M, N, K, 1, 1, 1, 0, 0, batch, batch_a, batch_w, batch_o,
-                                  float(out_scale), _stream()), "vsys_conv_bf16")
+                                  float(out_scale))
     return o
 
 
@@ -601,9 +629,9 @@ def group_norm(x, gs: VaeGrid, y, gd: VaeGrid, C, gamma, beta, eps, silu_act, gr
     lib = _lib.load()
     partial = torch.empty(gs.n * _GN_NBLK * (C // 4) * 2, dtype=torch.float32, device=x.device)
     stats = torch.empty(gs.n * groups * 2, dtype=torch.float32, device=x.device)
-    _lib.check(lib.vsys_gn_stats(_p(x), gs._c, gs.n, C, groups, float(eps), _p(partial), _GN_NBLK, _p(stats), _stream()), "vsys_gn_stats")
-    _lib.check(lib.vsys_gn_apply(_p(x), gs._c, _p(y), gd._c, gs.n, C, groups, _p(stats), _p(gamma), _p(beta),
-                                 ACT_SILU if silu_act else ACT_NONE, _stream()), "vsys_gn_apply")
+    _call("vsys_gn_stats", _p(x), gs._c, gs.n, C, groups, float(eps), _p(partial), _GN_NBLK, _p(stats))
+    _call("vsys_gn_apply", _p(x), gs._c, _p(y), gd._c, gs.n, C, groups, _p(stats), _p(gamma), _p(beta),
+                                 ACT_SILU if silu_act else ACT_NONE)
     return y
 
 
@@ -611,7 +639,7 @@ def regrid(x, gs: VaeGrid, y, gd: VaeGrid, C, up=0, tmode=0):
     _chk(x, y)
     _bf16(x, y)
     assert x.shape[0] == gs.rows and y.shape[0] == gd.rows and x.is_contiguous() and y.is_contiguous()
-    _lib.check(_lib.load().vsys_regrid(_p(x), gs._c, _p(y), gd._c, gs.n, C, up, tmode, _stream()), "vsys_regrid")
+    _call("vsys_regrid", _p(x), gs._c, _p(y), gd._c, gs.n, C, up, tmode)
     return y
 
 
@@ -620,8 +648,7 @@ def subsample(x, gs: VaeGrid, y, gd: VaeGrid, C, t_stride=1, s_stride=1, t_first
     _chk(x, y)
     _bf16(x, y)
     assert x.shape[0] == gs.rows and y.shape[0] == gd.rows and x.is_contiguous() and y.is_contiguous()
-    _lib.check(_lib.load().vsys_subsample(_p(x), gs._c, _p(y), gd._c, gs.n, C, t_stride, s_stride, t_first, s_first, _stream()),
-               "vsys_subsample")
+    _call("vsys_subsample", _p(x), gs._c, _p(y), gd._c, gs.n, C, t_stride, s_stride, t_first, s_first)
     return y
 
 
@@ -635,9 +662,8 @@ def spatial_norm_silu(x, gs: VaeGrid, y, gd: VaeGrid, C, gamma, beta, yb, zdims,
     lib = _lib.load()
     partial = torch.empty(gs.n * _GN_NBLK * (C // 4) * 2, dtype=torch.float32, device=x.device)
     stats = torch.empty(gs.n * groups * 2, dtype=torch.float32, device=x.device)
-    _lib.check(lib.vsys_gn_stats(_p(x), gs._c, gs.n, C, groups, float(eps), _p(partial), _GN_NBLK, _p(stats), _stream()), "vsys_gn_stats")
-    _lib.check(lib.vsys_spatial_norm_apply(_p(x), gs._c, _p(y), gd._c, gs.n, C, groups, _p(stats), _p(gamma), _p(beta), _p(yb), zT, zH, zW,
-                                           _stream()), "vsys_spatial_norm_apply")
+    _call("vsys_gn_stats", _p(x), gs._c, gs.n, C, groups, float(eps), _p(partial), _GN_NBLK, _p(stats))
+    _call("vsys_spatial_norm_apply", _p(x), gs._c, _p(y), gd._c, gs.n, C, groups, _p(stats), _p(gamma), _p(beta), _p(yb), zT, zH, zW)
     return y
 
 
@@ -647,8 +673,7 @@ def blend_edge(a, b, ext, axis):
     _bf16(a, b)
     assert a.is_contiguous() and b.is_contiguous() and a.shape[:-2] == b.shape[:-2]
     outer = a.numel() // (a.shape[-2] * a.shape[-1])
-    _lib.check(_lib.load().vsys_blend_edge(_p(a), _p(b), outer, a.shape[-2], a.shape[-1], b.shape[-2], b.shape[-1], ext, axis, _stream()),
-               "vsys_blend_edge")
+    _call("vsys_blend_edge", _p(a), _p(b), outer, a.shape[-2], a.shape[-1], b.shape[-2], b.shape[-1], ext, axis)
     return b
 
 
@@ -656,7 +681,7 @@ def d2s_time(x, gs: VaeGrid, y, gd: VaeGrid, Cout):
     _chk(x, y)
     _bf16(x, y)
     assert x.shape == (gs.rows, 2 * Cout) and y.shape == (gd.rows, Cout) and x.is_contiguous() and y.is_contiguous()
-    _lib.check(_lib.load().vsys_d2s_time(_p(x), gs._c, _p(y), gd._c, gs.n, Cout, _stream()), "vsys_d2s_time")
+    _call("vsys_d2s_time", _p(x), gs._c, _p(y), gd._c, gs.n, Cout)
     return y
 
 
@@ -668,7 +693,7 @@ def vae_first_im2col(z, kt, kcols, params):
     _, F, H, W = z.shape
     out = torch.empty(F * H * W, kcols, dtype=torch.bfloat16, device=z.device)
     arr = (_ct.c_float * 28)(*[float(v) for v in params])
-    _lib.check(_lib.load().vsys_vae_first_im2col(_p(z), F, H, W, kt, kcols, arr, _p(out), _stream()), "vsys_vae_first_im2col")
+    _call("vsys_vae_first_im2col", _p(z), F, H, W, kt, kcols, arr, _p(out))
     return out
 
 
@@ -677,8 +702,7 @@ def extract_planar(x, g: VaeGrid, nc, tskip, out, f0):
     _chk(x, out)
     _bf16(x, out)
     assert x.shape[0] == g.rows and out.is_contiguous() and out.shape[0] == nc and tuple(out.shape[2:]) == (g.H, g.W)
-    _lib.check(_lib.load().vsys_extract_planar(_p(x), g._c, g.n, x.stride(0), nc, tskip, _p(out), out.shape[1], f0, _stream()),
-               "vsys_extract_planar")
+    _call("vsys_extract_planar", _p(x), g._c, g.n, x.stride(0), nc, tskip, _p(out), out.shape[1], f0)
     return out
 
 
@@ -691,7 +715,7 @@ def softmax_rows(s_f32, n=None, out=None):
     rows = s_f32.numel() // ld
     if out is None:
         out = torch.empty(s_f32.shape, dtype=torch.bfloat16, device=s_f32.device)
-    _lib.check(_lib.load().vsys_softmax_rows(_p(s_f32), _p(out), rows, n, ld, _stream()), "vsys_softmax_rows")
+    _call("vsys_softmax_rows", _p(s_f32), _p(out), rows, n, ld)
     return out
 
 
@@ -714,8 +738,8 @@ def t5_attention_mfma(qkv, bias_pad, center, lens, B, L, heads, out=None, ws=Non
     lib = _lib.load()
     for b in range(B):
         q_b, o_b = qkv[b * L:(b + 1) * L], out[b * L:(b + 1) * L]
-        _lib.check(lib.vsys_t5_attention_mfma(_p(q_b), qkv.stride(0), inner, _p(bias_pad), bias_pad.shape[1], center, int(lens[b]),
-                                              _p(ws[0]), _p(ws[1]), _p(o_b), out.stride(0), L, heads, _stream()), "vsys_t5_attention_mfma")
+        _call("vsys_t5_attention_mfma", _p(q_b), qkv.stride(0), inner, _p(bias_pad), bias_pad.shape[1], center, int(lens[b]),
+                                              _p(ws[0]), _p(ws[1]), _p(o_b), out.stride(0), L, heads)
     return out
 
 
@@ -768,15 +792,12 @@ def linear_skinny(x, M, w, res=None, out=None, nsplit=None, part=None, wide=None
     lib = _lib.load()
     ldr = res.stride(0) if res is not None else 0
     if wide:
-        _lib.check(lib.vsys_gemm_skinny_slices(_p(w), w.stride(0), _p(x), x.stride(0), _p(part), M, Mp, N, K, nsplit, _stream()),
-                   "vsys_gemm_skinny_slices")
-        _lib.check(lib.vsys_splitk_reduce(_p(part), nsplit, Mp * N, N, _p(res), ldr, _p(out), out.stride(0), M, N, _stream()),
-                   "vsys_splitk_reduce")
+        _call("vsys_gemm_skinny_slices", _p(w), w.stride(0), _p(x), x.stride(0), _p(part), M, Mp, N, K, nsplit)
+        _call("vsys_splitk_reduce", _p(part), nsplit, Mp * N, N, _p(res), ldr, _p(out), out.stride(0), M, N)
         return out
     pv = part[:nsplit * N * Mp].view(nsplit, N, Mp)
     gemm128(w, x, out_f32=pv, batch=nsplit, batch_a=Ks, batch_w=Ks, batch_o=N * Mp, M=N, K=Ks)
-    _lib.check(lib.vsys_splitk_reduce_t(_p(pv), nsplit, N * Mp, Mp, _p(res), ldr, _p(out), out.stride(0), M, N, _stream()),
-               "vsys_splitk_reduce_t")
+    _call("vsys_splitk_reduce_t", _p(pv), nsplit, N * Mp, Mp, _p(res), ldr, _p(out), out.stride(0), M, N)
     return out
 
 
@@ -786,7 +807,7 @@ def gather_rows(table, ids):
     assert ids.dtype == torch.int64 and ids.is_contiguous() and table.is_contiguous()
     n, C = ids.numel(), table.shape[1]
     out = torch.empty(n, C, dtype=torch.bfloat16, device=table.device)
-    _lib.check(_lib.load().vsys_gather_rows(_p(table), _p(ids), _p(out), n, C, table.shape[0], _stream()), "vsys_gather_rows")
+    _call("vsys_gather_rows", _p(table), _p(ids), _p(out), n, C, table.shape[0])
     return out
 
 
@@ -796,7 +817,7 @@ def rms_norm_rows(x, w, eps=1e-6, out=None):
     assert x.is_contiguous() and x.dim() == 2
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(_lib.load().vsys_rms_norm_rows(_p(x), _p(w), _p(out), x.shape[0], x.shape[1], float(eps), _stream()), "vsys_rms_norm_rows")
+    _call("vsys_rms_norm_rows", _p(x), _p(w), _p(out), x.shape[0], x.shape[1], float(eps))
     return out
 
 
@@ -807,7 +828,7 @@ def geglu(h, out=None):
     F = h.shape[1] // 2
     if out is None:
         out = torch.empty(h.shape[0], F, dtype=torch.bfloat16, device=h.device)
-    _lib.check(_lib.load().vsys_geglu(_p(h), _p(out), h.shape[0], F, _stream()), "vsys_geglu")
+    _call("vsys_geglu", _p(h), _p(out), h.shape[0], F)
     return out
 
 
@@ -819,6 +840,5 @@ def t5_attention(qkv, relbias, klen, B, L, heads, out=None):
     assert relbias.shape == (heads, 2 * L - 1) and relbias.is_contiguous() and klen.numel() == B
     if out is None:
         out = torch.empty(B * L, inner, dtype=torch.bfloat16, device=qkv.device)
-    _lib.check(_lib.load().vsys_t5_attention(_p(qkv), qkv.stride(0), inner, _p(relbias), _p(klen), _p(out), out.stride(0), B, L, heads,
-                                             _stream()), "vsys_t5_attention")
+    _call("vsys_t5_attention", _p(qkv), qkv.stride(0), inner, _p(relbias), _p(klen), _p(out), out.stride(0), B, L, heads)
     return out

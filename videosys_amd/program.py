@@ -27,25 +27,15 @@ import torch
 
 from . import _lib
 
+from ._opcodes import OPCODES   # entry point -> VSYS_OP_* (generated from include/videosys_amd.h by csrc/gen/program_gen.py)
+
 _i64, _f32 = ctypes.c_int64, ctypes.c_float
-N_INT, N_FLOAT = 20, 2
+N_INT, N_FLOAT = 24, 4   # VSYS_CMD_MAX_INT / VSYS_CMD_MAX_FLOAT of include/videosys_amd.h
 
 
 class VsysCmd(ctypes.Structure):
     _fields_ = [("op", ctypes.c_int32), ("stream", ctypes.c_int32), ("a", _i64 * N_INT), ("f", _f32 * N_FLOAT)]
 
-
-# entry point -> VSYS_OP_* (include/videosys_amd.h); tests/test_host_cpu.py checks the table against the header and the arities
-OPCODES = {
-    "vsys_gemm_bf16": 1, "vsys_linear_small": 2, "vsys_adaln_modulate": 3, "vsys_mod_table": 4, "vsys_timestep_embedding": 5,
-    "vsys_patch_embed": 6, "vsys_final_layer": 7, "vsys_cfg_euler_step": 8, "vsys_add_rows": 9, "vsys_copy_4d_batch": 10,
-    "vsys_attn_prep_kv": 11, "vsys_flash_attn_d72": 12, "vsys_attn_temporal_d72": 13, "vsys_add_bcast_rows": 14,
-    "vsys_gemm_bf16_gate2": 15, "vsys_ln_modulate": 16, "vsys_gate_add_rows": 17, "vsys_attn_prep_kv64": 18,
-    "vsys_flash_attn_d64": 19, "vsys_patch_embed_shard": 20, "vsys_final_layer_tokens": 21, "vsys_unpatchify_tokens": 22,
-    "vsys_gemm_bf16_ln": 23, "vsys_gemm_bf16_stats": 24, "vsys_adaln_prescale": 25, "vsys_ln_row_stats": 26,
-    "vsys_gemm_bf16_gate_res_add": 27, "vsys_flash_attn_d72_kb": 28,
-    "vsys_flash_attn_d64_kb": 29, "vsys_flash_attn_d72_exact": 30, "vsys_p2p_exchange": 31,
-}
 
 _tls = threading.local()
 
@@ -158,14 +148,26 @@ class Program:
         flush()
         self._streams = (ctypes.c_void_p * len(self.stream_handles))(*self.stream_handles)
         self._failed = ctypes.c_int64(-1)
+        self._cmd_tensors = None
 
     def run(self):
         lib = _lib.load()
+        tv = _lib.torch_ops()
+        main = torch.cuda.current_stream().cuda_stream if self.n_launches else 0   # the main stream = whatever is current NOW
         if self.n_launches:
-            self._streams[0] = torch.cuda.current_stream().cuda_stream   # the main stream = whatever is current NOW
+            self._streams[0] = main
         ns = len(self.stream_handles)
-        for seg in self.segments:
+        if tv is not None and self._cmd_tensors is None:
+            # the dispatcher route (torch.ops.vsys.program_run, csrc/torch_binding.cpp): a CPU uint8 view of every segment's records
+            self._cmd_tensors = [torch.frombuffer(seg[0], dtype=torch.uint8) if isinstance(seg, tuple) else None for seg in self.segments]
+        for k, seg in enumerate(self.segments):
             if isinstance(seg, tuple):
+                if tv is not None:
+                    try:
+                        tv.program_run(self._cmd_tensors[k], seg[1], [main] + self.stream_handles[1:])
+                    except RuntimeError as e:
+                        raise _lib.VsysError(f"vsys_program_run ({seg[1]}-launch segment): {str(e).splitlines()[0]}") from None
+                    continue
                 rc = lib.vsys_program_run(seg[0], seg[1], self._streams, ns, ctypes.byref(self._failed))
                 if rc != 0:
                     _lib.check(rc, f"vsys_program_run (command {self._failed.value} of a {seg[1]}-launch segment)")
