@@ -293,6 +293,7 @@ def main():
 
         def replay(overlap):
             model._overlap = bool(overlap) and model._side is not None
+            model.use_programs = False   # eager: the event brackets around the exchanges (collectives or vsys_p2p_exchange launches) must run
             one_step(0)   # settle buffers of this mode
             vdsp.COMM_TIMER.reset()
             vdsp.COMM_TIMER.enabled = True
@@ -309,9 +310,14 @@ def main():
         was = model._overlap
         if model._side is None:
             model._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
-        t_off, comm_off, ncoll = replay(False)
-        t_on, comm_on, _ = replay(True)
+        was_prog2 = model.use_programs
+        try:
+            t_off, comm_off, ncoll = replay(False)
+            t_on, comm_on, _ = replay(True)
+        finally:
+            model.use_programs = was_prog2
         model._overlap = was
+        vdsp.check_exchange(model)   # a timed-out peer-to-peer exchange must fail the bench, not shape its number
         mine = torch.tensor([comm_off, comm_on, t_off * 1e3, t_on * 1e3], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -325,7 +331,13 @@ def main():
                 "step_ms_overlap_off": round(t_off_ms, 3), "step_ms_overlap_on": round(t_on_ms, 3),
                 "overlap_fraction": round(min(1.0, hidden / max(max(comm_off_all), 1e-9)), 4),
                 "overlap_default": bool(was), "switch_order": model._switch_order(2, T, (Hl // 2) * (Wl // 2)),
-                "note": "event brackets include the wait for the slowest peer; overlap_fraction = (step_off - step_on) / serialized comm",
+                # which exchange the group runs on and why: the one-time guarded trial of the one-kernel peer-to-peer exchange at
+                # enable_parallel (dsp.p2p_selftest: patterned payload, both paths timed on a config-2-sized message, the faster one wins;
+                # any failure -> RCCL on every rank)
+                "exchange_path": model._sp.exchange_info.get("exchange_path"), "p2p_selftest": model._sp.exchange_info.get("selftest"),
+                "p2p_ms_per_exchange": model._sp.exchange_info.get("p2p_ms"), "rccl_ms_per_exchange": model._sp.exchange_info.get("rccl_ms"),
+                "selftest_message_mb_per_peer": model._sp.exchange_info.get("message_mb_per_peer"),
+                "note": "event brackets include the wait for the slowest peer; overlap_fraction = (step_off - step_on) / serialized comm; these replays issue every launch from Python (eager) so that the brackets run",
             }
 
     # ---- CPU baseline (rank 0, N == 1 only): oracle = fp32 port of the reference path at the full token count

@@ -347,6 +347,59 @@ def test_bench_two_ranks_dry_run():
     assert len(d["comm_ms_per_step_per_rank_serialized"]) == 2 and d["collectives_per_step"] >= 2 * 2 + 1   # 2 spatial blocks x 2 exchanges + the final gather
     assert d["overlap_default"] is True and d["switch_order"] == "activations" and 0.0 <= d["overlap_fraction"] <= 1.0
     assert d["step_ms_overlap_off"] > 0 and d["step_ms_overlap_on"] > 0
+    # the guarded trial of the one-kernel peer-to-peer exchange ran at enable_parallel and its verdict + both timings are reported
+    assert d["p2p_selftest"] == "pass" and d["exchange_path"] in ("p2p", "rccl"), d
+    assert d["p2p_ms_per_exchange"] > 0 and d["rccl_ms_per_exchange"] > 0 and d["selftest_message_mb_per_peer"] > 1.0
+
+
+def _selftest_worker(rank, world, port, outdir, fault):
+    import traceback
+
+    import torch.distributed as dist
+
+    try:
+        if fault:
+            os.environ["VSYS_P2P_SELFTEST_FAULT"] = fault
+        os.environ["VSYS_P2P_SELFTEST_TIMEOUT_S"] = "2"
+        from videosys_amd import dsp
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        info = dsp.p2p_selftest(dist.group.WORLD, rows=96, C=576, rounds=3, timing_iters=5)
+        sp = dsp.SequenceParallel(dist.group.WORLD)          # VSYS_DSP_P2P unset = auto: the trial decides
+        if fault:
+            ok = info["selftest"].startswith("fail") and info["exchange_path"] == "rccl" and sp.p2p is None \
+                and sp.exchange_info["selftest"].startswith("fail")
+            if fault == "mismatch":
+                ok = ok and "differ from what it sent" in info["selftest"]
+            else:
+                ok = ok and ("never received" in info["selftest"] or "differ" in info["selftest"])
+        else:
+            ok = info["selftest"] == "pass" and info["p2p_ms"] > 0 and info["rccl_ms"] > 0 and info["exchange_path"] in ("p2p", "rccl") \
+                and (sp.p2p is not None) == (sp.exchange_info["exchange_path"] == "p2p")
+            if sp.p2p is not None:                           # and the chosen path really exchanges: a [B, T, Sl, C] switch and back
+                x = torch.arange(2 * 3 * 4 * 64, dtype=torch.float32, device="cuda:0").reshape(2, 3, 4, 64).to(torch.bfloat16) + rank
+                out = torch.zeros(2, 2, 8, 64, dtype=torch.bfloat16, device="cuda:0")
+                sp.to_temporal_shard(x, 8, out=out)
+                torch.cuda.synchronize()
+                sp.p2p.check()
+                ok = ok and sp.p2p.launches == 1
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write("ok" if ok else f"unexpected: {info} / {sp.exchange_info}")
+    except Exception:
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("fault", ["", "mismatch", "timeout"])
+def test_p2p_selftest_two_processes_pass_and_forced_fail(fault):
+    """dsp.p2p_selftest over two PROCESSES (HIP IPC mappings, flags polled on the device; both on the box's one GPU): it passes,
+    times both paths and picks one; with a forced payload mismatch on rank 0 or a skipped exchange on rank 1 (the peer's flag never
+    arrives: the kernel's wall-clock bound ends the wait) EVERY rank falls back to the RCCL path and says why — nothing hangs."""
+    _run(_selftest_worker, (fault,), world=2, timeout=240)
 
 
 def test_bench_plain_form_launches_its_own_ranks():

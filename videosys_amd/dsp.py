@@ -356,23 +356,42 @@ class IpcPeers:
         return out
 
     def share_tensor(self, t: torch.Tensor) -> List[torch.Tensor]:
+        """Collective.  A rank whose export fails still takes part in the all-gather (with None), so nobody is left waiting in it; the
+        error is raised on EVERY rank afterwards."""
         from torch.multiprocessing.reductions import reduce_tensor
 
-        fn, args = reduce_tensor(t)
-        every = self.all_gather_object((fn, args))
+        try:
+            payload, err = reduce_tensor(t), None
+        except Exception as e:     # noqa: BLE001 (whatever the IPC export raises on this driver)
+            payload, err = None, e
+        every = self.all_gather_object(payload)
+        if any(v is None for v in every):
+            bad = [q for q, v in enumerate(every) if v is None]
+            raise RuntimeError(f"HIP IPC export of a tensor failed on rank(s) {bad}" + (f": {err}" if err is not None else ""))
         return [t if q == self.rank else f(*a) for q, (f, a) in enumerate(every)]
 
     def share_flags(self, n: int):
+        """Collective, same failure discipline as share_tensor."""
         import ctypes
 
         from . import _lib
 
         lib = _lib.load()
         mine = ctypes.c_void_p()
-        _lib.check(lib.vsys_p2p_alloc(4 * n, 1, ctypes.byref(mine)), "vsys_p2p_alloc")
-        h = (ctypes.c_char * 64)()
-        _lib.check(lib.vsys_p2p_ipc_export(mine, h), "vsys_p2p_ipc_export")
-        every = self.all_gather_object(bytes(h))
+        payload, err = None, None
+        try:
+            _lib.check(lib.vsys_p2p_alloc(4 * n, 1, ctypes.byref(mine)), "vsys_p2p_alloc")
+            h = (ctypes.c_char * 64)()
+            _lib.check(lib.vsys_p2p_ipc_export(mine, h), "vsys_p2p_ipc_export")
+            payload = bytes(h)
+        except Exception as e:     # noqa: BLE001
+            err = e
+        every = self.all_gather_object(payload)
+        if any(v is None for v in every):
+            if mine.value:
+                lib.vsys_p2p_free(mine)
+            bad = [q for q, v in enumerate(every) if v is None]
+            raise RuntimeError(f"HIP IPC export of a flag array failed on rank(s) {bad}" + (f": {err}" if err is not None else ""))
         ptrs = []
         for q, hb in enumerate(every):
             if q == self.rank:
@@ -416,12 +435,16 @@ class PeerExchange:
         self.launches = 0
 
     def _site(self, key, out):
+        # A resident workspace that GROWS (stdit3._buf: a later call asks for more frames under the same name) is a new allocation on
+        # every rank at the same call — the requests are a function of the shapes, which all ranks share — so the allocation's size is
+        # part of the site's identity: growth opens a fresh site collectively, on all ranks together.
+        key = (key, out.untyped_storage().nbytes(), out.storage_offset())
         st = self.sites.get(key)
         if st is not None and st["out"].data_ptr() != out.data_ptr():
             # Creating a site is COLLECTIVE (tensor descriptors and flag handles are all-gathered): a rank that re-created one on its own
             # because ITS destination buffer moved would sit in that all-gather alone.  The callers hand over resident workspaces keyed
-            # by shape, so this only happens when a workspace grew on this rank — which must then have grown on every rank in the same
-            # call, or not at all: say so instead of hanging (or set VSYS_P2P_RESHARE=1 when every rank is known to re-create together).
+            # by shape and allocation size (above), so what is left is an allocation that moved on THIS rank only: say so instead of
+            # hanging (VSYS_P2P_RESHARE=1 when every rank is known to re-create together).
             import os
 
             if os.environ.get("VSYS_P2P_RESHARE") != "1" and not bool(getattr(self.peers, "same_process", False)):
@@ -465,8 +488,9 @@ class PeerExchange:
         # ranks that are threads of ONE process (tools/local_group) order the launches on the host instead of polling flags on the
         # device: their streams share a handful of hardware queues, where a polling kernel can sit in front of the launch it waits for
         host_sync = getattr(self.peers, "p2p_sync", None)
-        vops._call("vsys_p2p_exchange", vops._p(src), n, arr, st["my_flags"], self.P, self.rank, vops._p(st["state"]),
-                   -1 if host_sync is not None else self.timeout_ticks)
+        with COMM_TIMER.comm():   # (bench.py --gpus N: the launch ends when the slowest peer's rows are here, like a collective)
+            vops._call("vsys_p2p_exchange", vops._p(src), n, arr, st["my_flags"], self.P, self.rank, vops._p(st["state"]),
+                       -1 if host_sync is not None else self.timeout_ticks)
         if host_sync is not None:
             program.host_call(host_sync)
         self.launches += 1
@@ -502,25 +526,167 @@ class PeerExchange:
                                    f"(VSYS_P2P_TIMEOUT_S); set VSYS_DSP_P2P=0 to use the RCCL all_to_all_single path")
 
 
-def _make_peer_exchange(group, P, rank, copy_executor):
-    """VSYS_DSP_P2P = 1: peer-to-peer exchange (through HIP IPC when ``group`` is a torch ProcessGroup); 0: the pack + all_to_all_single
-    + unpack path; auto (default): peer-to-peer for in-process groups (which have no wire of their own), RCCL for process groups —
-    the IPC path has not run over xGMI on the build's one-GPU boxes, so it is opt-in there."""
+def _agree(group, ok: bool, why: str = ""):
+    """Collective: every rank learns every rank's (ok, why); returns (all ok, first reason)."""
+    P = dist.get_world_size(group)
+    every = [None] * P
+    dist.all_gather_object(every, (bool(ok), str(why)[:300]), group=group)
+    bad = [(q, w) for q, (o, w) in enumerate(every) if not o]
+    return (not bad), ("" if not bad else f"rank {bad[0][0]}: {bad[0][1]}")
+
+
+def p2p_selftest(group, device=None, rows: int = 768, C: int = 1152, rounds: int = 4, timing_iters: int = 20) -> dict:
+    """One-time guarded trial of the one-kernel peer-to-peer exchange over a REAL process group, before a model may use it (VERDICT r5
+    item 3: the first multi-GPU run should exercise vsys_p2p_exchange without anybody setting an environment variable, and must not be
+    able to corrupt a video or hang if the path does not work on that machine).  Collective: every rank of ``group`` calls it at the
+    same point (SequenceParallel / UlyssesParallel construction).
+
+      1. set-up: scratch source / destination tensors [P, rows, C] bf16 and flag arrays shared through HIP IPC (IpcPeers) — any rank's
+         failure is agreed on collectively;
+      2. ``rounds`` exchanges of a payload that is a function of (sender, receiver, round, row): the receiver compares every peer's block
+         with what that peer must have sent (a later launch on the stream, as the model's consumers are) — a stale or torn row, or a
+         flag that never arrives inside VSYS_P2P_SELFTEST_TIMEOUT_S (default 5 s; the kernel's own wall-clock bound), fails the test;
+      3. the ranks agree (all-gather of the verdicts): one failure anywhere sends EVERY rank to the RCCL path;
+      4. on a pass, ``timing_iters`` exchanges of the same 1.77 MB-per-peer message (config 2's size at 8 ranks) each way — the
+         one-kernel exchange against pack + all_to_all_single + unpack on the same buffers, HIP-event timed, slowest rank counts — and
+         the faster one is chosen.
+    Returns {"selftest": "pass" | "fail: ...", "exchange_path": "p2p" | "rccl", "p2p_ms": .., "rccl_ms": .., "message_mb_per_peer": ..}.
+    VSYS_P2P_SELFTEST_FAULT = mismatch | timeout (tests): rank 0 expects a wrong payload / rank P-1 skips its first exchange."""
+    import os
+    import time
+
+    P, rank = dist.get_world_size(group), dist.get_rank(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    fault = os.environ.get("VSYS_P2P_SELFTEST_FAULT", "")
+    info = {"selftest": "pass", "exchange_path": "rccl", "p2p_ms": None, "rccl_ms": None,
+            "message_mb_per_peer": round(rows * C * 2 / 1e6, 3), "ranks": P}
+    saved = os.environ.get("VSYS_P2P_TIMEOUT_S")
+    os.environ["VSYS_P2P_TIMEOUT_S"] = os.environ.get("VSYS_P2P_SELFTEST_TIMEOUT_S", "5")
+    px, ok, why = None, True, ""
+    try:
+        px = PeerExchange(IpcPeers(group), P, rank)
+    finally:
+        if saved is None:
+            os.environ.pop("VSYS_P2P_TIMEOUT_S", None)
+        else:
+            os.environ["VSYS_P2P_TIMEOUT_S"] = saved
+    src = torch.empty(P, rows, C, dtype=torch.bfloat16, device=dev)
+    dst = torch.zeros(P, rows, C, dtype=torch.bfloat16, device=dev)
+    n = rows * C
+    plan = [CopyOp(q * n, rank * n, 1, rows, 1, C, (n, C, C), (n, C, C), rows, 1) for q in range(P)]
+    row_id = torch.arange(rows, device=dev, dtype=torch.float32)[:, None]
+
+    def payload(sender, receiver, rnd):     # small integers: exact in bf16, different for every (sender, receiver, round, row)
+        return ((row_id + (sender * 131 + receiver * 17 + rnd * 7)) % 251.0).to(torch.bfloat16).expand(rows, C)
+
+    try:                                     # (1) collective set-up of the site; a local failure is agreed on below
+        px._site("selftest", dst)
+    except Exception as e:                   # noqa: BLE001
+        ok, why = False, f"set-up: {type(e).__name__}: {e}"
+    ok, why = _agree(group, ok, why)
+    for rnd in range(rounds if ok else 0):   # (2) patterned rounds; (3) the verdict of EVERY round is agreed on by all ranks (which is
+        try:                                 #     also the barrier that keeps a destination from being overwritten while a peer compares)
+            for q in range(P):
+                src[q].copy_(payload(rank, q, rnd))
+            if not (fault == "timeout" and rnd == 0 and rank == P - 1):
+                px.exchange("selftest", src, dst, plan)
+            torch.cuda.synchronize(dev)
+            px.check()
+            for q in range(P):
+                want = payload(q, rank, rnd + (1 if fault == "mismatch" and rank == 0 and q != rank else 0))
+                if not torch.equal(dst[q], want):
+                    bad = int((dst[q] != want).any(dim=1).sum())
+                    raise RuntimeError(f"round {rnd}: {bad} of {rows} rows from rank {q} differ from what it sent")
+        except Exception as e:               # noqa: BLE001
+            ok, why = False, f"{type(e).__name__}: {e}"
+        ok, why = _agree(group, ok, why)
+        if not ok:
+            break
+    if not ok:
+        info["selftest"] = "fail: " + why
+    else:                                    # (4) both paths on the same message, slowest rank counts
+        send = torch.empty(P, rows, C, dtype=torch.bfloat16, device=dev)
+        recv = torch.empty_like(send)
+        ident = [CopyOp(q * n, q * n, 1, rows, 1, C, (n, C, C), (n, C, C), rows, 1) for q in range(P)]
+
+        def rccl_once():
+            hip_copy_executor(src, send, ident)
+            dist.all_to_all_single(recv, send, group=group)
+            hip_copy_executor(recv, dst, ident)
+
+        def timed(fn):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize(dev)
+            dist.barrier(group)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(timing_iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize(dev)
+            every = [None] * P
+            dist.all_gather_object(every, e0.elapsed_time(e1) / timing_iters, group=group)
+            return max(every)
+
+        try:
+            t_p2p = timed(lambda: px.exchange("selftest", src, dst, plan))
+            px.check()
+            t_rccl = timed(rccl_once)
+            info.update(p2p_ms=round(t_p2p, 4), rccl_ms=round(t_rccl, 4), exchange_path="p2p" if t_p2p <= t_rccl else "rccl")
+        except Exception as e:               # noqa: BLE001  (a failure here is local: the ranks agree once more before anybody acts on it)
+            ok, why = False, f"timing: {type(e).__name__}: {e}"
+        ok2, why2 = _agree(group, ok, why)
+        if not ok2:
+            info.update(selftest="fail: " + why2, exchange_path="rccl")
+    torch.cuda.synchronize(dev)
+    dist.barrier(group)                      # every rank has left its last exchange: the scratch sites may go
+    if px is not None:
+        px.close()
+    if rank == 0:
+        logging.info(f"peer-to-peer exchange self-test over {P} ranks: {info}")
+    return info
+
+
+def _make_peer_exchange(group, P, rank, copy_executor, info: Optional[dict] = None):
+    """Which exchange a SequenceParallel / UlyssesParallel object uses.  In-process groups (tools/local_group: no wire of their own):
+    peer-to-peer unless VSYS_DSP_P2P=0.  A torch ProcessGroup: VSYS_DSP_P2P = 0 -> pack + all_to_all_single + unpack; 1 -> peer-to-peer
+    (the self-test still runs first and a failure raises); auto (default) -> ``p2p_selftest`` decides: the one-kernel exchange when it
+    passes AND is the faster of the two on this machine, RCCL otherwise.  VSYS_P2P_SELFTEST=0 skips the trial (auto then means RCCL).
+    Every rank takes the same path: the setting is compared and the verdict agreed collectively.  ``info`` receives what happened."""
     import os
 
+    info = {} if info is None else info
     mode = os.environ.get("VSYS_DSP_P2P", "auto")
     if copy_executor is not hip_copy_executor or P < 2:
+        info.update(exchange_path="rccl", selftest="not applicable (no HIP copy executor / single rank)")
         return None
     if hasattr(group, "all_gather_object"):
+        info.update(exchange_path="rccl" if mode == "0" else "p2p", selftest="not applicable (in-process group)")
         return None if mode == "0" else PeerExchange(group, P, rank)
     # a torch ProcessGroup: every rank must take the same path (a rank that waits for flags nobody raises would sit out its timeout,
     # one that waits in all_to_all_single for peers that never call it would hang) — compare the setting once, collectively
-    want = mode == "1"
     every = [None] * P
-    dist.all_gather_object(every, want, group=group)
-    if any(v != want for v in every):
-        raise RuntimeError(f"VSYS_DSP_P2P differs between the ranks of the sequence-parallel group: {every} (rank order); set it identically")
-    return PeerExchange(IpcPeers(group), P, rank) if want else None
+    dist.all_gather_object(every, (mode, os.environ.get("VSYS_P2P_SELFTEST", "1")), group=group)
+    if any(v != every[0] for v in every):
+        raise RuntimeError(f"VSYS_DSP_P2P / VSYS_P2P_SELFTEST differ between the ranks of the sequence-parallel group: {every} (rank order); set them identically")
+    if mode == "0" or not torch.cuda.is_available():
+        info.update(exchange_path="rccl", selftest="skipped (VSYS_DSP_P2P=0)" if mode == "0" else "skipped (no device)")
+        return None
+    if os.environ.get("VSYS_P2P_SELFTEST", "1") == "0":
+        info.update(exchange_path="p2p" if mode == "1" else "rccl", selftest="skipped (VSYS_P2P_SELFTEST=0)")
+        return PeerExchange(IpcPeers(group), P, rank) if mode == "1" else None
+    res = p2p_selftest(group)
+    info.update(res)
+    if mode == "1":
+        if res["selftest"] != "pass":
+            raise RuntimeError(f"VSYS_DSP_P2P=1 but the peer-to-peer self-test failed: {res['selftest']}")
+        info["exchange_path"] = "p2p"
+        return PeerExchange(IpcPeers(group), P, rank)
+    if res["selftest"] != "pass":
+        logging.warning(f"peer-to-peer exchange self-test failed ({res['selftest']}): using pack + all_to_all_single + unpack")
+        return None
+    return PeerExchange(IpcPeers(group), P, rank) if res["exchange_path"] == "p2p" else None
 
 
 def check_exchange(model) -> None:
@@ -542,7 +708,8 @@ class SequenceParallel:
         self.rank = group_rank(group)
         self.exec = copy_executor
         self._bufs = {}
-        self.p2p = _make_peer_exchange(group, self.P, self.rank, copy_executor)   # None: pack + all_to_all_single + unpack
+        self.exchange_info = {}   # what the set-up decided (self-test verdict, both timings, the path): bench.py reports it
+        self.p2p = _make_peer_exchange(group, self.P, self.rank, copy_executor, self.exchange_info)   # None: pack + all_to_all_single + unpack
 
     def _buf(self, name, shape, like):
         key = (name, tuple(shape))
@@ -689,9 +856,11 @@ class UlyssesParallel:
         self.rank = group_rank(group)
         self.exec = copy_executor
         self._bufs = {}
-        self.p2p = _make_peer_exchange(group, self.P, self.rank, copy_executor)   # None: pack + all_to_all_single + unpack
+        self.exchange_info = {}
+        self.p2p = _make_peer_exchange(group, self.P, self.rank, copy_executor, self.exchange_info)   # None: pack + all_to_all_single + unpack
         if self.p2p is not None and 2 * self.P > 16:
             self.p2p = None        # (the gather carries two problems per peer: at most 8 ranks in one launch)
+            self.exchange_info["exchange_path"] = "rccl"
 
     _buf = SequenceParallel._buf
 
