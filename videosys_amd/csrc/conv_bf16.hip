@@ -28,13 +28,17 @@ constexpr int OUT_ROW_BYTES = 64 * 2 + 16;
 constexpr int OUT_WAVE_BYTES = 64 * OUT_ROW_BYTES;  // 9216 per wave and pass
 static_assert(4 * OUT_WAVE_BYTES <= LDS_BYTES, "epilogue image must fit in the staging buffers");
 
-template <int F32OUT>
+// MF = 1 (round 6): the same walk on v_mfma_f32_16x16x32_bf16, as gemm2_bf16.hip MF (the matrix pipe is ~12 % cheaper per flop in that
+// shape under the power cap; same bits): one stage = one k-step of 8 token blocks x 4 column blocks of 16 x 16 in two halves of four token
+// blocks; a lane owns token 16 i + lane % 16 and columns 16 j + 4 (lane / 16) .. + 3; LDS chunk swizzle F = (0, 2, 3, 1).
+template <int F32OUT, int MF = 0>
 __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
 #if __HIP_DEVICE_COMPILE__  // buffer-resource types exist in the device pass only
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, hi = lane >> 5;
+  const int l15 = lane & 15, lq = lane >> 4;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
   // N-tiles of one row panel are neighbours in the (XCD-chunked) tile order: the panel's activation rows are fetched once
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
   const bf16_t* Ab = p.A + zb * p.batch_a;
   const bf16_t* Wb = p.W + zb * p.batch_w;
 
-  const int dchunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 16;
+  const int dchunk = ((lane & 3) ^ (MF ? ((0x78 >> (2 * ((lane >> 4) & 3))) & 3) : ((lane >> 4) & 3))) * 16;
   int a_off[4], b_off[2];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -83,17 +87,25 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
                                              b_off[i], t * (BK * 2), 0, 0);
   };
 
-  const int fsw = ((hi ^ ((l31 >> 2) & 3)) << 4);
-  const int xo = (wm * 128 + l31) * 64 + fsw;           // + i*2048 for m-block i
-  const int wo = W_BASE + (wn * 64 + l31) * 64 + fsw;   // + j*2048 for n-block j
+  const int fsw = MF ? ((lq ^ ((0x78 >> (2 * ((l15 >> 2) & 3))) & 3)) << 4) : ((hi ^ ((l31 >> 2) & 3)) << 4);
+  const int frow = MF ? l15 : l31;
+  const int xo = (wm * 128 + frow) * 64 + fsw;           // + i*2048 for m-block i (MF: + i*1024 for token block i)
+  const int wo = W_BASE + (wn * 64 + frow) * 64 + fsw;   // + j*2048 for n-block j (MF: + j*1024 for column block j)
 
-  f32x16 acc[4][2];
+  f32x16 acc[MF ? 1 : 4][MF ? 1 : 2];
+  f32x4 acc16[MF ? 8 : 1][MF ? 4 : 1];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < (MF ? 1 : 4); ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < (MF ? 1 : 2); ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < (MF ? 8 : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (MF ? 4 : 1); ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
 
   const int nt = p.K / BK;
   {
@@ -123,6 +135,48 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
     const char* ab = smem + sa * A_SLOT;
     const char* wb = smem + sw * W_SLOT;
     bf16x8 x0, x1, x2, x3, w0, w1, v0, v1;  // x: A fragments of the current k-step; w / v: W fragments of k-step 0 / 1
+    if constexpr (MF) {
+      // (w0, w1, v0, v1) = the four column blocks, x0..x3 = token blocks 0..3, reloaded with blocks 4..7 behind their MFMAs
+      x0 = *reinterpret_cast<const bf16x8*>(ab + xo);
+      w0 = *reinterpret_cast<const bf16x8*>(wb + wo);
+      w1 = *reinterpret_cast<const bf16x8*>(wb + wo + 1024);
+      v0 = *reinterpret_cast<const bf16x8*>(wb + wo + 2048);
+      v1 = *reinterpret_cast<const bf16x8*>(wb + wo + 3072);
+      x1 = *reinterpret_cast<const bf16x8*>(ab + xo + 1024);
+      x2 = *reinterpret_cast<const bf16x8*>(ab + xo + 2048);
+      x3 = *reinterpret_cast<const bf16x8*>(ab + xo + 3072);
+      __builtin_amdgcn_sched_barrier(0);
+#define CV16_ROW(i_, X_)                                                                              \
+  acc16[i_][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0, X_, acc16[i_][0], 0, 0, 0);              \
+  acc16[i_][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, X_, acc16[i_][1], 0, 0, 0);              \
+  acc16[i_][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v0, X_, acc16[i_][2], 0, 0, 0);              \
+  acc16[i_][3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(v1, X_, acc16[i_][3], 0, 0, 0)
+      CV16_ROW(0, x0);
+      __builtin_amdgcn_sched_barrier(0);
+      x0 = *reinterpret_cast<const bf16x8*>(ab + xo + 4096);
+      if (n1) { dma_w(0, t + 1, sw1); dma_w(1, t + 1, sw1); }
+      __builtin_amdgcn_sched_barrier(0);
+      CV16_ROW(1, x1);
+      __builtin_amdgcn_sched_barrier(0);
+      x1 = *reinterpret_cast<const bf16x8*>(ab + xo + 5120);
+      if (n2) { dma_a(0, s2, sa2); dma_a(1, s2, sa2); }
+      __builtin_amdgcn_sched_barrier(0);
+      CV16_ROW(2, x2);
+      __builtin_amdgcn_sched_barrier(0);
+      x2 = *reinterpret_cast<const bf16x8*>(ab + xo + 6144);
+      if (n2) dma_a(2, s2, sa2);
+      __builtin_amdgcn_sched_barrier(0);
+      CV16_ROW(3, x3);
+      __builtin_amdgcn_sched_barrier(0);
+      x3 = *reinterpret_cast<const bf16x8*>(ab + xo + 7168);
+      if (n2) dma_a(3, s2, sa2);
+      __builtin_amdgcn_sched_barrier(0);
+      CV16_ROW(4, x0);
+      CV16_ROW(5, x1);
+      CV16_ROW(6, x2);
+      CV16_ROW(7, x3);
+#undef CV16_ROW
+    } else {
     x0 = *reinterpret_cast<const bf16x8*>(ab + xo);
     w0 = *reinterpret_cast<const bf16x8*>(wb + wo);
     w1 = *reinterpret_cast<const bf16x8*>(wb + wo + 2048);
@@ -163,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
     CV_ROW(2, x2, v0, v1);
     CV_ROW(3, x3, v0, v1);
 #undef CV_ROW
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (n2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -178,8 +233,23 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
     // fp32 result straight from the accumulators (attention scores: no bf16 rounding before the softmax); element
     // (row l31 + 32 i, col 32 j + 8 g + 4 hi + r) sits in acc[i][j][4 g + r]
     float* o32 = p.out32 + zb * p.batch_o;
+    if constexpr (MF) {   // element (row 16 i + l15, col 16 j + 4 lq + r) sits in acc16[i][j][r]
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 8; ++i) {
+        const int64_t grow = row0 + wm * 128 + i * 16 + l15;
+        if (grow < p.M) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float4 v;
+            v.x = acc16[i][j][0] * p.out_scale; v.y = acc16[i][j][1] * p.out_scale;
+            v.z = acc16[i][j][2] * p.out_scale; v.w = acc16[i][j][3] * p.out_scale;
+            *reinterpret_cast<float4*>(o32 + grow * p.ldo + ncol0 + j * 16 + 4 * lq) = v;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < (MF ? 0 : 4); ++i) {
       const int64_t grow = row0 + wm * 128 + i * 32 + l31;
       if (grow < p.M) {
 #pragma unroll
@@ -203,7 +273,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int g = 0; g < 4; ++g) bb[j][g] = make_uint2(0, 0);
-    if (p.bias != nullptr) {
+    if (p.bias != nullptr && !MF) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -225,8 +295,28 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvParams p) {
           rres[it] = *reinterpret_cast<const uint4*>(rb + (int64_t)grow * p.ldr + ncol0 + c * 8);
         }
       }
+      if constexpr (MF) {
+        uint2 bb16[4];
 #pragma unroll
-      for (int i2 = 0; i2 < 2; ++i2) {
+        for (int j = 0; j < 4; ++j) bb16[j] = p.bias != nullptr ? *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 16 + 4 * lq) : make_uint2(0, 0);
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2) {
+          const int i = ih * 4 + i2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc16[i][j][r];
+            v[0] += bflo(bb16[j].x); v[1] += bfhi(bb16[j].x); v[2] += bflo(bb16[j].y); v[3] += bfhi(bb16[j].y);
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(st + (i2 * 16 + l15) * OUT_ROW_BYTES + (j * 16 + 4 * lq) * 2) = o;
+          }
+        }
+      }
+#pragma unroll
+      for (int i2 = 0; i2 < (MF ? 0 : 2); ++i2) {
         const int i = ih * 2 + i2;
         const int m_local = i2 * 32 + l31;
 #pragma unroll
@@ -290,12 +380,18 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
   if (nbm * nbn > 0x7fffffff || p.batch > 65535) return VSYS_ERR_SHAPE;
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
   for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
-    (void)hipFuncSetAttribute((const void*)conv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)conv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)conv_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   }
   const dim3 grid((unsigned)(nbm * nbn), (unsigned)p.batch);
-  if (p.out32 != nullptr) hipLaunchKernelGGL(conv_kernel<1>, grid, dim3(256), LDS_BYTES, stream, p);
-  else hipLaunchKernelGGL(conv_kernel<0>, grid, dim3(256), LDS_BYTES, stream, p);
+  static const bool mf16 = [] { const char* e = getenv("VSYS_GEMM_MF16"); return !(e && e[0] == '0'); }();   // (0: the 32x32x16 form)
+  if (mf16) {
+    if (p.out32 != nullptr) hipLaunchKernelGGL((conv_kernel<1, 1>), grid, dim3(256), LDS_BYTES, stream, p);
+    else hipLaunchKernelGGL((conv_kernel<0, 1>), grid, dim3(256), LDS_BYTES, stream, p);
+  } else if (p.out32 != nullptr) hipLaunchKernelGGL((conv_kernel<1, 0>), grid, dim3(256), LDS_BYTES, stream, p);
+  else hipLaunchKernelGGL((conv_kernel<0, 0>), grid, dim3(256), LDS_BYTES, stream, p);
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
 }
 
