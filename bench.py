@@ -256,22 +256,23 @@ def main():
         # HBM/fabric bytes per launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on the same
         # kernels and shapes, tools/gemm_traffic.py -> profiles/r01_gemm_traffic.json), config-2 launch mix
         traffic = None
-        tname = next((n for n in ("r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r01_gemm_traffic.json")
+        tname = next((n for n in ("r06_gemm_traffic.json", "r05_gemm_traffic.json", "r04_gemm_traffic.json", "r03_gemm_traffic.json", "r01_gemm_traffic.json")
                       if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         if tname is not None and world == 1:
             with open(os.path.join(ROOT, "profiles", tname)) as fh:
                 traffic = round(json.load(fh)["avg_bytes_per_launch_config2_mix"])
         roof = {
-            "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256> + vsys::gemm2_kernel<EPI> (256x192 tile, bf16 MFMA 32x32x16, shape-dispatched, all epilogues)",
+            "bound": "mfma", "kernel": "vsys::gemm_kernel<EPI, 8, 256, 1, 0, 1> + vsys::gemm2_kernel<EPI, 2, 0, 1> (256x192 tile, bf16 MFMA 16x16x32, shape-dispatched, all epilogues)",
             "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic if base_geo else None,
             "traffic_source": f"profiles/{tname} (committed rocprofv3 PMC passes of the same kernels and shapes with the shipped dispatch; "
                               "NOT re-measured by this run)",
             "annotations_not_measured_by_this_run": {
                 "power_limited_mfma_ceiling_tflops": 1816.0, "source": "profiles/r01_mfma_power_ceiling.json",
-                "note": "a bare MFMA loop with operands changing every instruction sustains 1816 TFLOP/s at the 1400 W cap (2465 "
-                        "with constant operands); profiles/r02_gemm_yardstick.json: this GEMM family reaches 1219 TFLOP/s on random "
-                        "and 1744 on zero operands at 8192x3072x4096 (vendor library 1307 / 1726)"},
+                "note": "a bare v_mfma_f32_32x32x16_bf16 loop with operands changing every instruction sustains 1816-1830 TFLOP/s at the 1400 W cap "
+                        "(2465 with constant operands), the 16x16x32 form these kernels use since round 6 2045-2060 (profiles/r06_kernel_bench_mf16.txt); "
+                        "profiles/r02_gemm_yardstick.json: the round-2 family reached 1219 TFLOP/s on random and 1744 on zero operands at "
+                        "8192x3072x4096 (vendor library 1307 / 1726)"},
             "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, fabric side incl. Infinity-Cache hits; algorithmic "
                             "operand + output (+ residual) bytes per launch: 305e6)",
             "launches_per_step": n // nrep, "avg_launch_ms": round(tot_ms / n, 4),

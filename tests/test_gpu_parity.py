@@ -152,6 +152,67 @@ def _gate_residual_aux(ops, M=1100, N=576, K=1152, rps=400):
     check(out2, res.float() + x.float() @ w.float().t() + b.float(), what="residual only")
 
 
+@pytest.mark.parametrize("K", [1152, 4608])
+def test_gemm_split_k_few_tiles(ops, K):
+    """One rank of an 8-way DSP group: 4864 rows x 1152 columns = 228 tiles of 128 rows on 256 CUs.  Id 123 runs TWO workgroups per tile, each over
+    half of K, the first handing its fp32 sums to the second through L2 (gemm_bf16.hip KS; measured slower than one workgroup per tile, so
+    opt-in).  Against the one-workgroup kernel (id 113): every epilogue within one bf16 neighbour on a small fraction of the elements (the summation order of
+    two fp32 partials), deterministic from launch to launch, flags lowered again (a second and third launch see the same result), and
+    the same under a recorded launch program replayed twice (identical arguments every replay)."""
+    from videosys_amd import _lib, program
+
+    lib = _lib.load()
+    M, N = 4864, 1152
+    g = torch.Generator().manual_seed(K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev())
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev())
+    b = (torch.randn(N, generator=g) * 0.1).to(torch.bfloat16).to(dev())
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).to(dev())
+    gate = (torch.randn(2, 6 * N, generator=g) * 0.3).to(torch.bfloat16).to(dev())
+
+    def run_all():
+        outs = [ops.gemm(x, w, b), ops.gemm(x, w, b, epilogue=ops.EPI_BIAS_GELU)]
+        r = res.clone()
+        ops.gemm(x, w, b, epilogue=ops.EPI_GATE_RES, gate=gate[0, 2 * N:3 * N], gate_stride=6 * N, rows_per_sample=M // 2, res=r, out=r)
+        outs.append(r)
+        r2, st = res.clone(), ops.ln_stats_buffer(M, N, dev())
+        ops.gemm_stats(x, w, b, st, res=r2, out=r2)
+        outs += [r2, st]
+        return outs
+
+    try:
+        assert lib.vsys_tune_gemm_variant(113) == 0
+        ref = run_all()
+        assert lib.vsys_tune_gemm_variant(123) == 0
+        got = run_all()
+        again = run_all()
+    finally:
+        lib.vsys_tune_gemm_variant(0)
+    for a, c, r in zip(got, again, ref):
+        assert torch.equal(a, c), "split K is not deterministic / a flag stayed up"
+        if a.dtype == torch.bfloat16:
+            d = (a.float() - r.float()).abs()
+            assert float((d > 0).float().mean()) < 5e-3 and float(d.max()) <= 2.0 ** -6 * float(r.float().abs().max())
+    want = ops.ln_stats_buffer(M, N, dev())
+    ops.ln_row_stats(got[3], want)
+    assert torch.equal(got[4], want), "the partials of the split-K statistics epilogue are not the statistics of what it stored"
+    # recorded + replayed twice: the same commands, the flags must have been lowered by the consuming workgroups every time
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev())
+    try:
+        assert lib.vsys_tune_gemm_variant(123) == 0
+        with program.Recorder() as rec:
+            ops.gemm(x, w, b, out=out)
+        prog = rec.finish()
+        first = out.clone()
+        for _ in range(2):
+            out.zero_()
+            prog.run()
+            assert torch.equal(out, first)
+    finally:
+        lib.vsys_tune_gemm_variant(0)
+    assert torch.equal(first, got[0])
+
+
 def test_gemm_rejects_bad_shapes(ops):
     from videosys_amd._lib import VsysError
 

@@ -17,6 +17,9 @@
 // The output tile goes back through LDS so HBM sees whole 192-byte row segments (16-byte stores), where the residual
 // is added and the optional PAB cache copy is written.  1-D grid with an XCD-aware bijective remap: consecutive
 // logical tiles (same token panel, different column tile) share an XCD's L2.
+#include <map>
+#include <mutex>
+
 #include "common.h"
 #include "vsys_internal.h"
 
@@ -66,7 +69,14 @@ struct Geo {
 // column blocks each, alternating per k-step) and X pairs A / B (two token blocks, alternating per phase), every set read one phase
 // ahead of its use.  A lane owns token 16 i + lane % 16 and the columns 16 j + 4 (lane / 16) .. + 3: the epilogues index by that;
 // the statistics of EPI_GATE_RES_STATS are taken from the wave's LDS image in the canonical 48-column order (same bits).
-template <int EPI, int PIPE, int BM_, int RASTER = 1, int PROD = 0, int MF = 0>
+// KS = 1 (round 6; 128-row geometry on 16x16x32 only): TWO workgroups per tile, each walks half of the K-tiles.  For problems with fewer
+// tiles than CUs (one rank of an 8-way DSP group: 4864 rows, 228 tiles) a CU then holds two workgroups whose LDS-DMA round trips,
+// barriers and epilogues overlap, and every K loop is half as long.  Workgroup 2 i (the first K half, dispatched first, same XCD as its
+// partner) dumps its fp32 accumulators with write-through stores, drains them and raises one flag per wave; workgroup 2 i + 1 adds
+// them to its own (second-half) sums — wave w, lane l reads exactly what wave w, lane l wrote — lowers the flags again (the next
+// launch, also a replayed one, finds them down) and runs the epilogue.  fp32 summation order differs from the unsplit kernels
+// (a + b instead of one running sum): deterministic, not bit-identical; dispatched only for tile counts <= the CU count.
+template <int EPI, int PIPE, int BM_, int RASTER = 1, int PROD = 0, int MF = 0, int KS = 0>
 __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_kernel(GemmParams p) {
 #if __HIP_DEVICE_COMPILE__  // the buffer-resource type below exists in the device pass only; the host pass needs just the stub
   using G = Geo<BM_>;
@@ -79,8 +89,14 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   const int l15 = lane & 15, lq = lane >> 4;   // MF: fragment row / 16-byte k-chunk; accumulator token / column quad
   static_assert(!MF || ((PIPE == 8 && BM_ == 256 && !PROD) || (PIPE == 3 && BM_ == 128)), "the 16x16x32 form exists for schedule 8 on the 256-row geometry and schedule 3 on the 128-row one");
 
+  static_assert(!KS || (MF && PIPE == 3 && BM_ == 128), "split K exists for the 128-row geometry on 16x16x32");
   const int nbn = p.N / BN;
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // KS: blockIdx = 16 g + 8 half + x  <->  pair 8 g + x, K half: both halves of a pair on XCD x, the dumping half dispatched first
+  const int ks_half = KS ? (int)((blockIdx.x >> 3) & 1) : 0;
+  const int ks_pair = KS ? (int)((blockIdx.x >> 4) * 8 + (blockIdx.x & 7)) : 0;
+  const int ks_ntiles = ((p.M + BM_ - 1) / BM_) * nbn;
+  if (KS && ks_pair >= ks_ntiles) return;
+  const int tile = KS ? xcd_remap(ks_pair, ks_ntiles) : xcd_remap(blockIdx.x, gridDim.x);
   // Raster (RASTER = 1): the row panels are split into 8 contiguous groups, one per XCD chunk of the remap; inside a group
   // the order is column-GROUP major (GW = 6 column tiles = 2.65 MB of W at K = 1152): for g: for panel: for j.  The 32
   // tiles an XCD runs at once are then ~5 row panels x 6 column tiles, so the W slab of the group stays in the XCD's
@@ -124,13 +140,14 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)(p.W + (int64_t)col0 * p.ldw), 0,
                                                         (int)(b_bytes < 0x7fffffff ? b_bytes : 0x7fffffff), 0x00020000);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  const int ks_k0 = KS ? ks_half * ((p.K / BK) / 2) : 0;   // the K-tile this workgroup's range starts at
   // piece i of tile kt_ into buffer buf_ (i < NA: A rows, else W rows); i must be a constant after unrolling
   auto dma_piece = [&](int i, int kt_, int buf_) {
     char* base_ = smem + buf_ * STAGE_BYTES;
     if (i < NA)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base_ + a_lds[i < NA ? i : 0]), 16, a_off[i < NA ? i : 0], kt_ * (BK * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(base_ + a_lds[i < NA ? i : 0]), 16, a_off[i < NA ? i : 0], (kt_ + ks_k0) * (BK * 2), 0, 0);
     else
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base_ + b_lds[i >= NA ? i - NA : 0]), 16, b_off[i >= NA ? i - NA : 0], kt_ * (BK * 2), 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (lds_ptr_t)(base_ + b_lds[i >= NA ? i - NA : 0]), 16, b_off[i >= NA ? i - NA : 0], (kt_ + ks_k0) * (BK * 2), 0, 0);
   };
 #define GEMM_DMA_RANGE(lo_, hi_, kt_, buf_)                          \
   do {                                                               \
@@ -228,7 +245,8 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  const int nt = p.K / BK;
+  const int nt_all = p.K / BK;
+  const int nt = KS ? (ks_half ? nt_all - nt_all / 2 : nt_all / 2) : nt_all;
   const int last = nt - 1;
   if constexpr (BASE != 8) {
     GEMM_DMA_RANGE(0, NP, 0, 0);
@@ -532,6 +550,43 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
     __syncthreads();
   }
 #undef GEMM_DMA_RANGE
+
+  if constexpr (KS) {
+    // ---- hand-off of the first K half (cdna_hip_programming.md section 6 G16: write-through payload, drained, then the flag)
+    typedef uint32_t ks_u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int KS_WAVE_BYTES = 24 * 64 * 16;
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(p.sk_ws) + (int64_t)(tile * 4 + wv) * KS_WAVE_BYTES), 0,
+                                                      KS_WAVE_BYTES, 0x00020000);
+    int* flag = p.sk_flags + tile * 4 + wv;
+    if (ks_half == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          ks_u32x4 v;
+          v.x = __float_as_uint(acc16[i][j][0]); v.y = __float_as_uint(acc16[i][j][1]);
+          v.z = __float_as_uint(acc16[i][j][2]); v.w = __float_as_uint(acc16[i][j][3]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rs, lane * 16, (i * 6 + j) * 1024, 16 /* sc1 */);
+        }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1) __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ks_u32x4 v[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, lane * 16, (i * 6 + j) * 1024, 16 /* sc1 */);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        acc16[i][j][0] += __uint_as_float(v[j].x); acc16[i][j][1] += __uint_as_float(v[j].y);
+        acc16[i][j][2] += __uint_as_float(v[j].z); acc16[i][j][3] += __uint_as_float(v[j].w);
+      }
+    }
+    if (lane == 0) __hip_atomic_store(flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the loads above have returned: their values were consumed)
+  }
 
   if constexpr (ABL == 1 && !MF) {
     // lab: keep the accumulators alive without an epilogue; lane 0 of a never-true condition writes them
@@ -986,7 +1041,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: case 113: break;
+    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: case 113: case 123: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -997,34 +1052,34 @@ int set_gemm_variant(int v) {
   return 0;
 }
 
-template <int PIPE, int BM_, int RASTER = 1, int PROD = 0, int MF = 0>
+template <int PIPE, int BM_, int RASTER = 1, int PROD = 0, int MF = 0, int KS = 0>
 static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   using G = Geo<BM_>;
-  if (PROD && epi != EPI_BIAS && epi != EPI_BIAS_GELU) return launch_gemm_t<PIPE, BM_, RASTER, 0, MF>(p, epi, stream);  // 208 VGPRs: no third wave
+  if (PROD && epi != EPI_BIAS && epi != EPI_BIAS_GELU) return launch_gemm_t<PIPE, BM_, RASTER, 0, MF, KS>(p, epi, stream);  // 208 VGPRs: no third wave
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
-  const int grid = nbm * nbn;
+  const int grid = KS ? ((nbm * nbn + 7) / 8) * 16 : nbm * nbn;   // KS: two workgroups per tile, pairs laid out XCD by XCD (gemm_kernel)
   const bool lnl = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
   const size_t lds = ((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (lnl && BM_ == 256 ? (BM_ + BN) * 8 : 0);
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
   for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
     const int lds = (int)(((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (BM_ == 256 ? (BM_ + BN) * 8 : 0));
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if constexpr (!PROD) {
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0, MF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
   }
   constexpr int NTH = G::NT + PROD * 256;
   switch (epi) {
-    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD, MF>), dim3(grid), dim3(NTH), lds, stream, p); break;
-    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD, MF>), dim3(grid), dim3(NTH), lds, stream, p); break;
-    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_GATE_RES_STATS: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
-    case EPI_LN_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0, MF>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD, MF, KS>), dim3(grid), dim3(NTH), lds, stream, p); break;
+    case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD, MF, KS>), dim3(grid), dim3(NTH), lds, stream, p); break;
+    case EPI_GATE_RES: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0, MF, KS>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_GATE_RES_STATS: hipLaunchKernelGGL((gemm_kernel<EPI_GATE_RES_STATS, PIPE, BM_, RASTER, 0, MF, KS>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_LN_BIAS: hipLaunchKernelGGL((gemm_kernel<EPI_LN_BIAS, PIPE, BM_, RASTER, 0, MF, KS>), dim3(grid), dim3(G::NT), lds, stream, p); break;
+    case EPI_LN_GELU: hipLaunchKernelGGL((gemm_kernel<EPI_LN_GELU, PIPE, BM_, RASTER, 0, MF, KS>), dim3(grid), dim3(G::NT), lds, stream, p); break;
     default: return VSYS_ERR_ARG;
   }
   return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
@@ -1035,9 +1090,48 @@ static bool mf16_default() {
   return on;
 }
 
-// the 128-row geometry (few tiles): 16x16x32 by default as well
-static int launch_rows128(const GemmParams& p, int epi, hipStream_t stream) {
-  return mf16_default() ? launch_gemm_t<3, 128, 1, 0, 1>(p, epi, stream) : launch_gemm_t<3, 128>(p, epi, stream);
+// split-K workspace of one stream (launches on a stream are serialised; two streams — the overlap mode of DSP — never share one):
+// partial sums of up to ``tiles`` tiles x 4 waves x 24 x 64 lanes float4, and one flag per (tile, wave), zeroed once: the consuming
+// workgroup lowers a flag after use, so a replayed launch program (same arguments every step) finds them down.  Allocated on first use,
+// never resized (sized for one tile per CU), freed with the process.
+namespace {
+struct SplitKWs { float* ws = nullptr; int* flags = nullptr; int tiles = 0; };
+std::mutex g_splitk_mutex;
+std::map<hipStream_t, SplitKWs> g_splitk_ws;
+}  // namespace
+static bool splitk_workspace(hipStream_t stream, int tiles, GemmParams& p) {
+  std::lock_guard<std::mutex> lock(g_splitk_mutex);
+  SplitKWs& w = g_splitk_ws[stream];
+  if (w.ws == nullptr) {
+    const int cap = cu_count_this_device();
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return false;   // no allocation under capture
+    if (hipMalloc(&w.ws, (size_t)cap * 4 * 24 * 64 * sizeof(float4)) != hipSuccess) { w.ws = nullptr; return false; }
+    if (hipMalloc(&w.flags, (size_t)cap * 4 * sizeof(int)) != hipSuccess || hipMemset(w.flags, 0, (size_t)cap * 4 * sizeof(int)) != hipSuccess) {
+      (void)hipFree(w.ws);
+      w.ws = nullptr;
+      return false;
+    }
+    (void)hipDeviceSynchronize();   // (the memset is ordered against the first launch on any stream)
+    w.tiles = cap;
+  }
+  if (tiles > w.tiles) return false;
+  p.sk_ws = w.ws;
+  p.sk_flags = w.flags;
+  return true;
+}
+// the 128-row geometry (few tiles): 16x16x32 by default as well.  Two workgroups per tile (KS) is OPT-IN (VSYS_GEMM_SPLITK=1 or id 123): at
+// 4864 rows the hand-off (98 KB of fp32 sums per tile through L2 + the flags) costs more than half a K loop of 18 tiles saves — proj
+// 31.1 vs 23.4 us, cross-q 27.6 vs 19.3, fc2 (K = 4608) 63.8 vs 62.9: profiles/r06_small_m_split_k.txt
+static int launch_rows128(const GemmParams& p_, int epi, hipStream_t stream, bool force_split = false) {
+  if (!mf16_default() && !force_split) return launch_gemm_t<3, 128>(p_, epi, stream);
+  static const bool splitk_on = [] { const char* e = getenv("VSYS_GEMM_SPLITK"); return e && e[0] == '1'; }();
+  const int tiles = ((p_.M + 127) / 128) * (p_.N / BN);
+  if ((splitk_on || force_split) && tiles >= 64 && tiles <= cu_count_this_device() && p_.K / BK >= 8) {
+    GemmParams p = p_;
+    if (splitk_workspace(stream, tiles, p)) return launch_gemm_t<3, 128, 1, 0, 1, 1>(p, epi, stream);
+  }
+  return launch_gemm_t<3, 128, 1, 0, 1>(p_, epi, stream);
 }
 // schedule 8 on the 256-row geometry: the 16x16x32 form by default (same bits), VSYS_GEMM_MF16=0 / variant 8 the 32x32x16 form
 static int launch_sched8(const GemmParams& p, int epi, hipStream_t stream) {
@@ -1063,17 +1157,17 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
   if (epi != EPI_GATE_RES && (p.add1 || p.add2)) return VSYS_ERR_ARG;
   if (epi == EPI_GATE_RES && (p.add1 || p.add2 || p.stats_out)) {   // folded broadcasts / statistics beside a slab copy: gemm_kernel only
     if ((p.add2 && !p.add1) || ((p.add1 || p.add2) && (!p.res || (p.ldr % 8))) || (p.stats_out && p.stats_ld < p.M)) return VSYS_ERR_ARG;
-    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream, g_gemm_variant_a.load(std::memory_order_relaxed) == 123);
     return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   // the statistics-emitting epilogue lives in gemm_kernel only (lab / forced variants of other kernel families fall back to it)
   if (epi == EPI_GATE_RES_STATS) {
-    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream, g_gemm_variant_a.load(std::memory_order_relaxed) == 123);
     if (g_gemm_variant_a.load(std::memory_order_relaxed) == 24) return launch_gemm2(p, epi, 2, stream);   // (A/B id: the two-workgroup 16x16x32 kernel)
     return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
   if (ln) {   // same shape dispatch as the store-only epilogues below
-    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
+    if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream, g_gemm_variant_a.load(std::memory_order_relaxed) == 123);
     if (p.K <= 1536 && p.N >= 2304 && g_gemm_variant_a.load(std::memory_order_relaxed) != 8) return launch_gemm2(p, epi, mf16_default() ? 2 : 0, stream);
     return g_gemm_variant_a.load(std::memory_order_relaxed) == 8 ? launch_gemm_t<8, 256>(p, epi, stream) : launch_sched8(p, epi, stream);
   }
@@ -1096,7 +1190,8 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
       return gemm4_supports(p, epi) ? launch_gemm4(p, epi, 2 + g_gemm_variant - 80, stream) : VSYS_ERR_ARG;
 #endif
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
-    case 113: return launch_gemm_t<3, 128, 1, 0, 1>(p, epi, stream);   // ... on v_mfma_f32_16x16x32_bf16
+    case 113: return launch_gemm_t<3, 128, 1, 0, 1>(p, epi, stream);   // ... on v_mfma_f32_16x16x32_bf16 (one workgroup per tile)
+    case 123: return launch_rows128(p, epi, stream, true);               // ... two workgroups per tile where the tile count allows (split K)
     case 106: return launch_gemm_t<6, 128>(p, epi, stream);   // the 128-row geometry on schedule 6 (DMA pieces interleaved with the MFMA pairs)
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
     case 24:   // the same on v_mfma_f32_16x16x32_bf16 (same bits); a gated launch with a slab copy falls back to schedule 8
@@ -1116,7 +1211,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
       // Few tiles (one rank of an 8-way DSP run has M = 4864: 114 tiles of 256 rows for the N = 1152 GEMMs on 256 CUs): the
       // 128-row geometry (two 4-wave workgroups per CU, 512 slots) fills the chip; measured at M = 4864 against schedule 8:
       // qkv -7 %, proj -15 %, fc2 -16 %, fc1 -2 % (tools/kernel_bench.py --rows 4864 --variants 8,20,103).
-      if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream);
+      if ((int64_t)((p.M + 255) / 256) * (p.N / BN) < 400) return launch_rows128(p, epi, stream, g_gemm_variant_a.load(std::memory_order_relaxed) == 123);
       // Round 6: the two-workgroup kernel on v_mfma_f32_16x16x32_bf16 (launch_gemm2 wide = 2; same bits, the matrix pipe ~12 % cheaper per
       // flop under the power cap): qkv 0.297 -> 0.276 ms, fc1 0.425 -> 0.404, and it now also beats schedule 8 on the N = K = 1152
       // store-only shape (cross-attention q: 0.111 -> 0.095 ms) — profiles/r06_kernel_bench_mf16.txt.  VSYS_GEMM_MF16=0: the 32x32x16 kernels.

@@ -88,6 +88,9 @@ struct GemmParams {
   const bf16_t* add1 = nullptr; const bf16_t* add2 = nullptr;
   // tile raster (common.h gemm_raster), filled in by launch_gemm: column-group width / panel-chunk height; 6 / 0 = the default
   int raster_gw = 6, raster_ph = 0;
+  // two-way split K of the 128-row geometry (gemm_bf16.hip KS): fp32 partial sums [tile][wave][24][64 lanes] float4 and one flag per
+  // (tile, wave), both owned by the library (one workspace per stream); filled in by launch_gemm
+  float* sk_ws = nullptr; int* sk_flags = nullptr;
 };
 
 // implicit-GEMM convolution / 128-column GEMM (conv_bf16.hip).  A points at the row that tap (0,0,0) reads for output row 0.
