@@ -87,7 +87,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, hi = lane >> 5;
   const int l15 = lane & 15, lq = lane >> 4;   // MF: fragment row / 16-byte k-chunk; accumulator token / column quad
-  static_assert(!MF || ((PIPE == 8 && BM_ == 256 && !PROD) || (PIPE == 3 && BM_ == 128)), "the 16x16x32 form exists for schedule 8 on the 256-row geometry and schedule 3 on the 128-row one");
+  static_assert(!MF || ((PIPE == 8 && !PROD) || (PIPE == 3 && BM_ == 128)), "the 16x16x32 form exists for schedule 8 and for schedule 3 on the 128-row geometry");
 
   static_assert(!KS || (MF && PIPE == 3 && BM_ == 128), "split K exists for the 128-row geometry on 16x16x32");
   const int nbn = p.N / BN;
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
     // tile t, W first, so the wait in front of tile t's barrier is the COUNTED vmcnt(4) = "everything but the four newest
     // pieces (= A(t+2)) has landed".  Raw s_barrier + inline waits: a __syncthreads() would drain the DMA queue.
     // Fragment double-buffering and the barrier in front of the last k-step are as in schedule 6.
-    static_assert(BM_ == 256 || BASE != 8, "schedule 8 is laid out for the 8-wave geometry");
+    static_assert(BM_ == 256 || BASE != 8 || MF, "schedule 8 on the 4-wave geometry exists in the 16x16x32 form only");
     constexpr int W_BASE = 3 * A_BYTES;
     auto dma_a = [&](int i, int kt_, int slot) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (lds_ptr_t)(smem + slot * A_BYTES + a_lds[i]), 16, a_off[i], kt_ * (BK * 2), 0, 0);
@@ -410,6 +410,26 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
     M16_MMA(W##2, X1, I0 + 1, 2); M16_MMA(W##3, X1, I0 + 1, 3); M16_MMA(W##4, X1, I0 + 1, 4); M16_MMA(W##5, X1, I0 + 1, 5); \
     V8_SB();                                                                                                \
   } while (0)
+      // the 4-wave (128-row) geometry stages SIX W pieces per wave and K-tile: three DMA statements per phase, behind MFMAs 3, 6 and 9 —
+      // W(t+1) pieces 2..5 first, A(t+2) last, so the counted wait in front of the barrier is still "everything but the four newest"
+#define M16_PHASE3(W, X0, X1, I0, d0_, d1_, d2_)                                                            \
+  do {                                                                                                      \
+    V8_SB();                                                                                                \
+    M16_MMA(W##0, X0, I0, 0); M16_MMA(W##1, X0, I0, 1); M16_MMA(W##2, X0, I0, 2);                            \
+    V8_SB();                                                                                                \
+    d0_;                                                                                                    \
+    V8_SB();                                                                                                \
+    M16_MMA(W##3, X0, I0, 3); M16_MMA(W##4, X0, I0, 4); M16_MMA(W##5, X0, I0, 5);                            \
+    V8_SB();                                                                                                \
+    d1_;                                                                                                    \
+    V8_SB();                                                                                                \
+    M16_MMA(W##0, X1, I0 + 1, 0); M16_MMA(W##1, X1, I0 + 1, 1); M16_MMA(W##2, X1, I0 + 1, 2);                \
+    V8_SB();                                                                                                \
+    d2_;                                                                                                    \
+    V8_SB();                                                                                                \
+    M16_MMA(W##3, X1, I0 + 1, 3); M16_MMA(W##4, X1, I0 + 1, 4); M16_MMA(W##5, X1, I0 + 1, 5);                \
+    V8_SB();                                                                                                \
+  } while (0)
       M16_W(wa0, 0, 0, 0); M16_W(wa1, 0, 1, 0); M16_W(wa2, 0, 2, 0); M16_W(wa3, 0, 3, 0); M16_W(wa4, 0, 4, 0); M16_W(wa5, 0, 5, 0);
       M16_X(xa0, 0, 0, 0); M16_X(xa1, 0, 1, 0);
       if (dma_on && nt > 1) { dma_w(0, 1, 1); dma_w(1, 1, 1); }
@@ -418,13 +438,16 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
         const bool n1 = dma_on && (t + 1 < nt), n2 = dma_on && (t + 2 < nt);
         // phase 0: k-step 0, token blocks 0 1 | ahead: X pair B of k-step 0, first half of W set B (k-step 1)
         M16_X(xb0, sa, 2, 0); M16_X(xb1, sa, 3, 0); M16_W(wb0, sw, 0, 1); M16_W(wb1, sw, 1, 1); M16_W(wb2, sw, 2, 1);
-        M16_PHASE(wa, xa0, xa1, 0, if (n1) dma_w(2, t + 1, sw1), if (n2) dma_a(0, t + 2, sa2));
+        if constexpr (NB == 6) M16_PHASE3(wa, xa0, xa1, 0, if (n1) dma_w(2, t + 1, sw1), if (n1) dma_w(3, t + 1, sw1), if (n1) dma_w(4, t + 1, sw1));
+        else M16_PHASE(wa, xa0, xa1, 0, if (n1) dma_w(2, t + 1, sw1), if (n2) dma_a(0, t + 2, sa2));
         // phase 1: k-step 0, token blocks 2 3 | ahead: X pair A of k-step 1, second half of W set B
         M16_X(xa0, sa, 0, 1); M16_X(xa1, sa, 1, 1); M16_W(wb3, sw, 3, 1); M16_W(wb4, sw, 4, 1); M16_W(wb5, sw, 5, 1);
-        M16_PHASE(wa, xb0, xb1, 2, if (n2) dma_a(1, t + 2, sa2), if (n2) dma_a(2, t + 2, sa2));
+        if constexpr (NB == 6) M16_PHASE3(wa, xb0, xb1, 2, if (n1) dma_w(5 < NB ? 5 : 0, t + 1, sw1), if (n2) dma_a(0, t + 2, sa2), if (n2) dma_a(1, t + 2, sa2));
+        else M16_PHASE(wa, xb0, xb1, 2, if (n2) dma_a(1, t + 2, sa2), if (n2) dma_a(2, t + 2, sa2));
         // phase 2: k-step 1, token blocks 0 1 | ahead: X pair B of k-step 1
         M16_X(xb0, sa, 2, 1); M16_X(xb1, sa, 3, 1);
-        M16_PHASE(wb, xa0, xa1, 0, if (n2) dma_a(3, t + 2, sa2), (void)0);
+        if constexpr (NB == 6) M16_PHASE3(wb, xa0, xa1, 0, if (n2) dma_a(2, t + 2, sa2), if (n2) dma_a(3, t + 2, sa2), (void)0);
+        else M16_PHASE(wb, xa0, xa1, 0, if (n2) dma_a(3, t + 2, sa2), (void)0);
         if (n2) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         V8_SB();
@@ -441,6 +464,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
 #undef M16_W
 #undef M16_MMA
 #undef M16_PHASE
+#undef M16_PHASE3
     } else {
     V8_READ(f0, 0, 0, 0);
     if (dma_on && nt > 1) { dma_w(0, 1, 1); dma_w(1, 1, 1); }
@@ -1041,7 +1065,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: case 113: case 123: break;
+    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: case 113: case 118: case 123: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -1131,6 +1155,11 @@ static int launch_rows128(const GemmParams& p_, int epi, hipStream_t stream, boo
     GemmParams p = p_;
     if (splitk_workspace(stream, tiles, p)) return launch_gemm_t<3, 128, 1, 0, 1, 1>(p, epi, stream);
   }
+  // (No more tiles than CUs: a CU holds one workgroup whatever its LDS footprint, so the 128-row tile could run on schedule 8 — id 118,
+  // VSYS_GEMM_ROWS128_S8=1.  Measured at 4864 rows: proj 22.6 vs 22.7 us, cross-q 19.0 vs 19.3, fc2 60.7 vs 62.8, one rank of eight
+  // 19.6 vs 19.5 ms per step — the few-tile launches are not bound by the K loop's schedule; not dispatched.)
+  static const bool s8_on = [] { const char* e = getenv("VSYS_GEMM_ROWS128_S8"); return e && e[0] == '1'; }();
+  if (s8_on && tiles <= cu_count_this_device() && p_.K / BK >= 3) return launch_gemm_t<8, 128, 1, 0, 1>(p_, epi, stream);
   return launch_gemm_t<3, 128, 1, 0, 1>(p_, epi, stream);
 }
 // schedule 8 on the 256-row geometry: the 16x16x32 form by default (same bits), VSYS_GEMM_MF16=0 / variant 8 the 32x32x16 form
@@ -1191,6 +1220,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
 #endif
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 113: return launch_gemm_t<3, 128, 1, 0, 1>(p, epi, stream);   // ... on v_mfma_f32_16x16x32_bf16 (one workgroup per tile)
+    case 118: return launch_gemm_t<8, 128, 1, 0, 1>(p, epi, stream);   // the 128-row geometry on schedule 8 (16x16x32)
     case 123: return launch_rows128(p, epi, stream, true);               // ... two workgroups per tile where the tile count allows (split K)
     case 106: return launch_gemm_t<6, 128>(p, epi, stream);   // the 128-row geometry on schedule 6 (DMA pieces interleaved with the MFMA pairs)
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
