@@ -105,6 +105,14 @@ def gemm(x, w, bias=None, *, epilogue=EPI_BIAS, gate=None, gate_stride=0, rows_p
 LN_BLOCK = 96   # columns per LayerNorm partial of the AdaLN fold (include/videosys_amd.h, vsys_gemm_bf16_ln)
 
 
+def _stats_ld(stats, rows, nblk):
+    """Leading dimension (rows per 96-column block) of a statistics buffer or of a ROW SLICE of one (``buf[:, r0:r1]``: the C side
+    addresses partial b of row r at base + (b * ld + r) * 8 bytes, so a slice is just another base pointer with the parent's ld)."""
+    assert stats.dtype == torch.float32 and stats.dim() == 3 and stats.shape[0] == nblk and stats.shape[1] >= rows and stats.shape[2] == 2
+    assert stats.stride(2) == 1 and stats.stride(1) == 2 and stats.stride(0) % 2 == 0 and stats.stride(0) // 2 >= stats.shape[1]
+    return stats.stride(0) // 2
+
+
 def ln_stats_buffer(rows, C, device):
     """fp32 [C / 96, rows, 2]: (mean, M2) of every 96-column block of every row (the statistics format of the AdaLN fold)."""
     assert C % LN_BLOCK == 0
@@ -119,12 +127,12 @@ def gemm_ln(x, wp, cs, cv, stats, *, gelu=False, eps=1e-6, out=None):
     assert x.dim() == 2 and x.stride(1) == 1 and wp.stride(1) == 1 and cs.dtype == torch.float32 and cv.dtype == torch.float32
     M, K = x.shape
     N = wp.shape[0]
-    assert wp.shape[1] == K and stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[0] == K // LN_BLOCK
-    assert stats.shape[1] >= M and stats.shape[2] == 2
+    assert wp.shape[1] == K
+    ld = _stats_ld(stats, M, K // LN_BLOCK)
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     _call("vsys_gemm_bf16_ln", _p(x), x.stride(0), _p(wp), wp.stride(0), _p(cs), _p(cv), _p(out), out.stride(0), M, N, K,
-          EPI_BIAS_GELU if gelu else EPI_BIAS, _p(stats), stats.shape[1], float(eps))
+          EPI_BIAS_GELU if gelu else EPI_BIAS, _p(stats), ld, float(eps))
     return out
 
 
@@ -135,11 +143,11 @@ def gemm_stats(x, w, bias, stats, *, gate=None, gate_stride=0, rows_per_sample=0
     assert x.dim() == 2 and x.stride(1) == 1 and w.stride(1) == 1
     M, K = x.shape
     N = w.shape[0]
-    assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[0] == N // LN_BLOCK and stats.shape[1] >= M
+    ld = _stats_ld(stats, M, N // LN_BLOCK)
     if out is None:
         out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     _call("vsys_gemm_bf16_stats", _p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K, _p(gate),
-          gate_stride, rows_per_sample, _p(res), res.stride(0) if res is not None else 0, _p(stats), stats.shape[1])
+          gate_stride, rows_per_sample, _p(res), res.stride(0) if res is not None else 0, _p(stats), ld)
     return out
 
 

@@ -804,6 +804,9 @@ class STDiT3:
                 self._ws.setdefault("mlp_slab_pool", []).append(slab)   # in stream order behind the add above
             return x
         hdim = w[p + ".mlp.fc1.weight"].shape[0]
+        # (Measured in round 6 and not kept: the MLP one CFG sample at a time through a half-size hidden buffer, so that fc2's A operand is
+        #  179 MB written a moment ago instead of 359 MB — same bits; fc2 + cross-proj 1005 -> 1021 TFLOP/s, but the half-size fc1 launches
+        #  993 -> 922: 97.0 -> 97.8 ms per step.)
         if fold:
             hbuf = folded(p + ".mlp.fc1", True, _buf("mlp_h", (N, hdim)))
         else:
