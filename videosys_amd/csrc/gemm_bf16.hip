@@ -622,6 +622,9 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   }
 
   // ---- epilogue: acc (+bias, act, gate) -> bf16 -> per-wave LDS image [64 tokens][96 cols] -> 16-byte HBM stores
+  // (Round 6: fetching them at the START of the K loop instead — 48 registers held across it, vmcnt(16) at the prologue — was built and
+  //  measured: proj 0.132 vs 0.126-0.129 ms, 97.25 vs 96.9 ms per step.  As in round 2's two-K-tiles-early form, WHEN the rows are
+  //  requested is not what the gate + residual epilogue costs.)
   // Residual rows for the store phase below are fetched NOW (12 x 16 B per lane, rows clamped instead of branched) so
   // their HBM latency hides under the accumulator -> LDS transposition; a load-wait-store chain per 16 bytes would
   // serialise 12 HBM round trips per wave (CDNA4 vmcnt also counts the stores).
