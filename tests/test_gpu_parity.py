@@ -509,10 +509,13 @@ def test_flash_resident_matches_streaming_and_torch(ops, q_len, kv_len, heads, b
         base = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
         assert lib.vsys_tune_flash_variant(8) == 0           # resident K/V (kv_len <= 320; otherwise the streaming kernel again)
         res = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)
+        assert lib.vsys_tune_flash_variant(23) == 0          # three workgroups per CU with the LDS-DMA pieces IN FRONT of the tile (the A/B
+        front = _run_flash(ops, q, k, v, qw, kw_, batch, heads, q_len, kv_len)   # partner of the shipped placement behind the first QK MFMAs)
         torch.cuda.synchronize()
     finally:
         lib.vsys_tune_flash_variant(0)
     assert torch.equal(res, base), f"resident-K/V flash differs from the streaming kernel: max {float((res.float() - base.float()).abs().max()):.3e}"
+    assert torch.equal(front, base), "the placement of the LDS-DMA pieces inside the tile must not change a bit"
     for bi in range(batch):
         for h in range(heads):
             qq = q[bi * q_len:(bi + 1) * q_len, h * 72:(h + 1) * 72]

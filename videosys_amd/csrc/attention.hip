@@ -320,6 +320,9 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
   // 48-register O rescale.  Mathematically the same softmax.
   const float defer_thr = 8.0f;
 
+  // Where the next tile's five LDS-DMA pieces of a wave are issued: in front of the tile (WPS 2), or one behind each of the tile's first five
+  // QK MFMAs (WPS 3, the spatial launch: 0.2328 -> 0.2280 / 0.2330 -> 0.2298 ms at config 2, same bits; ABL 4 = in front, the A/B partner)
+  constexpr bool DMA_BESIDE_QK = !RES && WPS == 3 && ABL != 4 && ABL != 1 && ABL != 5;
   unsigned long long tacc[5] = {0, 0, 0, 0, 0}, tprev = 0;
 #define FLASH_STAMP(i_)                                              \
   do {                                                               \
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
       tprev = now_;                                                  \
     }                                                                \
   } while (0)
-  auto tile = [&](int t, int cur, const bool masked) {
+  auto tile = [&](int t, int cur, const bool masked, const bool stage_next = false) {
     const char* sk = smem + cur * KV_STAGE;
 
     // ---- S^T - m = K Q^T - m : two 32-key tiles.  All 20 K fragment reads are issued before the first MFMA (hipcc
@@ -350,8 +353,18 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
       for (int cc = 0; cc < 5; ++cc) kf1[cc] = *reinterpret_cast<const bf16x8*>(krp + 32 * cc);
       // D != C on purpose (the builtin ties them and hipcc would first copy the 16 minit registers into s)
       asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[0]) : "v"(kf0[0]), "v"(qf[0]), "v"(minit));
+      if (DMA_BESIDE_QK && stage_next) {   // one LDS-DMA piece behind each of the first MFMAs: the piece's issue time runs beside the matrix pipe
+        stage(t + 1, cur ^ 1);
+#pragma unroll
+        for (int cc = 1; cc < 5; ++cc) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[cc], qf[cc], s[0], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+      } else {
 #pragma unroll
       for (int cc = 1; cc < 5; ++cc) s[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0[cc], qf[cc], s[0], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(s[1]) : "v"(kf1[0]), "v"(qf[0]), "v"(minit));
@@ -487,10 +500,15 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
       }
       finish_q();
       __builtin_amdgcn_sched_barrier(0);
-      if (blk + 1 < qb1) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads above are done before the image is overwritten
-        dma_q(q0 + 256);
-      }
+      // the next block's Q rows: requested behind the first tile's QK MFMAs of the pipelined sequence (a piece costs its wave ~100+ cycles
+      // at issue; there they run beside the matrix pipe), in front of the tiles otherwise
+      auto next_q = [&]() {
+        if (blk + 1 < qb1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the image reads above are done before the image is overwritten
+          dma_q(q0 + 256);
+        }
+      };
+      if (ABL == 3) next_q();
       __builtin_amdgcn_sched_barrier(0);
       if (ABL == 3) {   // lab: the unpipelined tile() sequence (A/B of the software pipeline below; same bits)
         for (int t = 0; t < ntiles - 1; ++t) tile(t, t, false);
@@ -608,6 +626,9 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
           if constexpr (has_next) rescale(t + 1, sn, mxn);
         };
         qk(0, sa);
+        __builtin_amdgcn_sched_barrier(0);
+        next_q();
+        __builtin_amdgcn_sched_barrier(0);
         rescale(0, sa, (ragged && ntiles == 1) ? tile_max(0, sa, true) : tile_max(0, sa, false));
         int t = 0;
         for (; t + 2 < ntiles; t += 2) {   // two steps per trip: the S buffers swap roles without register copies
@@ -636,10 +657,11 @@ __global__ __launch_bounds__(RES ? 512 : 256, RES ? 2 : WPS) void flash_attn_d72
     if (ABL == 2) tprev = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < ntiles - 1; ++t) {  // last tile peeled: no conditional staging inside the loop
       const int cur = t & 1;
-      if (ABL != 1) stage(t + 1, cur ^ 1);  // every wave finished reading buffer cur^1 before the barrier of tile t-1
+      if (ABL != 1 && ABL != 5 && !DMA_BESIDE_QK) stage(t + 1, cur ^ 1);  // every wave finished reading buffer cur^1 before the barrier of tile t-1
       __builtin_amdgcn_sched_barrier(0);
-      tile(t, cur, false);
+      tile(t, cur, false, true);
       __builtin_amdgcn_sched_barrier(0);
+      if (ABL == 5) { __builtin_amdgcn_sched_barrier(0); continue; }   // lab: no fetch, no wait, no barrier (compute + fragment reads only)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces have landed ...
       FLASH_STAMP(3);
       __syncthreads();                                   // ... and so have everybody else's
@@ -958,9 +980,9 @@ static unsigned long long* g_flash_dbg = nullptr;
 // fetched: output NOT valid) and 2 (phase timers) exist in -DVSYS_LAB builds only.
 int set_flash_variant(int v) {
   switch (v) {
-    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 140: case 141: case 143: case 144: break;
+    case 0: case 3: case 4: case 8: case 9: case 10: case 12: case 14: case 15: case 16: case 17: case 18: case 19: case 21: case 22: case 23: case 140: case 141: case 143: case 144: break;
 #ifdef VSYS_LAB
-    case 1: case 2: case 146: case 147: case 148: case 149: case 150: break;
+    case 1: case 2: case 6: case 146: case 147: case 148: case 149: case 150: break;
 #endif
     default: return VSYS_ERR_ARG;
   }
@@ -1060,11 +1082,21 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
   static const bool wps3_ok = [] { const char* e = getenv("VSYS_FLASH_WPS3"); return !(e && e[0] == '0'); }();
 #ifdef VSYS_LAB
   if (g_flash_variant == 1 || g_flash_variant == 2) {
-    if (g_flash_variant == 1) hipLaunchKernelGGL((flash_attn_d72_kernel<1, 2>), grid, dim3(256), lds, stream, p);
-    else hipLaunchKernelGGL((flash_attn_d72_kernel<2, 2>), grid, dim3(256), lds, stream, p);
+    if (g_flash_variant == 1) hipLaunchKernelGGL((flash_attn_d72_kernel<1, 3>), grid, dim3(256), lds, stream, p);
+    else hipLaunchKernelGGL((flash_attn_d72_kernel<2, 3>), grid, dim3(256), lds, stream, p);   // (three workgroups per CU, as the shipped spatial launch)
     return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
   }
 #endif
+#ifdef VSYS_LAB
+  if (g_flash_variant == 6) {   // no fetch, no wait, no barrier: output NOT valid
+    hipLaunchKernelGGL((flash_attn_d72_kernel<5, 3>), grid, dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
+#endif
+  if (g_flash_variant == 23) {   // A/B: the next tile's LDS-DMA pieces in front of the tile instead of between its first QK MFMAs (three workgroups per CU)
+    hipLaunchKernelGGL((flash_attn_d72_kernel<4, 3>), grid, dim3(256), lds, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
+  }
   if (g_flash_variant == 3 || (g_flash_variant == 0 && wps3_ok && kv_len >= 512 && (kv_len & 63) == 0))
     hipLaunchKernelGGL((flash_attn_d72_kernel<0, 3>), grid, dim3(256), lds, stream, p);
   else hipLaunchKernelGGL((flash_attn_d72_kernel<0, 2>), grid, dim3(256), lds, stream, p);
