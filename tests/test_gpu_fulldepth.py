@@ -164,7 +164,7 @@ def test_cogvideox_config5_full_depth():
     torch.cuda.empty_cache()
 
 
-def test_open_sora_720p_128f_geometry_two_block_pairs():
+def _open_sora_720p_128f(depth):
     """BASELINE configs[3] geometry on ONE GPU (the 8-way DSP run shards exactly this): 720p x 128 frames -> latent [4, 38, 90, 160]
     = 38 frames x 3600 tokens, CFG batch 2 = 273 600 token rows; spatial attention over 3600 keys (57 KV tiles, ragged last tile),
     temporal attention over T = 38 (the register-resident VALU kernel: the MFMA kernel covers T <= 32), 300 text keys (resident-K/V
@@ -175,7 +175,6 @@ def test_open_sora_720p_128f_geometry_two_block_pairs():
 
     T, Hl, Wl = get_latent_size(128, 720, 1280)
     assert (T, Hl, Wl) == (38, 90, 160)
-    depth = 2
     sd = U.bf16_round(O.synth_state_dict(depth, 1152, 16, seed=4321))
     hip = STDiT3(STDiT3Config(depth=depth), device="cuda:0")
     hip.load_state_dict(sd)
@@ -195,8 +194,18 @@ def test_open_sora_720p_128f_geometry_two_block_pairs():
     out_hip = hip(x, t, yy, **kw)
     torch.cuda.synchronize()
     r = dict(out_hip=U.stats(out_hip, out_ref), out_floor=U.stats(out_floor, out_ref))
-    print("\n[fulldepth] open-sora 720p x 128f, 2 block pairs: " + json.dumps(r))
+    print(f"\n[fulldepth] open-sora 720p x 128f, {depth} block pairs: " + json.dumps(r))
     why = U.verdict(r["out_hip"], r["out_floor"])
-    assert not why, f"720p x 128f geometry: {why}"
+    assert not why, f"720p x 128f geometry, {depth} block pairs: {why}"
     del hip, ref, floor
     torch.cuda.empty_cache()
+
+
+def test_open_sora_720p_128f_geometry_two_block_pairs():
+    _open_sora_720p_128f(2)
+
+
+def test_open_sora_720p_128f_geometry_eight_block_pairs():
+    """The same geometry eight block pairs deep: error growth with depth at 273 600 rows stays under the bf16 floor's.
+    (All 28 pairs: tools/parity_full_depth.py -> profiles/r06_parity_full_depth_720p128f.json.)"""
+    _open_sora_720p_128f(8)
