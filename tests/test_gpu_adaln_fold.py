@@ -63,7 +63,7 @@ def test_ln_row_stats_matches_torch(ops, M, C, offset):
     assert torch.allclose(st[..., 1].double().cpu().t(), ((blk - blk.mean(2, keepdim=True)) ** 2).sum(2), rtol=5e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("variant", [0, 8, 16, 24, 103, 113, 118])
+@pytest.mark.parametrize("variant", [0, 8, 16, 24, 103, 113, 118, 119])
 @pytest.mark.parametrize("M,N,K,rps", [(1100, 576, 1152, 400), (2048, 1152, 1152, 1024), (300, 1152, 4608, 300), (25856, 1152, 1152, 12928)])
 def test_gemm_stats_same_bits_and_right_statistics(ops, M, N, K, rps, variant):
     """The statistics-emitting epilogue stores what the plain gate + residual epilogue stores (in place, as the model calls it),

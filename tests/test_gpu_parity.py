@@ -71,7 +71,7 @@ def _gemm_bias(ops, M, N, K):
     check(out, O.gelu_tanh(ref), what="gemm+gelu")
 
 
-@pytest.mark.parametrize("variant", [3, 6, 8, 9, 16, 20, 24, 28, 30, 34, 103, 106, 113, 118])
+@pytest.mark.parametrize("variant", [3, 6, 8, 9, 16, 20, 24, 28, 30, 34, 103, 106, 113, 118, 119])
 def test_gemm_pipeline_variants(ops, variant):
     """Every main-loop schedule of the GEMM (LDS-DMA burst / interleaved, 2-stage / 3+2-slot, 8-wave / 4-wave geometry)
     must give the same result;
@@ -113,7 +113,7 @@ def test_gemm_is_transpose_exact(ops):
     assert torch.equal(out, x[:, perm])
 
 
-@pytest.mark.parametrize("variant", [0, 8, 16, 20, 24, 103, 113, 118])
+@pytest.mark.parametrize("variant", [0, 8, 16, 20, 24, 103, 113, 118, 119])
 def test_gemm_gate_residual_aux(ops, variant):
     """variant 0 = the shape dispatch (small problems take the 128-row geometry); 8 / 20 / 103 force each kernel family
     through the gate + residual + aux epilogue."""

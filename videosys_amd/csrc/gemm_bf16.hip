@@ -87,7 +87,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, hi = lane >> 5;
   const int l15 = lane & 15, lq = lane >> 4;   // MF: fragment row / 16-byte k-chunk; accumulator token / column quad
-  static_assert(!MF || ((PIPE == 8 && !PROD) || (PIPE == 3 && BM_ == 128)), "the 16x16x32 form exists for schedule 8 and for schedule 3 on the 128-row geometry");
+  static_assert(!MF || ((PIPE == 8 && !PROD) || ((PIPE == 3 || PIPE == 9) && BM_ == 128)), "the 16x16x32 form exists for schedule 8 and for schedules 3 / 9 on the 128-row geometry");
 
   static_assert(!KS || (MF && PIPE == 3 && BM_ == 128), "split K exists for the 128-row geometry on 16x16x32");
   const int nbn = p.N / BN;
@@ -248,7 +248,21 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   const int nt_all = p.K / BK;
   const int nt = KS ? (ks_half ? nt_all - nt_all / 2 : nt_all / 2) : nt_all;
   const int last = nt - 1;
-  if constexpr (BASE != 8) {
+  // schedule 9: ring of NS9 stages (four = the whole 160 KiB of a CU was measured too: fc2 0.0532 vs 0.0530 ms, proj 0.0214 vs 0.0204 — no gain
+  // over three: with two tiles in flight a CU fills its LDS at ~70 GB/s, 0.57 us per 40-KiB K-tile, and more depth does not raise that)
+  constexpr int NS9 = 3;
+  auto wait9 = [&](int tiles_in_flight) {   // counted wait: everything but this wave's newest ``tiles_in_flight`` tiles has landed
+    if (tiles_in_flight >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else if (tiles_in_flight == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  if constexpr (BASE == 9) {   // tiles 0 .. NS9 - 2 are requested, tile 0 is waited for (counted: the others stay in flight)
+    static_assert(NS9 <= 4, "wait9 counts up to two tiles in flight behind the awaited one");
+    const int npro = nt < NS9 - 1 ? nt : NS9 - 1;
+    for (int j = 0; j < npro; ++j) GEMM_DMA_RANGE(0, NP, j, j);
+    wait9(npro - 1);
+    __builtin_amdgcn_s_barrier();   // raw: __syncthreads() would drain the DMA queue
+  } else if constexpr (BASE != 8) {
     GEMM_DMA_RANGE(0, NP, 0, 0);
     ln_prologue();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -559,6 +573,56 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
 #undef V6_MMA2
 #undef V6_STEP
 #undef V6_TILE
+  } else if constexpr (BASE == 9) {
+    // ---- the few-tile schedule (128-row geometry, 16x16x32; no more tiles than CUs, so a CU holds ONE workgroup = one wave per SIMD and
+    // nothing else covers a DMA round trip): ring of NS9 = THREE 40-KiB stages, tile t + 2 requested during tile t — both operands two tiles
+    // ahead — with its ten pieces per wave placed one behind every fourth MFMA (a piece holds its wave ~60-180 cycles at issue; there
+    // that time runs beside the matrix pipe), counted wait ("all but my newest ten pieces" = tile t + 1 has landed), raw s_barrier.
+    // Schedule 3 here has one tile in flight and schedule 8 one W tile: measured 0.72 us per K-tile for 0.37 us of MFMA whatever the
+    // tile count (60 / 114 / 228 tiles: fc2 58.7 / 60.3 / 62.4 us) — one L2 round trip per K-tile.
+    static_assert(BASE != 9 || (MF && BM_ == 128 && !KS), "schedule 9 exists for the 128-row geometry on 16x16x32");
+    auto tile9 = [&](auto dma_tag, int cur, int kt2, int buf2) {
+      constexpr bool dma = decltype(dma_tag)::value;
+      const char* sb_ = smem + cur * STAGE_BYTES;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 xf[4], wf[6];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xf[i] = *reinterpret_cast<const bf16x8*>(sb_ + (xo16[i] ^ (ks << 6)));
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wf[j] = *reinterpret_cast<const bf16x8*>(sb_ + (wo16[j] ^ (ks << 6)));
+        if constexpr (dma) GEMM_DMA_RANGE(ks * (NP / 2), (ks + 1) * (NP / 2), kt2, buf2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j)
+            acc16[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc16[i][j], 0, 0, 0);
+        if constexpr (dma) {   // (all ten pieces in the first k-step instead: fc2 0.86 vs 0.81 of schedule 3's time — the issue stalls then bunch up)
+          __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+          for (int q = 0; q < NP / 2; ++q) { __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x010, 1, 0); }
+          __builtin_amdgcn_sched_group_barrier(0x008, 24 - 4 * (NP / 2), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+    int cur = 0, kt = 0;
+    for (; kt + NS9 - 1 < nt; ++kt) {   // steady state: tile kt + NS9 - 1 goes into the stage tile kt - 1 was read from
+      tile9(std::true_type{}, cur, kt + NS9 - 1, cur == 0 ? NS9 - 1 : cur - 1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS9 - 2) * NP) : "memory");   // everything but my newest NS9 - 2 tiles: tile kt + 1 has landed
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur == NS9 - 1 ? 0 : cur + 1;
+    }
+    for (; kt + 1 < nt; ++kt) {   // the last NS9 - 1 tiles request nothing
+      tile9(std::false_type{}, cur, 0, 0);
+      wait9(nt - 2 - kt);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      cur = cur == NS9 - 1 ? 0 : cur + 1;
+    }
+    tile9(std::false_type{}, cur, 0, 0);
+    __syncthreads();
   } else {
     for (int kt = 0; kt < last; ++kt) {
       const int cur = kt & 1;
@@ -1068,7 +1132,7 @@ int set_gemm_variant(int v) {
     return 0;
   }
   switch (v) {
-    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: case 113: case 118: case 123: break;
+    case 0: case 3: case 6: case 8: case 9: case 16: case 20: case 24: case 34: case 28: case 30: case 50: case 103: case 106: case 113: case 118: case 119: case 123: break;
 #ifdef VSYS_LAB
     case 60: case 70: case 80:   // ping-pong wave groups / persistent grid / stream-K tail (gemm4_bf16.hip): valid, measured, not shipped
     case 18: case 38: case 48: case 31: case 40: case 61: case 62: case 63: case 64: case 71: case 72: case 73: case 74: case 78: case 81: case 82: case 83: case 84: break;
@@ -1086,10 +1150,10 @@ static int launch_gemm_t(const GemmParams& p, int epi, hipStream_t stream) {
   const int nbm = (p.M + BM_ - 1) / BM_, nbn = p.N / BN;
   const int grid = KS ? ((nbm * nbn + 7) / 8) * 16 : nbm * nbn;   // KS: two workgroups per tile, pairs laid out XCD by XCD (gemm_kernel)
   const bool lnl = epi == EPI_LN_BIAS || epi == EPI_LN_GELU;
-  const size_t lds = ((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (lnl && BM_ == 256 ? (BM_ + BN) * 8 : 0);
+  const size_t lds = ((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : (PIPE % 10 == 9 ? 3 : 2) * G::STAGE) + (lnl && BM_ == 256 ? (BM_ + BN) * 8 : 0);
   static std::atomic<unsigned long long> attr_seen{0};   // per device (and per template instance)
   for (DeviceOnce once(attr_seen); once.todo(); once.done()) {
-    const int lds = (int)(((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : 2 * G::STAGE) + (BM_ == 256 ? (BM_ + BN) * 8 : 0));
+    const int lds = (int)(((PIPE % 10 == 8) ? 3 * G::A_BYTES + 2 * B_BYTES : (PIPE % 10 == 9 ? 3 : 2) * G::STAGE) + (BM_ == 256 ? (BM_ + BN) * 8 : 0));
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS, PIPE, BM_, RASTER, PROD, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_BIAS_GELU, PIPE, BM_, RASTER, PROD, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_GATE_RES, PIPE, BM_, RASTER, 0, MF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1163,6 +1227,12 @@ static int launch_rows128(const GemmParams& p_, int epi, hipStream_t stream, boo
   // 19.6 vs 19.5 ms per step — the few-tile launches are not bound by the K loop's schedule; not dispatched.)
   static const bool s8_on = [] { const char* e = getenv("VSYS_GEMM_ROWS128_S8"); return e && e[0] == '1'; }();
   if (s8_on && tiles <= cu_count_this_device() && p_.K / BK >= 3) return launch_gemm_t<8, 128, 1, 0, 1>(p_, epi, stream);
+  // What does bind them is the L2 -> LDS round trip: one CU = one workgroup = one wave per SIMD, and schedule 3 has ONE tile in flight
+  // (schedule 8: one W tile): 0.72 us per K-tile for 0.37 us of MFMA whatever the tile count.  Schedule 9 (ring of three stages, both
+  // operands two tiles ahead, id 119) at 4864 rows: fc2 62.3 -> 51.5 us (973-1035 TFLOP/s), proj 23.0 -> 20.0, cross-q 19.3 -> 17.0;
+  // with MORE tiles than CUs two workgroups of schedule 3 share a CU and cover each other (qkv 43.4 vs 46.6 us): not dispatched there.
+  static const bool ring_off = [] { const char* e = getenv("VSYS_GEMM_ROWS128_RING"); return e && e[0] == '0'; }();
+  if (!ring_off && tiles <= cu_count_this_device() && p_.K / BK >= 3) return launch_gemm_t<9, 128, 1, 0, 1>(p_, epi, stream);
   return launch_gemm_t<3, 128, 1, 0, 1>(p_, epi, stream);
 }
 // schedule 8 on the 256-row geometry: the 16x16x32 form by default (same bits), VSYS_GEMM_MF16=0 / variant 8 the 32x32x16 form
@@ -1224,6 +1294,7 @@ int launch_gemm(const GemmParams& p_, int epi, hipStream_t stream) {
     case 103: return launch_gemm_t<3, 128>(p, epi, stream);
     case 113: return launch_gemm_t<3, 128, 1, 0, 1>(p, epi, stream);   // ... on v_mfma_f32_16x16x32_bf16 (one workgroup per tile)
     case 118: return launch_gemm_t<8, 128, 1, 0, 1>(p, epi, stream);   // the 128-row geometry on schedule 8 (16x16x32)
+    case 119: return launch_gemm_t<9, 128, 1, 0, 1>(p, epi, stream);   // the 128-row geometry on the three-stage ring (16x16x32)
     case 123: return launch_rows128(p, epi, stream, true);               // ... two workgroups per tile where the tile count allows (split K)
     case 106: return launch_gemm_t<6, 128>(p, epi, stream);   // the 128-row geometry on schedule 6 (DMA pieces interleaved with the MFMA pairs)
     case 20: return launch_gemm2(p, epi, 0, stream);  // 4-wave workgroups, two per CU (gemm2_bf16.hip)
