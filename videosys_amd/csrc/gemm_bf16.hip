@@ -245,6 +245,31 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // Residual rows of the gated epilogues (12 x 16 B per lane, rows clamped instead of branched): requested after the K loop, their HBM
+  // latency hides under the accumulator -> LDS transposition.  Requesting them in FRONT of the loop was measured twice and bought nothing:
+  // schedule 8 at 38 912 rows 0.132 vs 0.126-0.129 ms for proj; schedule 9 (one wave per SIMD, where a round trip is fully exposed)
+  // 22.8 vs 22.8 us per launch in the rank-of-eight trace.  What the gated epilogue did lose there were FOUR dependent round trips for
+  // the gate rows (one per token block; now one burst, below).
+  constexpr bool GATED_ = EPI == EPI_GATE_RES || EPI == EPI_GATE_RES_STATS;
+  constexpr bool RES_EARLY = false;
+  uint4 rres[12];
+  auto fetch_res = [&]() {
+    if (GATED_) {
+#pragma unroll
+      for (int it = 0; it < 12; ++it) rres[it] = make_uint4(0, 0, 0, 0);
+      if (p.res != nullptr) {
+#pragma unroll
+        for (int it = 0; it < 12; ++it) {
+          const int q = lane + 64 * it;
+          const int m_local = q / 12, c = q - m_local * 12;
+          int grow = row0 + wm * 64 + m_local;
+          grow = grow < p.M ? grow : p.M - 1;
+          rres[it] = *reinterpret_cast<const uint4*>(p.res + (int64_t)grow * p.ldr + col0 + wn * 96 + c * 8);
+        }
+      }
+    }
+  };
+  if constexpr (RES_EARLY) fetch_res();
   const int nt_all = p.K / BK;
   const int nt = KS ? (ks_half ? nt_all - nt_all / 2 : nt_all / 2) : nt_all;
   const int last = nt - 1;
@@ -694,21 +719,7 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
   // serialise 12 HBM round trips per wave (CDNA4 vmcnt also counts the stores).
   constexpr bool GATED = EPI == EPI_GATE_RES || EPI == EPI_GATE_RES_STATS;
   constexpr bool LN = EPI == EPI_LN_BIAS || EPI == EPI_LN_GELU;
-  uint4 rres[12];
-  if (GATED) {
-#pragma unroll
-    for (int it = 0; it < 12; ++it) rres[it] = make_uint4(0, 0, 0, 0);
-    if (p.res != nullptr) {
-#pragma unroll
-      for (int it = 0; it < 12; ++it) {
-        const int q = lane + 64 * it;
-        const int m_local = q / 12, c = q - m_local * 12;
-        int grow = row0 + wm * 64 + m_local;
-        grow = grow < p.M ? grow : p.M - 1;
-        rres[it] = *reinterpret_cast<const uint4*>(p.res + (int64_t)grow * p.ldr + col0 + wn * 96 + c * 8);
-      }
-    }
-  }
+  if constexpr (!RES_EARLY) fetch_res();
   char* st = smem + wave * OUT_WAVE_BYTES;
   const int ncol0 = col0 + wn * 96;
   if constexpr (EPI == EPI_GATE_RES_STATS) {
@@ -791,23 +802,30 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
 #pragma unroll
         for (int j = 0; j < 6; ++j) bb16[j] = *reinterpret_cast<const uint2*>(p.bias + ncol0 + j * 16 + 4 * lq);
       }
+      // the gate rows of all four token blocks in ONE burst (24 x 8 B per lane): loaded per token block inside the loop below they were
+      // four dependent global round trips per wave (vmcnt(5) .. vmcnt(0) four times over), ~1 us each with one wave per SIMD
+      uint2 gg[GATED ? 4 : 1][6];
+      if (GATED) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int m_local = i * 16 + l15;
-        uint2 gg[6];
-        if (GATED) {
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 6; ++j) gg[j] = make_uint2(0x3f803f80u, 0x3f803f80u);  // bf16 1.0 pairs
-          if (p.gate != nullptr) {
-            int grow = row0 + wm * 64 + m_local;
+          for (int j = 0; j < 6; ++j) gg[i][j] = make_uint2(0x3f803f80u, 0x3f803f80u);  // bf16 1.0 pairs
+        if (p.gate != nullptr) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            int grow = row0 + wm * 64 + i * 16 + l15;
             grow = grow < p.M ? grow : p.M - 1;
             const int sample = grow / p.rows_per_sample;
             const bf16_t* gate_row = p.gate + (int64_t)sample * p.gate_stride + ncol0 + 4 * lq;
             if (p.seg_split > 0 && grow - sample * p.rows_per_sample < p.seg_split) gate_row += p.gate_alt;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) gg[j] = *reinterpret_cast<const uint2*>(gate_row + j * 16);
+            for (int j = 0; j < 6; ++j) gg[i][j] = *reinterpret_cast<const uint2*>(gate_row + j * 16);
           }
         }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m_local = i * 16 + l15;
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
           const int n_local = j * 16 + 4 * lq;
@@ -820,7 +838,8 @@ __global__ __launch_bounds__(Geo<BM_>::NT + PROD * 256, PROD ? 3 : 2) void gemm_
             for (int r = 0; r < 4; ++r) v[r] = gelu_tanh(v[r]);
           }
           if (GATED) {
-            v[0] *= bflo(gg[j].x); v[1] *= bfhi(gg[j].x); v[2] *= bflo(gg[j].y); v[3] *= bfhi(gg[j].y);
+            const uint2 g_ = gg[GATED ? i : 0][j];
+            v[0] *= bflo(g_.x); v[1] *= bfhi(g_.x); v[2] *= bflo(g_.y); v[3] *= bfhi(g_.y);
           }
           uint2 o;
           o.x = pack2bf(v[0], v[1]);
