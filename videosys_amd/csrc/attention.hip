@@ -1093,7 +1093,7 @@ int launch_flash_attn_d72(const bf16_t* q, int64_t q_stride, const bf16_t* q_nor
     return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
   }
 #endif
-  if (g_flash_variant == 23) {   // A/B: the next tile's LDS-DMA pieces in front of the tile instead of between its first QK MFMAs (three workgroups per CU)
+  if (g_flash_variant == 23 && kv_len >= 512 && (kv_len & 63) == 0) {   // A/B (same shapes as the shipped rule below): the next tile's LDS-DMA pieces in front of the tile instead of between its first QK MFMAs (three workgroups per CU)
     hipLaunchKernelGGL((flash_attn_d72_kernel<4, 3>), grid, dim3(256), lds, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : VSYS_ERR_LAUNCH;
   }
