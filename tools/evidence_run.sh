@@ -29,4 +29,8 @@ timeout 300 python tools/vae_bench.py --shard 8 > gpurun_out/ev/vae_shard8.log 2
 (cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ev/prof720 -o bench -- python $R/bench.py --geometry 720p128f --steps 3 --warmup 1 > $R/gpurun_out/ev/bench_720p.log 2>&1); tail -1 gpurun_out/ev/bench_720p.log | cut -c150-330
 python tools/prof_summary.py $(find gpurun_out/ev/prof720 -name "*.db" | head -1) "# rocprofv3 --kernel-trace --stats -- python bench.py --geometry 720p128f --steps 3 --warmup 1   (1280x720x128f: 273 600 token rows on one GPU; 1 warm-up + 3 timed + 3 instrumented-replay steps in the trace; round-6 final tree; box: $(grep -i unique gpurun_out/ev/box.txt | head -1))" > gpurun_out/ev/kernel_stats_720p128f.txt 2>&1; head -8 gpurun_out/ev/kernel_stats_720p128f.txt | cut -c1-60,100-170
 timeout 600 python tools/issue_time.py --dsp-rank 8 --geometry 720p128f --steps 2 > gpurun_out/ev/issue_dsp8_720p.log 2>&1; tail -1 gpurun_out/ev/issue_dsp8_720p.log | cut -c1-300
-rm -rf gpurun_out/ev/prof gpurun_out/ev/prof720 gpurun_out/ev/pmc2 gpurun_out/ev/tf gpurun_out/ev/tw
+(cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/ev/rk8 -o r -- python $R/tools/issue_time.py --dsp-rank 8 --no-overlap --steps 5 > $R/gpurun_out/ev/rk8.log 2>&1)
+python tools/prof_summary.py $(find gpurun_out/ev/rk8 -name "*.db" | head -1) "# rocprofv3 --kernel-trace of: python tools/issue_time.py --dsp-rank 8 --no-overlap --steps 5 (ONE rank of an 8-way DSP group at config 2, wire stubbed; round-6 final tree; box: $(grep -i unique gpurun_out/ev/box.txt | head -1))" > gpurun_out/ev/dsp_rank8_kernel_stats.txt 2>&1
+VSYS_GEMM_ROWS128_RING=0 timeout 600 python tools/issue_time.py --dsp-rank 8 --no-overlap > gpurun_out/ev/issue_dsp8_noov_noring.log 2>&1; tail -1 gpurun_out/ev/issue_dsp8_noov_noring.log | cut -c1-300
+timeout 200 python tools/cold_weight_probe.py > gpurun_out/ev/cold_weight.log 2>&1
+rm -rf gpurun_out/ev/rk8 gpurun_out/ev/prof gpurun_out/ev/prof720 gpurun_out/ev/pmc2 gpurun_out/ev/tf gpurun_out/ev/tw
