@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed-region) VAE decode measurement")
     ap.add_argument("--no-t5", action="store_true", help="skip the (untimed-region) T5 encode measurement")
     ap.add_argument("--text-len", type=int, default=300)
+    ap.add_argument("--no-cp", action="store_true",
+                    help="N > 1: plain sequence parallelism over all N ranks (the reference pipeline's default) instead of the reference's "
+                         "enable_cp decomposition (the CFG pair on two rank groups, sequence parallelism over N / 2 ranks inside each)")
     ap.add_argument("--geometry", default="512x512x64f", choices=["512x512x64f", "720p128f"],
                     help="512x512x64f = BASELINE config 2 (the contract's workload); 720p128f = BASELINE configs[3] geometry "
                          "(1280x720, 128 frames: 273 600 token rows), reported as its own workload, DiT step only")
@@ -125,7 +128,12 @@ def main():
     model = STDiT3(cfg, device=dev)
     model.load_state_dict(synth_state_dict(cfg, seed=1234))
     if world > 1:
-        model.enable_parallel(dp_size=1, sp_size=world)
+        # enable_cp (open_sora_transformer_3d.py:466-482): with an even world the conditional and the unconditional sample of the CFG pair go
+        # to two rank groups and the sequence is split over N / 2 ranks inside each — the same results (tests/test_gpu_sp.py), half the
+        # all-to-all group (N = 2: no exchange inside the blocks at all), one small all-gather of the output per step
+        model.enable_parallel(dp_size=1, sp_size=world, enable_cp=(world % 2 == 0 and not args.no_cp))
+    cp_size = getattr(model.parallel_manager, "cp_size", 1) or 1
+    sp_size = getattr(model.parallel_manager, "sp_size", 1) or 1
     if args.pab:
         pab.set_pab_manager(OpenSoraPABConfig(mlp_broadcast=False))
         pab.update_steps(STEPS_PER_VIDEO)
@@ -309,16 +317,18 @@ def main():
             return dt_, rep["comm_ms"] / nrep, rep["collectives"] // nrep
 
         was = model._overlap
-        if model._side is None:
+        seq_par = model._sp is not None   # (N = 2 with enable_cp: sp = 1, the blocks exchange nothing — only the output all-gather is timed)
+        if seq_par and model._side is None:
             model._side = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         was_prog2 = model.use_programs
         try:
             t_off, comm_off, ncoll = replay(False)
-            t_on, comm_on, _ = replay(True)
+            t_on, comm_on, _ = replay(True) if seq_par else (t_off, comm_off, ncoll)
         finally:
             model.use_programs = was_prog2
         model._overlap = was
-        vdsp.check_exchange(model)   # a timed-out peer-to-peer exchange must fail the bench, not shape its number
+        if seq_par:
+            vdsp.check_exchange(model)   # a timed-out peer-to-peer exchange must fail the bench, not shape its number
         mine = torch.tensor([comm_off, comm_on, t_off * 1e3, t_on * 1e3], device=dev, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -326,18 +336,20 @@ def main():
             comm_off_all = [round(float(v[0]), 3) for v in allr]
             t_off_ms, t_on_ms = max(float(v[2]) for v in allr), max(float(v[3]) for v in allr)
             hidden = max(0.0, t_off_ms - t_on_ms)
+            xi = model._sp.exchange_info if seq_par else {}
             dsp_info = {
                 "collectives_per_step": ncoll, "comm_ms_per_step_per_rank_serialized": comm_off_all,
                 "comm_ms_per_step_per_rank_overlapped_streams": [round(float(v[1]), 3) for v in allr],
                 "step_ms_overlap_off": round(t_off_ms, 3), "step_ms_overlap_on": round(t_on_ms, 3),
                 "overlap_fraction": round(min(1.0, hidden / max(max(comm_off_all), 1e-9)), 4),
-                "overlap_default": bool(was), "switch_order": model._switch_order(2, T, (Hl // 2) * (Wl // 2)),
+                "cfg_parallel": cp_size, "sequence_parallel": sp_size,
+                "overlap_default": bool(was), "switch_order": model._switch_order(2 // cp_size, T, (Hl // 2) * (Wl // 2)) if seq_par else None,
                 # which exchange the group runs on and why: the one-time guarded trial of the one-kernel peer-to-peer exchange at
                 # enable_parallel (dsp.p2p_selftest: patterned payload, both paths timed on a config-2-sized message, the faster one wins;
                 # any failure -> RCCL on every rank)
-                "exchange_path": model._sp.exchange_info.get("exchange_path"), "p2p_selftest": model._sp.exchange_info.get("selftest"),
-                "p2p_ms_per_exchange": model._sp.exchange_info.get("p2p_ms"), "rccl_ms_per_exchange": model._sp.exchange_info.get("rccl_ms"),
-                "selftest_message_mb_per_peer": model._sp.exchange_info.get("message_mb_per_peer"),
+                "exchange_path": xi.get("exchange_path", "none: cfg-parallel only (one all-gather of the output per step)"),
+                "p2p_selftest": xi.get("selftest"), "p2p_ms_per_exchange": xi.get("p2p_ms"), "rccl_ms_per_exchange": xi.get("rccl_ms"),
+                "selftest_message_mb_per_peer": xi.get("message_mb_per_peer"),
                 "note": "event brackets include the wait for the slowest peer; overlap_fraction = (step_off - step_on) / serialized comm; these replays issue every launch from Python (eager) so that the brackets run",
             }
 
@@ -429,7 +441,7 @@ def main():
                 "workload": ((f"open-sora-v1.2 STDiT3-XL/2 {'512x512x64f' if base_geo else '1280x720x128f (BASELINE configs[3] geometry)'}, "
                               f"latent [4,{T},{Hl},{Wl}], CFG batch 2 = {2 * T * (Hl // 2) * (Wl // 2)} token rows, ") +
                              f"{L} text tokens, depth {args.depth}" + (", PAB attention-only (config 3)" if args.pab else "")),
-                "steps_per_video": STEPS_PER_VIDEO, "parallelism": f"dsp{world}",
+                "steps_per_video": STEPS_PER_VIDEO, "parallelism": (f"dsp{world}" if cp_size == 1 else f"cfg-parallel 2 x dsp{sp_size} (the reference's enable_cp; --no-cp: dsp{world})"),
                 "not_included": "value is DiT denoising only; vae_decode / t5_encode report the other two terms of the metric beside it",
                 "algorithmic_tflop_per_step": 89.4 if args.depth == 28 and L == 300 and base_geo else None,
                 "launch_path": ("recorded launch program: " + json.dumps(model.program_stats)) if model.use_programs else "eager (every launch from Python)",

@@ -94,6 +94,55 @@ def _stdit3_worker(rank, world, port, outdir, T, HW, p2p=False):
             dist.destroy_process_group()
 
 
+def _stdit3_cp_sp_worker(rank, world, port, outdir, T, HW):
+    """enable_cp with sequence parallelism inside each CFG group (world 4 = cp 2 x sp 2): what bench.py runs for an even N."""
+    import traceback
+
+    import torch.distributed as dist
+
+    try:
+        from oracle import stdit3_oracle as O
+        from videosys_amd.stdit3 import STDiT3, STDiT3Config
+
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+        cfg = dict(depth=2, hidden_size=576, num_heads=8, caption_channels=64, model_max_length=16)
+        sd = O.synth_state_dict(**cfg, seed=31)
+        sd = {k: (v if k == "rope.freqs" else v.to(torch.bfloat16).float()) for k, v in sd.items()}
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(2, 4, T, HW, HW, generator=g).to(torch.bfloat16).float()
+        y = torch.randn(2, 1, 16, 64, generator=g).to(torch.bfloat16).float()
+        mask = torch.zeros(1, 16, dtype=torch.long)
+        mask[:, :11] = 1
+        kw = dict(mask=mask, fps=torch.tensor([24.0, 24.0]), height=torch.tensor([float(HW * 8)] * 2),
+                  width=torch.tensor([float(HW * 8)] * 2))
+        t = torch.tensor([500.0, 500.0])
+        model = STDiT3(STDiT3Config(**cfg), device="cuda:0")
+        model.load_state_dict(sd)
+        model.fold_spatial_qkv = False      # (what a rank whose modulated activations travel computes: see _stdit3_worker)
+        ref = model(x, t, y, **kw).float().cpu()
+        model.fold_spatial_qkv = True
+        outs = []
+        for overlap in (False, True):
+            model.enable_parallel(1, world, True, overlap=overlap)
+            pm = model.parallel_manager
+            assert pm.cp_size == 2 and pm.sp_size == world // 2 and model._sp is not None
+            outs.append(model(x, t, y, **kw).float().cpu())
+            outs.append(model(x, t, y, **kw).float().cpu())     # the replayed launch program
+        torch.cuda.synchronize()
+        if model._sp.p2p is not None:
+            model._sp.p2p.check()
+        ok = all(torch.equal(o, ref) for o in outs)
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write("ok" if ok else f"mismatch max|diff| {max((o - ref).abs().max().item() for o in outs)} of {ref.abs().max().item()}")
+    except Exception:
+        with open(os.path.join(outdir, f"r{rank}.txt"), "w") as f:
+            f.write(traceback.format_exc())
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def _run(worker, args, world=2, timeout=300):
     ctx = mp.get_context("spawn")
     port = _free_port()
@@ -233,6 +282,13 @@ def test_stdit3_dsp_two_ranks_equals_single(T, HW):
     _run(_stdit3_worker, (T, HW))
 
 
+@pytest.mark.parametrize("T,HW", [(5, 16), (4, 12)])
+def test_stdit3_cfg_parallel_times_dsp_four_processes_equals_single(T, HW):
+    """enable_cp (open_sora_transformer_3d.py:466-482,545-557,621) on four processes: the CFG pair on two rank groups, DSP over two
+    ranks inside each, outputs gathered along the batch — bit-identical to the single-process model, eager and replayed."""
+    _run(_stdit3_cp_sp_worker, (T, HW), world=4, timeout=600)
+
+
 def test_latte_and_cogvideox_two_processes_peer_to_peer_over_ipc():
     """The same one-kernel exchange under Latte's frame-sharded sequence parallelism (the two switches around every temporal block,
     latte_transformer_3d.py:826-843,1300-1308) and CogVideoX's Ulysses exchange (heads <-> sequence, two problems per peer on the way
@@ -323,9 +379,12 @@ def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
         assert torch.equal(pr, px.cpu()), f"rank {r}: tile-sharded decode differs"
 
 
-def test_bench_two_ranks_dry_run():
+@pytest.mark.parametrize("nproc,cp", [(2, False), (2, True), (4, True)])
+def test_bench_two_ranks_dry_run(nproc, cp):
     """bench.py's N > 1 path (rank-0 build, barriers, DSP model, max-over-ranks timing, one JSON line from rank 0), launched the
-    way the driver launches it, with both ranks on the one GPU of the test box over gloo (VSYS_BENCH_ONE_GPU=1), depth 2."""
+    way the driver launches it, with every rank on the one GPU of the test box over gloo (VSYS_BENCH_ONE_GPU=1), depth 2.
+    cp = the default decomposition for an even N (the reference's enable_cp: the CFG pair on two rank groups, sequence parallelism
+    over N / 2 ranks inside each — N = 2: no exchange inside the blocks); --no-cp = sequence parallelism over all N ranks."""
     import json
     import subprocess
     import sys
@@ -333,20 +392,26 @@ def test_bench_two_ranks_dry_run():
     from conftest import ROOT
 
     env = dict(os.environ, VSYS_BENCH_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--depth", "2", "--no-cpu-baseline", "--no-vae", "--no-t5"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+           "--depth", "2", "--no-cpu-baseline", "--no-vae", "--no-t5"] + ([] if cp else ["--no-cp"])
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
+    assert j["n_gpus"] == nproc and j["steps"] == 2 and j["value"] > 0
     assert j["roofline"]["frac"] > 0
     d = j["dsp"]   # per-rank collective time and the overlap report the first multi-GPU run is meant to deliver
-    assert len(d["comm_ms_per_step_per_rank_serialized"]) == 2 and d["collectives_per_step"] >= 2 * 2 + 1   # 2 spatial blocks x 2 exchanges + the final gather
+    sp = nproc // 2 if cp else nproc
+    assert j["config"]["parallelism"].startswith(f"cfg-parallel 2 x dsp{sp}" if cp else f"dsp{nproc}"), j["config"]["parallelism"]
+    assert d["cfg_parallel"] == (2 if cp else 1) and d["sequence_parallel"] == sp
+    assert len(d["comm_ms_per_step_per_rank_serialized"]) == nproc and d["step_ms_overlap_off"] > 0 and d["step_ms_overlap_on"] > 0
+    if sp == 1:   # the blocks exchange nothing: one all-gather of the output per step
+        assert d["collectives_per_step"] == 1 and d["exchange_path"].startswith("none") and d["switch_order"] is None, d
+        return
+    assert d["collectives_per_step"] >= 2 * 2 + 1   # 2 spatial blocks x 2 exchanges + the final gather
     assert d["overlap_default"] is True and d["switch_order"] == "activations" and 0.0 <= d["overlap_fraction"] <= 1.0
-    assert d["step_ms_overlap_off"] > 0 and d["step_ms_overlap_on"] > 0
     # the guarded trial of the one-kernel peer-to-peer exchange ran at enable_parallel and its verdict + both timings are reported
     assert d["p2p_selftest"] == "pass" and d["exchange_path"] in ("p2p", "rccl"), d
     assert d["p2p_ms_per_exchange"] > 0 and d["rccl_ms_per_exchange"] > 0 and d["selftest_message_mb_per_peer"] > 1.0
@@ -420,7 +485,7 @@ def test_bench_plain_form_launches_its_own_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]
     j = json.loads(lines[0])
-    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["parallelism"] == "dsp2"
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["parallelism"].startswith("cfg-parallel 2 x dsp1")
     v = j["vae_decode"]      # N > 1: the decode is sharded by output frame and gathered once
     assert v.get("sharded_over_ranks") == 2 and v["frames_per_rank"] == [32, 32] and v["output"] == [1, 64, 512, 512, 3], v
 

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--rank", type=int, default=0)
     ap.add_argument("--scatter", default=None, choices=["flat", "sample"])
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--cp", action="store_true", help="with --dsp-rank P: the reference's enable_cp decomposition — this rank holds ONE sample of the "
+                                                      "CFG pair and splits its sequence over P / 2 ranks (bench.py's default for an even N)")
     ap.add_argument("--geometry", default="512x512x64f", choices=["512x512x64f", "720p128f"])
     ap.add_argument("--depth", type=int, default=28)
     ap.add_argument("--sweep", action="store_true", help="with --dsp-rank: every (scatter, overlap) setting in one process")
@@ -49,8 +51,14 @@ def main():
         from tools.local_group import StubGroup
 
         P = args.dsp_rank
-        pm = SimpleNamespace(sp_size=P, cp_size=1, dp_size=1, dp_rank=0, sp_rank=args.rank, cp_rank=0,
-                             sp_group=StubGroup(P, args.rank), cp_group=None)
+        if args.cp:
+            assert P % 2 == 0
+            sp = P // 2
+            pm = SimpleNamespace(sp_size=sp, cp_size=2, dp_size=1, dp_rank=0, sp_rank=args.rank % sp, cp_rank=0,
+                                 sp_group=StubGroup(sp, args.rank % sp) if sp > 1 else None, cp_group=StubGroup(2, 0))
+        else:
+            pm = SimpleNamespace(sp_size=P, cp_size=1, dp_size=1, dp_rank=0, sp_rank=args.rank, cp_rank=0,
+                                 sp_group=StubGroup(P, args.rank), cp_group=None)
         model.enable_parallel(parallel_mgr=pm, overlap=not args.no_overlap)
         if args.scatter:
             model._scatter = args.scatter
@@ -87,8 +95,9 @@ def main():
         if args.dsp_rank > 1:
             from videosys_amd import dsp
 
-            rec.update(dsp_rank=args.dsp_rank, rank=args.rank, scatter=model._scatter, overlap=model._overlap,
-                       frames_on_this_rank_padded=dsp.frames_per_rank(2, T, args.dsp_rank, model._scatter),
+            rec.update(dsp_rank=args.dsp_rank, rank=args.rank, scatter=model._scatter, overlap=model._overlap, cfg_parallel=2 if args.cp else 1,
+                       frames_on_this_rank_padded=(dsp.frames_per_rank(1, T, args.dsp_rank // 2, model._scatter) if args.cp and args.dsp_rank > 2
+                                                   else (T if args.cp else dsp.frames_per_rank(2, T, args.dsp_rank, model._scatter))),
                        ideal_frames=round(2 * T / args.dsp_rank, 3),
                        exchange=("one-kernel peer-to-peer (vsys_p2p_exchange; every peer folded onto this rank: the same bytes, the same "
                                  "flag traffic)" if model._sp is not None and model._sp.p2p is not None
