@@ -49,8 +49,11 @@ def parse():
     ap.add_argument("--no-t5", action="store_true", help="skip the (untimed-region) T5 encode measurement")
     ap.add_argument("--text-len", type=int, default=300)
     ap.add_argument("--no-cp", action="store_true",
-                    help="N > 1: plain sequence parallelism over all N ranks (the reference pipeline's default) instead of the reference's "
-                         "enable_cp decomposition (the CFG pair on two rank groups, sequence parallelism over N / 2 ranks inside each)")
+                    help="N = 2: plain sequence parallelism over both ranks (the reference pipeline's default) instead of the reference's "
+                         "enable_cp decomposition (the CFG pair on the two ranks, no exchange inside the blocks)")
+    ap.add_argument("--cp", action="store_true",
+                    help="even N > 2: force enable_cp (CFG pair on two rank groups x sequence parallelism over N / 2 ranks); not the default "
+                         "there: xGMI is point-to-point, and half the group size doubles the bytes every link carries per exchange")
     ap.add_argument("--geometry", default="512x512x64f", choices=["512x512x64f", "720p128f"],
                     help="512x512x64f = BASELINE config 2 (the contract's workload); 720p128f = BASELINE configs[3] geometry "
                          "(1280x720, 128 frames: 273 600 token rows), reported as its own workload, DiT step only")
@@ -128,10 +131,13 @@ def main():
     model = STDiT3(cfg, device=dev)
     model.load_state_dict(synth_state_dict(cfg, seed=1234))
     if world > 1:
-        # enable_cp (open_sora_transformer_3d.py:466-482): with an even world the conditional and the unconditional sample of the CFG pair go
-        # to two rank groups and the sequence is split over N / 2 ranks inside each — the same results (tests/test_gpu_sp.py), half the
-        # all-to-all group (N = 2: no exchange inside the blocks at all), one small all-gather of the output per step
-        model.enable_parallel(dp_size=1, sp_size=world, enable_cp=(world % 2 == 0 and not args.no_cp))
+        # enable_cp (open_sora_transformer_3d.py:466-482): the conditional and the unconditional sample of the CFG pair go to two rank groups and
+        # the sequence is split over N / 2 ranks inside each — the same results (tests/test_gpu_sp.py).  Default at N = 2 only, where it
+        # removes every exchange inside the blocks (one small all-gather of the output per step: 49.1 vs 54.0-56.5 ms per rank, wire
+        # stubbed).  For N >= 4 the group stays all N ranks: a rank's rows spread over N - 1 point-to-point xGMI links instead of N / 2 - 1,
+        # i.e. half the bytes per link and exchange (and with the wire stubbed cp 2 x sp 2 is 5 % slower than sp 4 anyway).
+        use_cp = world % 2 == 0 and not args.no_cp and (world == 2 or args.cp)
+        model.enable_parallel(dp_size=1, sp_size=world, enable_cp=use_cp)
     cp_size = getattr(model.parallel_manager, "cp_size", 1) or 1
     sp_size = getattr(model.parallel_manager, "sp_size", 1) or 1
     if args.pab:

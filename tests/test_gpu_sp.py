@@ -379,12 +379,12 @@ def test_cogvideox_pab_ulysses_four_ranks_in_process_and_tiled_decode():
         assert torch.equal(pr, px.cpu()), f"rank {r}: tile-sharded decode differs"
 
 
-@pytest.mark.parametrize("nproc,cp", [(2, False), (2, True), (4, True)])
+@pytest.mark.parametrize("nproc,cp", [(2, False), (2, True), (4, True), (4, False)])
 def test_bench_two_ranks_dry_run(nproc, cp):
     """bench.py's N > 1 path (rank-0 build, barriers, DSP model, max-over-ranks timing, one JSON line from rank 0), launched the
     way the driver launches it, with every rank on the one GPU of the test box over gloo (VSYS_BENCH_ONE_GPU=1), depth 2.
-    cp = the default decomposition for an even N (the reference's enable_cp: the CFG pair on two rank groups, sequence parallelism
-    over N / 2 ranks inside each — N = 2: no exchange inside the blocks); --no-cp = sequence parallelism over all N ranks."""
+    cp = the reference's enable_cp (the CFG pair on two rank groups, sequence parallelism over N / 2 ranks inside each): the default
+    at N = 2 (no exchange inside the blocks; --no-cp = plain DSP), forced with --cp at N = 4 (default there: DSP over all N ranks)."""
     import json
     import subprocess
     import sys
@@ -394,7 +394,7 @@ def test_bench_two_ranks_dry_run(nproc, cp):
     env = dict(os.environ, VSYS_BENCH_ONE_GPU="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
-           "--depth", "2", "--no-cpu-baseline", "--no-vae", "--no-t5"] + ([] if cp else ["--no-cp"])
+           "--depth", "2", "--no-cpu-baseline", "--no-vae", "--no-t5"] + (["--cp"] if cp and nproc > 2 else ([] if cp or nproc > 2 else ["--no-cp"]))
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
